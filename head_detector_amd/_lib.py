@@ -1,0 +1,139 @@
+"""ctypes binding of libvgh.so (include/vgh.h).  There is NO fallback: if the HIP library is missing
+or fails to load, everything that needs it raises -- loudly -- instead of computing on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvgh.so")
+
+VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL = 0, 1, 2
+VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
+VGH_IMG_F32_NCHW, VGH_IMG_U8_NHWC = 0, 1
+NUM_FLAME_PARAMS = 413
+
+
+class BufDesc(C.Structure):
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("pitch", C.c_int32), ("is_f32", C.c_int32)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("in_buf", C.c_int32), ("in_coff", C.c_int32), ("cin", C.c_int32),
+        ("out_buf", C.c_int32), ("out_coff", C.c_int32), ("cout_pad", C.c_int32),
+        ("cout_store", C.c_int32),
+        ("out_split", C.c_int32), ("out_coff2", C.c_int32),
+        ("res_buf", C.c_int32), ("res_coff", C.c_int32),
+        ("alpha", C.c_float),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32),
+        ("shuffle", C.c_int32),
+        ("w_off", C.c_int64),
+        ("b_off", C.c_int64),
+        ("force_cfg", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class ConvCall(C.Structure):
+    _fields_ = [
+        ("in_dev", C.c_void_p), ("in_pitch", C.c_int64), ("in_coff", C.c_int32), ("cin", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("wpack_dev", C.c_void_p), ("bias_dev", C.c_void_p),
+        ("out_dev", C.c_void_p), ("out_pitch", C.c_int64),
+        ("out_coff", C.c_int32), ("cout_pad", C.c_int32), ("cout_store", C.c_int32), ("out_split", C.c_int32),
+        ("out_coff2", C.c_int32), ("out_f32", C.c_int32),
+        ("res_dev", C.c_void_p), ("res_pitch", C.c_int64), ("res_coff", C.c_int32),
+        ("alpha", C.c_float),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32), ("shuffle", C.c_int32),
+        ("force_cfg", C.c_int32),
+    ]
+
+
+class HeadLevel(C.Structure):
+    _fields_ = [("pred_dev", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("pitch", C.c_int32), ("stride", C.c_int32)]
+
+
+# every symbol include/vgh.h declares: (restype, argtypes)
+_P, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "vgh_version": (C.c_char_p, []),
+    "vgh_last_error": (C.c_char_p, []),
+    "vgh_net_create": (_I, [_I, _I, _I, C.POINTER(BufDesc), _I, C.POINTER(OpDesc), _I, _P, _I64, _P, _I64, C.POINTER(_P)]),
+    "vgh_net_destroy": (None, [_P]),
+    "vgh_net_forward": (_I, [_P, _P, _I, _I, _P]),
+    "vgh_net_profile": (_I, [_P, _P, _I, _I, _P, _P]),
+    "vgh_net_capture": (_I, [_P, _P, _I, _I, _P]),
+    "vgh_net_forward_graph": (_I, [_P, _P]),
+    "vgh_net_buffer": (_P, [_P, _I]),
+    "vgh_net_buffer_bytes": (_I64, [_P, _I]),
+    "vgh_net_set_cfg": (_I, [_P, _I, _I]),
+    "vgh_conv2d": (_I, [C.POINTER(ConvCall), _P]),
+    "vgh_pack_conv_weights": (_I, [_P, _I, _I, _I, _P]),
+    "vgh_conv_num_cfgs": (_I, []),
+    "vgh_conv_cfg_name": (C.c_char_p, [_I]),
+    "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),
+    "vgh_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "vgh_gather_candidates": (_I, [C.POINTER(HeadLevel), _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "vgh_nms": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P]),
+    "vgh_compact": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "vgh_flame_create": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, C.POINTER(_P)]),
+    "vgh_flame_destroy": (None, [_P]),
+    "vgh_flame_decode": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "vgh_flame_lbs": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "vgh_stream_create": (_I, [_I, C.POINTER(_P)]),
+    "vgh_stream_destroy": (_I, [_P]),
+    "vgh_stream_sync": (_I, [_P]),
+    "vgh_event_create": (_I, [C.POINTER(_P)]),
+    "vgh_event_destroy": (_I, [_P]),
+    "vgh_event_record": (_I, [_P, _P]),
+    "vgh_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class VghError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libvgh.so and bind every declared symbol. Raises VghError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VghError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m head_detector_amd.build` "
+            "(needs hipcc). There is no CPU fallback in this package."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise VghError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise VghError(f"{LIB_PATH} does not export {name} (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().vgh_last_error().decode("utf-8", "replace")
+        raise VghError(f"libvgh error {rc}: {msg}")
+
+
+def ptr(t) -> int:
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

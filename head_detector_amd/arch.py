@@ -1,0 +1,498 @@
+"""VGGHeads network -> flat op program for libvgh.so.
+
+The reference never spells the network out: it ships a TorchScript blob (head_detector/detector.py:25-30)
+whose graph is YoloHeads (yolo_head_training/yolo_head/yolo_heads.py:89-112) built from
+yolo_head_training/configs/arch_params/yolo_heads_{m,l}_arch_params.yaml:4-137 with super_gradients
+blocks.  This module (1) enumerates that module tree with super_gradients' parameter names
+(``layer_specs``), (2) folds eval-mode BN / QARepVGG branches into one conv + bias per block in fp64
+(``fold_state_dict``), and (3) lowers the folded network to the op program the C engine runs
+(``build_program``): NHWC bf16 buffers, concat-by-offset (no torch.cat), fused sibling convs
+(CSP conv1|conv2, head stems, cls|reg towers, first layers of the six FLAME branches, block-diagonal
+prediction convs), residual-add and ConvTranspose pixel-shuffle in the conv epilogue.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+BN_EPS = 1e-6  # arch yaml :139
+
+VARIANTS: Dict[str, dict] = {
+    # yolo_heads_l_arch_params.yaml:4-137
+    "vgg_heads_l": dict(
+        stem=48,
+        stages=[(96, 2, 96, True), (192, 3, 128, True), (384, 5, 256, True), (768, 2, 512, True)],  # (out, blocks, hidden, concat_intermediates)
+        spp_out=768,
+        neck=[(192, 4, 128), (96, 4, 128), (192, 4, 128), (384, 4, 256)],  # (out, blocks, hidden)
+        head=dict(bbox=(128, 256, 512), flame=256, blocks=3, shape_inter=256, expr_inter=128, shape_out=128, expr_out=64, tr_inter=32, width_mult=1.0),
+    ),
+    # yolo_heads_m_arch_params.yaml (diff vs L: :16,37-38,55-56,65-66,75-76,84,95-134)
+    "vgg_heads_m": dict(
+        stem=48,
+        stages=[(96, 2, 64, True), (192, 3, 128, True), (384, 5, 256, True), (768, 2, 384, False)],
+        spp_out=768,
+        neck=[(192, 2, 192), (96, 3, 64), (192, 2, 192), (384, 3, 256)],
+        head=dict(bbox=(256, 256, 256), flame=256, blocks=2, shape_inter=128, expr_inter=64, shape_out=64, expr_out=32, tr_inter=16, width_mult=0.75),
+    ),
+}
+TR_OUTS = (("rotation", 6), ("jaw", 3), ("translation", 3), ("scale", 1))  # order of the transform branches in the prediction buffer
+STRIDES = (8, 16, 32)
+
+
+def _wm(ch: int, factor: float, divisor: int = 8) -> int:
+    return int(math.ceil(int(ch * factor) / divisor) * divisor)  # super_gradients width_multiplier
+
+
+def head_dims(v: dict, level: int) -> dict:
+    h = v["head"]
+    return dict(bbox=_wm(h["bbox"][level], h["width_mult"]), fl=_wm(h["flame"], h["width_mult"]), **{k: h[k] for k in ("blocks", "shape_inter", "expr_inter", "shape_out", "expr_out", "tr_inter")})
+
+
+# ------------------------------------------------------------------------------------------------------
+# 1. module tree with super_gradients parameter names
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class Spec:
+    kind: str  # qarep | conv | cbr | plain | convT | alpha
+    name: str
+    cin: int = 0
+    cout: int = 0
+    k: int = 1
+    stride: int = 1
+    residual: bool = False
+    use_alpha: bool = False
+
+
+def _csp_specs(p: str, cin: int, cout: int, n: int, hidden: int, ci: bool, block: str) -> List[Spec]:
+    s = [Spec("conv", f"{p}.conv1", cin, hidden, 1), Spec("conv", f"{p}.conv2", cin, hidden, 1), Spec("conv", f"{p}.conv3", hidden * (2 + (n if ci else 0)), cout, 1)]
+    for i in range(n):
+        for cv in ("cv1", "cv2"):
+            if block == "qarep":
+                s.append(Spec("qarep", f"{p}.bottlenecks.{i}.{cv}", hidden, hidden, 3, 1, residual=True))
+            else:
+                s.append(Spec("conv", f"{p}.bottlenecks.{i}.{cv}", hidden, hidden, 3, 1))
+        s.append(Spec("alpha", f"{p}.bottlenecks.{i}.alpha"))
+    return s
+
+
+def layer_specs(variant: str) -> List[Spec]:
+    v = VARIANTS[variant]
+    s: List[Spec] = [Spec("qarep", "backbone.stem.conv", 3, v["stem"], 3, 2)]
+    c = v["stem"]
+    for i, (co, n, hid, ci) in enumerate(v["stages"]):
+        p = f"backbone.stage{i + 1}"
+        s.append(Spec("qarep", f"{p}.downsample", c, co, 3, 2))
+        s += _csp_specs(f"{p}.blocks", co, co, n, hid, ci, "qarep")
+        c = co
+    s += [Spec("conv", "backbone.context_module.cv1", c, c // 2, 1), Spec("conv", "backbone.context_module.cv2", c // 2 * 4, v["spp_out"], 1)]
+    c2, c3, c4 = (st[0] for st in v["stages"][:3])
+    c5 = v["spp_out"]
+    (o1, n1, h1), (o2, n2, h2), (o3, n3, h3), (o4, n4, h4) = v["neck"]
+    for p, cin, s1, s2, o, n, h in (("neck.neck1", c5, c4, c3, o1, n1, h1), ("neck.neck2", o1, c3, c2, o2, n2, h2)):
+        s += [
+            Spec("conv", f"{p}.reduce_skip1", s1, o, 1),
+            Spec("conv", f"{p}.reduce_skip2", s2, o, 1),
+            Spec("conv", f"{p}.conv", cin, o, 1),
+            Spec("convT", f"{p}.upsample", o, o, 2, 2),
+            Spec("conv", f"{p}.downsample", o, o, 3, 2),
+            Spec("conv", f"{p}.reduce_after_concat", 3 * o, o, 1),
+        ]
+        s += _csp_specs(f"{p}.blocks", o, o, n, h, False, "qarep")
+    for p, cin, skip, o, n, h in (("neck.neck3", o2, o2, o3, n3, h3), ("neck.neck4", o3, o1, o4, n4, h4)):
+        s.append(Spec("conv", f"{p}.conv", cin, o // 2, 3, 2))
+        s += _csp_specs(f"{p}.blocks", o // 2 + skip, o, n, h, False, "conv")
+    for lv, cin in enumerate((o2, o3, o4)):
+        d = head_dims(v, lv)
+        p = f"heads.head{lv + 1}"
+        s += [
+            Spec("cbr", f"{p}.pose_stem", cin, d["fl"], 1),
+            Spec("cbr", f"{p}.bbox_stem", cin, d["bbox"], 1),
+            Spec("cbr", f"{p}.cls_convs.0", d["bbox"], d["bbox"], 3),
+            Spec("cbr", f"{p}.reg_convs.0", d["bbox"], d["bbox"], 3),
+            Spec("plain", f"{p}.reg_pred", d["bbox"], 68, 1),
+            Spec("plain", f"{p}.cls_pred", d["bbox"], 1, 1),
+        ]
+        branches = [("shape", d["shape_inter"], d["shape_out"]), ("expression", d["expr_inter"], d["expr_out"])] + [(n_, d["tr_inter"], o_) for n_, o_ in TR_OUTS]
+        for bn, inter, out in branches:
+            c_in = d["fl"]
+            for b in range(d["blocks"]):
+                s.append(Spec("qarep", f"{p}.flame_{bn}_pred.{b}", c_in, inter, 3, 1, residual=False, use_alpha=True))
+                c_in = inter
+            s.append(Spec("plain", f"{p}.flame_{bn}_pred.{d['blocks']}", inter, out, 1))
+    return s
+
+
+def _bn_names(p: str) -> List[str]:
+    return [f"{p}.weight", f"{p}.bias", f"{p}.running_mean", f"{p}.running_var"]
+
+
+def random_state_dict(variant: str, seed: int = 1) -> Dict[str, np.ndarray]:
+    """Seeded synthetic weights of the architecture's exact shapes:
+    He-normal convs, BN gamma~U(0.5,1.5), beta~N(0,0.1), mean~N(0,0.1), var~U(0.5,1.5)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+
+    def conv_w(co, ci, k, gain=2.0):
+        return (rng.standard_normal((co, ci, k, k)) * math.sqrt(gain / (ci * k * k))).astype(np.float32)
+
+    def bn(p, c):
+        sd[f"{p}.weight"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[f"{p}.bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[f"{p}.running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[f"{p}.running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    for sp in layer_specs(variant):
+        if sp.kind == "qarep":
+            sd[f"{sp.name}.branch_3x3.conv.weight"] = conv_w(sp.cout, sp.cin, 3, 1.0)
+            bn(f"{sp.name}.branch_3x3.bn", sp.cout)
+            sd[f"{sp.name}.branch_1x1.weight"] = conv_w(sp.cout, sp.cin, 1, 1.0)
+            sd[f"{sp.name}.branch_1x1.bias"] = (rng.standard_normal(sp.cout) * 0.1).astype(np.float32)
+            bn(f"{sp.name}.post_bn", sp.cout)
+            if sp.use_alpha:
+                sd[f"{sp.name}.alpha"] = rng.uniform(0.5, 1.5, 1).astype(np.float32)
+        elif sp.kind == "conv":
+            sd[f"{sp.name}.conv.weight"] = conv_w(sp.cout, sp.cin, sp.k)
+            bn(f"{sp.name}.bn", sp.cout)
+        elif sp.kind == "cbr":
+            sd[f"{sp.name}.seq.conv.weight"] = conv_w(sp.cout, sp.cin, sp.k)
+            bn(f"{sp.name}.seq.bn", sp.cout)
+        elif sp.kind == "plain":
+            sd[f"{sp.name}.weight"] = conv_w(sp.cout, sp.cin, sp.k, 1.0)
+            sd[f"{sp.name}.bias"] = (rng.standard_normal(sp.cout) * 0.1).astype(np.float32)
+        elif sp.kind == "convT":
+            sd[f"{sp.name}.weight"] = (rng.standard_normal((sp.cin, sp.cout, 2, 2)) * math.sqrt(1.0 / sp.cin)).astype(np.float32)
+            sd[f"{sp.name}.bias"] = (rng.standard_normal(sp.cout) * 0.1).astype(np.float32)
+        elif sp.kind == "alpha":
+            sd[sp.name] = rng.uniform(0.5, 1.5, 1).astype(np.float32)
+    # keep scores in a useful range: the cls bias prior of YoloHeadsDFLHead._initialize_biases (yolo_head_dfl_head.py:188-190)
+    for lv in range(3):
+        sd[f"heads.head{lv + 1}.cls_pred.bias"][:] = -math.log((1 - 1e-2) / 1e-2)
+    return sd
+
+
+# ------------------------------------------------------------------------------------------------------
+# 2. folding (fp64)
+# ------------------------------------------------------------------------------------------------------
+def _bn_affine(sd, p) -> Tuple[np.ndarray, np.ndarray]:
+    g, b, m, var = (np.asarray(sd[n], dtype=np.float64) for n in _bn_names(p))
+    s = g / np.sqrt(var + BN_EPS)
+    return s, b - m * s
+
+
+def fold_state_dict(variant: str, sd: Dict[str, np.ndarray]) -> Dict[str, Tuple[np.ndarray, np.ndarray]]:
+    """name -> (W [Cout,Cin,k,k] f64, b [Cout] f64); bottleneck alphas as name -> (alpha, None).
+    Raises KeyError / ValueError on missing keys or shape mismatches (the manifest check of SURVEY.md N1)."""
+    out: Dict[str, Tuple[np.ndarray, Optional[np.ndarray]]] = {}
+
+    def need(key, shape):
+        a = np.asarray(sd[key])
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{key}: expected shape {tuple(shape)}, got {tuple(a.shape)}")
+        return a.astype(np.float64)
+
+    for sp in layer_specs(variant):
+        n = sp.name
+        if sp.kind == "qarep":
+            w3 = need(f"{n}.branch_3x3.conv.weight", (sp.cout, sp.cin, 3, 3))
+            s3, t3 = _bn_affine(sd, f"{n}.branch_3x3.bn")
+            w1 = need(f"{n}.branch_1x1.weight", (sp.cout, sp.cin, 1, 1))
+            b1 = need(f"{n}.branch_1x1.bias", (sp.cout,))
+            alpha = float(np.asarray(sd[f"{n}.alpha"]).reshape(-1)[0]) if sp.use_alpha else 1.0
+            K = w3 * s3[:, None, None, None]
+            K[:, :, 1, 1] += alpha * w1[:, :, 0, 0]
+            if sp.residual:
+                K[np.arange(sp.cout), np.arange(sp.cout), 1, 1] += 1.0
+            bias = t3 + alpha * b1
+            sp_, tp = _bn_affine(sd, f"{n}.post_bn")
+            out[n] = (K * sp_[:, None, None, None], bias * sp_ + tp)
+        elif sp.kind in ("conv", "cbr"):
+            p = n if sp.kind == "conv" else f"{n}.seq"
+            w = need(f"{p}.conv.weight", (sp.cout, sp.cin, sp.k, sp.k))
+            s, t = _bn_affine(sd, f"{p}.bn")
+            out[n] = (w * s[:, None, None, None], t)
+        elif sp.kind == "plain":
+            out[n] = (need(f"{n}.weight", (sp.cout, sp.cin, sp.k, sp.k)), need(f"{n}.bias", (sp.cout,)))
+        elif sp.kind == "convT":
+            out[n] = (need(f"{n}.weight", (sp.cin, sp.cout, 2, 2)), need(f"{n}.bias", (sp.cout,)))
+        elif sp.kind == "alpha":
+            out[n] = (float(np.asarray(sd[n]).reshape(-1)[0]), None)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# 3. lowering to the op program
+# ------------------------------------------------------------------------------------------------------
+def _r32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+@dataclass
+class View:
+    buf: int
+    coff: int
+    c: int  # channels visible through this view (padded to 32 where it feeds a conv)
+
+
+@dataclass
+class Program:
+    variant: str
+    image_size: int
+    bufs: List[dict] = field(default_factory=list)
+    ops: List[dict] = field(default_factory=list)
+    weights: List[np.ndarray] = field(default_factory=list)
+    biases: List[np.ndarray] = field(default_factory=list)
+    w_elems: int = 0
+    b_elems: int = 0
+    levels: List[dict] = field(default_factory=list)  # prediction buffers per level
+    shape_c: int = 0
+    expr_c: int = 0
+    flops: float = 0.0  # algorithmic 2*MACs per image (fused-conv accounting)
+
+    def buf(self, name: str, h: int, w: int, pitch: int, f32: bool = False) -> int:
+        self.bufs.append(dict(name=name, h=h, w=w, pitch=pitch, is_f32=int(f32)))
+        return len(self.bufs) - 1
+
+    def _push_w(self, W: np.ndarray, b: np.ndarray) -> Tuple[int, int]:
+        wo, bo = self.w_elems, self.b_elems
+        self.weights.append(np.ascontiguousarray(W, dtype=np.float32).reshape(-1))
+        self.biases.append(np.ascontiguousarray(b, dtype=np.float32).reshape(-1))
+        self.w_elems += self.weights[-1].size
+        self.b_elems += self.biases[-1].size
+        return wo, bo
+
+    def conv(self, name: str, src: View, dst: View, W: np.ndarray, b: np.ndarray, k: int, stride: int = 1, act: int = 1, res: Optional[Tuple[View, float]] = None,
+             split: Optional[Tuple[int, int]] = None, shuffle: bool = False, cout_store: Optional[int] = None, flops_macs: Optional[float] = None):
+        """W: [rows, k, k, cin_view] (rows padded to 32 here); b: [rows]."""
+        rows, kk1, kk2, cin = W.shape
+        assert kk1 == k and kk2 == k and cin == src.c and cin % 32 == 0, (name, W.shape, src)
+        rp = _r32(rows)
+        Wp = np.zeros((rp, k, k, cin), dtype=np.float64)
+        Wp[:rows] = W
+        bp = np.zeros(rp, dtype=np.float64)
+        bp[:rows] = b
+        wo, bo = self._push_w(Wp, bp)
+        ib = self.bufs[src.buf]
+        ho = (ib["h"] + 2 * (k // 2) - k) // stride + 1
+        wo_ = (ib["w"] + 2 * (k // 2) - k) // stride + 1
+        self.ops.append(dict(
+            name=name, kind=1, in_buf=src.buf, in_coff=src.coff, cin=cin, out_buf=dst.buf, out_coff=dst.coff, cout_pad=rp,
+            cout_store=cout_store if cout_store is not None else rows, out_split=split[0] if split else rp, out_coff2=split[1] if split else 0,
+            res_buf=res[0].buf if res else -1, res_coff=res[0].coff if res else 0, alpha=float(res[1]) if res else 0.0,
+            ksize=k, stride=stride, act=act, shuffle=int(shuffle), w_off=wo, b_off=bo, force_cfg=-1,
+            macs=float(ho * wo_) * float(flops_macs if flops_macs is not None else rows * k * k * cin),
+            gemm=(ho * wo_, rp, k * k * cin),
+        ))
+
+    def arrays(self):
+        return np.concatenate(self.weights), np.concatenate(self.biases)
+
+
+def _ohwi(W: np.ndarray, cin_pad: int) -> np.ndarray:
+    """torch OIHW -> [O,H,W,I] with the input channels zero-padded to cin_pad."""
+    o, i, kh, kw = W.shape
+    out = np.zeros((o, kh, kw, cin_pad), dtype=np.float64)
+    out[..., :i] = np.transpose(W, (0, 2, 3, 1))
+    return out
+
+
+def _stack(parts: List[Tuple[np.ndarray, np.ndarray]], pad_to: int = 1) -> Tuple[np.ndarray, np.ndarray, List[int]]:
+    """Stack [rows_i,k,k,cin] blocks along rows, each padded to a multiple of pad_to. Returns W, b, row offsets."""
+    ws, bs, offs, cur = [], [], [], 0
+    for W, b in parts:
+        r = W.shape[0]
+        rp = (r + pad_to - 1) // pad_to * pad_to
+        Wp = np.zeros((rp,) + W.shape[1:], dtype=np.float64)
+        Wp[:r] = W
+        bp = np.zeros(rp, dtype=np.float64)
+        bp[:r] = b
+        ws.append(Wp)
+        bs.append(bp)
+        offs.append(cur)
+        cur += rp
+    return np.concatenate(ws), np.concatenate(bs), offs
+
+
+def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640) -> Program:
+    v = VARIANTS[variant]
+    F = fold_state_dict(variant, sd)
+    P = Program(variant=variant, image_size=image_size)
+    S = image_size
+    assert S % 32 == 0
+
+    # ---------------- stem (own kernel: exact fp32, K = 27) ----------------
+    W, b = F["backbone.stem.conv"]
+    assert v["stem"] == 48
+    wo, bo = P._push_w(np.transpose(W, (0, 2, 3, 1)), b)  # [48][ky][kx][ci]
+    stem_buf = P.buf("stem", S // 2, S // 2, 64)
+    P.ops.append(dict(name="backbone.stem.conv", kind=0, in_buf=-1, in_coff=0, cin=3, out_buf=stem_buf, out_coff=0, cout_pad=64, cout_store=64, out_split=64,
+                      out_coff2=0, res_buf=-1, res_coff=0, alpha=0.0, ksize=3, stride=2, act=1, shuffle=0, w_off=wo, b_off=bo, force_cfg=-1,
+                      macs=float((S // 2) ** 2) * 48 * 27, gemm=((S // 2) ** 2, 48, 27)))
+    x = View(stem_buf, 0, 64)
+    x_real = 48
+
+    def csp(p: str, xin: View, cin_real: int, out: View, n: int, hid: int, ci: bool, res_px: int):
+        """YoloNASCSPLayer. Buffer layout: ci -> [x1_0 | b_1 .. b_n | x2]; else [b_n | x2 | scratch A | scratch B]."""
+        assert hid % 32 == 0
+        slots = (n + 2) if ci else 2
+        cat = P.buf(f"{p}.cat", res_px, res_px, hid * slots + (0 if ci else 2 * hid))
+        mid = P.buf(f"{p}.mid", res_px, res_px, hid)
+        w1, b1 = F[f"{p}.conv1"]
+        w2, b2 = F[f"{p}.conv2"]
+        Wf, bf, _ = _stack([(_ohwi(w1, xin.c), b1), (_ohwi(w2, xin.c), b2)])
+        x2_off = hid * (slots - 1)
+        x1_off = 0 if ci else hid * 2  # scratch A
+        P.conv(f"{p}.conv1|conv2", xin, View(cat, x1_off, hid), Wf, bf, 1, split=(hid, x2_off), flops_macs=2 * hid * cin_real)
+        prev = x1_off
+        for i in range(n):
+            if ci:
+                dst = hid * (i + 1)
+            else:
+                dst = 0 if i == n - 1 else (hid * 3 if prev == hid * 2 else hid * 2)
+            wa, ba = F[f"{p}.bottlenecks.{i}.cv1"]
+            wb, bb = F[f"{p}.bottlenecks.{i}.cv2"]
+            alpha = F[f"{p}.bottlenecks.{i}.alpha"][0]
+            P.conv(f"{p}.bottlenecks.{i}.cv1", View(cat, prev, hid), View(mid, 0, hid), _ohwi(wa, hid), ba, 3)
+            P.conv(f"{p}.bottlenecks.{i}.cv2", View(mid, 0, hid), View(cat, dst, hid), _ohwi(wb, hid), bb, 3, res=(View(cat, prev, hid), alpha))
+            prev = dst
+        w3, b3 = F[f"{p}.conv3"]
+        P.conv(f"{p}.conv3", View(cat, 0, hid * slots), out, _ohwi(w3, hid * slots), b3, 1)
+
+    # ---------------- backbone stages ----------------
+    feats: List[View] = []
+    res_px = S // 2
+    for i, (co, n, hid, ci) in enumerate(v["stages"]):
+        p = f"backbone.stage{i + 1}"
+        res_px //= 2
+        ds = P.buf(f"{p}.ds", res_px, res_px, co)
+        W, b = F[f"{p}.downsample"]
+        P.conv(f"{p}.downsample", x, View(ds, 0, co), _ohwi(W, x.c), b, 3, stride=2, flops_macs=co * 9 * x_real)
+        ob = P.buf(f"{p}.out", res_px, res_px, co)
+        csp(f"{p}.blocks", View(ds, 0, co), co, View(ob, 0, co), n, hid, ci, res_px)
+        x, x_real = View(ob, 0, co), co
+        feats.append(x)
+    # ---------------- SPP ----------------
+    c = v["stages"][3][0]
+    hidden = c // 2
+    spp = P.buf("spp.cat", res_px, res_px, hidden * 4)
+    W, b = F["backbone.context_module.cv1"]
+    P.conv("backbone.context_module.cv1", x, View(spp, 0, hidden), _ohwi(W, c), b, 1)
+    P.ops.append(dict(name="backbone.context_module.m", kind=2, in_buf=spp, in_coff=0, cin=hidden, out_buf=spp, out_coff=hidden, cout_pad=0, cout_store=0, out_split=0,
+                      out_coff2=0, res_buf=-1, res_coff=0, alpha=0.0, ksize=5, stride=1, act=0, shuffle=0, w_off=0, b_off=0, force_cfg=-1, macs=0.0, gemm=(0, 0, 0)))
+    c5b = P.buf("c5", res_px, res_px, v["spp_out"])
+    W, b = F["backbone.context_module.cv2"]
+    P.conv("backbone.context_module.cv2", View(spp, 0, hidden * 4), View(c5b, 0, v["spp_out"]), _ohwi(W, hidden * 4), b, 1)
+    c2, c3, c4 = feats[0], feats[1], feats[2]
+    c5 = View(c5b, 0, v["spp_out"])
+    px = {2: S // 4, 3: S // 8, 4: S // 16, 5: S // 32}
+
+    # ---------------- neck ----------------
+    (o1, n1, h1), (o2, n2, h2), (o3, n3, h3), (o4, n4, h4) = v["neck"]
+    # concat buffers of the two down stages are allocated first: the up stages' x_inter land directly inside them
+    n3cat = P.buf("neck3.cat", px[4], px[4], o3 // 2 + o2)  # [conv(p3) | x_n2_inter]
+    n4cat = P.buf("neck4.cat", px[5], px[5], o4 // 2 + o1)  # [conv(p4) | x_n1_inter]
+
+    def up_stage(p: str, xin: View, s1: View, s2: View, o: int, n: int, hid: int, res_lo: int, inter_dst: View, out: View):
+        """YoloNASUpStage (3 inputs, reduce_channels): cat = [upsample(conv(x)) | reduce_skip1(s1) | downsample(reduce_skip2(s2))]."""
+        res_hi = res_lo * 2
+        cat = P.buf(f"{p}.cat", res_hi, res_hi, 3 * o)
+        W, b = F[f"{p}.conv"]
+        P.conv(f"{p}.conv", xin, inter_dst, _ohwi(W, xin.c), b, 1)
+        Wt, bt = F[f"{p}.upsample"]  # [cin, cout, 2, 2]
+        Wg = np.zeros((4 * o, 1, 1, o), dtype=np.float64)
+        for dy in range(2):
+            for dx in range(2):
+                Wg[(dy * 2 + dx) * o : (dy * 2 + dx + 1) * o, 0, 0, :] = Wt[:, :, dy, dx].T
+        P.conv(f"{p}.upsample", inter_dst, View(cat, 0, o), Wg, np.tile(bt, 4), 1, act=0, shuffle=True)
+        W, b = F[f"{p}.reduce_skip1"]
+        P.conv(f"{p}.reduce_skip1", s1, View(cat, o, o), _ohwi(W, s1.c), b, 1)
+        rs2 = P.buf(f"{p}.rs2", res_hi * 2, res_hi * 2, o)
+        W, b = F[f"{p}.reduce_skip2"]
+        P.conv(f"{p}.reduce_skip2", s2, View(rs2, 0, o), _ohwi(W, s2.c), b, 1)
+        W, b = F[f"{p}.downsample"]
+        P.conv(f"{p}.downsample", View(rs2, 0, o), View(cat, 2 * o, o), _ohwi(W, o), b, 3, stride=2)
+        rac = P.buf(f"{p}.rac", res_hi, res_hi, o)
+        W, b = F[f"{p}.reduce_after_concat"]
+        P.conv(f"{p}.reduce_after_concat", View(cat, 0, 3 * o), View(rac, 0, o), _ohwi(W, 3 * o), b, 1)
+        csp(f"{p}.blocks", View(rac, 0, o), o, out, n, hid, False, res_hi)
+
+    n1out = P.buf("neck1.out", px[4], px[4], o1)
+    up_stage("neck.neck1", c5, c4, c3, o1, n1, h1, px[5], View(n4cat, o4 // 2, o1), View(n1out, 0, o1))
+    p3b = P.buf("p3", px[3], px[3], o2)
+    up_stage("neck.neck2", View(n1out, 0, o1), c3, c2, o2, n2, h2, px[4], View(n3cat, o3 // 2, o2), View(p3b, 0, o2))
+    p3 = View(p3b, 0, o2)
+    W, b = F["neck.neck3.conv"]
+    P.conv("neck.neck3.conv", p3, View(n3cat, 0, o3 // 2), _ohwi(W, o2), b, 3, stride=2)
+    p4b = P.buf("p4", px[4], px[4], o3)
+    csp("neck.neck3.blocks", View(n3cat, 0, o3 // 2 + o2), o3 // 2 + o2, View(p4b, 0, o3), n3, h3, False, px[4])
+    p4 = View(p4b, 0, o3)
+    W, b = F["neck.neck4.conv"]
+    P.conv("neck.neck4.conv", p4, View(n4cat, 0, o4 // 2), _ohwi(W, o3), b, 3, stride=2)
+    p5b = P.buf("p5", px[5], px[5], o4)
+    csp("neck.neck4.blocks", View(n4cat, 0, o4 // 2 + o1), o4 // 2 + o1, View(p5b, 0, o4), n4, h4, False, px[5])
+    p5 = View(p5b, 0, o4)
+
+    # ---------------- heads ----------------
+    for lv, (feat, stride) in enumerate(zip((p3, p4, p5), STRIDES)):
+        d = head_dims(v, lv)
+        p = f"heads.head{lv + 1}"
+        r = S // stride
+        fl, bb, nb = d["fl"], d["bbox"], d["blocks"]
+        Sc, Ec, tr = d["shape_out"], d["expr_out"], d["tr_inter"]
+        trp = _r32(tr)
+        pred_pitch = 69 + Sc + Ec + 13
+        pred = P.buf(f"{p}.pred", r, r, pred_pitch, f32=True)
+        # stems: [pose | bbox]
+        hs = P.buf(f"{p}.stems", r, r, fl + bb)
+        (wp, bp_), (wb, bb_) = F[f"{p}.pose_stem"], F[f"{p}.bbox_stem"]
+        Wf, bf, _ = _stack([(_ohwi(wp, feat.c), bp_), (_ohwi(wb, feat.c), bb_)])
+        P.conv(f"{p}.pose_stem|bbox_stem", feat, View(hs, 0, fl + bb), Wf, bf, 1)
+        # towers: [cls_feat | reg_feat]
+        cr = P.buf(f"{p}.clsreg", r, r, 2 * bb)
+        (wc, bc), (wr, br) = F[f"{p}.cls_convs.0"], F[f"{p}.reg_convs.0"]
+        Wf, bf, _ = _stack([(_ohwi(wc, bb), bc), (_ohwi(wr, bb), br)])
+        P.conv(f"{p}.cls_convs|reg_convs", View(hs, fl, bb), View(cr, 0, 2 * bb), Wf, bf, 3)
+        # reg_pred (rows 0..67 <- reg_feat) + cls_pred (row 68 <- cls_feat): block-diagonal 1x1, fp32 out
+        (wrp, brp), (wcp, bcp) = F[f"{p}.reg_pred"], F[f"{p}.cls_pred"]
+        Wd = np.zeros((69, 1, 1, 2 * bb), dtype=np.float64)
+        Wd[:68, 0, 0, bb:] = wrp[:, :, 0, 0]
+        Wd[68, 0, 0, :bb] = wcp[0, :, 0, 0]
+        P.conv(f"{p}.reg_pred|cls_pred", View(cr, 0, 2 * bb), View(pred, 0, 69), Wd, np.concatenate([brp, bcp]), 1, act=0, flops_macs=69 * bb)
+        # FLAME branches: layer 0 of all six fused (shared input pose_features)
+        names = ["shape", "expression"] + [n_ for n_, _ in TR_OUTS]
+        inters = [d["shape_inter"], d["expr_inter"]] + [tr] * 4
+        outs = [Sc, Ec] + [o_ for _, o_ in TR_OUTS]
+        parts = [(_ohwi(F[f"{p}.flame_{n_}_pred.0"][0], fl), F[f"{p}.flame_{n_}_pred.0"][1]) for n_ in names]
+        Wf, bf, offs = _stack(parts, pad_to=32)
+        width = Wf.shape[0]
+        cur = P.buf(f"{p}.f0", r, r, width)
+        P.conv(f"{p}.flame_*_pred.0", View(hs, 0, fl), View(cur, 0, width), Wf, bf, 3, cout_store=width, flops_macs=sum(inters) * 9 * fl)
+        for bi in range(1, nb):
+            nxt = P.buf(f"{p}.f{bi}", r, r, width)
+            for n_, inter, off in zip(names, inters, offs):
+                W, b = F[f"{p}.flame_{n_}_pred.{bi}"]
+                ip = _r32(inter)
+                P.conv(f"{p}.flame_{n_}_pred.{bi}", View(cur, off, ip), View(nxt, off, ip), _ohwi(W, ip), b, 3, cout_store=ip, flops_macs=inter * 9 * inter)
+            cur = nxt
+        # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | shape | expr | rot6 | jaw3 | trans3 | scale1]
+        W, b = F[f"{p}.flame_shape_pred.{nb}"]
+        P.conv(f"{p}.flame_shape_pred.{nb}", View(cur, offs[0], _r32(inters[0])), View(pred, 69, Sc), _ohwi(W, _r32(inters[0])), b, 1, act=0)
+        W, b = F[f"{p}.flame_expression_pred.{nb}"]
+        P.conv(f"{p}.flame_expression_pred.{nb}", View(cur, offs[1], _r32(inters[1])), View(pred, 69 + Sc, Ec), _ohwi(W, _r32(inters[1])), b, 1, act=0)
+        Wd = np.zeros((13, 1, 1, 4 * trp), dtype=np.float64)
+        bd = np.zeros(13, dtype=np.float64)
+        row = 0
+        for j, (n_, o_) in enumerate(TR_OUTS):
+            W, b = F[f"{p}.flame_{n_}_pred.{nb}"]
+            Wd[row : row + o_, 0, 0, j * trp : j * trp + tr] = W[:, :, 0, 0]
+            bd[row : row + o_] = b
+            row += o_
+        assert offs[3] == offs[2] + trp and offs[5] == offs[2] + 3 * trp
+        P.conv(f"{p}.flame_transform_pred.{nb}", View(cur, offs[2], 4 * trp), View(pred, 69 + Sc + Ec, 13), Wd, bd, 1, act=0, flops_macs=13 * tr)
+        P.levels.append(dict(buf=pred, h=r, w=r, pitch=pred_pitch, stride=stride))
+        P.shape_c, P.expr_c = Sc, Ec
+
+    P.flops = 2.0 * sum(o["macs"] for o in P.ops)
+    return P

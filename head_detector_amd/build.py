@@ -1,0 +1,63 @@
+"""In-tree build of libvgh.so (hipcc, gfx950 only). `python -m head_detector_amd.build`."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvgh.so")
+SOURCES = ["conv_igemm.hip", "stem_pool.hip", "postproc.hip", "flame.hip", "net.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "vgh.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    objs, procs = [], []
+    t0 = time.time()
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"[vgh build] {src} FAILED\n{out}\n")
+        elif verbose and out.strip():
+            sys.stderr.write(f"[vgh build] {src}:\n{out}\n")
+    if failed:
+        raise RuntimeError("libvgh.so: compilation failed")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"libvgh.so: link failed\n{r.stdout}")
+    if verbose:
+        sys.stderr.write(f"[vgh build] built {LIB} in {time.time() - t0:.1f}s\n")
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)

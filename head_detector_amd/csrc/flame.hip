@@ -1,0 +1,504 @@
+// FLAME decode for gfx950: blendshapes + pose correctives + linear-blend skinning + rigid reprojection.
+//
+// Replaces FLAMELayer.forward (head_detector/flame.py:122-169) -> smplx.lbs.lbs (third-party, call site
+// flame.py:152-161) -> reproject_spatial_vertices (flame.py:179-208) -> rot_mat_from_6dof
+// (head_detector/utils.py:120-128) -> vertex un-pad/un-scale of HeadDetector._parse_predictions
+// (head_detector/detector.py:67-69).
+//
+// MI355X-first restructure (not a translation of the einsum chain):
+//  * the joint regressor is folded into the shape basis at create time (fp64 on the host):
+//      J = J_regressor (v_template + S beta) = J0 + (J_regressor S) beta,   JS is [3*NJ x NB]
+//    which removes the global "all vertices -> joints" dependency, so one tiny per-head prologue kernel
+//    produces everything the vertex kernel needs (5 skinning transforms, 36 pose features, R, s, t);
+//  * basis / template / skinning weights are stored as SoA planes [k][xyz][Vp] so one lane owns 4 consecutive
+//    vertices and streams the 26 MB basis with 16-byte loads (it stays resident in the 256 MB Infinity Cache);
+//  * a block owns (256 x 4 vertices) x HT heads: every basis value fetched feeds HT FMAs (coefficients
+//    broadcast from LDS), the skinning / rigid / un-pad epilogue runs in registers and results leave with
+//    16-byte stores.  Exact fp32 FMA chains in fixed k order.
+#include <math.h>
+
+#include <vector>
+
+#include "vgh_internal.h"
+
+namespace {
+
+constexpr int MAXJ = 8;
+constexpr int HP_A = 0;                      // A[j][12] (3x4 row major) : MAXJ*12 floats
+constexpr int HP_R = MAXJ * 12;              // R[9]
+constexpr int HP_S = HP_R + 9;               // clamp(scale, 1e-8)
+constexpr int HP_T = HP_S + 1;               // translation[3]
+constexpr int HP_U = HP_T + 3;               // unpad (pad_x, pad_y, scale_factor)
+constexpr int HP_SIZE = 128;                 // floats per head
+
+}  // namespace
+
+struct vgh_flame {
+    int device, V, Vp, NB, NJ, NP, K, Kp;  // NP = 9*(NJ-1); K = NB + NP; Kp = K rounded up to 8
+    int max_heads;
+    float* basis;    // [K][3][Vp]
+    float* vt;       // [3][Vp]
+    float* wts;      // [NJ][Vp]
+    float* J0;       // [3*NJ]
+    float* JS;       // [3*NJ][NB]
+    int32_t* parents;  // [NJ]
+    float* coef;     // scratch [max_heads][Kp]
+    float* headpack; // scratch [max_heads][HP_SIZE]
+};
+
+namespace {
+
+struct PrepArgs {
+    const float* params;  // [n,413] or null
+    const float* betas;   // [n,NB] or null
+    const float* pose;    // [n,3*NJ] or null
+    const float* unpad;   // [n,3] or null
+    const float* J0;
+    const float* JS;
+    const int32_t* parents;
+    float* coef;
+    float* headpack;
+    float* rot_out;     // [n,9] or null
+    float* joints_out;  // [n,NJ,3] or null
+    int NB, NJ, Kp;
+};
+
+// one wave per head
+__global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
+    __shared__ float s_beta[1024];
+    __shared__ float s_J[MAXJ * 3];
+    __shared__ float s_R[MAXJ * 9];
+    __shared__ float s_pose[MAXJ * 3];
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const int NB = a.NB, NJ = a.NJ;
+    float* coef = a.coef + (int64_t)h * a.Kp;
+    float* hp = a.headpack + (int64_t)h * HP_SIZE;
+    const float* p = a.params ? a.params + (int64_t)h * VGH_NUM_FLAME_PARAMS : nullptr;
+    // betas = [shape(300) | expression(100)]  (flame.py:132-140; FLAME_CONSTS widths make the padding empty)
+    for (int l = lane; l < NB; l += 64) {
+        const float v = p ? p[l] : a.betas[(int64_t)h * NB + l];
+        s_beta[l] = v;
+        coef[l] = v;
+    }
+    // full_pose = [global 0 | neck 0 | jaw | eyes 0]  (flame.py:141-148)
+    if (lane < NJ * 3) {
+        float v;
+        if (p)
+            v = (lane >= 6 && lane < 9) ? p[400 + lane - 6] : 0.0f;
+        else
+            v = a.pose[(int64_t)h * NJ * 3 + lane];
+        s_pose[lane] = v;
+    }
+    __syncthreads();
+    // joints: J = J0 + JS beta
+    for (int o = 0; o < NJ * 3; ++o) {
+        float s = 0.0f;
+        const float* js = a.JS + (int64_t)o * NB;
+        for (int l = lane; l < NB; l += 64) s = fmaf(js[l], s_beta[l], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) s_J[o] = a.J0[o] + s;
+    }
+    // smplx batch_rodrigues per joint
+    if (lane < NJ) {
+        const float rx0 = s_pose[lane * 3 + 0], ry0 = s_pose[lane * 3 + 1], rz0 = s_pose[lane * 3 + 2];
+        const float ex = rx0 + 1e-8f, ey = ry0 + 1e-8f, ez = rz0 + 1e-8f;
+        const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float rx = rx0 / angle, ry = ry0 / angle, rz = rz0 / angle;
+        const float sn = sinf(angle), cs = cosf(angle);
+        const float K[9] = {0.0f, -rz, ry, rz, 0.0f, -rx, -ry, rx, 0.0f};
+        float KK[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) KK[r * 3 + c] = K[r * 3 + 0] * K[0 * 3 + c] + K[r * 3 + 1] * K[1 * 3 + c] + K[r * 3 + 2] * K[2 * 3 + c];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) s_R[lane * 9 + e] = ((e % 4 == 0) ? 1.0f : 0.0f) + sn * K[e] + (1.0f - cs) * KK[e];
+    }
+    __syncthreads();
+    // pose_feature = (rot_mats[:,1:] - I).view(-1)
+    const int NP = 9 * (NJ - 1);
+    if (lane < NP) coef[NB + lane] = s_R[9 + lane] - ((lane % 9) % 4 == 0 ? 1.0f : 0.0f);
+    if (lane >= NP && NB + lane < a.Kp) coef[NB + lane] = 0.0f;
+    if (lane == 0) {
+        // batch_rigid_transform: chain along parents, A_j = [Rg_j | tg_j - Rg_j J_j]
+        float Rg[MAXJ][9], tg[MAXJ][3];
+        for (int j = 0; j < NJ; ++j) {
+            const int par = a.parents[j];
+            float rel[3];
+            for (int c = 0; c < 3; ++c) rel[c] = s_J[j * 3 + c] - (j > 0 ? s_J[par * 3 + c] : 0.0f);
+            if (j == 0) {
+                for (int e = 0; e < 9; ++e) Rg[0][e] = s_R[e];
+                for (int c = 0; c < 3; ++c) tg[0][c] = rel[c];
+            } else {
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c)
+                        Rg[j][r * 3 + c] = Rg[par][r * 3 + 0] * s_R[j * 9 + 0 * 3 + c] + Rg[par][r * 3 + 1] * s_R[j * 9 + 1 * 3 + c] +
+                                           Rg[par][r * 3 + 2] * s_R[j * 9 + 2 * 3 + c];
+                    tg[j][r] = Rg[par][r * 3 + 0] * rel[0] + Rg[par][r * 3 + 1] * rel[1] + Rg[par][r * 3 + 2] * rel[2] + tg[par][r];
+                }
+            }
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) hp[HP_A + j * 12 + r * 4 + c] = Rg[j][r * 3 + c];
+                hp[HP_A + j * 12 + r * 4 + 3] =
+                    tg[j][r] - (Rg[j][r * 3 + 0] * s_J[j * 3 + 0] + Rg[j][r * 3 + 1] * s_J[j * 3 + 1] + Rg[j][r * 3 + 2] * s_J[j * 3 + 2]);
+                if (a.joints_out) a.joints_out[((int64_t)h * NJ + j) * 3 + r] = tg[j][r];
+            }
+        }
+        // rot_mat_from_6dof (utils.py:120-128): F.normalize eps = 1e-12, columns (b1, b2, b3)
+        float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        float sc = 1.0f, t[3] = {0, 0, 0};
+        if (p) {
+            const float* v = p + 403;
+            float b1[3], b3[3], b2[3];
+            float n1 = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+            for (int c = 0; c < 3; ++c) b1[c] = v[c] / n1;
+            float cr[3] = {b1[1] * v[5] - b1[2] * v[4], b1[2] * v[3] - b1[0] * v[5], b1[0] * v[4] - b1[1] * v[3]};
+            float n3 = fmaxf(sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]), 1e-12f);
+            for (int c = 0; c < 3; ++c) b3[c] = cr[c] / n3;
+            b2[0] = -(b1[1] * b3[2] - b1[2] * b3[1]);
+            b2[1] = -(b1[2] * b3[0] - b1[0] * b3[2]);
+            b2[2] = -(b1[0] * b3[1] - b1[1] * b3[0]);
+            for (int r = 0; r < 3; ++r) {
+                R[r * 3 + 0] = b1[r];
+                R[r * 3 + 1] = b2[r];
+                R[r * 3 + 2] = b3[r];
+            }
+            sc = fmaxf(p[412], 1e-8f);  // torch.clamp(scale, 1e-8)
+            for (int c = 0; c < 3; ++c) t[c] = p[409 + c];
+        }
+        for (int e = 0; e < 9; ++e) {
+            hp[HP_R + e] = R[e];
+            if (a.rot_out) a.rot_out[(int64_t)h * 9 + e] = R[e];
+        }
+        hp[HP_S] = sc;
+        for (int c = 0; c < 3; ++c) hp[HP_T + c] = t[c];
+        hp[HP_U + 0] = a.unpad ? a.unpad[(int64_t)h * 3 + 0] : 0.0f;
+        hp[HP_U + 1] = a.unpad ? a.unpad[(int64_t)h * 3 + 1] : 0.0f;
+        hp[HP_U + 2] = a.unpad ? a.unpad[(int64_t)h * 3 + 2] : 1.0f;
+    }
+}
+
+struct VertArgs {
+    const float* basis;  // [K][3][Vp]
+    const float* vt;     // [3][Vp]
+    const float* wts;    // [NJ][Vp]
+    const float* coef;   // [n][Kp]
+    const float* headpack;
+    float* verts;  // [n][V][3] or null
+    float* proj;   // [n][V][3] or null
+    int n, V, Vp, NJ, Kp;
+    int r0_begin, r0_end, r1_begin, r1_end, r2_begin, r2_end;  // k ranges (shape live, expr live, pose)
+    float z_offset;
+    int do_unpad;
+};
+
+template <int HT>
+__global__ __launch_bounds__(256) void flame_vertex_kernel(VertArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* s_coef = fsm;                   // [Kp][HT]
+    float* s_hp = fsm + (size_t)a.Kp * HT; // [HT][HP_SIZE]
+    const int tid = threadIdx.x;
+    const int h0 = blockIdx.y * HT;
+    for (int e = tid; e < a.Kp * HT; e += 256) {
+        const int k = e / HT, hh = e - k * HT;
+        s_coef[e] = (h0 + hh < a.n) ? a.coef[(int64_t)(h0 + hh) * a.Kp + k] : 0.0f;
+    }
+    for (int e = tid; e < HT * HP_SIZE; e += 256) {
+        const int hh = e / HP_SIZE;
+        s_hp[e] = (h0 + hh < a.n) ? a.headpack[(int64_t)(h0 + hh) * HP_SIZE + (e - hh * HP_SIZE)] : 0.0f;
+    }
+    __syncthreads();
+    const int v0 = (blockIdx.x * 256 + tid) * 4;
+    if (v0 >= a.Vp) return;
+    const int64_t plane = a.Vp;
+    f32x4_t acc[HT][3];
+    {
+        const f32x4_t tx = *(const f32x4_t*)(a.vt + 0 * plane + v0);
+        const f32x4_t ty = *(const f32x4_t*)(a.vt + 1 * plane + v0);
+        const f32x4_t tz = *(const f32x4_t*)(a.vt + 2 * plane + v0);
+#pragma unroll
+        for (int hh = 0; hh < HT; ++hh) {
+            acc[hh][0] = tx;
+            acc[hh][1] = ty;
+            acc[hh][2] = tz;
+        }
+    }
+    auto run = [&](int kb, int ke) {
+        const float* bp = a.basis + (int64_t)kb * 3 * plane + v0;
+#pragma unroll 2
+        for (int k = kb; k < ke; ++k, bp += 3 * plane) {
+            const f32x4_t bx = *(const f32x4_t*)(bp);
+            const f32x4_t by = *(const f32x4_t*)(bp + plane);
+            const f32x4_t bz = *(const f32x4_t*)(bp + 2 * plane);
+            const float* ck = s_coef + k * HT;
+#pragma unroll
+            for (int hh = 0; hh < HT; ++hh) {
+                const float c = ck[hh];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[hh][0][e] = fmaf(c, bx[e], acc[hh][0][e]);
+                    acc[hh][1][e] = fmaf(c, by[e], acc[hh][1][e]);
+                    acc[hh][2][e] = fmaf(c, bz[e], acc[hh][2][e]);
+                }
+            }
+        }
+    };
+    run(a.r0_begin, a.r0_end);
+    run(a.r1_begin, a.r1_end);
+    run(a.r2_begin, a.r2_end);
+    // skinning weights for the 4 vertices
+    f32x4_t wj[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+        if (j < a.NJ) wj[j] = *(const f32x4_t*)(a.wts + (int64_t)j * plane + v0);
+#pragma unroll
+    for (int hh = 0; hh < HT; ++hh) {
+        if (h0 + hh >= a.n) break;
+        const float* hp = s_hp + hh * HP_SIZE;
+        float outv[12], outp[12];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float T[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) T[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j)
+                if (j < a.NJ) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) T[q] = fmaf(wj[j][e], hp[HP_A + j * 12 + q], T[q]);
+                }
+            const float px = acc[hh][0][e], py = acc[hh][1][e], pz = acc[hh][2][e];
+            const float vx = fmaf(T[0], px, fmaf(T[1], py, fmaf(T[2], pz, T[3])));
+            const float vy = fmaf(T[4], px, fmaf(T[5], py, fmaf(T[6], pz, T[7])));
+            const float vz = fmaf(T[8], px, fmaf(T[9], py, fmaf(T[10], pz, T[11]))) + a.z_offset;
+            outv[e * 3 + 0] = vx;
+            outv[e * 3 + 1] = vy;
+            outv[e * 3 + 2] = vz;
+            const float* R = hp + HP_R;
+            const float s = hp[HP_S];
+            float qx = (R[0] * vx + R[1] * vy + R[2] * vz) * s + hp[HP_T + 0];
+            float qy = (R[3] * vx + R[4] * vy + R[5] * vz) * s + hp[HP_T + 1];
+            float qz = (R[6] * vx + R[7] * vy + R[8] * vz) * s + hp[HP_T + 2];
+            if (a.do_unpad) {  // detector.py:67-69: x -= pad_x; y -= pad_y; all /= scale
+                qx = (qx - hp[HP_U + 0]) / hp[HP_U + 2];
+                qy = (qy - hp[HP_U + 1]) / hp[HP_U + 2];
+                qz = qz / hp[HP_U + 2];
+            }
+            outp[e * 3 + 0] = qx;
+            outp[e * 3 + 1] = qy;
+            outp[e * 3 + 2] = qz;
+        }
+        const int64_t obase = ((int64_t)(h0 + hh) * a.V + v0) * 3;
+        const int nv = min(4, a.V - v0);
+        if (a.verts) {
+            if (nv == 4 && (obase & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *(f32x4_t*)(a.verts + obase + q * 4) = f32x4_t{outv[q * 4], outv[q * 4 + 1], outv[q * 4 + 2], outv[q * 4 + 3]};
+            } else {
+                for (int q = 0; q < nv * 3; ++q) a.verts[obase + q] = outv[q];
+            }
+        }
+        if (a.proj) {
+            if (nv == 4 && (obase & 3) == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *(f32x4_t*)(a.proj + obase + q * 4) = f32x4_t{outp[q * 4], outp[q * 4 + 1], outp[q * 4 + 2], outp[q * 4 + 3]};
+            } else {
+                for (int q = 0; q < nv * 3; ++q) a.proj[obase + q] = outp[q];
+            }
+        }
+    }
+}
+
+template <int HT>
+int launch_vertex(const VertArgs& va, hipStream_t st) {
+    const size_t lds = ((size_t)va.Kp * HT + (size_t)HT * HP_SIZE) * sizeof(float);
+    const int quads = va.Vp / 4;
+    dim3 grid((quads + 255) / 256, (va.n + HT - 1) / HT);
+    hipLaunchKernelGGL(flame_vertex_kernel<HT>, grid, dim3(256), lds, st, va);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
+int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int done = 0; done < n; done += f->max_heads) {
+        const int m = (n - done < f->max_heads) ? n - done : f->max_heads;
+        PrepArgs pa = pa_in;
+        if (pa.params) pa.params += (int64_t)done * VGH_NUM_FLAME_PARAMS;
+        if (pa.betas) pa.betas += (int64_t)done * f->NB;
+        if (pa.pose) pa.pose += (int64_t)done * f->NJ * 3;
+        if (pa.unpad) pa.unpad += (int64_t)done * 3;
+        if (pa.rot_out) pa.rot_out += (int64_t)done * 9;
+        if (pa.joints_out) pa.joints_out += (int64_t)done * f->NJ * 3;
+        hipLaunchKernelGGL(flame_prep_kernel, dim3(m), dim3(64), 0, st, pa);
+        VGH_HIP(hipGetLastError());
+        if (!verts && !proj) continue;
+        VertArgs va;
+        va.basis = f->basis;
+        va.vt = f->vt;
+        va.wts = f->wts;
+        va.coef = f->coef;
+        va.headpack = f->headpack;
+        va.verts = verts ? verts + (int64_t)done * f->V * 3 : nullptr;
+        va.proj = proj ? proj + (int64_t)done * f->V * 3 : nullptr;
+        va.n = m;
+        va.V = f->V;
+        va.Vp = f->Vp;
+        va.NJ = f->NJ;
+        va.Kp = f->Kp;
+        if (detector_mode) {
+            // betas = [shape 300 | expr 100]: only the leading *_live entries of each part can be non-zero
+            va.r0_begin = 0;
+            va.r0_end = shape_live;
+            va.r1_begin = 300;
+            va.r1_end = 300 + expr_live;
+        } else {
+            va.r0_begin = 0;
+            va.r0_end = f->NB;
+            va.r1_begin = va.r1_end = 0;
+        }
+        va.r2_begin = f->NB;
+        va.r2_end = f->K;
+        va.z_offset = detector_mode ? 0.05f : 0.0f;  // MESH_OFFSET_Z, flame.py:34,164
+        va.do_unpad = pa.unpad != nullptr;
+        int rc;
+        if (m <= 2)
+            rc = launch_vertex<1>(va, st);
+        else if (m <= 24)
+            rc = launch_vertex<4>(va, st);
+        else
+            rc = launch_vertex<8>(va, st);
+        if (rc) return rc;
+    }
+    return VGH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template, const float* shapedirs, const float* posedirs, const float* J_regressor,
+                     const int32_t* parents, const float* lbs_weights, int max_heads, vgh_flame** out) {
+    VGH_REQUIRE(out && v_template && shapedirs && posedirs && J_regressor && parents && lbs_weights, "flame_create: null argument");
+    VGH_REQUIRE(NJ >= 1 && NJ <= MAXJ, "flame_create: NJ=%d unsupported (max %d)", NJ, MAXJ);
+    VGH_REQUIRE(NB >= 1 && NB <= 1024 && V >= 1, "flame_create: bad NB/V");
+    VGH_REQUIRE(9 * (NJ - 1) <= 64, "flame_create: too many pose features");
+    VGH_REQUIRE(parents[0] == -1, "flame_create: parents[0] must be -1 (flame.py:91-93)");
+    for (int j = 1; j < NJ; ++j) VGH_REQUIRE(parents[j] >= 0 && parents[j] < j, "flame_create: parents must be topologically ordered");
+    VGH_HIP(hipSetDevice(device));
+    vgh_flame* f = new vgh_flame();
+    memset(f, 0, sizeof(*f));
+    f->device = device;
+    f->V = V;
+    f->Vp = (V + 3) / 4 * 4;
+    f->NB = NB;
+    f->NJ = NJ;
+    f->NP = 9 * (NJ - 1);
+    f->K = NB + f->NP;
+    f->Kp = (f->K + 7) / 8 * 8;
+    f->max_heads = max_heads > 0 ? max_heads : 1024;
+    const int Vp = f->Vp, K = f->K;
+    std::vector<float> basis((size_t)K * 3 * Vp, 0.0f), vt((size_t)3 * Vp, 0.0f), wts((size_t)NJ * Vp, 0.0f);
+    for (int v = 0; v < V; ++v)
+        for (int c = 0; c < 3; ++c) {
+            vt[(size_t)c * Vp + v] = v_template[(size_t)v * 3 + c];
+            const float* sd = shapedirs + ((size_t)v * 3 + c) * NB;
+            for (int l = 0; l < NB; ++l) basis[((size_t)l * 3 + c) * Vp + v] = sd[l];
+            for (int pz = 0; pz < f->NP; ++pz) basis[((size_t)(NB + pz) * 3 + c) * Vp + v] = posedirs[(size_t)pz * 3 * V + (size_t)v * 3 + c];
+        }
+    for (int v = 0; v < V; ++v)
+        for (int j = 0; j < NJ; ++j) wts[(size_t)j * Vp + v] = lbs_weights[(size_t)v * NJ + j];
+    // fold the joint regressor into the shape basis (fp64)
+    std::vector<float> J0((size_t)3 * NJ), JS((size_t)3 * NJ * NB);
+    {
+        std::vector<double> accS((size_t)NB);
+        for (int j = 0; j < NJ; ++j)
+            for (int c = 0; c < 3; ++c) {
+                double a0 = 0.0;
+                std::fill(accS.begin(), accS.end(), 0.0);
+                for (int v = 0; v < V; ++v) {
+                    const double w = J_regressor[(size_t)j * V + v];
+                    if (w == 0.0) continue;
+                    a0 += w * (double)v_template[(size_t)v * 3 + c];
+                    const float* sd = shapedirs + ((size_t)v * 3 + c) * NB;
+                    for (int l = 0; l < NB; ++l) accS[l] += w * (double)sd[l];
+                }
+                J0[(size_t)j * 3 + c] = (float)a0;
+                for (int l = 0; l < NB; ++l) JS[((size_t)j * 3 + c) * NB + l] = (float)accS[l];
+            }
+    }
+#define UP(dst, vec)                                                                              \
+    VGH_HIP(hipMalloc((void**)&f->dst, (vec).size() * sizeof((vec)[0])));                         \
+    VGH_HIP(hipMemcpy(f->dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice))
+    UP(basis, basis);
+    UP(vt, vt);
+    UP(wts, wts);
+    UP(J0, J0);
+    UP(JS, JS);
+#undef UP
+    VGH_HIP(hipMalloc((void**)&f->parents, NJ * sizeof(int32_t)));
+    VGH_HIP(hipMemcpy(f->parents, parents, NJ * sizeof(int32_t), hipMemcpyHostToDevice));
+    VGH_HIP(hipMalloc((void**)&f->coef, (size_t)f->max_heads * f->Kp * sizeof(float)));
+    VGH_HIP(hipMalloc((void**)&f->headpack, (size_t)f->max_heads * HP_SIZE * sizeof(float)));
+    *out = f;
+    return VGH_OK;
+}
+
+void vgh_flame_destroy(vgh_flame* f) {
+    if (!f) return;
+    hipFree(f->basis);
+    hipFree(f->vt);
+    hipFree(f->wts);
+    hipFree(f->J0);
+    hipFree(f->JS);
+    hipFree(f->parents);
+    hipFree(f->coef);
+    hipFree(f->headpack);
+    delete f;
+}
+
+int vgh_flame_decode(vgh_flame* f, const float* params_dev, int n, int shape_live, int expr_live, const float* unpad_dev, float* verts_dev,
+                     float* rot_dev, float* proj_dev, void* stream) {
+    VGH_REQUIRE(f, "flame_decode: null handle");
+    VGH_REQUIRE(f->NB == 400 && f->NJ == 5, "flame_decode: the 413-parameter layout needs NB=400, NJ=5 (FLAME_CONSTS, head_info.py:12-21)");
+    VGH_REQUIRE(shape_live >= 0 && shape_live <= 300 && expr_live >= 0 && expr_live <= 100, "flame_decode: live counts out of range");
+    if (n == 0) return VGH_OK;  // flame.py:186-189 fast path: empty outputs
+    VGH_REQUIRE(params_dev, "flame_decode: null params");
+    PrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.params = params_dev;
+    pa.unpad = unpad_dev;
+    pa.J0 = f->J0;
+    pa.JS = f->JS;
+    pa.parents = f->parents;
+    pa.coef = f->coef;
+    pa.headpack = f->headpack;
+    pa.rot_out = rot_dev;
+    pa.NB = f->NB;
+    pa.NJ = f->NJ;
+    pa.Kp = f->Kp;
+    return run_decode(f, pa, n, shape_live, expr_live, true, verts_dev, proj_dev, stream);
+}
+
+int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream) {
+    VGH_REQUIRE(f, "flame_lbs: null handle");
+    if (n == 0) return VGH_OK;
+    VGH_REQUIRE(betas_dev && pose_dev, "flame_lbs: null input");
+    PrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.betas = betas_dev;
+    pa.pose = pose_dev;
+    pa.J0 = f->J0;
+    pa.JS = f->JS;
+    pa.parents = f->parents;
+    pa.coef = f->coef;
+    pa.headpack = f->headpack;
+    pa.joints_out = joints_dev;
+    pa.NB = f->NB;
+    pa.NJ = f->NJ;
+    pa.Kp = f->Kp;
+    return run_decode(f, pa, n, 0, 0, false, verts_dev, nullptr, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,359 @@
+// Host side of libvgh.so: static-schedule network executor (pre-planned arena, concat-by-offset, one
+// stream, optional hipGraph replay), stand-alone conv entry point, error/stream/event helpers.
+//
+// Replaces the TorchScript interpreter call `self.model(image)` (head_detector/detector.py:58-59).
+#include <stdarg.h>
+
+#include <vector>
+
+#include "vgh_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void vgh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct NetOp {
+    vgh_op_desc d;
+    uint16_t* wpack = nullptr;  // device (conv)
+    float* wf32 = nullptr;      // device (stem [27][48])
+    float* bias = nullptr;      // device
+};
+
+struct vgh_net {
+    int device = 0, image_size = 0, max_batch = 0;
+    std::vector<vgh_buf_desc> bufs;
+    std::vector<void*> buf_ptr;
+    std::vector<int64_t> buf_bytes;
+    std::vector<NetOp> ops;
+    char* arena = nullptr;
+    int64_t arena_bytes = 0;
+    char* wblob = nullptr;  // all packed weights + biases
+    uint16_t* zeros = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+};
+
+static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+static int net_conv_args(vgh_net* n, const NetOp& op, int B, ConvArgs* a) {
+    const vgh_op_desc& d = op.d;
+    const vgh_buf_desc& ib = n->bufs[d.in_buf];
+    const vgh_buf_desc& ob = n->bufs[d.out_buf];
+    memset(a, 0, sizeof(*a));
+    a->in = (const uint16_t*)n->buf_ptr[d.in_buf];
+    a->in_pitch = ib.pitch;
+    a->in_coff = d.in_coff;
+    a->cin = d.cin;
+    a->B = B;
+    a->H = ib.h;
+    a->W = ib.w;
+    a->ksize = d.ksize;
+    a->stride = d.stride;
+    a->pad = d.ksize / 2;
+    a->Ho = (ib.h + 2 * a->pad - d.ksize) / d.stride + 1;
+    a->Wo = (ib.w + 2 * a->pad - d.ksize) / d.stride + 1;
+    a->wpack = op.wpack;
+    a->bias = op.bias;
+    a->out = n->buf_ptr[d.out_buf];
+    a->out_pitch = ob.pitch;
+    a->out_coff = d.out_coff;
+    a->out_coff2 = d.out_coff2;
+    a->out_split = d.out_split;
+    a->cout_pad = d.cout_pad;
+    a->cout_store = d.cout_store;
+    a->out_f32 = ob.is_f32;
+    a->res = d.res_buf >= 0 ? (const uint16_t*)n->buf_ptr[d.res_buf] : nullptr;
+    a->res_pitch = d.res_buf >= 0 ? n->bufs[d.res_buf].pitch : 0;
+    a->res_coff = d.res_coff;
+    a->alpha = d.alpha;
+    a->act = d.act;
+    a->shuffle = d.shuffle;
+    a->shuffle_c = d.shuffle ? d.cout_pad / 4 : 0;
+    a->zeros = n->zeros;
+    a->P = B * a->Ho * a->Wo;
+    a->cblocks = d.cin / 32;
+    a->nkb = d.ksize * d.ksize * a->cblocks;
+    const int eh = d.shuffle ? 2 * a->Ho : a->Ho, ew = d.shuffle ? 2 * a->Wo : a->Wo;
+    VGH_REQUIRE(ob.h == eh && ob.w == ew, "net: op output buffer %d is %dx%d, conv produces %dx%d", d.out_buf, ob.h, ob.w, eh, ew);
+    VGH_REQUIRE(d.in_coff + d.cin <= ib.pitch, "net: conv reads past the input pitch (buf %d)", d.in_buf);
+    return VGH_OK;
+}
+
+static int net_run_op(vgh_net* n, const NetOp& op, const void* image, int fmt, int B, hipStream_t st) {
+    const vgh_op_desc& d = op.d;
+    switch (d.kind) {
+        case VGH_OP_STEM: {
+            const vgh_buf_desc& ob = n->bufs[d.out_buf];
+            return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)n->buf_ptr[d.out_buf], ob.pitch, d.out_coff, st);
+        }
+        case VGH_OP_CONV: {
+            ConvArgs a;
+            if (int rc = net_conv_args(n, op, B, &a)) return rc;
+            return vgh_launch_conv(a, d.force_cfg, st);
+        }
+        case VGH_OP_SPP_POOL: {
+            const vgh_buf_desc& ib = n->bufs[d.in_buf];
+            return vgh_launch_spp_pool((uint16_t*)n->buf_ptr[d.in_buf], ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
+        }
+        default:
+            VGH_REQUIRE(false, "net: unknown op kind %d", d.kind);
+    }
+    return VGH_OK;
+}
+
+extern "C" {
+
+const char* vgh_version(void) { return "vgh 0.1.0 (gfx950)"; }
+const char* vgh_last_error(void) { return g_err; }
+
+int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc* bufs, int n_bufs, const vgh_op_desc* ops, int n_ops,
+                   const float* weights_host, int64_t n_weights, const float* biases_host, int64_t n_biases, vgh_net** out) {
+    VGH_REQUIRE(out && bufs && ops && weights_host && biases_host, "net_create: null argument");
+    VGH_REQUIRE(max_batch >= 1 && image_size >= 32 && image_size % 32 == 0, "net_create: bad max_batch / image_size");
+    VGH_HIP(hipSetDevice(device));
+    vgh_net* n = new vgh_net();
+    n->device = device;
+    n->image_size = image_size;
+    n->max_batch = max_batch;
+    n->bufs.assign(bufs, bufs + n_bufs);
+    // ---- arena plan: one slab, every buffer live for the whole forward (288 GB HBM: no aliasing games) ----
+    int64_t off = 0;
+    std::vector<int64_t> offs(n_bufs);
+    for (int i = 0; i < n_bufs; ++i) {
+        const int64_t bytes = (int64_t)max_batch * bufs[i].h * bufs[i].w * bufs[i].pitch * (bufs[i].is_f32 ? 4 : 2);
+        offs[i] = off;
+        n->buf_bytes.push_back(bytes);
+        off += align_up(bytes + 256, 256);  // +256: slack so 16-byte gathers at the very end stay in-bounds
+    }
+    n->arena_bytes = off;
+    VGH_HIP(hipMalloc((void**)&n->arena, off));
+    VGH_HIP(hipMemset(n->arena, 0, off));  // padding channels that no op writes must be exact zeros
+    for (int i = 0; i < n_bufs; ++i) n->buf_ptr.push_back(n->arena + offs[i]);
+    VGH_HIP(hipMalloc((void**)&n->zeros, 256));
+    VGH_HIP(hipMemset(n->zeros, 0, 256));
+    // ---- weights: pack on the host, one upload ----
+    int64_t wbytes = 0;
+    std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0);
+    for (int i = 0; i < n_ops; ++i) {
+        const vgh_op_desc& d = ops[i];
+        if (d.kind == VGH_OP_CONV) {
+            VGH_REQUIRE(d.cin % 32 == 0 && d.cout_pad % 32 == 0, "net_create: op %d channel padding", i);
+            VGH_REQUIRE(d.in_buf >= 0 && d.in_buf < n_bufs && d.out_buf >= 0 && d.out_buf < n_bufs && d.res_buf < n_bufs, "net_create: op %d buffer ids", i);
+            const int64_t we = (int64_t)d.cout_pad * d.ksize * d.ksize * d.cin;
+            VGH_REQUIRE(d.w_off >= 0 && d.w_off + we <= n_weights && d.b_off >= 0 && d.b_off + d.cout_pad <= n_biases, "net_create: op %d weight range", i);
+            woff[i] = wbytes;
+            wbytes += align_up(we * 2, 256);
+            boff[i] = wbytes;
+            wbytes += align_up((int64_t)d.cout_pad * 4, 256);
+        } else if (d.kind == VGH_OP_STEM) {
+            VGH_REQUIRE(d.w_off >= 0 && d.w_off + 27 * 48 <= n_weights && d.b_off + 48 <= n_biases, "net_create: stem weight range");
+            woff[i] = wbytes;
+            wbytes += align_up(27 * 48 * 4, 256);
+            boff[i] = wbytes;
+            wbytes += align_up(64 * 4, 256);
+        }
+    }
+    std::vector<char> host(wbytes > 0 ? wbytes : 1, 0);
+    for (int i = 0; i < n_ops; ++i) {
+        const vgh_op_desc& d = ops[i];
+        if (d.kind == VGH_OP_CONV) {
+            vgh_pack_conv_weights_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint16_t*)(host.data() + woff[i]));
+            memcpy(host.data() + boff[i], biases_host + d.b_off, (size_t)d.cout_pad * 4);
+        } else if (d.kind == VGH_OP_STEM) {
+            // host gives [48][3(ky)][3(kx)][3(ci)] -> device [27][48]
+            float* dst = (float*)(host.data() + woff[i]);
+            for (int co = 0; co < 48; ++co)
+                for (int k = 0; k < 27; ++k) dst[k * 48 + co] = weights_host[d.w_off + co * 27 + k];
+            memcpy(host.data() + boff[i], biases_host + d.b_off, 48 * 4);
+        }
+    }
+    VGH_HIP(hipMalloc((void**)&n->wblob, host.size()));
+    VGH_HIP(hipMemcpy(n->wblob, host.data(), host.size(), hipMemcpyHostToDevice));
+    for (int i = 0; i < n_ops; ++i) {
+        NetOp op;
+        op.d = ops[i];
+        if (ops[i].kind == VGH_OP_CONV) {
+            op.wpack = (uint16_t*)(n->wblob + woff[i]);
+            op.bias = (float*)(n->wblob + boff[i]);
+        } else if (ops[i].kind == VGH_OP_STEM) {
+            op.wf32 = (float*)(n->wblob + woff[i]);
+            op.bias = (float*)(n->wblob + boff[i]);
+        }
+        n->ops.push_back(op);
+    }
+    *out = n;
+    return VGH_OK;
+}
+
+void vgh_net_destroy(vgh_net* n) {
+    if (!n) return;
+    if (n->graph_exec) hipGraphExecDestroy(n->graph_exec);
+    if (n->graph) hipGraphDestroy(n->graph);
+    hipFree(n->arena);
+    hipFree(n->wblob);
+    hipFree(n->zeros);
+    delete n;
+}
+
+int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, void* stream) {
+    VGH_REQUIRE(n && image_dev, "net_forward: null argument");
+    VGH_REQUIRE(B >= 0 && B <= n->max_batch, "net_forward: B=%d exceeds max_batch=%d", B, n->max_batch);
+    for (const NetOp& op : n->ops)
+        if (int rc = net_run_op(n, op, image_dev, image_fmt, B, (hipStream_t)stream)) return rc;
+    return VGH_OK;
+}
+
+int vgh_net_profile(vgh_net* n, const void* image_dev, int image_fmt, int B, void* stream, float* op_ms) {
+    VGH_REQUIRE(n && image_dev && op_ms, "net_profile: null argument");
+    VGH_REQUIRE(B >= 0 && B <= n->max_batch, "net_profile: B=%d exceeds max_batch=%d", B, n->max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t m = n->ops.size();
+    std::vector<hipEvent_t> ev(m + 1);
+    for (auto& e : ev) VGH_HIP(hipEventCreate(&e));
+    VGH_HIP(hipEventRecord(ev[0], st));
+    for (size_t i = 0; i < m; ++i) {
+        if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, B, st)) return rc;
+        VGH_HIP(hipEventRecord(ev[i + 1], st));
+    }
+    VGH_HIP(hipEventSynchronize(ev[m]));
+    for (size_t i = 0; i < m; ++i) VGH_HIP(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) hipEventDestroy(e);
+    return VGH_OK;
+}
+
+int vgh_net_capture(vgh_net* n, const void* image_dev, int image_fmt, int B, void* stream) {
+    VGH_REQUIRE(n && stream, "net_capture: needs a non-null stream");
+    hipStream_t st = (hipStream_t)stream;
+    if (n->graph_exec) {
+        hipGraphExecDestroy(n->graph_exec);
+        n->graph_exec = nullptr;
+    }
+    if (n->graph) {
+        hipGraphDestroy(n->graph);
+        n->graph = nullptr;
+    }
+    VGH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = vgh_net_forward(n, image_dev, image_fmt, B, stream);
+    hipError_t e = hipStreamEndCapture(st, &n->graph);
+    if (rc) return rc;
+    VGH_HIP(e);
+    VGH_HIP(hipGraphInstantiate(&n->graph_exec, n->graph, nullptr, nullptr, 0));
+    return VGH_OK;
+}
+
+int vgh_net_forward_graph(vgh_net* n, void* stream) {
+    VGH_REQUIRE(n && n->graph_exec, "net_forward_graph: call vgh_net_capture first");
+    VGH_HIP(hipGraphLaunch(n->graph_exec, (hipStream_t)stream));
+    return VGH_OK;
+}
+
+void* vgh_net_buffer(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_ptr.size()) ? n->buf_ptr[buf_id] : nullptr; }
+int64_t vgh_net_buffer_bytes(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_bytes.size()) ? n->buf_bytes[buf_id] : -1; }
+
+int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {
+    VGH_REQUIRE(n && op_index >= 0 && op_index < (int)n->ops.size(), "net_set_cfg: bad op index");
+    VGH_REQUIRE(cfg >= -1 && cfg < vgh_conv_num_cfgs(), "net_set_cfg: bad cfg");
+    n->ops[op_index].d.force_cfg = cfg;
+    return VGH_OK;
+}
+
+static uint16_t* g_zeros[16] = {nullptr};
+
+int vgh_conv2d(const vgh_conv_call* c, void* stream) {
+    VGH_REQUIRE(c && c->in_dev && c->wpack_dev && c->bias_dev && c->out_dev, "conv2d: null argument");
+    int dev = 0;
+    VGH_HIP(hipGetDevice(&dev));
+    VGH_REQUIRE(dev >= 0 && dev < 16, "conv2d: device index");
+    if (!g_zeros[dev]) {
+        VGH_HIP(hipMalloc((void**)&g_zeros[dev], 256));
+        VGH_HIP(hipMemset(g_zeros[dev], 0, 256));
+    }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = (const uint16_t*)c->in_dev;
+    a.in_pitch = c->in_pitch;
+    a.in_coff = c->in_coff;
+    a.cin = c->cin;
+    a.B = c->B;
+    a.H = c->H;
+    a.W = c->W;
+    a.ksize = c->ksize;
+    a.stride = c->stride;
+    a.pad = c->ksize / 2;
+    a.Ho = (c->H + 2 * a.pad - c->ksize) / c->stride + 1;
+    a.Wo = (c->W + 2 * a.pad - c->ksize) / c->stride + 1;
+    a.wpack = (const uint16_t*)c->wpack_dev;
+    a.bias = c->bias_dev;
+    a.out = c->out_dev;
+    a.out_pitch = c->out_pitch;
+    a.out_coff = c->out_coff;
+    a.out_coff2 = c->out_coff2;
+    a.out_split = c->out_split;
+    a.cout_pad = c->cout_pad;
+    a.cout_store = c->cout_store;
+    a.out_f32 = c->out_f32;
+    a.res = (const uint16_t*)c->res_dev;
+    a.res_pitch = c->res_pitch;
+    a.res_coff = c->res_coff;
+    a.alpha = c->alpha;
+    a.act = c->act;
+    a.shuffle = c->shuffle;
+    a.shuffle_c = c->shuffle ? c->cout_pad / 4 : 0;
+    a.zeros = g_zeros[dev];
+    a.P = c->B * a.Ho * a.Wo;
+    a.cblocks = c->cin / 32;
+    a.nkb = c->ksize * c->ksize * a.cblocks;
+    return vgh_launch_conv(a, c->force_cfg, (hipStream_t)stream);
+}
+
+int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin, uint16_t* wpack_host) {
+    VGH_REQUIRE(w_host && wpack_host, "pack: null argument");
+    VGH_REQUIRE(cin % 32 == 0 && cout_pad % 32 == 0 && (ksize == 1 || ksize == 3), "pack: cin/cout_pad must be multiples of 32, ksize 1 or 3");
+    vgh_pack_conv_weights_host(w_host, cout_pad, ksize, cin, wpack_host);
+    return VGH_OK;
+}
+
+int vgh_stream_create(int device, void** stream_out) {
+    VGH_REQUIRE(stream_out, "stream_create: null");
+    VGH_HIP(hipSetDevice(device));
+    hipStream_t s;
+    VGH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = (void*)s;
+    return VGH_OK;
+}
+int vgh_stream_destroy(void* stream) {
+    VGH_HIP(hipStreamDestroy((hipStream_t)stream));
+    return VGH_OK;
+}
+int vgh_stream_sync(void* stream) {
+    VGH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return VGH_OK;
+}
+int vgh_event_create(void** ev_out) {
+    VGH_REQUIRE(ev_out, "event_create: null");
+    hipEvent_t e;
+    VGH_HIP(hipEventCreate(&e));
+    *ev_out = (void*)e;
+    return VGH_OK;
+}
+int vgh_event_destroy(void* ev) {
+    VGH_HIP(hipEventDestroy((hipEvent_t)ev));
+    return VGH_OK;
+}
+int vgh_event_record(void* ev, void* stream) {
+    VGH_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return VGH_OK;
+}
+int vgh_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
+    VGH_REQUIRE(ms_out, "event_elapsed: null");
+    VGH_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+    VGH_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return VGH_OK;
+}
+
+}  // extern "C"

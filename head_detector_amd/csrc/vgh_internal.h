@@ -1,0 +1,77 @@
+// Internal declarations shared by the libvgh.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vgh.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- error plumbing: never throw across the C ABI --------------------------------------
+void vgh_set_error(const char* fmt, ...);
+
+#define VGH_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            vgh_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return VGH_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+#define VGH_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            vgh_set_error(__VA_ARGS__);   \
+            return VGH_ERR_INVALID;       \
+        }                                 \
+    } while (0)
+
+// ---- conv launch descriptor (device pointers resolved) ---------------------------------
+struct ConvArgs {
+    const uint16_t* in;    // bf16 NHWC, pixel pitch in_pitch elements, first channel in_coff
+    const uint16_t* wpack; // packed weights [nkb][cout_pad][32] bf16, 16B chunks pre-swizzled
+    const float* bias;     // [cout_pad]
+    void* out;             // bf16 (or f32 when out_f32) NHWC
+    const uint16_t* res;   // residual, same spatial dims as out (or nullptr)
+    const uint16_t* zeros; // >= 64 B of zeros (im2col padding source)
+    int64_t in_pitch, out_pitch, res_pitch;
+    int in_coff, out_coff, out_coff2, out_split, res_coff;
+    int B, H, W, Ho, Wo;
+    int cin;        // multiple of 32
+    int cout_pad;   // rows in wpack (multiple of 32)
+    int cout_store; // channels actually written (<= cout_pad)
+    int ksize, stride, pad;
+    int act;        // VGH_ACT_*
+    int out_f32;    // 1: write float
+    int shuffle;    // 1: ConvTranspose2d(k=2,s=2) pixel-shuffle store, cout_pad = 4*C
+    int shuffle_c;  // C of the transposed conv
+    float alpha;    // residual scale
+    int P;          // B*Ho*Wo output pixels
+    int nkb;        // ksize*ksize*cin/32
+    int cblocks;    // cin/32
+};
+
+int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);
+int vgh_conv_pick_cfg(const ConvArgs& a);
+// host-side weight packing: dense [cout_pad][ks][ks][cin] f32 -> wpack bf16 image
+void vgh_pack_conv_weights_host(const float* w, int cout_pad, int ksize, int cin, uint16_t* dst);
+static inline size_t vgh_wpack_elems(int cout_pad, int ksize, int cin) { return (size_t)cout_pad * ksize * ksize * cin; }
+
+static inline uint16_t vgh_f32_to_bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ---- other launchers --------------------------------------------------------------------
+int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w /*[64][27] dev*/,
+                    const float* bias /*[64] dev*/, uint16_t* out, int64_t out_pitch, int out_coff, hipStream_t stream);
+int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, int H, int W, hipStream_t stream);

@@ -1,0 +1,148 @@
+"""HeadDetector: the reference's facade (head_detector/detector.py:18-102) on the MI355X engine.
+
+    detector = HeadDetector()                       # model="vgg_heads_l", image_size=640
+    predictions = detector(image, confidence_threshold=0.5)
+    predictions.heads -> List[HeadMetadata(bbox, score, flame_params, vertices_3d, head_pose)]
+
+Differences that are forced, not chosen:
+  * weights: the reference downloads ``okupyn/vgg_heads/<model>.trcd`` from the HF hub (detector.py:25-30).
+    There is no network here, so ``weights`` is a path to a user-supplied .trcd / state_dict, or None for
+    seeded synthetic weights of the same architecture (throughput / plumbing only);
+  * FLAME constants: ``flame_path`` / ``flame_model`` as in FLAMELayer (user-supplied licensed asset);
+  * letterbox resize: cv2.INTER_LANCZOS4 (detector.py:47) when cv2 is importable, else PIL LANCZOS
+    (not bit-identical to OpenCV's fixed-point kernel).
+Preserved quirks: nms() looks at image 0 only; FlameParams.translation is left in padded-640 space while
+scale is divided by the letterbox scale (detector.py:78-79); bbox via np.rint -> int; z is divided by scale too.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .detection_result import PredictionResult
+from .engine import VGHeadsEngine
+from .flame import FLAMELayer
+from .head_info import Bbox, FlameParams, HeadMetadata
+from .utils import calculate_rpy
+
+REPO_ID = "okupyn/vgg_heads"
+
+
+def load_weights(path: str) -> Dict[str, np.ndarray]:
+    """state_dict of a released TorchScript archive (.trcd) or of a torch checkpoint -> {name: ndarray} with the
+    ``model.`` prefix of ConvertableCompletePipelineModel stripped (exportable_mesh_model.py:421-427)."""
+    try:
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
+    except Exception:
+        obj = torch.load(path, map_location="cpu")
+        sd = obj.get("net", obj.get("ema_net", obj)) if isinstance(obj, dict) else obj.state_dict()
+    out = {}
+    for k, v in sd.items():
+        k = k[len("model."):] if k.startswith("model.") else k
+        out[k] = v.detach().float().numpy()
+    return out
+
+
+class HeadDetector:
+    def __init__(self, model: str = "vgg_heads_l", image_size: int = 640, *, weights: Optional[str] = None, flame_path: Optional[str] = None,
+                 flame_model: Optional[Dict[str, Any]] = None, seed: int = 1):
+        if not torch.cuda.is_available():
+            raise _lib.VghError("HeadDetector: no GPU visible. This package is the MI355X HIP path only; it does not fall back to the CPU.")
+        self._image_size = image_size
+        self._device = torch.device("cuda", torch.cuda.current_device())
+        self._flame = FLAMELayer(flame_path=flame_path, model=flame_model, device=self._device)
+        self.model = self._read_model(model, weights, seed)
+
+    def _read_model(self, model: str, weights: Optional[str], seed: int) -> VGHeadsEngine:
+        sd = load_weights(weights) if weights is not None else None
+        return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=1, seed=seed)
+
+    # ---- host-side image handling (detector.py:32-56) ----------------------------------------------------
+    def _convert_image(self, image) -> np.ndarray:
+        if isinstance(image, str):
+            try:
+                import cv2
+
+                image = cv2.cvtColor(cv2.imread(image), cv2.COLOR_BGR2RGB)
+            except ImportError:
+                from PIL import Image
+
+                image = np.array(Image.open(image).convert("RGB"))
+        elif not isinstance(image, np.ndarray):
+            image = np.array(image)  # PIL.Image
+        return image
+
+    def _transform_image(self, image: np.ndarray) -> Tuple[torch.Tensor, Tuple[int, int], float]:
+        S = self._image_size
+        h, w = image.shape[:2]
+        if h > w:
+            new_h, new_w = S, int(w * S / h)
+        else:
+            new_h, new_w = int(h * S / w), S
+        scale = S / max(image.shape[:2])
+        if (new_h, new_w) != (h, w):
+            try:
+                import cv2
+
+                image = cv2.resize(image, (new_w, new_h), interpolation=cv2.INTER_LANCZOS4)
+            except ImportError:
+                from PIL import Image
+
+                image = np.array(Image.fromarray(image).resize((new_w, new_h), Image.LANCZOS))
+        pad_w, pad_h = S - image.shape[1], S - image.shape[0]
+        canvas = np.full((S, S, 3), 127, dtype=np.uint8)  # cv2.copyMakeBorder(..., BORDER_CONSTANT, value=127)
+        canvas[pad_h // 2 : pad_h // 2 + image.shape[0], pad_w // 2 : pad_w // 2 + image.shape[1]] = image[..., :3]
+        # the u8 -> float /255 conversion (detector.py:51) is fused into the stem kernel
+        image_input = torch.from_numpy(canvas).to(self._device).unsqueeze(0).contiguous()
+        return image_input, (pad_w // 2, pad_h // 2), scale
+
+    def _preprocess(self, image: np.ndarray):
+        image, padding, scale = self._transform_image(image)
+        return image, {"padding": padding, "scale": scale}
+
+    def _process(self, image: torch.Tensor):
+        return self.model.model(image)
+
+    # ---- post-processing (detector.py:61-95) -------------------------------------------------------------------
+    def _parse_predictions(self, bboxes_xyxy: torch.Tensor, scores: torch.Tensor, flame_params: torch.Tensor, cache: Dict[str, Any]) -> List[HeadMetadata]:
+        padding, scale = cache["padding"], cache["scale"]
+        n = flame_params.shape[0]
+        P = self.model.program
+        unpad = torch.tensor([[padding[0], padding[1], scale]], dtype=torch.float32, device=self._device).expand(n, 3).contiguous()
+        # decode + (x - pad_x, y - pad_y, z) / scale fused in the kernel epilogue (detector.py:66-69)
+        if n:
+            _, _, final_3d_pts = self._flame.decode(flame_params, unpad=unpad, shape_live=P.shape_c, expr_live=P.expr_c, want_vertices=False)
+            final_3d_pts = final_3d_pts.cpu().numpy()
+        else:
+            final_3d_pts = np.zeros((0, self._flame.v_template.shape[0], 3), dtype=np.float32)
+        bboxes_xyxy = bboxes_xyxy.cpu().numpy().clip(0, self._image_size)
+        scores = scores.cpu().numpy()
+        bboxes_xyxy[:, [0, 2]] -= padding[0]
+        bboxes_xyxy[:, [1, 3]] -= padding[1]
+        bboxes_xyxy /= scale
+        bboxes_xyxy = np.rint(bboxes_xyxy).astype(int)
+        result = []
+        flame_params = flame_params.detach().cpu()
+        for bbox, score, params, vertices in zip(bboxes_xyxy, scores, flame_params, final_3d_pts):
+            params = FlameParams.from_3dmm(params.unsqueeze(0))
+            params.scale = params.scale / scale
+            box = Bbox(x=bbox[0], y=bbox[1], w=bbox[2] - bbox[0], h=bbox[3] - bbox[1])
+            result.append(HeadMetadata(bbox=box, score=score, flame_params=params, vertices_3d=vertices, head_pose=calculate_rpy(params)))
+        return result
+
+    def _postprocess(self, predictions, cache: Dict[str, Any], confidence_threshold: float) -> List[HeadMetadata]:
+        from .utils import nms
+
+        boxes, scores, flame_params = predictions
+        boxes, scores, flame_params = nms(boxes, scores, flame_params, confidence_threshold=confidence_threshold)
+        return self._parse_predictions(boxes, scores, flame_params, cache)
+
+    def __call__(self, image: Union[str, "np.ndarray", Any], confidence_threshold: float = 0.5) -> PredictionResult:
+        original_image = self._convert_image(image)
+        image, cache = self._preprocess(original_image)
+        predictions = self._process(image)
+        heads = self._postprocess(predictions, cache, confidence_threshold)
+        return PredictionResult(original_image=original_image, heads=heads, faces=self._flame.faces)

@@ -1,0 +1,193 @@
+/* libvgh.so -- C ABI of the MI355X-native VGGHeads forward path (gfx950 only).
+ *
+ * The reference (KupynOrest/head_detector) is pure Python: its hot path is three pluggable
+ * callables inside HeadDetector (head_detector/detector.py:58-59,92-95).  Each entry point below
+ * names the reference interface it replaces.  Conventions:
+ *   - return 0 (VGH_OK) or a negative VGH_ERR_*; nothing is thrown across the ABI;
+ *     vgh_last_error() returns a thread-local message for the last failure;
+ *   - every `*_dev` pointer is caller-owned DEVICE memory (e.g. a torch-ROCm tensor's data_ptr());
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
+ *     with respect to the host unless stated otherwise;
+ *   - handles (vgh_net, vgh_flame) are NOT thread-safe: one handle per (device, stream);
+ *   - no hidden device allocation after *_create (arenas are planned up front).
+ */
+#ifndef VGH_H_
+#define VGH_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGH_OK 0
+#define VGH_ERR_INVALID (-1)
+#define VGH_ERR_HIP (-2)
+#define VGH_ERR_NOMEM (-3)
+
+#define VGH_ACT_NONE 0
+#define VGH_ACT_RELU 1 /* every backbone/neck/head block: activation_type: relu (arch yaml :15..86) */
+#define VGH_ACT_SILU 2
+
+#define VGH_IMG_F32_NCHW 0 /* what HeadDetector._transform_image hands the model (detector.py:51) */
+#define VGH_IMG_U8_NHWC 1  /* raw letterboxed image before .permute().float()/255 (detector.py:48-51) */
+
+#define VGH_NUM_FLAME_PARAMS 413 /* FLAME_CONSTS, head_detector/head_info.py:12-21 */
+
+const char* vgh_version(void);
+const char* vgh_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Network: replaces `self.model(image)` -- the TorchScript blob called at detector.py:58-59 whose
+ * graph is YoloHeads.forward (yolo_heads.py:89-112, arch yaml :4-137) + YoloHeadsNDFLHeads.forward
+ * (yolo_head_ndfl_heads.py:117-175) + VGGHeadDecodingModule (yolo_heads.py:44-86).
+ * The host describes the folded network as a flat op program over NHWC bf16 buffers.
+ * ---------------------------------------------------------------------------------------------- */
+#define VGH_OP_STEM 0     /* 3x3 s2 conv on the raw image, fused /255 + bias + ReLU (YoloNASStem)      */
+#define VGH_OP_CONV 1     /* implicit-GEMM conv k in {1,3}, stride in {1,2}, fused bias/act/residual    */
+#define VGH_OP_SPP_POOL 2 /* SPP max-pool 5/9/13 written next to its input (concat-by-offset)          */
+
+typedef struct vgh_buf_desc {
+    int32_t h, w;   /* spatial size per image */
+    int32_t pitch;  /* channels per pixel (concat width); bf16: multiple of 8, f32: any */
+    int32_t is_f32; /* 0: bf16 activations, 1: fp32 (head prediction outputs) */
+} vgh_buf_desc;
+
+typedef struct vgh_op_desc {
+    int32_t kind;
+    int32_t in_buf, in_coff, cin;        /* cin padded to a multiple of 32 (zero channels)             */
+    int32_t out_buf, out_coff, cout_pad; /* rows of the weight matrix, multiple of 32                  */
+    int32_t cout_store;                  /* channels written; [cout_real, cout_store) are exact zeros  */
+    int32_t out_split, out_coff2;        /* channels >= out_split go to out_coff2 + (c - out_split)    */
+    int32_t res_buf, res_coff;           /* residual added AFTER the activation (YoloNASBottleneck),   */
+    float alpha;                         /*   out = act(conv + b) + alpha * res;  res_buf < 0: none    */
+    int32_t ksize, stride, act;
+    int32_t shuffle;                     /* 1: ConvTranspose2d(k=2,s=2) as 4 pointwise GEMMs + shuffle */
+    int64_t w_off;                       /* offset (floats) of [cout_pad][k][k][cin] in `weights`      */
+    int64_t b_off;                       /* offset (floats) of [cout_pad] in `biases`                  */
+    int32_t force_cfg;                   /* -1: heuristic tile choice; else kernel config index        */
+    int32_t reserved;
+} vgh_op_desc;
+
+typedef struct vgh_net vgh_net;
+
+int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc* bufs, int n_bufs, const vgh_op_desc* ops, int n_ops,
+                   const float* weights_host, int64_t n_weights, const float* biases_host, int64_t n_biases, vgh_net** out);
+void vgh_net_destroy(vgh_net* net);
+/* image_dev: [B,3,S,S] f32 (VGH_IMG_F32_NCHW) or [B,S,S,3] u8 (VGH_IMG_U8_NHWC). Runs every op. */
+int vgh_net_forward(vgh_net* net, const void* image_dev, int image_fmt, int B, void* stream);
+/* As vgh_net_forward but host-synchronous, bracketing every op with HIP events on `stream`;
+ * op_ms[n_ops] receives each op's device time in milliseconds (tuning / roofline reporting). */
+int vgh_net_profile(vgh_net* net, const void* image_dev, int image_fmt, int B, void* stream, float* op_ms);
+/* Capture vgh_net_forward into a hipGraph (replayed by vgh_net_forward_graph with the same B / image_dev). */
+int vgh_net_capture(vgh_net* net, const void* image_dev, int image_fmt, int B, void* stream);
+int vgh_net_forward_graph(vgh_net* net, void* stream);
+void* vgh_net_buffer(vgh_net* net, int buf_id);         /* device pointer of an activation buffer   */
+int64_t vgh_net_buffer_bytes(vgh_net* net, int buf_id); /* bytes for max_batch                       */
+int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
+
+/* Stand-alone conv launch on caller-owned device tensors (per-layer parity tests, micro-benchmarks).
+ * `wpack_dev` must come from vgh_pack_conv_weights. */
+typedef struct vgh_conv_call {
+    const void* in_dev;
+    int64_t in_pitch;
+    int32_t in_coff, cin;
+    int32_t B, H, W;
+    const void* wpack_dev;
+    const float* bias_dev;
+    void* out_dev;
+    int64_t out_pitch;
+    int32_t out_coff, cout_pad, cout_store, out_split, out_coff2, out_f32;
+    const void* res_dev;
+    int64_t res_pitch;
+    int32_t res_coff;
+    float alpha;
+    int32_t ksize, stride, act, shuffle;
+    int32_t force_cfg;
+} vgh_conv_call;
+int vgh_conv2d(const vgh_conv_call* c, void* stream);
+/* dense [cout_pad][k][k][cin] f32 (host) -> kernel-private bf16 image (host, cout_pad*k*k*cin u16) */
+int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin, uint16_t* wpack_host);
+int vgh_conv_num_cfgs(void);
+const char* vgh_conv_cfg_name(int cfg);
+
+/* ------------------------------------------------------------------------------------------------
+ * Head decode: replaces YoloHeadsNDFLHeads.forward's tail (yolo_head_ndfl_heads.py:143-172) and the
+ * activations of YoloHeadsDFLHead.forward (yolo_head_dfl_head.py:162-184).  `levels` describe the
+ * fp32 NHWC prediction buffers written by the *_pred 1x1 convs, channel order per pixel:
+ *   [reg 68 (side*17+bin) | cls 1 | shape S | expr E | rot 6 | jaw 3 | trans 3 | scale 1].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vgh_head_level {
+    const float* pred_dev; /* [B, h*w, pitch] */
+    int32_t h, w, pitch, stride;
+} vgh_head_level;
+
+/* boxes_dev [B,A,4] xyxy px, scores_dev [B,A] = sigmoid(cls).  A = sum(h*w), level-major, row-major. */
+int vgh_head_decode(const vgh_head_level* levels, int n_levels, int B, float* boxes_dev, float* scores_dev, void* stream);
+
+/* VGGHeadDecodingModule.forward (yolo_heads.py:63-86): per image top-k (sorted descending, ties by
+ * ascending anchor index).  idx_dev [B,k] int32 anchor indices, topk_scores_dev [B,k] (may be NULL). */
+int vgh_topk(const float* scores_dev, int B, int A, int k, int32_t* idx_dev, float* topk_scores_dev, void* stream);
+
+/* Gather boxes + build the 413-vector for the selected anchors only (never materialises [B,A,413]):
+ * tanh*3 / exp/0.05 activations, zero padding to 300/100, translation[:2] += cell centre,
+ * scale *= stride, and the from_3dmm -> to_3dmm_tensor channel permutation
+ * (yolo_head_ndfl_heads.py:167-172; head_info.py:44-109).  shape_c / expr_c = live channels S / E. */
+int vgh_gather_candidates(const vgh_head_level* levels, int n_levels, int B, int A, int shape_c, int expr_c, const float* boxes_dev,
+                          const int32_t* idx_dev, int k, float* out_boxes_dev /*[B,k,4]*/, float* out_flame_dev /*[B,k,413]*/, void* stream);
+
+/* nms() of head_detector/utils.py:159-194 for EVERY image (the batched twin,
+ * yolo_heads_post_prediction_callback.py:55-84): conf filter (>=), greedy NMS with torchvision
+ * semantics (suppress when IoU > iou_thr, float32 IEEE arithmetic), first keep_k survivors.
+ * Inputs must be sorted by descending score per image (vgh_topk output order), n_in <= 1024.
+ * keep_idx_dev [B,keep_k] int32 positions into the n_in candidates (-1 padded), counts_dev [B]. */
+int vgh_nms(const float* boxes_dev /*[B,n_in,4]*/, const float* scores_dev /*[B,n_in]*/, int B, int n_in, float conf_thr, float iou_thr,
+            int keep_k, int32_t* keep_idx_dev, int32_t* counts_dev, void* stream);
+
+/* Compact survivors into fixed-capacity slabs: boxes [B,keep_k,4], scores [B,keep_k], flame [B,keep_k,413]. */
+int vgh_compact(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int B, int n_in, const int32_t* keep_idx_dev,
+                int keep_k, float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FLAME: replaces FLAMELayer (head_detector/flame.py:37-169) + smplx.lbs.lbs + rot_mat_from_6dof
+ * (utils.py:120-128) + reproject_spatial_vertices (flame.py:179-208) + the vertex un-pad/un-scale of
+ * HeadDetector._parse_predictions (detector.py:67-69).
+ * vgh_flame_create takes exactly the buffers FLAMELayer.__init__ registers (flame.py:75-95), host f32:
+ *   v_template [V,3], shapedirs [V,3,NB], posedirs [(NJ-1)*9, 3V], J_regressor [NJ,V] dense,
+ *   parents [NJ] (parents[0] = -1), lbs_weights [V,NJ].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vgh_flame vgh_flame;
+int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template, const float* shapedirs, const float* posedirs,
+                     const float* J_regressor, const int32_t* parents, const float* lbs_weights, int max_heads, vgh_flame** out);
+void vgh_flame_destroy(vgh_flame* f);
+
+/* reproject_spatial_vertices(flame, params, to_2d=False): params_dev [n,413] (network OUTPUT layout,
+ * read as from_3dmm does: shape300|expr100|jaw3|rot6|trans3|scale1).  Any output may be NULL.
+ *   verts_dev [n,V,3]  FLAMELayer.forward(zero_rot=True) (incl. z += 0.05)
+ *   rot_dev   [n,3,3]  rot_mat_from_6dof
+ *   proj_dev  [n,V,3]  (R v) * clamp(scale,1e-8) + translation, then if unpad_dev != NULL
+ *                      (x - pad_x, y - pad_y, z) / scale_factor with unpad_dev [n,3] = (pad_x,pad_y,scale)
+ * shape_live / expr_live: number of leading shape / expression coefficients that can be non-zero
+ * (300/100 = no assumption). Coefficients beyond them MUST be exactly 0 (the detector zero-pads them,
+ * yolo_head_dfl_head.py:170-182); skipping them is then bit-exact. */
+int vgh_flame_decode(vgh_flame* f, const float* params_dev, int n, int shape_live, int expr_live, const float* unpad_dev, float* verts_dev,
+                     float* rot_dev, float* proj_dev, void* stream);
+
+/* General FLAMELayer.forward core = smplx lbs(betas, full_pose): betas_dev [n,NB], pose_dev [n,3*NJ]
+ * axis-angle per joint -> verts_dev [n,V,3] (NO z offset, NO global rotation), joints_dev [n,NJ,3] or NULL. */
+int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HIP-event helpers so Python can time work on the stream the kernels actually run on.
+ * ---------------------------------------------------------------------------------------------- */
+int vgh_stream_create(int device, void** stream_out);
+int vgh_stream_destroy(void* stream);
+int vgh_stream_sync(void* stream);
+int vgh_event_create(void** ev_out);
+int vgh_event_destroy(void* ev);
+int vgh_event_record(void* ev, void* stream);
+int vgh_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGH_H_ */
