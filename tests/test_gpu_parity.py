@@ -1,0 +1,477 @@
+"""GPU (-m gpu): parity of every HIP kernel, called through the C ABI, against the CPU oracle / golden vectors.
+Integer / index results must be bit-exact; floating point within the tolerance written next to each check."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import program_ref as pr
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _sp():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ======================================================================================================
+# FLAME decode (K9)
+# ======================================================================================================
+@pytest.fixture(scope="module")
+def flame_layer(gpu_lib, flame_model):
+    from head_detector_amd.flame import FLAMELayer
+
+    return FLAMELayer(model=flame_model, device=_dev(), max_heads=64)
+
+
+def test_flame_decode_matches_reference_vectors(flame_layer):
+    """Golden vectors produced by the reference's FLAMELayer / reproject_spatial_vertices (make_golden.py)."""
+    from head_detector_amd.flame import reproject_spatial_vertices
+
+    g = golden("flame_decode.npz")
+    params = torch.from_numpy(g["params"]).to(_dev())
+    v, R, p = reproject_spatial_vertices(flame_layer, params, to_2d=False)
+    # north_star tolerance: FLAME vertices within 1e-4 (metres-scale mesh, |v| ~ 0.2)
+    assert np.abs(v.cpu().numpy() - g["vertices"]).max() < 1e-5
+    assert np.abs(R.cpu().numpy() - g["R"]).max() < 1e-5
+    pg = g["projected"]
+    assert (np.abs(p.cpu().numpy() - pg) / (np.abs(pg) + 1.0)).max() < 1e-5  # pixel-space values up to ~700: relative
+    _, _, p2 = reproject_spatial_vertices(flame_layer, params, to_2d=True)
+    assert p2.shape == (5, 5023, 2) and torch.equal(p2, p[..., :2])
+    ev, eR, ep = reproject_spatial_vertices(flame_layer, torch.zeros(0, 413, device=_dev()), to_2d=False)
+    assert [list(ev.shape), list(eR.shape), list(ep.shape)] == g["empty_shapes"].tolist()
+    with pytest.raises(ValueError):
+        reproject_spatial_vertices(flame_layer, torch.zeros(2, 412, device=_dev()))
+    sub = [0, 17, 5022]
+    _, _, ps = reproject_spatial_vertices(flame_layer, params, to_2d=False, subset_indexes=sub)
+    assert torch.equal(ps, p[:, sub])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 24, 25, 64, 65, 150])
+def test_flame_decode_vs_oracle_f64(flame_layer, flame_model, n):
+    from oracle import flame_oracle as fo
+
+    c64 = fo.FlameConstants(flame_model, torch.float64)
+    params = fo.synthetic_params(n, seed=100 + n)
+    v64, R64, p64 = fo.reproject(c64, params.double())
+    unpad = torch.tensor([[80.0, 0.0, 0.625]]).repeat(n, 1)
+    v, R, p = flame_layer.decode(params.to(_dev()), unpad=unpad.to(_dev()), shape_live=300, expr_live=100)
+    assert (v.cpu().double() - v64).abs().max() < 2e-6
+    assert (R.cpu().double() - R64).abs().max() < 2e-6
+    q64 = p64.clone()
+    q64[:, :, 0] -= 80.0
+    q64 = q64 / 0.625  # detector.py:67-69
+    assert ((p.cpu().double() - q64).abs() / (q64.abs() + 1.0)).max() < 2e-6
+    # structural-zero skipping is bit-exact when the skipped coefficients are exactly zero
+    v2, _, p2 = flame_layer.decode(params.to(_dev()), unpad=unpad.to(_dev()), shape_live=128, expr_live=64)
+    assert torch.equal(v, v2) and torch.equal(p, p2)
+
+
+def test_flame_layer_forward_general_pose(flame_layer, flame_model):
+    """FLAMELayer.forward with non-zero neck / eyeballs widths (flame.py:141-143 accepts them): general 5-joint LBS."""
+    from head_detector_amd.flame import FLAMELayer
+    from head_detector_amd.head_info import FlameParams
+    from oracle import flame_oracle as fo
+
+    consts = {"shape": 300, "expression": 100, "rotation": 6, "jaw": 3, "eyeballs": 6, "neck": 3, "translation": 3, "scale": 1}
+    layer = FLAMELayer(consts=consts, model=flame_model, device=_dev())
+    g = torch.Generator().manual_seed(4)
+    n = 6
+    x = torch.randn(n, sum(consts.values()), generator=g) * 0.3
+    fp = FlameParams.from_3dmm(x, consts)
+    out = layer.forward(fp, zero_rot=False)
+    c64 = fo.FlameConstants(flame_model, torch.float64)
+    d = fo.split_3dmm(x.double(), consts)
+    ref = fo.flame_forward(c64, d, zero_rot=False)
+    assert (out.cpu().double() - ref).abs().max() < 5e-6
+    out_zj = layer.forward(fp, zero_rot=True, zero_jaw=True)
+    assert (out_zj.cpu().double() - fo.flame_forward(c64, d, zero_rot=True, zero_jaw=True)).abs().max() < 5e-6
+
+
+# ======================================================================================================
+# top-k (K7), NMS (K8)
+# ======================================================================================================
+@pytest.mark.parametrize("A,k", [(8400, 1000), (1000, 1000), (33600, 1000), (1500, 7), (64, 64)])
+def test_topk_bit_exact(gpu_lib, A, k):
+    from head_detector_amd import _lib
+    from oracle import postproc_oracle as po
+
+    g = torch.Generator().manual_seed(A + k)
+    B = 3
+    scores = torch.rand(B, A, generator=g)
+    scores[1] = (scores[1] * 50).round() / 50  # massive ties -> index tie-break must match
+    scores[2, ::3] = 0.75
+    d = scores.to(_dev())
+    idx = torch.empty(B, k, dtype=torch.int32, device=_dev())
+    out = torch.empty(B, k, device=_dev())
+    _lib.check(gpu_lib.vgh_topk(_lib.ptr(d), B, A, k, _lib.ptr(idx), _lib.ptr(out), _sp()))
+    for b in range(B):
+        ref = po.stable_topk(scores[b], k)
+        assert torch.equal(idx[b].cpu().long(), ref), (A, k, b)
+        assert torch.equal(out[b].cpu(), scores[b][ref])
+
+
+@pytest.mark.parametrize("seed,mean_heads,conf", [(1, 3, 0.5), (2, 30, 0.5), (3, 100, 0.02), (4, 3, 0.999), (5, 60, 0.55)])
+def test_nms_bit_exact_vs_oracle(gpu_lib, seed, mean_heads, conf):
+    from head_detector_amd.utils import nms, nms_batched
+    from oracle import postproc_oracle as po
+
+    B = 4
+    boxes, scores = po.synthetic_detections(B, seed=seed, mean_heads=mean_heads)
+    bb, ss, ff, _ = po.decoding_topk(boxes, scores, torch.randn(B, boxes.shape[1], 413, generator=torch.Generator().manual_seed(seed)), 1000)
+    ob, os_, of, counts = nms_batched(bb.to(_dev()), ss.to(_dev()), ff.to(_dev()), confidence_threshold=conf)
+    ref = po.postprocess_batched(bb, ss, ff, conf, 0.5)
+    for b in range(B):
+        n = int(counts[b])
+        assert n == ref[b][0].shape[0], (b, n, ref[b][0].shape)
+        assert torch.equal(ob[b, :n].cpu(), ref[b][0]) and torch.equal(os_[b, :n].cpu(), ref[b][1]) and torch.equal(of[b, :n].cpu(), ref[b][2])
+        assert float(ob[b, n:].abs().sum()) == 0.0
+    # reference quirk: nms() returns image 0 only (utils.py:194)
+    b0, s0, f0 = nms(bb.to(_dev()), ss.to(_dev()), ff.to(_dev()), confidence_threshold=conf)
+    r0 = po.nms_reference(bb, ss, ff, confidence_threshold=conf)
+    assert torch.equal(b0.cpu(), r0[0]) and torch.equal(s0.cpu(), r0[1]) and torch.equal(f0.cpu(), r0[2])
+
+
+def test_nms_reference_golden(gpu_lib):
+    from head_detector_amd.utils import nms
+
+    g = golden("nms_glue.npz")
+    boxes, scores = torch.from_numpy(g["boxes"]).to(_dev()), torch.from_numpy(g["scores"]).to(_dev())
+    flame = torch.randn(2, 1000, 413, generator=torch.Generator().manual_seed(int(g["flame_seed"]))).to(_dev())
+    for tag, conf in (("c50", 0.5), ("c02", 0.02), ("c999", 0.999)):
+        ob, os_, of = nms(boxes, scores, flame, confidence_threshold=conf)
+        assert np.array_equal(ob.cpu().numpy(), g[f"{tag}_boxes"]) and np.array_equal(os_.cpu().numpy(), g[f"{tag}_scores"])
+        np.testing.assert_allclose(of.sum(1).cpu().numpy(), g[f"{tag}_flame_rowsum"], rtol=1e-5)
+
+
+def test_nms_exact_threshold_and_degenerate(gpu_lib):
+    from head_detector_amd.utils import nms_batched
+
+    b = torch.tensor([[[0, 0, 2, 2], [0, 0, 2, 1], [0, 0, 0, 0], [0, 0, 0, 0], [5, 5, 6, 6]]], dtype=torch.float32)
+    s = torch.tensor([[[0.9], [0.8], [0.7], [0.6], [0.55]]])
+    f = torch.zeros(1, 5, 413)
+    _, os_, _, counts = nms_batched(b.to(_dev()), s.to(_dev()), f.to(_dev()), 0.5, 0.5)
+    assert int(counts[0]) == 5  # IoU exactly 0.5 is NOT suppressed (strict >); 0/0 = nan -> kept
+    _, _, _, counts = nms_batched(b.to(_dev()), s.to(_dev()), f.to(_dev()), 0.5, 0.49)
+    assert int(counts[0]) == 4
+
+
+# ======================================================================================================
+# head decode (K6) + candidate gather (K6b)
+# ======================================================================================================
+@pytest.mark.parametrize("S_c,E_c", [(128, 64), (64, 32)])
+def test_head_decode_and_gather_vs_oracle(gpu_lib, S_c, E_c):
+    from head_detector_amd import _lib
+    from oracle import postproc_oracle as po
+
+    torch.manual_seed(S_c)
+    B, sizes, strides = 2, [(20, 20), (10, 10), (5, 5)], (8, 16, 32)
+    pitch = 69 + S_c + E_c + 13 + 3
+    preds, olevels = [], []
+    for h, w in sizes:
+        t = torch.randn(B, h, w, pitch) * 1.5
+        preds.append(t)
+        nchw = t.permute(0, 3, 1, 2)
+        o = 69
+        fl = po.assemble_flame_channels(nchw[:, o : o + S_c], nchw[:, o + S_c : o + S_c + E_c], nchw[:, o + S_c + E_c : o + S_c + E_c + 6],
+                                        nchw[:, o + S_c + E_c + 6 : o + S_c + E_c + 9], nchw[:, o + S_c + E_c + 9 : o + S_c + E_c + 12],
+                                        nchw[:, o + S_c + E_c + 12 : o + S_c + E_c + 13])
+        olevels.append((nchw[:, :68], nchw[:, 68:69], fl))
+    rb, rs, rf = po.ndfl_decode(olevels, strides)
+    A = rb.shape[1]
+    dp = [t.to(_dev()).contiguous() for t in preds]
+    lv = (_lib.HeadLevel * 3)(*[_lib.HeadLevel(dp[i].data_ptr(), sizes[i][0], sizes[i][1], pitch, strides[i]) for i in range(3)])
+    boxes = torch.empty(B, A, 4, device=_dev())
+    scores = torch.empty(B, A, device=_dev())
+    _lib.check(gpu_lib.vgh_head_decode(lv, 3, B, _lib.ptr(boxes), _lib.ptr(scores), _sp()))
+    assert (boxes.cpu() - rb).abs().max() < 2e-4  # px; IoU >= 0.999 needs ~1e-2 px on a 20 px box
+    assert (scores.cpu() - rs[..., 0]).abs().max() < 2e-6
+    k = 100
+    bb, ss, ff, idx = po.decoding_topk(rb, rs, rf, k)
+    didx = idx.to(torch.int32).to(_dev())
+    ob = torch.empty(B, k, 4, device=_dev())
+    of = torch.empty(B, k, 413, device=_dev())
+    _lib.check(gpu_lib.vgh_gather_candidates(lv, 3, B, A, S_c, E_c, _lib.ptr(boxes), _lib.ptr(didx), k, _lib.ptr(ob), _lib.ptr(of), _sp()))
+    assert (ob.cpu() - bb).abs().max() < 2e-4
+    d = (of.cpu() - ff).abs() / (ff.abs() + 1.0)
+    assert d.max() < 1e-5, d.max()  # north_star: FLAME params within 1e-4
+    assert float(of[..., S_c:300].abs().max()) == 0.0 and float(of[..., 300 + E_c : 400].abs().max()) == 0.0
+
+
+# ======================================================================================================
+# implicit-GEMM conv (K2/K3/K4), per configuration
+# ======================================================================================================
+def _run_conv(lib, x, W, b, k, stride, act=1, res=None, alpha=0.0, split=None, out_f32=False, shuffle=False, cfg=-1, cout_store=None, in_coff=0, in_pitch=None):
+    """x [B,H,W,Cin] float (bf16-representable); W [rows,k,k,Cin] float; returns engine output + torch reference."""
+    from head_detector_amd import _lib
+
+    B, H, Wd, Cin = x.shape
+    rows = W.shape[0]
+    rp = (rows + 31) // 32 * 32
+    Wp = torch.zeros(rp, k, k, Cin)
+    Wp[:rows] = W
+    bp = torch.zeros(rp)
+    bp[:rows] = b
+    pack = np.zeros(Wp.numel(), dtype=np.uint16)
+    w_np = np.ascontiguousarray(Wp.numpy())
+    _lib.check(lib.vgh_pack_conv_weights(_lib.ptr(w_np), rp, k, Cin, _lib.ptr(pack)))
+    d_pack = torch.from_numpy(pack.view(np.int16)).to(_dev())
+    d_bias = bp.to(_dev())
+    in_pitch = in_pitch or (Cin + in_coff)
+    xin = torch.zeros(B, H, Wd, in_pitch)
+    xin[..., in_coff : in_coff + Cin] = x
+    d_x = xin.to(torch.bfloat16).to(_dev()).contiguous()
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (Wd + 2 * (k // 2) - k) // stride + 1
+    store = cout_store if cout_store is not None else rows
+    oc = rp // 4 if shuffle else rp
+    oh, ow = (2 * Ho, 2 * Wo) if shuffle else (Ho, Wo)
+    out_pitch = oc + 8
+    d_out = torch.full((B, oh, ow, out_pitch), -768.0, dtype=torch.float32 if out_f32 else torch.bfloat16, device=_dev())
+    d_res = res.to(torch.bfloat16).to(_dev()).contiguous() if res is not None else None
+    call = _lib.ConvCall(
+        in_dev=d_x.data_ptr(), in_pitch=in_pitch, in_coff=in_coff, cin=Cin, B=B, H=H, W=Wd, wpack_dev=d_pack.data_ptr(), bias_dev=d_bias.data_ptr(),
+        out_dev=d_out.data_ptr(), out_pitch=out_pitch, out_coff=4 if not split else split[1], cout_pad=rp, cout_store=store,
+        out_split=rp if not split else split[0], out_coff2=0 if not split else split[2], out_f32=int(out_f32),
+        res_dev=d_res.data_ptr() if d_res is not None else None, res_pitch=d_res.shape[-1] if d_res is not None else 0, res_coff=0, alpha=alpha,
+        ksize=k, stride=stride, act=act, shuffle=int(shuffle), force_cfg=cfg,
+    )
+    _lib.check(lib.vgh_conv2d(C.byref(call), _sp()))
+    torch.cuda.synchronize()
+    # reference: fp32 conv on the bf16-rounded operands
+    xr = x.to(torch.bfloat16).float().permute(0, 3, 1, 2)
+    wr = Wp.to(torch.bfloat16).float().permute(0, 3, 1, 2)
+    y = F.conv2d(xr, wr, None, stride=stride, padding=k // 2) + bp[None, :, None, None]
+    if act == 1:
+        y = torch.relu(y)
+    y = y.permute(0, 2, 3, 1)
+    if shuffle:
+        Cc = rp // 4
+        z = torch.zeros(B, oh, ow, Cc)
+        for d in range(4):
+            z[:, d // 2 :: 2, d % 2 :: 2] = y[..., d * Cc : (d + 1) * Cc]
+        y = z
+    if res is not None:
+        y = y + alpha * res.to(torch.bfloat16).float()[..., : y.shape[-1]]
+    return d_out.float().cpu(), y, store
+
+
+def _assert_close(out, ref, out_f32, where):
+    if out_f32:
+        tol = 2e-3 + 1e-4 * ref.abs()
+    else:
+        tol = 1e-2 + 1.0 / 128 * ref.abs()  # one bf16 ulp (2^-8 relative) + accumulation-order slack
+    bad = (out - ref).abs() > tol
+    if bad.any():
+        idx = bad.nonzero()
+        pix = (idx[:, 1] * ref.shape[2] + idx[:, 2]) % 32
+        raise AssertionError(f"{where}: {int(bad.sum())}/{bad.numel()} mismatches; max err {float((out - ref).abs().max()):.4f}; "
+                             f"first {idx[:5].tolist()}; pixel%32 hist {torch.bincount(pix, minlength=32).tolist()}; "
+                             f"chan%32 hist {torch.bincount(idx[:, 3] % 32, minlength=32).tolist()}")
+
+
+CONV_CASES = [
+    # (B, H, W, Cin, Cout, k, stride)
+    (1, 16, 16, 32, 32, 1, 1),
+    (2, 20, 20, 64, 64, 3, 1),
+    (1, 24, 24, 96, 96, 3, 1),
+    (2, 40, 40, 64, 128, 3, 2),
+    (1, 32, 32, 128, 256, 3, 1),
+    (3, 20, 20, 192, 192, 1, 1),
+    (1, 33, 17, 64, 96, 3, 2),  # odd sizes, ragged tiles
+    (1, 8, 8, 768, 384, 1, 1),
+    (1, 5, 5, 32, 13, 1, 1),  # tiny cout (prediction conv)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_all_configs_vs_torch(gpu_lib, case):
+    B, H, W, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).float()
+    Wt = torch.randn(Cout, k, k, Cin, generator=g) * (1.5 / np.sqrt(k * k * Cin))
+    # asymmetric structure so that a transposed / permuted fragment layout cannot pass
+    Wt = Wt * (1.0 + 0.5 * torch.arange(Cout).float()[:, None, None, None] / Cout)
+    b = torch.randn(Cout, generator=g)
+    rp = (Cout + 31) // 32 * 32
+    ncfg = gpu_lib.vgh_conv_num_cfgs()
+    tested = 0
+    for cfg in [-1] + list(range(ncfg)):
+        if cfg >= 0:
+            name = gpu_lib.vgh_conv_cfg_name(cfg).decode()
+            bc = int(name.split("_")[0].split("x")[1])
+            if rp % bc:
+                continue
+        store = Cout if Cout % 4 == 0 else None
+        out_f32 = Cout % 4 != 0
+        out, ref, st = _run_conv(gpu_lib, x, Wt, b, k, stride, cfg=cfg, out_f32=out_f32)
+        _assert_close(out[..., 4 : 4 + st], ref[..., :st], out_f32, f"{case} cfg={cfg}")
+        assert float((out[..., :4] + 768.0).abs().max()) == 0.0, "wrote outside its channel range"
+        assert float((out[..., 4 + st :] + 768.0).abs().max()) < 1.0, "wrote past cout_store"
+        tested += 1
+    assert tested >= 2
+
+
+def test_conv_epilogues(gpu_lib):
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 2, 12, 12, 64, 128
+    x = torch.randn(B, H, W, Cin, generator=g)
+    Wt = torch.randn(Cout, 3, 3, Cin, generator=g) * 0.06
+    b = torch.randn(Cout, generator=g)
+    # residual added AFTER the activation (YoloNASBottleneck)
+    res = torch.randn(B, H, W, Cout, generator=g)
+    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, res=res, alpha=0.7)
+    _assert_close(out[..., 4 : 4 + st], ref, False, "residual")
+    # no activation
+    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, act=0)
+    _assert_close(out[..., 4 : 4 + st], ref, False, "act none")
+    assert float(ref.min()) < -0.5 and float(out[..., 4 : 4 + st].min()) < -0.5
+    # two-segment output (CSP conv1|conv2): first 64 rows at offset 72, the rest at offset 0
+    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, split=(64, 72, 0))
+    _assert_close(out[..., 72:136], ref[..., :64], False, "split seg0")
+    _assert_close(out[..., 0:64], ref[..., 64:128], False, "split seg1")
+    # fp32 output with a ragged channel count (prediction convs): 69 channels
+    W69 = torch.randn(69, 1, 1, Cin, generator=g) * 0.1
+    out, ref, st = _run_conv(gpu_lib, x, W69, torch.randn(69, generator=g), 1, 1, act=0, out_f32=True)
+    _assert_close(out[..., 4 : 4 + 69], ref[..., :69], True, "f32 out")
+    assert float((out[..., 4 + 69 :] + 768.0).abs().max()) == 0.0
+    # input view at a channel offset inside a wider (concat) buffer
+    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, in_coff=32, in_pitch=160)
+    _assert_close(out[..., 4 : 4 + st], ref, False, "in_coff")
+    # ConvTranspose2d(k=2, s=2) as 4 pointwise GEMMs + pixel-shuffle store, checked against torch's own op
+    Ct = 96
+    xt = torch.randn(B, H, W, Ct, generator=g).to(torch.bfloat16).float()
+    Wct = (torch.randn(Ct, Ct, 2, 2, generator=g) * 0.1).to(torch.bfloat16).float()
+    bt = torch.randn(Ct, generator=g)
+    Wg = torch.zeros(4 * Ct, 1, 1, Ct)
+    for dy in range(2):
+        for dx in range(2):
+            Wg[(dy * 2 + dx) * Ct : (dy * 2 + dx + 1) * Ct, 0, 0] = Wct[:, :, dy, dx].T
+    out, ref, st = _run_conv(gpu_lib, xt, Wg, bt.repeat(4), 1, 1, act=0, shuffle=True)
+    tref = F.conv_transpose2d(xt.permute(0, 3, 1, 2), Wct, bt, stride=2).permute(0, 2, 3, 1)
+    assert (ref - tref).abs().max() < 1e-4
+    _assert_close(out[..., 4 : 4 + Ct], tref, False, "convT shuffle")
+
+
+# ======================================================================================================
+# whole network: every op of the engine against the torch executor on the engine's own inputs
+# ======================================================================================================
+@pytest.mark.parametrize("variant,S,B", [("vgg_heads_m", 192, 2), ("vgg_heads_l", 128, 1)])
+def test_network_every_op(gpu_lib, variant, S, B):
+    from head_detector_amd.engine import VGHeadsEngine
+
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=7, use_tuning=False)
+    P = eng.program
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(2))
+    eng.forward_net(x.to(_dev()))
+    got = [eng.buffer(i, B).float().cpu() for i in range(len(P.bufs))]
+    w_all, b_all = P.arrays()
+    worst = []
+    for op in P.ops:
+        ob = op["out_buf"] if op["kind"] != 2 else op["in_buf"]
+        exp = list(got)  # engine's own inputs -> no error accumulation across layers
+        exp[ob] = got[ob].clone()
+        pr.run_op(P, op, exp, x, True, w_all, b_all)
+        is_f32 = bool(P.bufs[ob]["is_f32"])
+        a, e = got[ob], exp[ob]
+        tol = (2e-3 + 1e-4 * e.abs()) if is_f32 else (2e-2 + 1.0 / 128 * e.abs())
+        bad = (a - e).abs() > tol
+        worst.append((float(((a - e).abs() / (e.abs() + 1.0)).max()), op["name"]))
+        assert not bad.any(), f"{variant} S={S} op {op['name']}: {int(bad.sum())} mismatches, max abs err {float((a - e).abs().max())}"
+    eng.close()
+
+
+def test_u8_nhwc_input_equals_f32_nchw(gpu_lib):
+    """The fused /255 (detector.py:51) must reproduce the float path exactly."""
+    from head_detector_amd.engine import VGHeadsEngine
+
+    S = 128
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=1, seed=3, use_tuning=False)
+    u8 = torch.randint(0, 256, (1, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    f = (u8.permute(0, 3, 1, 2).float() / 255.0).contiguous()
+    eng.forward_net(u8.to(_dev()))
+    a = eng.buffer("stem", 1).float().cpu()
+    eng.forward_net(f.to(_dev()))
+    b = eng.buffer("stem", 1).float().cpu()
+    assert torch.equal(a, b)
+    eng.close()
+
+
+def test_end_to_end_vs_fp32_oracle_and_bf16_emulation(gpu_lib, flame_model):
+    """engine.model() against (i) the torch executor with bf16 storage emulation: same candidates / tight tolerances;
+    (ii) the unfused fp32 oracle network: reported deviation of the bf16 throughput mode (loose bound)."""
+    from head_detector_amd import arch
+    from head_detector_amd.engine import VGHeadsEngine
+    from oracle import net_oracle, postproc_oracle as po
+
+    variant, S, B = "vgg_heads_m", 256, 1
+    sd = arch.random_state_dict(variant, 11)
+    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, use_tuning=False)
+    P = eng.program
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(3))
+    boxes, scores, flame = eng.model(x.to(_dev()))
+    assert boxes.shape == (B, 1000, 4) and scores.shape == (B, 1000, 1) and flame.shape == (B, 1000, 413)
+    # (i) bf16-emulating executor -> oracle post-network stages
+    bufs = pr.run_program(P, x, bf16=True)
+    lv = [(reg, cls, po.assemble_flame_channels(raw["shape"], raw["expr"], raw["rot"], raw["jaw"], raw["trans"], raw["scale"])) for reg, cls, raw in pr.head_outputs(P, bufs)]
+    rb, rs, rf = po.ndfl_decode(lv)
+    s_gpu = scores[..., 0].cpu()
+    assert (s_gpu[:, :-1] >= s_gpu[:, 1:]).all(), "candidates must be sorted by descending score"
+    # layer-to-layer bf16 rounding flips make the two nets differ slightly -> compare the dense score field statistically
+    dense = eng.scores_all[:B].cpu()
+    assert (dense - rs[..., 0]).abs().max() < 3e-2
+    # (ii) fp32 unfused oracle
+    oracle = net_oracle.YoloHeadsOracle("m")
+    oracle.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    ob, os_, of = oracle.dense(x)
+    rel = float((eng.boxes_all[:B].cpu() - ob).abs().mean() / ob.abs().mean())
+    print(f"[bf16 vs fp32 oracle] mean rel box err {rel:.4f}, max score err {float((dense - os_[..., 0]).abs().max()):.4f}")
+    assert rel < 5e-2
+    eng.close()
+
+
+def test_detect_pipeline_and_facade(gpu_lib, flame_model):
+    """HeadDetector()(image).heads: API surface, types and the post-network stages against the oracle, given the engine's own
+    network output (the random-weight network's scores are arbitrary, so the threshold is lowered to get detections)."""
+    from head_detector_amd.detector import HeadDetector
+    from head_detector_amd.head_info import Bbox, FlameParams, HeadMetadata, RPY
+    from oracle import flame_oracle as fo
+    from oracle import postproc_oracle as po
+
+    det = HeadDetector("vgg_heads_m", 640, flame_model=flame_model, seed=4)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (480, 600, 3), dtype=np.uint8)  # letterboxed: scale 640/600, pad (0, 64)
+    image, cache = det._preprocess(img)
+    assert image.shape == (1, 640, 640, 3) and cache["padding"] == (0, (640 - int(480 * 640 / 600)) // 2) and abs(cache["scale"] - 640 / 600) < 1e-12
+    b, s, f = det._process(image)
+    conf = float(s[0, 20, 0])  # keep roughly the 20 best candidates before NMS
+    res = det(img, confidence_threshold=conf)
+    assert len(res.heads) >= 1 and all(isinstance(h, HeadMetadata) for h in res.heads)
+    rb, rs, rf = po.nms_reference(b.cpu(), s.cpu(), f.cpu(), confidence_threshold=conf)
+    c32 = fo.FlameConstants(flame_model, torch.float32)
+    xywh, verts, pout = fo.parse_predictions(c32, rb.numpy(), rf, cache["padding"], cache["scale"])
+    assert len(res.heads) == rb.shape[0]
+    for i, h in enumerate(res.heads):
+        assert isinstance(h.bbox, Bbox) and isinstance(h.head_pose, RPY) and isinstance(h.flame_params, FlameParams)
+        assert (h.bbox.x, h.bbox.y, h.bbox.w, h.bbox.h) == tuple(int(v) for v in xywh[i])
+        assert h.vertices_3d.shape == (5023, 3) and h.vertices_3d.dtype == np.float32
+        assert (np.abs(h.vertices_3d - verts[i]) / (np.abs(verts[i]) + 1.0)).max() < 1e-5
+        assert abs(float(h.score) - float(rs[i])) == 0.0
+        np.testing.assert_allclose(h.flame_params.scale.numpy(), pout[i : i + 1, 412:413].numpy(), rtol=1e-6)
+        np.testing.assert_allclose(h.flame_params.translation.numpy(), rf[i : i + 1, 409:412].numpy())  # NOT un-padded (detector.py:78-79)
+        rpy = fo.calculate_rpy(rf[i, 403:409])
+        np.testing.assert_allclose(np.array(h.head_pose), np.array(rpy), atol=1e-3)
+    # batched twin on the engine: every image, slabs + counts, vertices for every valid head
+    eng = det.model
+    d = eng.detect(image, confidence_threshold=conf, flame=det._flame)
+    assert int(d.counts[0]) == len(res.heads) and d.vertices_3d.shape == (len(res.heads), 5023, 3)
+    assert torch.equal(d.boxes[0, : len(res.heads)].cpu(), rb)
+    # empty result path (detector must not fail when nothing passes the threshold; flame.py:186-189)
+    empty = det(img, confidence_threshold=1.1)
+    assert empty.heads == []

@@ -1,0 +1,160 @@
+"""CPU: host-side logic of the product -- weight folding + lowering to the op program (vs the unfused oracle
+network), API containers, error behaviour, and the C ABI's exported symbol set.  No GPU compute."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import program_ref as pr
+from conftest import ROOT
+from head_detector_amd import _lib, arch
+from head_detector_amd.head_info import FLAME_CONSTS, FlameParams
+from oracle import net_oracle, postproc_oracle as po
+
+
+def _oracle_with(variant, sd):
+    m = net_oracle.YoloHeadsOracle({"vgg_heads_m": "m", "vgg_heads_l": "l"}[variant])
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing[:3], unexpected[:3])
+    return m
+
+
+@pytest.mark.parametrize("variant,gflop", [("vgg_heads_m", 103.7721216), ("vgg_heads_l", 166.6826496)])
+def test_program_flops_match_survey(variant, gflop):
+    sd = arch.random_state_dict(variant, 1)
+    P = arch.build_program(variant, sd, 640)
+    assert abs(P.flops / 1e9 - gflop) < 1e-6  # 51.89 / 83.34 GMAC
+    assert abs(net_oracle.conv_flops(_oracle_with(variant, sd)) - P.flops) < 1.0
+    for op in P.ops:  # structural invariants the kernels rely on
+        if op["kind"] == 1:
+            assert op["cin"] % 32 == 0 and op["cout_pad"] % 32 == 0 and op["in_coff"] % 8 == 0
+            if not P.bufs[op["out_buf"]]["is_f32"]:
+                assert op["out_coff"] % 4 == 0 and op["out_coff2"] % 4 == 0 and op["out_split"] % 4 == 0 and op["cout_store"] % 4 == 0
+
+
+@pytest.mark.parametrize("variant", ["vgg_heads_m", "vgg_heads_l"])
+def test_lowering_reproduces_unfused_oracle(variant):
+    """fold (BN, RepVGG branches, alpha) + sibling fusion + concat-by-offset + pixel-shuffle ConvTranspose, executed in fp32
+    with torch ops, must equal the unfused module graph."""
+    S = 128
+    sd = arch.random_state_dict(variant, 3)
+    P = arch.build_program(variant, sd, S)
+    oracle = _oracle_with(variant, sd)
+    x = torch.rand(2, 3, S, S, generator=torch.Generator().manual_seed(0))
+    bufs = pr.run_program(P, x, bf16=False)
+    ref = oracle.raw_heads(x)
+    for (reg, cls, raw), (oreg, ocls, _, oraw) in zip(pr.head_outputs(P, bufs), ref):
+        for a, b, name in [(reg, oreg, "reg"), (cls, ocls, "cls")] + [(raw[k], oraw[k], k) for k in raw]:
+            scale = float(b.abs().max()) + 1e-6
+            err = float((a - b).abs().max()) / scale
+            assert err < 2e-4, (variant, name, err)
+    # padded channels must be exact zeros (they are K-padding of downstream convs)
+    stem = bufs[0]
+    assert float(stem[..., 48:].abs().max()) == 0.0
+
+
+def test_u8_input_equals_float_input_in_program_ref():
+    S = 64
+    sd = arch.random_state_dict("vgg_heads_m", 5)
+    P = arch.build_program("vgg_heads_m", sd, S)
+    u8 = torch.randint(0, 256, (1, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    f = u8.permute(0, 3, 1, 2).float() / 255.0  # detector.py:51
+    a = pr.alloc(P, 1)
+    b = pr.alloc(P, 1)
+    pr.run_op(P, P.ops[0], a, u8, False)
+    pr.run_op(P, P.ops[0], b, f, False)
+    assert torch.equal(a[0], b[0])
+
+
+def test_fold_rejects_bad_state_dict():
+    sd = arch.random_state_dict("vgg_heads_m", 1)
+    bad = dict(sd)
+    bad.pop("backbone.stage1.downsample.post_bn.weight")
+    with pytest.raises(KeyError):
+        arch.fold_state_dict("vgg_heads_m", bad)
+    bad = dict(sd)
+    bad["heads.head1.reg_pred.weight"] = np.zeros((68, 7, 1, 1), np.float32)
+    with pytest.raises(ValueError):
+        arch.fold_state_dict("vgg_heads_m", bad)
+
+
+def test_flame_params_container_matches_reference_layout():
+    from conftest import golden
+
+    g = golden("layout.npz")
+    x = torch.arange(413, dtype=torch.float32)[None]
+    fp = FlameParams.from_3dmm(x)
+    for k in ("shape", "expression", "jaw", "rotation", "eyeballs", "neck", "translation", "scale"):
+        assert np.array_equal(getattr(fp, k).numpy().astype(np.int32)[0], g[f"read_{k}"])
+    assert np.array_equal(fp.to_3dmm_tensor().numpy().astype(np.int32)[0], g["perm"])
+    assert sum(FLAME_CONSTS.values()) == 413
+    with pytest.raises(ValueError, match="Invalid number of parameters. Expected: 413. Got: 412."):
+        FlameParams.from_3dmm(torch.zeros(1, 412))
+    z = FlameParams.from_3dmm(torch.ones(2, 413), zero_expr=True)
+    assert float(z.expression.abs().sum()) == 0.0 and z.shape.shape == (2, 300)
+
+
+def test_host_rotation_helpers_match_reference():
+    from conftest import golden
+    from head_detector_amd.utils import calculate_rpy, limit_angle, rot_mat_from_6dof
+
+    g = golden("rotation.npz")
+    np.testing.assert_allclose(rot_mat_from_6dof(torch.from_numpy(g["v6"])).numpy(), g["R"], atol=1e-6)
+    np.testing.assert_allclose([limit_angle(a) for a in g["lim_in"]], g["lim_out"])
+    for i in range(1, 16):
+        p = FlameParams.from_3dmm(torch.zeros(1, 413))
+        p.rotation = torch.from_numpy(g["v6"][i : i + 1])
+        np.testing.assert_allclose(np.array(calculate_rpy(p)), g["rpy"][i], atol=1e-3)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The drop-in boundary: libvgh.so loads without a GPU and exports exactly what include/vgh.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "vgh.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vgh_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vgh_version().startswith(b"vgh")
+    assert lib.vgh_conv_num_cfgs() >= 4 and lib.vgh_conv_cfg_name(0)
+    # host-only entry point: weight packing is a pure permutation + bf16 rounding of the dense weights
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((64, 3, 3, 32)).astype(np.float32)
+    out = np.zeros(w.size, dtype=np.uint16)
+    assert lib.vgh_pack_conv_weights(_lib.ptr(w), 64, 3, 32, _lib.ptr(out)) == 0
+    ref = torch.from_numpy(w).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert sorted(out.tolist()) == sorted(ref.reshape(-1).tolist())
+    img = out.reshape(9, 64, 4, 8)  # [kb][cout][slot][8], slot = chunk ^ ((cout>>2)&3)
+    for co in (0, 5, 13, 63):
+        for chunk in range(4):
+            assert np.array_equal(img[4, co, chunk ^ ((co >> 2) & 3)], ref[co, 1, 1, chunk * 8 : chunk * 8 + 8])
+    assert lib.vgh_pack_conv_weights(_lib.ptr(w), 64, 3, 31, _lib.ptr(out)) != 0 and b"multiples of 32" in lib.vgh_last_error()
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from head_detector_amd.detector import HeadDetector
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+    from head_detector_amd.utils import nms
+
+    with pytest.raises(_lib.VghError):
+        HeadDetector()
+    with pytest.raises(_lib.VghError):
+        VGHeadsEngine("vgg_heads_m")
+    with pytest.raises(_lib.VghError):
+        nms(torch.zeros(1, 4, 4), torch.zeros(1, 4, 1), torch.zeros(1, 4, 413))
+    with pytest.raises(FileNotFoundError):
+        FLAMELayer()  # generic_model.pkl is a user-supplied asset (flame.py:18-24)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "head_detector_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn

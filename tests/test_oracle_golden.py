@@ -1,0 +1,154 @@
+"""CPU: pin the oracle (oracle/) against vectors produced by running the reference's own Python
+(tests/golden/make_golden.py) and against the reference's only known-answer fixture (tests/1.json)."""
+import numpy as np
+import torch
+
+from conftest import golden
+from oracle import flame_oracle as fo
+from oracle import postproc_oracle as po
+
+
+def test_param_layout_matches_reference():
+    g = golden("layout.npz")
+    x = torch.arange(413, dtype=torch.float32)[None]
+    d = fo.split_3dmm(x)
+    for k in ("shape", "expression", "jaw", "rotation", "eyeballs", "neck", "translation", "scale"):
+        assert np.array_equal(d[k].numpy().astype(np.int32)[0], g[f"read_{k}"]), k
+    perm = fo.join_3dmm(d).numpy().astype(np.int32)[0]
+    assert np.array_equal(perm, g["perm"])
+    # SURVEY.md 8a row a6': perm = [0..399, 403..408, 400..402, 409..412]
+    assert np.array_equal(perm, np.r_[0:400, 403:409, 400:403, 409:413])
+    assert bool(g["raised"])
+    try:
+        fo.split_3dmm(torch.zeros(1, 412))
+        assert False, "must raise on a wrong width (head_info.py:51-52)"
+    except ValueError:
+        pass
+
+
+def test_rotation_helpers_match_reference():
+    g = golden("rotation.npz")
+    v6 = torch.from_numpy(g["v6"])
+    R = fo.rot_mat_from_6dof(v6).numpy()
+    np.testing.assert_allclose(R, g["R"], atol=1e-6)
+    # proper rotations
+    np.testing.assert_allclose(np.einsum("nij,nkj->nik", R, R), np.broadcast_to(np.eye(3), R.shape), atol=1e-5)
+    for i in range(1, 16):  # row 0 is the gimbal-lock case scipy warns about
+        np.testing.assert_allclose(np.array(fo.calculate_rpy(v6[i])), g["rpy"][i], atol=1e-3)
+    np.testing.assert_allclose([fo.limit_angle(a) for a in g["lim_in"]], g["lim_out"])
+
+
+def test_flame_decode_matches_reference_glue(flame_model):
+    g = golden("flame_decode.npz")
+    params = torch.from_numpy(g["params"])
+    c32 = fo.FlameConstants(flame_model, torch.float32)
+    v, R, p = fo.reproject(c32, params)
+    np.testing.assert_allclose(v.numpy(), g["vertices"], atol=2e-6)
+    np.testing.assert_allclose(R.numpy(), g["R"], atol=1e-6)
+    np.testing.assert_allclose(p.numpy(), g["projected"], rtol=1e-5, atol=1e-3)
+    fp = fo.split_3dmm(params)
+    np.testing.assert_allclose(fo.flame_forward(c32, fp, zero_rot=False).numpy(), g["forward_rot"], atol=2e-6)
+    np.testing.assert_allclose(fo.flame_forward(c32, fp, zero_rot=True, zero_jaw=True).numpy(), g["forward_zero_jaw"], atol=2e-6)
+    ev, eR, ep = fo.reproject(c32, torch.zeros(0, 413))
+    assert [list(ev.shape), list(eR.shape), list(ep.shape)] == g["empty_shapes"].tolist()
+    # float64 arbiter agrees with the float32 reference path to fp32 round-off
+    c64 = fo.FlameConstants(flame_model, torch.float64)
+    v64, _, p64 = fo.reproject(c64, params.double())
+    assert (v64 - v.double()).abs().max() < 5e-6
+    rel = ((p64 - p.double()).abs() / (p64.abs() + 1.0)).max()
+    assert rel < 1e-5
+    # scale clamp case (flame.py:198): row 2 has scale 1e-9 -> clamped to 1e-8
+    assert abs(float(params[2, 412]) - 1e-9) < 1e-12
+    np.testing.assert_allclose(p[2].numpy(), (torch.matmul(R[2], v[2].T).T * 1e-8 + params[2, 409:412]).numpy(), rtol=1e-5, atol=1e-3)
+
+
+def test_jaw_only_pose_collapses_to_one_joint(flame_model):
+    """with global = neck = eyes = 0 the general lbs equals a single-joint closed form."""
+    c = fo.FlameConstants(flame_model, torch.float64)
+    params = fo.synthetic_params(3, seed=9, dtype=torch.float64)
+    fp = fo.split_3dmm(params)
+    v = fo.flame_forward(c, fp, zero_rot=True)
+    betas = torch.cat([fp["shape"], fp["expression"]], 1)
+    v_shaped = c.v_template[None] + torch.einsum("bl,mkl->bmk", betas, c.shapedirs)
+    J = torch.einsum("bik,ji->bjk", v_shaped, c.J_regressor)
+    Rj = fo.batch_rodrigues(fp["jaw"])
+    pf = torch.zeros(3, 36, dtype=torch.float64)
+    pf[:, 9:18] = (Rj - torch.eye(3, dtype=torch.float64)).reshape(3, 9)
+    v_posed = v_shaped + (pf @ c.posedirs).view(3, -1, 3)
+    w = c.lbs_weights[:, 2][None, :, None]
+    Jj = J[:, 2][:, None]
+    closed = v_posed + w * (torch.einsum("bij,bvj->bvi", Rj, v_posed - Jj) + Jj - v_posed)
+    closed[:, :, 2] += 0.05
+    assert (closed - v).abs().max() < 1e-12
+
+
+def test_nms_glue_matches_reference():
+    g = golden("nms_glue.npz")
+    boxes, scores = torch.from_numpy(g["boxes"]), torch.from_numpy(g["scores"])
+    flame = torch.randn(2, 1000, 413, generator=torch.Generator().manual_seed(int(g["flame_seed"])))
+    for tag, conf in (("c50", 0.5), ("c02", 0.02), ("c999", 0.999)):
+        ob, os_, of = po.nms_reference(boxes, scores, flame, confidence_threshold=conf)
+        assert np.array_equal(ob.numpy(), g[f"{tag}_boxes"]), tag
+        assert np.array_equal(os_.numpy(), g[f"{tag}_scores"]), tag
+        np.testing.assert_allclose(of.sum(1).numpy(), g[f"{tag}_flame_rowsum"], rtol=1e-6)
+    assert g["c50_boxes"].shape[0] >= 1 and g["c999_boxes"].shape[0] == 0 and g["c02_boxes"].shape[0] == 100
+    # the batched twin returns one result per image and agrees with nms() on image 0
+    res = po.postprocess_batched(boxes, scores, flame, 0.5, 0.5)
+    assert len(res) == 2 and np.array_equal(res[0][0].numpy(), g["c50_boxes"])
+
+
+def test_nms_torchvision_semantics():
+    # strict '>' on IoU: two boxes with IoU exactly 0.5 both survive at thr 0.5
+    b = np.array([[0, 0, 2, 1], [1, 0, 3, 1], [0, 0, 2, 1.0001]], dtype=np.float32)  # IoU(0,1) = 1/3; IoU(0,2) ~ 1
+    keep = po.nms_torchvision(b, np.array([0.9, 0.8, 0.7], np.float32), 0.5)
+    assert keep.tolist() == [0, 1]
+    b2 = np.array([[0, 0, 2, 2], [0, 0, 2, 1]], dtype=np.float32)  # IoU exactly 0.5
+    assert po.nms_torchvision(b2, np.array([0.9, 0.8], np.float32), 0.5).tolist() == [0, 1]
+    assert po.nms_torchvision(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5).tolist() == []
+    # degenerate zero-area boxes: 0/0 = nan -> comparison false -> kept (CPU kernel behaviour)
+    z = np.zeros((2, 4), np.float32)
+    assert po.nms_torchvision(z, np.array([0.9, 0.8], np.float32), 0.5).tolist() == [0, 1]
+
+
+def test_fixture_1json_pins_layout_and_rigid_stage():
+    """The reference's only numeric fixture (yolo_head_training/tests/1.json). Without the licensed FLAME pickle it pins:
+    (i) which 6 of the 413 numbers are the rotation (from_3dmm layout, not the to_3dmm one), and
+    (ii) rot_mat_from_6dof + the rigid stage: R^T * 3d_vertices - 0.05 z is the un-posed mesh, which must sit within a few mm of
+    v_template (blendshape offsets are mm-scale), and
+    (iii) the DAD-style projection of dataset_parsing.py:183-188 reproduces projected_vertices from 3d_vertices."""
+    g = golden("fixture_1json.npz")
+    vt = golden("flame_decode.npz")["v_template"].astype(np.float64)
+    p = torch.from_numpy(g["params"])[None]
+    v3 = g["vertices_3d"].astype(np.float64)
+    fp = fo.split_3dmm(p)
+    R = fo.rot_mat_from_6dof(fp["rotation"]).numpy()[0]
+    unposed = v3 @ R - np.array([0, 0, 0.05])  # R^T v
+    err_read = np.abs(unposed - vt).mean()
+    R_wrong = fo.rot_mat_from_6dof(p[:, 400:406]).numpy()[0]  # to_3dmm layout would put rotation first
+    err_wrong = np.abs(v3 @ R_wrong - np.array([0, 0, 0.05]) - vt).mean()
+    assert err_read < 5e-3 and err_wrong > 10 * err_read, (err_read, err_wrong)
+    s, t = float(fp["scale"][0, 0]), fp["translation"][0].numpy()
+    proj = ((v3 * (s + 1.0) + np.array([t[0], t[1], 0.0])) + 1.0) / 2.0 * 256.0
+    assert np.abs(proj[:, :2] - g["projected_vertices"]).max() < 1e-3
+
+
+def test_ndfl_decode_anchor_order_and_permutation():
+    torch.manual_seed(0)
+    B = 2
+    levels = []
+    for s in (4, 2, 1):
+        levels.append((torch.randn(B, 68, s, s), torch.randn(B, 1, s, s), torch.randn(B, 413, s, s)))
+    boxes, scores, flame = po.ndfl_decode(levels, strides=(8, 16, 32))
+    A = 16 + 4 + 1
+    assert boxes.shape == (B, A, 4) and scores.shape == (B, A, 1) and flame.shape == (B, A, 413)
+    # anchor 5 of level 0 = (y=1, x=1): centre (1.5, 1.5) * 8
+    reg = levels[0][0][0, :, 1, 1].view(4, 17)
+    d = (torch.softmax(reg, 1) * torch.arange(17.0)).sum(1)
+    exp = torch.stack([1.5 - d[0], 1.5 - d[1], 1.5 + d[2], 1.5 + d[3]]) * 8
+    assert torch.allclose(boxes[0, 5], exp, atol=1e-5)
+    O = levels[0][2][0, :, 1, 1]
+    T = flame[0, 5]
+    assert torch.equal(T[:400], O[:400]) and torch.equal(T[400:406], O[403:409]) and torch.equal(T[406:409], O[400:403])
+    assert torch.allclose(T[409:411], O[409:411] + 12.0) and T[411] == O[411] and torch.allclose(T[412], O[412] * 8)
+    # level 2 single anchor index 20: stride 32 centre 16
+    assert torch.allclose(flame[1, 20, 409:411], levels[2][2][1, 409:411, 0, 0] + 16.0)
