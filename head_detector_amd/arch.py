@@ -13,6 +13,7 @@ prediction convs), residual-add and ConvTranspose pixel-shuffle in the conv epil
 from __future__ import annotations
 
 import math
+import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -170,6 +171,11 @@ def random_state_dict(variant: str, seed: int = 1) -> Dict[str, np.ndarray]:
     # keep scores in a useful range: the cls bias prior of YoloHeadsDFLHead._initialize_biases (yolo_head_dfl_head.py:188-190)
     for lv in range(3):
         sd[f"heads.head{lv + 1}.cls_pred.bias"][:] = -math.log((1 - 1e-2) / 1e-2)
+        sd[f"heads.head{lv + 1}.cls_pred.weight"] *= np.float32(0.02)  # un-saturated sigmoid: scores spread around the 1e-2 prior
+        # random features are O(1..10): keep the raw FLAME predictions in a sane range (scale = exp(x)/0.05 must stay finite)
+        for k in list(sd):
+            if re.fullmatch(rf"heads\.head{lv + 1}\.flame_(scale|translation|rotation|jaw)_pred\.\d+\.(weight|bias)", k):
+                sd[k] = (sd[k] * 0.05).astype(np.float32)
     return sd
 
 
@@ -334,23 +340,21 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     x_real = 48
 
     def csp(p: str, xin: View, cin_real: int, out: View, n: int, hid: int, ci: bool, res_px: int):
-        """YoloNASCSPLayer. Buffer layout: ci -> [x1_0 | b_1 .. b_n | x2]; else [b_n | x2 | scratch A | scratch B]."""
+        """YoloNASCSPLayer. One buffer holds every tensor of the layer, each written exactly once:
+        ci -> [x1_0 | b_1 .. b_n | x2] (conv3 reads all of it); else [b_n | x2 | x1_0 | b_1 .. b_{n-1}] (conv3 reads the first two)."""
         assert hid % 32 == 0
         slots = (n + 2) if ci else 2
-        cat = P.buf(f"{p}.cat", res_px, res_px, hid * slots + (0 if ci else 2 * hid))
-        mid = P.buf(f"{p}.mid", res_px, res_px, hid)
+        cat = P.buf(f"{p}.cat", res_px, res_px, hid * (n + 2))
         w1, b1 = F[f"{p}.conv1"]
         w2, b2 = F[f"{p}.conv2"]
         Wf, bf, _ = _stack([(_ohwi(w1, xin.c), b1), (_ohwi(w2, xin.c), b2)])
-        x2_off = hid * (slots - 1)
-        x1_off = 0 if ci else hid * 2  # scratch A
+        x2_off = hid * (n + 1) if ci else hid
+        x1_off = 0 if ci else hid * 2
         P.conv(f"{p}.conv1|conv2", xin, View(cat, x1_off, hid), Wf, bf, 1, split=(hid, x2_off), flops_macs=2 * hid * cin_real)
         prev = x1_off
         for i in range(n):
-            if ci:
-                dst = hid * (i + 1)
-            else:
-                dst = 0 if i == n - 1 else (hid * 3 if prev == hid * 2 else hid * 2)
+            dst = hid * (i + 1) if ci else (0 if i == n - 1 else hid * (3 + i))
+            mid = P.buf(f"{p}.mid{i}", res_px, res_px, hid)
             wa, ba = F[f"{p}.bottlenecks.{i}.cv1"]
             wb, bb = F[f"{p}.bottlenecks.{i}.cv2"]
             alpha = F[f"{p}.bottlenecks.{i}.alpha"][0]

@@ -42,7 +42,7 @@ def test_flame_decode_matches_reference_vectors(flame_layer):
     assert np.abs(v.cpu().numpy() - g["vertices"]).max() < 1e-5
     assert np.abs(R.cpu().numpy() - g["R"]).max() < 1e-5
     pg = g["projected"]
-    assert (np.abs(p.cpu().numpy() - pg) / (np.abs(pg) + 1.0)).max() < 1e-5  # pixel-space values up to ~700: relative
+    assert np.abs(p.cpu().numpy() - pg).max() < 1e-6 * max(1000.0, np.abs(pg).max())  # pixel space: a few fp32 ulps of the largest coordinate
     _, _, p2 = reproject_spatial_vertices(flame_layer, params, to_2d=True)
     assert p2.shape == (5, 5023, 2) and torch.equal(p2, p[..., :2])
     ev, eR, ep = reproject_spatial_vertices(flame_layer, torch.zeros(0, 413, device=_dev()), to_2d=False)
@@ -68,7 +68,8 @@ def test_flame_decode_vs_oracle_f64(flame_layer, flame_model, n):
     q64 = p64.clone()
     q64[:, :, 0] -= 80.0
     q64 = q64 / 0.625  # detector.py:67-69
-    assert ((p.cpu().double() - q64).abs() / (q64.abs() + 1.0)).max() < 2e-6
+    # pixel space (|coords| up to ~1600): a few fp32 ulps of the largest coordinate; metric space is checked at 2e-6 m above
+    assert (p.cpu().double() - q64).abs().max() < 1e-6 * max(1000.0, float(q64.abs().max()))
     # structural-zero skipping is bit-exact when the skipped coefficients are exactly zero
     v2, _, p2 = flame_layer.decode(params.to(_dev()), unpad=unpad.to(_dev()), shape_live=128, expr_live=64)
     assert torch.equal(v, v2) and torch.equal(p, p2)
@@ -461,7 +462,8 @@ def test_detect_pipeline_and_facade(gpu_lib, flame_model):
         assert isinstance(h.bbox, Bbox) and isinstance(h.head_pose, RPY) and isinstance(h.flame_params, FlameParams)
         assert (h.bbox.x, h.bbox.y, h.bbox.w, h.bbox.h) == tuple(int(v) for v in xywh[i])
         assert h.vertices_3d.shape == (5023, 3) and h.vertices_3d.dtype == np.float32
-        assert (np.abs(h.vertices_3d - verts[i]) / (np.abs(verts[i]) + 1.0)).max() < 1e-5
+        assert np.isfinite(verts[i]).all() and np.isfinite(h.vertices_3d).all()
+        assert np.abs(h.vertices_3d - verts[i]).max() < 2e-6 * max(1000.0, float(np.abs(verts[i]).max()))
         assert abs(float(h.score) - float(rs[i])) == 0.0
         np.testing.assert_allclose(h.flame_params.scale.numpy(), pout[i : i + 1, 412:413].numpy(), rtol=1e-6)
         np.testing.assert_allclose(h.flame_params.translation.numpy(), rf[i : i + 1, 409:412].numpy())  # NOT un-padded (detector.py:78-79)

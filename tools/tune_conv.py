@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Measure every conv tile configuration on every distinct conv shape of a network (per-op HIP events through
+vgh_net_profile) and write the winners to head_detector_amd/tuning/conv_cfg.json (merged with what is there).
+Run on the GPU box:  python tools/tune_conv.py --variant vgg_heads_m --batch 32 [--reps 5]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from head_detector_amd.engine import TUNING_DIR, VGHeadsEngine, tuning_key  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="vgg_heads_m")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--image-size", type=int, default=640)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--out", default=os.path.join(TUNING_DIR, "conv_cfg.json"))
+    ap.add_argument("--report", default=None)
+    args = ap.parse_args()
+    eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, use_tuning=False)
+    names = eng.cfg_names()
+    bc = [int(n.split("_")[0].split("x")[1]) for n in names]
+    x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8).cuda()
+    ops = eng.program.ops
+    conv_idx = [i for i, op in enumerate(ops) if op["kind"] == 1]
+    best = {}
+    times = {i: {} for i in conv_idx}
+    for c, name in enumerate(names):
+        ok = [i for i in conv_idx if ops[i]["cout_pad"] % bc[c] == 0]
+        if not ok:
+            continue
+        for i in conv_idx:
+            eng.set_cfg(i, c if i in ok else -1)
+        runs = [eng.profile_ops(x) for _ in range(args.reps + 1)][1:]
+        for i in ok:
+            times[i][name] = min(r[i]["ms"] for r in runs)
+    table, report = {}, []
+    for i in conv_idx:
+        key = tuning_key(ops[i], args.batch)
+        w = min(times[i], key=times[i].get)
+        if key not in best or times[i][w] < best[key][1]:
+            best[key] = (w, times[i][w])
+        fl = 2.0 * ops[i]["macs"] * args.batch
+        report.append(dict(name=ops[i]["name"], key=key, best=w, ms=times[i][w], tflops=fl / times[i][w] / 1e9, all={k: round(v, 4) for k, v in sorted(times[i].items(), key=lambda kv: kv[1])}))
+    table = {k: v[0] for k, v in best.items()}
+    old = json.load(open(args.out)) if os.path.exists(args.out) else {}
+    old.update(table)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(old, open(args.out, "w"), indent=0, sort_keys=True)
+    tot = sum(r["ms"] for r in report)
+    print(f"{args.variant} B={args.batch}: sum of best conv times {tot:.3f} ms -> {eng.flops_per_image * args.batch / tot / 1e9:.1f} TFLOP/s over convs; {len(table)} shapes")
+    if args.report:
+        json.dump(report, open(args.report, "w"), indent=0)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
