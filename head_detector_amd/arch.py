@@ -131,27 +131,33 @@ def _bn_names(p: str) -> List[str]:
 
 
 def random_state_dict(variant: str, seed: int = 1) -> Dict[str, np.ndarray]:
-    """Seeded synthetic weights of the architecture's exact shapes:
-    He-normal convs, BN gamma~U(0.5,1.5), beta~N(0,0.1), mean~N(0,0.1), var~U(0.5,1.5)."""
+    """Seeded synthetic weights of the architecture's exact shapes, variance-preserving so
+    that activations stay O(1) through ~150 layers like a trained network's (random BN statistics that are NOT matched
+    to the data would otherwise multiply the signal by ~1.1 per layer and overflow the exp() in the scale branch):
+      conv+BN+ReLU     W ~ N(0, 2/K), BN scale gamma/sqrt(var) = s,        s = exp(U(-0.1, 0.1))
+      QARepVGG         W3 ~ N(0, 1/K), W1 ~ N(0, 0.25/Cin), post-BN scale 1.26 s (0.85 s with the identity branch)
+      bottleneck alpha ~ U(0.05, 0.2);  BN beta, mean ~ N(0, 0.1), var ~ U(0.5, 1.5)."""
     rng = np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
 
     def conv_w(co, ci, k, gain=2.0):
         return (rng.standard_normal((co, ci, k, k)) * math.sqrt(gain / (ci * k * k))).astype(np.float32)
 
-    def bn(p, c):
-        sd[f"{p}.weight"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    def bn(p, c, target=1.0):
+        var = rng.uniform(0.5, 1.5, c)
+        scale = target * np.exp(rng.uniform(-0.1, 0.1, c))
+        sd[f"{p}.weight"] = (scale * np.sqrt(var + BN_EPS)).astype(np.float32)
         sd[f"{p}.bias"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
         sd[f"{p}.running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
-        sd[f"{p}.running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[f"{p}.running_var"] = var.astype(np.float32)
 
     for sp in layer_specs(variant):
         if sp.kind == "qarep":
             sd[f"{sp.name}.branch_3x3.conv.weight"] = conv_w(sp.cout, sp.cin, 3, 1.0)
             bn(f"{sp.name}.branch_3x3.bn", sp.cout)
-            sd[f"{sp.name}.branch_1x1.weight"] = conv_w(sp.cout, sp.cin, 1, 1.0)
+            sd[f"{sp.name}.branch_1x1.weight"] = conv_w(sp.cout, sp.cin, 1, 0.25)
             sd[f"{sp.name}.branch_1x1.bias"] = (rng.standard_normal(sp.cout) * 0.1).astype(np.float32)
-            bn(f"{sp.name}.post_bn", sp.cout)
+            bn(f"{sp.name}.post_bn", sp.cout, 0.85 if sp.residual else 1.26)
             if sp.use_alpha:
                 sd[f"{sp.name}.alpha"] = rng.uniform(0.5, 1.5, 1).astype(np.float32)
         elif sp.kind == "conv":
@@ -167,13 +173,12 @@ def random_state_dict(variant: str, seed: int = 1) -> Dict[str, np.ndarray]:
             sd[f"{sp.name}.weight"] = (rng.standard_normal((sp.cin, sp.cout, 2, 2)) * math.sqrt(1.0 / sp.cin)).astype(np.float32)
             sd[f"{sp.name}.bias"] = (rng.standard_normal(sp.cout) * 0.1).astype(np.float32)
         elif sp.kind == "alpha":
-            sd[sp.name] = rng.uniform(0.5, 1.5, 1).astype(np.float32)
-    # keep scores in a useful range: the cls bias prior of YoloHeadsDFLHead._initialize_biases (yolo_head_dfl_head.py:188-190)
+            sd[sp.name] = rng.uniform(0.05, 0.2, 1).astype(np.float32)
     for lv in range(3):
+        # cls bias prior of YoloHeadsDFLHead._initialize_biases (yolo_head_dfl_head.py:188-190); modest logit spread
         sd[f"heads.head{lv + 1}.cls_pred.bias"][:] = -math.log((1 - 1e-2) / 1e-2)
-        sd[f"heads.head{lv + 1}.cls_pred.weight"] *= np.float32(0.02)  # un-saturated sigmoid: scores spread around the 1e-2 prior
-        # random features are O(1..10): keep the raw FLAME predictions in a sane range (scale = exp(x)/0.05 must stay finite)
-        for k in list(sd):
+        sd[f"heads.head{lv + 1}.cls_pred.weight"] *= np.float32(0.02)
+        for k in list(sd):  # keep scale = exp(x)/0.05, translation, 6D rotation, jaw in a sane range
             if re.fullmatch(rf"heads\.head{lv + 1}\.flame_(scale|translation|rotation|jaw)_pred\.\d+\.(weight|bias)", k):
                 sd[k] = (sd[k] * 0.05).astype(np.float32)
     return sd

@@ -381,7 +381,7 @@ def test_network_every_op(gpu_lib, variant, S, B):
         pr.run_op(P, op, exp, x, True, w_all, b_all)
         is_f32 = bool(P.bufs[ob]["is_f32"])
         a, e = got[ob], exp[ob]
-        tol = (2e-3 + 1e-4 * e.abs()) if is_f32 else (2e-2 + 1.0 / 128 * e.abs())
+        tol = (2e-3 + 1e-4 * e.abs()) if is_f32 else (2e-2 + 1.0 / 64 * e.abs())  # bf16: 2 ulps (accumulation order can cross a rounding boundary)
         bad = (a - e).abs() > tol
         worst.append((float(((a - e).abs() / (e.abs() + 1.0)).max()), op["name"]))
         assert not bad.any(), f"{variant} S={S} op {op['name']}: {int(bad.sum())} mismatches, max abs err {float((a - e).abs().max())}"

@@ -18,7 +18,7 @@ fi
 timeout 600 python bench.py --steps ${BENCH_STEPS:-20} --warmup 3 --per-layer gpurun_out/per_layer.json > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log; tail -3 gpurun_out/bench.log
 timeout 300 python bench.py --steps 10 --warmup 3 --variant vgg_heads_l --batch 64 --no-cpu-baseline > gpurun_out/bench_l64.log 2>&1; tail -2 gpurun_out/bench_l64.log
 if [ "${RUN_PROF:-1}" = "1" ]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1)
   find gpurun_out/prof -name "*stats*" | head; ls -la gpurun_out/prof | head
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
 fi
