@@ -16,6 +16,8 @@
 //   LDS-DMA destination is lane-linear, the swizzle is applied on the SOURCE side: per-lane gather
 //   address for activations (which also implements im2col + zero padding), host pre-swizzled image for
 //   weights (vgh_pack_conv_weights_host).
+#include <stdlib.h>
+
 #include "vgh_internal.h"
 
 #define AS1 __attribute__((address_space(1)))
@@ -33,8 +35,8 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     return v;
 }
 
-template <int BP, int BC, int WP, int WC, int KBS>
-__global__ __launch_bounds__((BP / WP) * (BC / WC) * 64) void conv_igemm_kernel(const ConvArgs a, const int ntc, const int total_tiles,
+template <int BP, int BC, int WP, int WC, int KBS, int EPI>
+__global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((WP / 32) * (WC / 32) <= 4 ? 3 : 1)) void conv_igemm_kernel(const ConvArgs a, const int ntc, const int total_tiles,
                                                                                  const int chunk) {
     constexpr int NWP = BP / WP, NWC = BC / WC, NW = NWP * NWC;
     constexpr int XR = BP / 16 / NW;  // activation row-blocks (16 rows = 1 KiB) staged by each wave per k-block
@@ -153,13 +155,94 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64) void conv_igemm_kernel(
     for (int s = 0; s < nsteps; ++s) {
         char* cur = smem + (s & 1) * STAGE;
         char* nxt = smem + ((s + 1) & 1) * STAGE;
-        if (s + 1 < nsteps) stage_load(s + 1, nxt);
-        stage_compute(cur);
+        if (s + 1 < nsteps && !(a.ablate & 1)) stage_load(s + 1, nxt);
+        if (!(a.ablate & 2)) stage_compute(cur);
         __syncthreads();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
     const int half4 = (lane >> 5) * 4;
+    if constexpr (EPI == 1) {
+        // Fast path (bf16 out, every channel offset a multiple of 8): each wave transposes its accumulators through a
+        // private LDS strip [32 pixels][WC floats] so that results leave as 16-byte stores covering whole 128-B lines
+        // per pixel (the MFMA layout would give 8-byte stores scattered over 64 lines per instruction), and the
+        // residual arrives by 16-byte loads in the same pattern.  Single rounding: fp32 until the final convert.
+        constexpr int EP = WC + 4;  // floats per staged pixel row (+16 B: conflict-free ds_write_b128)
+        constexpr int CH = WC / 8;  // 16-byte output chunks per pixel
+        constexpr int NIT = 32 * CH / 64;  // 16-byte items per lane per 32-pixel strip
+        float* stg = (float*)smem + w * (32 * EP);
+        // per-item geometry is the same for every strip j: item it -> (pixel px, chunk ch)
+        int ipx[NIT], ich[NIT];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int it = lane + 64 * t;
+            ipx[t] = it / CH;
+            ich[t] = it - ipx[t] * CH;
+        }
+        // residual tile of this wave: issue every 16-byte load up front so they are all in flight together
+        bf16x8_t rres[TJ][NIT];
+        if (a.res) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int t = 0; t < NIT; ++t) {
+                    const int m = p0 + wp * WP + j * 32 + ipx[t];
+                    const int c = c0 + wc * WC + ich[t] * 8;
+                    const int oc = a.shuffle ? c % a.shuffle_c : c;
+                    if (m < a.P && c < a.cout_store) rres[j][t] = *(const bf16x8_t*)(a.res + (int64_t)m * a.res_pitch + a.res_coff + oc);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = i * 32 + q * 8 + half4;
+                    const f32x4_t bv = *(const f32x4_t*)(a.bias + c0 + wc * WC + cl);
+                    f32x4_t v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][q * 4 + e] + bv[e], a.act);
+                    *(f32x4_t*)(stg + lrow * EP + cl) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int px = ipx[t], ch = ich[t];
+                const int m = p0 + wp * WP + j * 32 + px;
+                const int c = c0 + wc * WC + ch * 8;
+                if (m < a.P && c < a.cout_store) {
+                    const f32x4_t v0 = *(const f32x4_t*)(stg + px * EP + ch * 8);
+                    const f32x4_t v1 = *(const f32x4_t*)(stg + px * EP + ch * 8 + 4);
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    int oc = c;
+                    int64_t opix = m;
+                    if (a.shuffle) {
+                        const int sb = m / HoWo;
+                        const int rem = m - sb * HoWo;
+                        const int sy = rem / a.Wo, sx = rem - sy * a.Wo;
+                        const int d = c / a.shuffle_c;
+                        oc = c - d * a.shuffle_c;
+                        opix = ((int64_t)sb * (2 * a.Ho) + 2 * sy + (d >> 1)) * (2 * a.Wo) + 2 * sx + (d & 1);
+                    }
+                    if (a.res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += a.alpha * (float)rres[j][t][e];
+                    }
+                    const int ochan = (oc >= a.out_split) ? a.out_coff2 + (oc - a.out_split) : a.out_coff + oc;
+                    bf16x8_t ov;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
+                    *(bf16x8_t*)((uint16_t*)a.out + opix * a.out_pitch + ochan) = ov;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+    // General path (fp32 prediction buffers, ragged channel counts, unaligned offsets): direct stores from the MFMA layout.
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int m = p0 + wp * WP + j * 32 + lrow;
@@ -207,6 +290,7 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64) void conv_igemm_kernel(
             }
         }
     }
+    }
 }
 
 struct CfgEntry {
@@ -217,11 +301,25 @@ struct CfgEntry {
 
 template <int BP, int BC, int WP, int WC, int KBS>
 void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS>), dim3(chunk * 8), dim3((BP / WP) * (BC / WC) * 64), lds, st, a, ntc, total, chunk);
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64);
+    if (a.fast_epi)
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1>), grid, block, lds, st, a, ntc, total, chunk);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0>), grid, block, lds, st, a, ntc, total, chunk);
 }
 
+constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS) {
+    const int loop = 2 * KBS * (BP + BC) * 64, epi = (BP / WP) * (BC / WC) * 32 * (WC + 4) * 4;
+    return loop > epi ? loop : epi;
+}
 #define CFG(BP, BC, WP, WC, KBS) \
-    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS, BP, BC, (BP / WP) * (BC / WC) * 64, 2 * KBS * (BP + BC) * 64, launch_cfg<BP, BC, WP, WC, KBS> }
+    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS), launch_cfg<BP, BC, WP, WC, KBS> }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -278,6 +376,11 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     VGH_REQUIRE(!a.res || (a.res_coff % 4 == 0 && a.res_pitch % 4 == 0), "conv: residual alignment");
     VGH_REQUIRE(!a.shuffle || (a.shuffle_c % 4 == 0 && a.cout_pad >= 4 * a.shuffle_c && a.ksize == 1 && a.stride == 1), "conv: bad shuffle");
     if (a.P == 0) return VGH_OK;
+    static const int ablate = getenv("VGH_CONV_ABLATE") ? atoi(getenv("VGH_CONV_ABLATE")) : 0;  // perf experiments only
+    const_cast<ConvArgs&>(a).ablate = ablate;
+    const bool al8 = a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_split % 8 == 0 && a.cout_store % 8 == 0 && a.out_pitch % 8 == 0 &&
+                     (!a.res || (a.res_coff % 8 == 0 && a.res_pitch % 8 == 0)) && (!a.shuffle || a.shuffle_c % 8 == 0);
+    const_cast<ConvArgs&>(a).fast_epi = (!a.out_f32 && al8 && !(ablate & 4)) ? 1 : 0;
     int cfg = force_cfg >= 0 ? force_cfg : vgh_conv_pick_cfg(a);
     VGH_REQUIRE(cfg < kNumCfgs, "conv: cfg %d out of range", cfg);
     if (a.cout_pad % g_cfgs[cfg].BC != 0) {

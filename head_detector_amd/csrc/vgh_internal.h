@@ -55,6 +55,8 @@ struct ConvArgs {
     int P;          // B*Ho*Wo output pixels
     int nkb;        // ksize*ksize*cin/32
     int cblocks;    // cin/32
+    int fast_epi;   // 1: LDS-transposed 16-byte epilogue (bf16 out, 8-channel aligned offsets)
+    int ablate;     // perf experiments: bit0 skip tile loads, bit1 skip MFMAs (results are garbage)
 };
 
 int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);
