@@ -74,6 +74,7 @@ SYMBOLS = {
     "vgh_pack_conv_weights": (_I, [_P, _I, _I, _I, _P]),
     "vgh_conv_num_cfgs": (_I, []),
     "vgh_conv_cfg_name": (C.c_char_p, [_I]),
+    "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),
     "vgh_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "vgh_gather_candidates": (_I, [C.POINTER(HeadLevel), _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),

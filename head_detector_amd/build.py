@@ -54,6 +54,13 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"libvgh.so: link failed\n{r.stdout}")
+    import ctypes
+
+    try:  # catches undefined symbols (e.g. a kernel whose host stub was silently dropped) at build time, not on the GPU box
+        ctypes.CDLL(LIB)
+    except OSError as e:
+        os.remove(LIB)
+        raise RuntimeError(f"libvgh.so: built but does not load: {e}")
     if verbose:
         sys.stderr.write(f"[vgh build] built {LIB} in {time.time() - t0:.1f}s\n")
     return LIB

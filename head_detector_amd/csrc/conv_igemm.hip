@@ -29,14 +29,35 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const AS1 void*)gsrc, (AS3 void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: 16 bytes per lane to lds_wave_base + lane*16; an out-of-range voffset reads zeros.
+__device__ __forceinline__ void bload_lds16(const void* base, unsigned voffset, unsigned soffset, char* lds_wave_base) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == VGH_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == VGH_ACT_SILU) return v / (1.0f + __expf(-v));
     return v;
 }
 
-template <int BP, int BC, int WP, int WC, int KBS, int EPI>
-__global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((WP / 32) * (WC / 32) <= 4 ? 3 : 1)) void conv_igemm_kernel(const ConvArgs a, const int ntc, const int total_tiles,
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `stages_in_flight` * LPS of this wave's LDS-DMA loads are outstanding (counted, never a full drain)
+template <int LPS>
+__device__ __forceinline__ void wait_stages(int stages_in_flight) {
+    switch (stages_in_flight) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<LPS>(); break;
+        case 2: wait_vmcnt<2 * LPS>(); break;
+        default: wait_vmcnt<3 * LPS>(); break;
+    }
+}
+
+template <int BP, int BC, int WP, int WC, int KBS, int EPI, int NST>
+__global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) >= 8 ? ((BP / WP) * (BC / WC)) / 4 : ((WP / 32) * (WC / 32) <= 4 ? (NST > 2 ? 2 : 3) : 1))) void conv_igemm_kernel(const ConvArgs a, const int ntc, const int total_tiles,
                                                                                  const int chunk) {
     constexpr int NWP = BP / WP, NWC = BC / WC, NW = NWP * NWC;
     constexpr int XR = BP / 16 / NW;  // activation row-blocks (16 rows = 1 KiB) staged by each wave per k-block
@@ -62,10 +83,15 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((WP / 32) * (WC / 32) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w % NWP, wc = w / NWP;
 
-    // ---- per-lane gather state for the activation rows this lane stages -------------------------
+    // ---- loader ------------------------------------------------------------------------------------
+    // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): everything per-lane is computed ONCE --
+    // a 32-bit offset of the row's centre tap and a 9-bit "tap in bounds" mask -- and the per-k-block work is scalar:
+    // the tap / channel-block displacement moves the descriptor BASE (2 SALU), the weight tile is addressed through
+    // soffset.  A lane whose tap falls into the zero padding uses an out-of-range voffset: the hardware range check
+    // returns 0 for it, which is exactly the im2col zero.  (The counters showed ~17 VALU+SALU per MFMA with 64-bit
+    // per-lane pointer arithmetic; the matrix pipe starved on instruction issue, not on bandwidth.)
     const int HoWo = a.Ho * a.Wo;
-    const char* xbase[XR];
-    int xiy[XR], xix[XR];
+    unsigned xoff[XR], xmask[XR];
 #pragma unroll
     for (int t = 0; t < XR; ++t) {
         const int r = (w + NW * t) * 16 + (lane >> 2);
@@ -76,38 +102,54 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((WP / 32) * (WC / 32) 
         const int rem = mm - b * HoWo;
         const int oy = rem / a.Wo;
         const int ox = rem - oy * a.Wo;
-        const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-        xbase[t] = (const char*)a.in + 2 * ((((int64_t)b * a.H + iy0) * a.W + ix0) * a.in_pitch + a.in_coff);
-        xiy[t] = valid ? iy0 : -(1 << 20);
-        xix[t] = ix0;
+        const int cy = oy * a.stride, cx = ox * a.stride;  // centre tap (always inside the image)
+        xoff[t] = 2u * (unsigned)(((b * a.H + cy) * a.W + cx) * (int)a.in_pitch + a.in_coff) + (((lane & 3) ^ ((lane >> 4) & 3))) * 16;
+        unsigned mask = 0;
+        for (int ky = 0; ky < a.ksize; ++ky)
+            for (int kx = 0; kx < a.ksize; ++kx) {
+                const int iy = cy + ky - a.pad, ix = cx + kx - a.pad;
+                if (valid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) mask |= 1u << (ky * a.ksize + kx);
+            }
+        xmask[t] = mask;
     }
-    const int csel16 = (((lane & 3) ^ ((lane >> 4) & 3))) * 16;  // logical 16-B chunk this lane fetches (source swizzle)
-    const char* zsrc = (const char*)a.zeros + csel16;
-    const char* wlane = (const char*)a.wpack + (int64_t)c0 * 64 + lane * 16;  // pre-swizzled image: linear copy
+    constexpr unsigned OOB = 0xFFFFFFF0u;  // >= num_records: the buffer range check returns zeros
+    const unsigned wvoff = lane * 16;
+    const char* const wbase = (const char*)a.wpack + (int64_t)c0 * 64;
+    // running k-block state (stage_load is called for consecutive steps 0,1,2,...)
+    int l_kb = 0, l_cb = 0, l_kx = 0, l_tap = 0;
+    int64_t l_xdelta = -2 * (int64_t)((a.pad * a.W + a.pad) * (int)a.in_pitch);  // tap (0,0) relative to the centre tap
+    unsigned l_woff = 0;
 
-    auto stage_load = [&](int step, char* sbase) {
+    auto stage_load = [&](char* sbase) {
 #pragma unroll
         for (int kbs = 0; kbs < KBS; ++kbs) {
-            const int kb = step * KBS + kbs;  // wave-uniform
-            const bool kvalid = kb < a.nkb;
-            const int tap = kb / a.cblocks;
-            const int cb = kb - tap * a.cblocks;
-            const int ky = tap / a.ksize;
-            const int kx = tap - ky * a.ksize;
-            const int delta = 2 * ((ky * a.W + kx) * (int)a.in_pitch + cb * 32) + csel16;
+            const bool kvalid = l_kb < a.nkb;
+            const char* const xbase = (const char*)a.in + l_xdelta;
 #pragma unroll
             for (int t = 0; t < XR; ++t) {
-                const bool ok = kvalid && (unsigned)(xiy[t] + ky) < (unsigned)a.H && (unsigned)(xix[t] + kx) < (unsigned)a.W;
-                const char* src = ok ? xbase[t] + delta : zsrc;
-                glds16(src, sbase + kbs * XBYTES + (w + NW * t) * 1024);
+                const bool ok = kvalid && ((xmask[t] >> l_tap) & 1u);
+                bload_lds16(xbase, ok ? xoff[t] : OOB, 0, sbase + kbs * XBYTES + (w + NW * t) * 1024);
             }
-            const char* wsrc = wlane + (int64_t)kb * a.cout_pad * 64;
 #pragma unroll
             for (int t = 0; t < WR; ++t) {
                 const int rb = w + NW * t;  // wave-uniform
                 if (rb < WRB) {
-                    const char* src = kvalid ? wsrc + rb * 1024 : (const char*)a.zeros + (lane & 3) * 16;
-                    glds16(src, sbase + KBS * XBYTES + kbs * WBYTES + rb * 1024);
+                    bload_lds16(wbase, kvalid ? wvoff + rb * 1024 : OOB, l_woff, sbase + KBS * XBYTES + kbs * WBYTES + rb * 1024);
+                } else if (NST > 2) {
+                    bload_lds16(wbase, OOB, 0, smem + NST * STAGE + w * 1024);  // keeps the vmcnt arithmetic wave-uniform
+                }
+            }
+            // advance to the next k-block: channel block fastest, then kx, then ky
+            ++l_kb;
+            l_woff += (unsigned)a.cout_pad * 64u;
+            l_xdelta += 64;
+            if (++l_cb == a.cblocks) {
+                l_cb = 0;
+                ++l_tap;
+                l_xdelta += 2 * (int64_t)a.in_pitch - 64 * (int64_t)a.cblocks;
+                if (++l_kx == a.ksize) {
+                    l_kx = 0;
+                    l_xdelta += 2 * (int64_t)(a.W - a.ksize) * a.in_pitch;
                 }
             }
         }
@@ -127,37 +169,78 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((WP / 32) * (WC / 32) 
     const int foff0 = lrow * 64 + (((0 + (lane >> 5)) ^ sw) * 16);
     const int foff1 = lrow * 64 + (((2 + (lane >> 5)) ^ sw) * 16);
 
+    // Fragment loads are software-pipelined by hand: the ds_reads of sub-step n+1 are issued before the MFMAs of
+    // sub-step n (two named register sets), so the matrix pipe does not idle behind every LDS round trip.
+    auto load_frags = [&](const char* sbase, int sub, bf16x8_t (&af)[TI], bf16x8_t (&bfr)[TJ]) {
+        const int kbs = sub >> 1, h = sub & 1;
+        const char* xt = sbase + kbs * XBYTES + (wp * WP) * 64;
+        const char* wt = sbase + KBS * XBYTES + kbs * WBYTES + (wc * WC) * 64;
+        const int fo = h ? foff1 : foff0;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8_t*)(wt + i * 2048 + fo);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8_t*)(xt + j * 2048 + fo);
+    };
+    auto mma = [&](const bf16x8_t (&af)[TI], const bf16x8_t (&bfr)[TJ]) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    };
     auto stage_compute = [&](const char* sbase) {
+        constexpr int NSUB = 2 * KBS;
+        bf16x8_t a0[TI], b0[TJ], a1[TI], b1[TJ];
+        load_frags(sbase, 0, a0, b0);
 #pragma unroll
-        for (int kbs = 0; kbs < KBS; ++kbs) {
-            const char* xt = sbase + kbs * XBYTES + (wp * WP) * 64;
-            const char* wt = sbase + KBS * XBYTES + kbs * WBYTES + (wc * WC) * 64;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int fo = h ? foff1 : foff0;
-                bf16x8_t af[TI], bfr[TJ];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8_t*)(wt + i * 2048 + fo);
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8_t*)(xt + j * 2048 + fo);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
+        for (int sub = 0; sub < NSUB; sub += 2) {
+            load_frags(sbase, sub + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc would sink it to its first use)
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sub + 2 < NSUB) load_frags(sbase, sub + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- main loop: 2-stage LDS ring, loads of step s+1 in flight under the MFMAs of step s -------
+    // ---- main loop ------------------------------------------------------------------------------------
     const int nsteps = (a.nkb + KBS - 1) / KBS;
-    stage_load(0, smem);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        char* cur = smem + (s & 1) * STAGE;
-        char* nxt = smem + ((s + 1) & 1) * STAGE;
-        if (s + 1 < nsteps && !(a.ablate & 1)) stage_load(s + 1, nxt);
-        if (!(a.ablate & 2)) stage_compute(cur);
+    if constexpr (NST == 2) {
+        // 2-stage ring, __syncthreads(): loads of step s+1 fly under the MFMAs of step s, drained at every barrier
+        stage_load(smem);
         __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            char* cur = smem + (s & 1) * STAGE;
+            char* nxt = smem + ((s + 1) & 1) * STAGE;
+            if (s + 1 < nsteps && !(a.ablate & 1)) stage_load(nxt);
+            if (!(a.ablate & 2)) stage_compute(cur);
+            __syncthreads();
+        }
+    } else {
+        // NST-stage ring with COUNTED vmcnt and a raw s_barrier: NST-1 stages of LDS-DMA stay in flight across barriers
+        // (a __syncthreads() would drain vmcnt(0) and serialise load latency with the MFMA phase).  One barrier per step:
+        //   wait(own loads of step s) ; barrier (=> everybody's step-s tiles landed AND everybody finished reading step s-1)
+        //   ; issue loads of step s+NST-1 into the buffer step s-1 used ; compute step s.
+        constexpr int LPS = KBS * (XR + WR);  // LDS-DMA instructions per wave per stage (uniform across waves)
+#pragma unroll
+        for (int p = 0; p < NST - 1; ++p)
+            if (p < nsteps) stage_load(smem + p * STAGE);
+        int buf = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            const int last_issued = (s + NST - 2 < nsteps - 1) ? s + NST - 2 : nsteps - 1;
+            wait_stages<LPS>(last_issued - s);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int nb = buf + NST - 1;
+            if (nb >= NST) nb -= NST;
+            if (s + NST - 1 < nsteps && !(a.ablate & 1)) stage_load(smem + nb * STAGE);
+            if (!(a.ablate & 2)) stage_compute(smem + buf * STAGE);
+            if (++buf == NST) buf = 0;
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // all waves done reading the last stage before the epilogue reuses the LDS
+        asm volatile("" ::: "memory");
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -293,33 +376,274 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((WP / 32) * (WC / 32) 
     }
 }
 
+// =====================================================================================================
+// Patch kernel for 3x3 / stride 1 / pad 1 convolutions: the input halo patch of one 32-channel block stays
+// resident in LDS and is re-read by all 9 taps (the implicit-GEMM kernel above re-fetches every pixel 9x
+// from L2); weights stream through LDS one kernel row (3 taps) at a time.  Per (channel-block, ky) step every
+// wave issues 3 * TI * TJ * 2 MFMAs between barriers.
+//   block tile : TH x TW output pixels of ONE image (raster order, 32-pixel MFMA groups) x BC couts
+//   wave tile  : TJ = groups/NW pixel groups x ALL BC couts (TI = BC/32) -> full 2*BC-byte lines per pixel
+//   LDS        : X[2][(TH+2)*(TW+2) halo pixels][64 B] + W[2][3 taps][BC][64 B], both 16-B-chunk swizzled
+//   bytes/FLOP : (HP + 9*BC) * 64 B per 9*BP*BC*64 FLOP  ->  ~200 FLOP/B at 256 px x 128 couts (v1: 64-85)
+// =====================================================================================================
+template <int TW, int TH, int BC, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a, const int ntc, const int ntx, const int nty, const int total_tiles,
+                                                                const int chunk) {
+    constexpr int NPX = TW * TH, NG = (NPX + 31) / 32, TJ = NG / NW, TI = BC / 32;
+    constexpr int HW = TW + 2, HP = HW * (TH + 2), HPU = (HP + 15) / 16;
+    constexpr int XBYTES = HPU * 1024, WTAP = BC * 64, WSTEP = 3 * WTAP;
+    constexpr int XUW = (HPU + NW - 1) / NW;   // halo units (16 pixels) staged per wave per channel block
+    constexpr int WU = 3 * BC / 16, WUW = (WU + NW - 1) / NW;
+    static_assert(NG % NW == 0, "pixel groups must split evenly across waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xbuf = smem;
+    char* const wbuf = smem + 2 * XBYTES;
+
+    const int bid = blockIdx.x;
+    int tile = (bid & 7) * chunk + (bid >> 3);
+    if (tile >= total_tiles) return;
+    const int ctile = tile % ntc;
+    tile /= ntc;
+    const int txi = tile % ntx;
+    tile /= ntx;
+    const int tyi = tile % nty;
+    const int b = tile / nty;
+    const int y0 = tyi * TH, x0 = txi * TW, c0 = ctile * BC;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31;
+    const int csel16 = (((lane & 3) ^ ((lane >> 4) & 3))) * 16;  // source-side swizzle: chunk = slot ^ ((halo_row>>2)&3)
+
+    // ---- halo loader state (fixed over the whole K loop; only the channel offset moves) ----
+    const char* xsrc[XUW];
+#pragma unroll
+    for (int t = 0; t < XUW; ++t) {
+        const int hp = (w + NW * t) * 16 + (lane >> 2);
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        xsrc[t] = ok ? (const char*)a.in + 2 * ((((int64_t)b * a.H + iy) * a.W + ix) * a.in_pitch + a.in_coff) + csel16 : nullptr;
+    }
+    const char* zsrc = (const char*)a.zeros + csel16;
+    const char* wlane = (const char*)a.wpack + (int64_t)c0 * 64 + lane * 16;
+
+    auto load_x = [&](int cb, char* dst) {
+#pragma unroll
+        for (int t = 0; t < XUW; ++t) {
+            const int u = w + NW * t;
+            if (u < HPU) glds16(xsrc[t] ? xsrc[t] + cb * 64 : zsrc, dst + u * 1024);
+        }
+    };
+    auto load_w = [&](int cb, int ky, char* dst) {
+#pragma unroll
+        for (int t = 0; t < WUW; ++t) {
+            const int v = w + NW * t;  // wave-uniform
+            if (v < WU) {
+                const int kx = v / (BC / 16), rb = v - kx * (BC / 16);
+                const int kb = (ky * 3 + kx) * a.cblocks + cb;
+                glds16(wlane + (int64_t)kb * a.cout_pad * 64 + rb * 1024, dst + kx * WTAP + rb * 1024);
+            }
+        }
+    };
+
+    // ---- fragment addressing ----
+    int r0[TJ];  // halo row of this lane's pixel at tap (0,0)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int p = (w * TJ + j) * 32 + lrow;
+        const int ty = p / TW, tx = p - ty * TW;
+        r0[j] = (p < NPX) ? ty * HW + tx : 0;
+    }
+    const int hi = lane >> 5;
+    const int sw = (lane >> 2) & 3;
+    const int aoff0 = lrow * 64 + (((0 + hi) ^ sw) * 16);
+    const int aoff1 = lrow * 64 + (((2 + hi) ^ sw) * 16);
+
+    f32x16_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto load_frags = [&](const char* X, const char* Wt, int ky, int sub, bf16x8_t (&af)[TI], bf16x8_t (&bfr)[TJ]) {
+        const int kx = sub >> 1, h = sub & 1;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8_t*)(Wt + kx * WTAP + i * 2048 + (h ? aoff1 : aoff0));
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int r = r0[j] + ky * HW + kx;
+            bfr[j] = *(const bf16x8_t*)(X + r * 64 + ((((h ? 2 : 0) + hi) ^ ((r >> 2) & 3)) * 16));
+        }
+    };
+    auto mma = [&](const bf16x8_t (&af)[TI], const bf16x8_t (&bfr)[TJ]) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    };
+    // 6 sub-steps (3 taps x 2 k16 halves) per step, fragment loads one sub-step ahead of the MFMAs
+    auto compute = [&](const char* X, const char* Wt, int ky) {
+        bf16x8_t a0[TI], b0[TJ], a1[TI], b1[TJ];
+        load_frags(X, Wt, ky, 0, a0, b0);
+#pragma unroll
+        for (int sub = 0; sub < 6; sub += 2) {
+            load_frags(X, Wt, ky, sub + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc would sink it to its first use)
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sub + 2 < 6) load_frags(X, Wt, ky, sub + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- main loop over (channel block, kernel row) steps; loads of step s+1 fly under the MFMAs of step s ----
+    const int nsteps = a.cblocks * 3;
+    load_x(0, xbuf);
+    load_w(0, 0, wbuf);
+    __syncthreads();
+    int cb = 0, ky = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        int ncb = cb, nky = ky + 1;
+        if (nky == 3) {
+            nky = 0;
+            ++ncb;
+        }
+        if (s + 1 < nsteps && !(a.ablate & 1)) {
+            load_w(ncb, nky, wbuf + ((s + 1) & 1) * WSTEP);
+            if (nky == 0) load_x(ncb, xbuf + (ncb & 1) * XBYTES);
+        }
+        if (!(a.ablate & 2)) compute(xbuf + (cb & 1) * XBYTES, wbuf + (s & 1) * WSTEP, ky);
+        __syncthreads();
+        cb = ncb;
+        ky = nky;
+    }
+
+    // ---- epilogue: LDS transpose -> 16-byte stores (same scheme as the fast path of the implicit-GEMM kernel) ----
+    constexpr int EP = BC + 4, CH = BC / 8, NIT = 32 * CH / 64;
+    float* stg = (float*)smem + w * (32 * EP);
+    const int half4 = hi * 4;
+    int ipx[NIT], ich[NIT];
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+        const int it = lane + 64 * t;
+        ipx[t] = it / CH;
+        ich[t] = it - ipx[t] * CH;
+    }
+    int64_t opix[TJ][NIT];  // output pixel index or -1
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int p = (w * TJ + j) * 32 + ipx[t];
+            const int ty = p / TW, tx = p - ty * TW;
+            const int y = y0 + ty, x = x0 + tx;
+            const bool ok = p < NPX && y < a.H && x < a.W && (c0 + ich[t] * 8) < a.cout_store;
+            opix[j][t] = ok ? ((int64_t)b * a.H + y) * a.W + x : -1;
+        }
+    bf16x8_t rres[TJ][NIT];
+    if (a.res) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int t = 0; t < NIT; ++t)
+                if (opix[j][t] >= 0) rres[j][t] = *(const bf16x8_t*)(a.res + opix[j][t] * a.res_pitch + a.res_coff + c0 + ich[t] * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = i * 32 + q * 8 + half4;
+                const f32x4_t bv = *(const f32x4_t*)(a.bias + c0 + cl);
+                f32x4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][q * 4 + e] + bv[e], a.act);
+                *(f32x4_t*)(stg + lrow * EP + cl) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            if (opix[j][t] >= 0) {
+                const int px = ipx[t], ch = ich[t];
+                const f32x4_t v0 = *(const f32x4_t*)(stg + px * EP + ch * 8);
+                const f32x4_t v1 = *(const f32x4_t*)(stg + px * EP + ch * 8 + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (a.res) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += a.alpha * (float)rres[j][t][e];
+                }
+                const int oc = c0 + ch * 8;
+                const int ochan = (oc >= a.out_split) ? a.out_coff2 + (oc - a.out_split) : a.out_coff + oc;
+                bf16x8_t ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
+                *(bf16x8_t*)((uint16_t*)a.out + opix[j][t] * a.out_pitch + ochan) = ov;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 struct CfgEntry {
     const char* name;
     int BP, BC, threads, lds;
     void (*launch)(const ConvArgs&, int, int, int, int, hipStream_t);
+    int patch, TW, TH;  // patch != 0: conv3x3_patch_kernel (3x3, stride 1, fast epilogue only), tile TH x TW
+    void (*launch_patch)(const ConvArgs&, int, int, int, int, int, int, hipStream_t);
 };
 
-template <int BP, int BC, int WP, int WC, int KBS>
+template <int TW, int TH, int BC, int NW>
+constexpr int patch_lds() {
+    constexpr int HP = (TW + 2) * (TH + 2), HPU = (HP + 15) / 16;
+    constexpr int loop = 2 * HPU * 1024 + 2 * 3 * BC * 64, epi = NW * 32 * (BC + 4) * 4;
+    return loop > epi ? loop : epi;
+}
+
+template <int TW, int TH, int BC, int NW>
+void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TW, TH, BC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NW>), dim3(chunk * 8), dim3(NW * 64), lds, st, a, ntc, ntx, nty, total, chunk);
+}
+
+template <int BP, int BC, int WP, int WC, int KBS, int NST>
 void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64);
     if (a.fast_epi)
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1>), grid, block, lds, st, a, ntc, total, chunk);
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>), grid, block, lds, st, a, ntc, total, chunk);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0>), grid, block, lds, st, a, ntc, total, chunk);
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST>), grid, block, lds, st, a, ntc, total, chunk);
 }
 
-constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS) {
-    const int loop = 2 * KBS * (BP + BC) * 64, epi = (BP / WP) * (BC / WC) * 32 * (WC + 4) * 4;
+constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
+    const int nw = (BP / WP) * (BC / WC);
+    const int loop = NST * KBS * (BP + BC) * 64 + (NST > 2 ? nw * 1024 : 0), epi = nw * 32 * (WC + 4) * 4;
     return loop > epi ? loop : epi;
 }
 #define CFG(BP, BC, WP, WC, KBS) \
-    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS), launch_cfg<BP, BC, WP, WC, KBS> }
+    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, 2), launch_cfg<BP, BC, WP, WC, KBS, 2>, 0, 0, 0, nullptr }
+#define CFGR(BP, BC, WP, WC, KBS, NST) \
+    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg<BP, BC, WP, WC, KBS, NST>, 0, 0, 0, nullptr }
+#define PCFG(TW, TH, BC, NW) \
+    { "p" #TH "x" #TW "x" #BC "_n" #NW, (TW) * (TH), BC, (NW) * 64, patch_lds<TW, TH, BC, NW>(), nullptr, 1, TW, TH, launch_patch_cfg<TW, TH, BC, NW> }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -337,12 +661,51 @@ const CfgEntry g_cfgs[] = {
     CFG(64, 32, 32, 32, 1),    // 12 (2 waves)
     CFG(256, 128, 64, 128, 1), // 13
     CFG(128, 64, 32, 64, 2),   // 14
+    PCFG(16, 16, 64, 4),       // 15  256 px x 64
+    PCFG(16, 16, 128, 4),      // 16  256 px x 128, 1 wave/SIMD
+    PCFG(16, 16, 128, 8),      // 17  256 px x 128, 2 waves/SIMD
+    PCFG(16, 16, 96, 4),       // 18
+    PCFG(40, 8, 64, 5),        // 19  320 px (full-width rows of a 40-wide map)
+    PCFG(40, 8, 128, 5),       // 20
+    PCFG(40, 8, 96, 5),        // 21
+    PCFG(16, 8, 128, 4),       // 22  128 px x 128
+    PCFG(20, 8, 128, 5),       // 23  160 px (20-wide maps)
+    PCFG(16, 16, 32, 4),       // 24
+    CFGR(128, 128, 64, 64, 1, 3),  // 25  counted-vmcnt rings
+    CFGR(128, 128, 64, 64, 1, 4),  // 26
+    CFGR(128, 64, 32, 64, 1, 4),   // 27
+    CFGR(256, 64, 64, 64, 1, 3),   // 28
+    CFGR(128, 96, 32, 96, 1, 4),   // 29
+    CFGR(64, 128, 32, 64, 1, 4),   // 30
+    CFGR(64, 64, 32, 32, 1, 4),    // 31
+    CFGR(128, 128, 64, 64, 2, 3),  // 32
+    CFGR(128, 64, 32, 64, 2, 3),   // 33
+    CFGR(128, 32, 32, 32, 1, 4),   // 34
+    CFGR(256, 128, 64, 64, 1, 3),  // 35  8 waves
+    CFGR(256, 128, 64, 64, 1, 2),  // 36  8 waves, 2-stage
+    CFGR(256, 128, 64, 64, 2, 2),  // 37
+    CFGR(256, 256, 64, 64, 1, 2),  // 38  16 waves
+    CFGR(256, 256, 64, 64, 1, 3),  // 39
+    CFGR(512, 128, 64, 64, 1, 2),  // 40  16 waves
+    CFGR(256, 64, 32, 64, 1, 2),   // 41  8 waves, 32x64 wave tiles
+    CFGR(256, 64, 32, 64, 1, 3),   // 42
+    CFGR(256, 96, 32, 96, 1, 2),   // 43  8 waves
+    CFGR(128, 128, 32, 64, 1, 2),  // 44  8 waves
+    CFGR(128, 128, 32, 64, 1, 3),  // 45
+    CFGR(512, 64, 64, 64, 1, 2),   // 46  8 waves
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
 }  // namespace
 
 int vgh_conv_num_cfgs() { return kNumCfgs; }
+int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle) {
+    if (cfg < 0 || cfg >= kNumCfgs) return 0;
+    const CfgEntry& e = g_cfgs[cfg];
+    if (cout_pad % e.BC) return 0;
+    if (e.patch && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    return 1;
+}
 const char* vgh_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].name : "?"; }
 
 int vgh_conv_pick_cfg(const ConvArgs& a) {
@@ -374,6 +737,7 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     VGH_REQUIRE(a.out_f32 || (a.out_split % 4 == 0 && a.out_coff % 4 == 0 && a.out_coff2 % 4 == 0 && a.cout_store % 4 == 0 && a.out_pitch % 4 == 0),
                 "conv: bf16 output needs 8-byte aligned channel offsets and cout_store %% 4 == 0");
     VGH_REQUIRE(!a.res || (a.res_coff % 4 == 0 && a.res_pitch % 4 == 0), "conv: residual alignment");
+    VGH_REQUIRE((int64_t)a.B * a.H * a.W * a.in_pitch * 2 < (1ll << 31), "conv: input tensor must stay below 2 GiB (32-bit buffer offsets); run the batch in chunks");
     VGH_REQUIRE(!a.shuffle || (a.shuffle_c % 4 == 0 && a.cout_pad >= 4 * a.shuffle_c && a.ksize == 1 && a.stride == 1), "conv: bad shuffle");
     if (a.P == 0) return VGH_OK;
     static const int ablate = getenv("VGH_CONV_ABLATE") ? atoi(getenv("VGH_CONV_ABLATE")) : 0;  // perf experiments only
@@ -383,11 +747,20 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     const_cast<ConvArgs&>(a).fast_epi = (!a.out_f32 && al8 && !(ablate & 4)) ? 1 : 0;
     int cfg = force_cfg >= 0 ? force_cfg : vgh_conv_pick_cfg(a);
     VGH_REQUIRE(cfg < kNumCfgs, "conv: cfg %d out of range", cfg);
-    if (a.cout_pad % g_cfgs[cfg].BC != 0) {
-        VGH_REQUIRE(force_cfg < 0, "conv: cfg %s does not divide cout_pad=%d", g_cfgs[cfg].name, a.cout_pad);
+    if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi, a.shuffle)) {
+        VGH_REQUIRE(force_cfg < 0, "conv: cfg %s cannot run this conv (cout_pad=%d k=%d s=%d)", g_cfgs[cfg].name, a.cout_pad, a.ksize, a.stride);
         cfg = 4;
     }
     const CfgEntry& e = g_cfgs[cfg];
+    if (e.patch) {
+        const int ntc = a.cout_pad / e.BC, ntx = (a.W + e.TW - 1) / e.TW, nty = (a.H + e.TH - 1) / e.TH;
+        const int64_t total = (int64_t)a.B * nty * ntx * ntc;
+        VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
+        const int chunk = (int)((total + 7) / 8);
+        e.launch_patch(a, ntc, ntx, nty, (int)total, chunk, e.lds, stream);
+        VGH_HIP(hipGetLastError());
+        return VGH_OK;
+    }
     const int ntc = a.cout_pad / e.BC;
     const int64_t ntp = ((int64_t)a.P + e.BP - 1) / e.BP;
     const int64_t total = ntp * ntc;

@@ -109,6 +109,8 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream);
 int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin, uint16_t* wpack_host);
 int vgh_conv_num_cfgs(void);
 const char* vgh_conv_cfg_name(int cfg);
+/* 1 if tile configuration `cfg` can run a conv of this kind (tuning tools). */
+int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle);
 
 /* ------------------------------------------------------------------------------------------------
  * Head decode: replaces YoloHeadsNDFLHeads.forward's tail (yolo_head_ndfl_heads.py:143-172) and the

@@ -209,7 +209,7 @@ def test_head_decode_and_gather_vs_oracle(gpu_lib, S_c, E_c):
 # ======================================================================================================
 # implicit-GEMM conv (K2/K3/K4), per configuration
 # ======================================================================================================
-def _run_conv(lib, x, W, b, k, stride, act=1, res=None, alpha=0.0, split=None, out_f32=False, shuffle=False, cfg=-1, cout_store=None, in_coff=0, in_pitch=None):
+def _run_conv(lib, x, W, b, k, stride, act=1, res=None, alpha=0.0, split=None, out_f32=False, shuffle=False, cfg=-1, cout_store=None, in_coff=0, in_pitch=None, out_coff=8):
     """x [B,H,W,Cin] float (bf16-representable); W [rows,k,k,Cin] float; returns engine output + torch reference."""
     from head_detector_amd import _lib
 
@@ -233,12 +233,12 @@ def _run_conv(lib, x, W, b, k, stride, act=1, res=None, alpha=0.0, split=None, o
     store = cout_store if cout_store is not None else rows
     oc = rp // 4 if shuffle else rp
     oh, ow = (2 * Ho, 2 * Wo) if shuffle else (Ho, Wo)
-    out_pitch = oc + 8
+    out_pitch = oc + 16
     d_out = torch.full((B, oh, ow, out_pitch), -768.0, dtype=torch.float32 if out_f32 else torch.bfloat16, device=_dev())
     d_res = res.to(torch.bfloat16).to(_dev()).contiguous() if res is not None else None
     call = _lib.ConvCall(
         in_dev=d_x.data_ptr(), in_pitch=in_pitch, in_coff=in_coff, cin=Cin, B=B, H=H, W=Wd, wpack_dev=d_pack.data_ptr(), bias_dev=d_bias.data_ptr(),
-        out_dev=d_out.data_ptr(), out_pitch=out_pitch, out_coff=4 if not split else split[1], cout_pad=rp, cout_store=store,
+        out_dev=d_out.data_ptr(), out_pitch=out_pitch, out_coff=out_coff if not split else split[1], cout_pad=rp, cout_store=store,
         out_split=rp if not split else split[0], out_coff2=0 if not split else split[2], out_f32=int(out_f32),
         res_dev=d_res.data_ptr() if d_res is not None else None, res_pitch=d_res.shape[-1] if d_res is not None else 0, res_coff=0, alpha=alpha,
         ksize=k, stride=stride, act=act, shuffle=int(shuffle), force_cfg=cfg,
@@ -260,7 +260,7 @@ def _run_conv(lib, x, W, b, k, stride, act=1, res=None, alpha=0.0, split=None, o
         y = z
     if res is not None:
         y = y + alpha * res.to(torch.bfloat16).float()[..., : y.shape[-1]]
-    return d_out.float().cpu(), y, store
+    return d_out.float().cpu(), y, store, out_coff
 
 
 def _assert_close(out, ref, out_f32, where):
@@ -288,6 +288,9 @@ CONV_CASES = [
     (1, 33, 17, 64, 96, 3, 2),  # odd sizes, ragged tiles
     (1, 8, 8, 768, 384, 1, 1),
     (1, 5, 5, 32, 13, 1, 1),  # tiny cout (prediction conv)
+    (2, 40, 40, 64, 128, 3, 1),  # 40-wide map (row-strip patch tiles)
+    (1, 21, 37, 32, 64, 3, 1),  # ragged in both directions for every patch tile shape
+    (2, 16, 48, 96, 96, 3, 1),
 ]
 
 
@@ -304,18 +307,16 @@ def test_conv_all_configs_vs_torch(gpu_lib, case):
     ncfg = gpu_lib.vgh_conv_num_cfgs()
     tested = 0
     for cfg in [-1] + list(range(ncfg)):
-        if cfg >= 0:
-            name = gpu_lib.vgh_conv_cfg_name(cfg).decode()
-            bc = int(name.split("_")[0].split("x")[1])
-            if rp % bc:
-                continue
-        store = Cout if Cout % 4 == 0 else None
         out_f32 = Cout % 4 != 0
-        out, ref, st = _run_conv(gpu_lib, x, Wt, b, k, stride, cfg=cfg, out_f32=out_f32)
-        _assert_close(out[..., 4 : 4 + st], ref[..., :st], out_f32, f"{case} cfg={cfg}")
-        assert float((out[..., :4] + 768.0).abs().max()) == 0.0, "wrote outside its channel range"
-        assert float((out[..., 4 + st :] + 768.0).abs().max()) < 1.0, "wrote past cout_store"
-        tested += 1
+        for oc0 in (8, 4):  # 8: LDS-transposed 16-byte epilogue (when Cout % 8 == 0); 4: general epilogue
+            fast = int(oc0 == 8 and Cout % 8 == 0 and not out_f32)
+            if cfg >= 0 and not gpu_lib.vgh_conv_cfg_ok(cfg, k, stride, rp, fast, 0):
+                continue
+            out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, k, stride, cfg=cfg, out_f32=out_f32, out_coff=oc0)
+            _assert_close(out[..., o0 : o0 + st], ref[..., :st], out_f32, f"{case} cfg={cfg} out_coff={oc0}")
+            assert float((out[..., :o0] + 768.0).abs().max()) == 0.0, "wrote outside its channel range"
+            assert float((out[..., o0 + st :] + 768.0).abs().max()) < 1.0, "wrote past cout_store"
+            tested += 1
     assert tested >= 2
 
 
@@ -327,24 +328,33 @@ def test_conv_epilogues(gpu_lib):
     b = torch.randn(Cout, generator=g)
     # residual added AFTER the activation (YoloNASBottleneck)
     res = torch.randn(B, H, W, Cout, generator=g)
-    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, res=res, alpha=0.7)
-    _assert_close(out[..., 4 : 4 + st], ref, False, "residual")
+    for cfg in range(-1, gpu_lib.vgh_conv_num_cfgs()):
+        if cfg >= 0 and not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, 128, 1, 0):
+            continue
+        out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, res=res, alpha=0.7, cfg=cfg)
+        _assert_close(out[..., o0 : o0 + st], ref, False, f"residual cfg={cfg}")
+    out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, res=res, alpha=0.7, out_coff=4)
+    _assert_close(out[..., o0 : o0 + st], ref, False, "residual general epilogue")
     # no activation
-    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, act=0)
-    _assert_close(out[..., 4 : 4 + st], ref, False, "act none")
-    assert float(ref.min()) < -0.5 and float(out[..., 4 : 4 + st].min()) < -0.5
+    out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, act=0)
+    _assert_close(out[..., o0 : o0 + st], ref, False, "act none")
+    assert float(ref.min()) < -0.5 and float(out[..., o0 : o0 + st].min()) < -0.5
     # two-segment output (CSP conv1|conv2): first 64 rows at offset 72, the rest at offset 0
-    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, split=(64, 72, 0))
-    _assert_close(out[..., 72:136], ref[..., :64], False, "split seg0")
-    _assert_close(out[..., 0:64], ref[..., 64:128], False, "split seg1")
+    for cfg in range(-1, gpu_lib.vgh_conv_num_cfgs()):
+        if cfg >= 0 and not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, 128, 1, 0):
+            continue
+        out, ref, st, _ = _run_conv(gpu_lib, x, Wt, b, 3, 1, split=(64, 72, 0), cfg=cfg)
+        _assert_close(out[..., 72:136], ref[..., :64], False, f"split seg0 cfg={cfg}")
+        _assert_close(out[..., 0:64], ref[..., 64:128], False, f"split seg1 cfg={cfg}")
     # fp32 output with a ragged channel count (prediction convs): 69 channels
     W69 = torch.randn(69, 1, 1, Cin, generator=g) * 0.1
-    out, ref, st = _run_conv(gpu_lib, x, W69, torch.randn(69, generator=g), 1, 1, act=0, out_f32=True)
-    _assert_close(out[..., 4 : 4 + 69], ref[..., :69], True, "f32 out")
-    assert float((out[..., 4 + 69 :] + 768.0).abs().max()) == 0.0
+    out, ref, st, o0 = _run_conv(gpu_lib, x, W69, torch.randn(69, generator=g), 1, 1, act=0, out_f32=True, out_coff=5)
+    _assert_close(out[..., 5 : 5 + 69], ref[..., :69], True, "f32 out")
+    assert float((out[..., 5 + 69 :] + 768.0).abs().max()) == 0.0
     # input view at a channel offset inside a wider (concat) buffer
-    out, ref, st = _run_conv(gpu_lib, x, Wt, b, 3, 1, in_coff=32, in_pitch=160)
-    _assert_close(out[..., 4 : 4 + st], ref, False, "in_coff")
+    for cfg in (-1, 15, 16):
+        out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, in_coff=32, in_pitch=160, cfg=cfg)
+        _assert_close(out[..., o0 : o0 + st], ref, False, f"in_coff cfg={cfg}")
     # ConvTranspose2d(k=2, s=2) as 4 pointwise GEMMs + pixel-shuffle store, checked against torch's own op
     Ct = 96
     xt = torch.randn(B, H, W, Ct, generator=g).to(torch.bfloat16).float()
@@ -354,10 +364,11 @@ def test_conv_epilogues(gpu_lib):
     for dy in range(2):
         for dx in range(2):
             Wg[(dy * 2 + dx) * Ct : (dy * 2 + dx + 1) * Ct, 0, 0] = Wct[:, :, dy, dx].T
-    out, ref, st = _run_conv(gpu_lib, xt, Wg, bt.repeat(4), 1, 1, act=0, shuffle=True)
-    tref = F.conv_transpose2d(xt.permute(0, 3, 1, 2), Wct, bt, stride=2).permute(0, 2, 3, 1)
-    assert (ref - tref).abs().max() < 1e-4
-    _assert_close(out[..., 4 : 4 + Ct], tref, False, "convT shuffle")
+    for oc0 in (8, 4):
+        out, ref, st, o0 = _run_conv(gpu_lib, xt, Wg, bt.repeat(4), 1, 1, act=0, shuffle=True, out_coff=oc0)
+        tref = F.conv_transpose2d(xt.permute(0, 3, 1, 2), Wct, bt, stride=2).permute(0, 2, 3, 1)
+        assert (ref - tref).abs().max() < 1e-4
+        _assert_close(out[..., o0 : o0 + Ct], tref, False, f"convT shuffle out_coff={oc0}")
 
 
 # ======================================================================================================

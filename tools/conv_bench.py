@@ -40,7 +40,7 @@ def main():
     flops = 2.0 * B * Ho * Wo * Cout * k * k * Cin
     st = torch.cuda.current_stream().cuda_stream
     for c in cfgs:
-        if c >= 0 and rp % int(names[c].split("_")[0].split("x")[1]):
+        if c >= 0 and not lib.vgh_conv_cfg_ok(c, k, stride, rp, 1, 0):
             continue
         call = _lib.ConvCall(in_dev=x.data_ptr(), in_pitch=Cin, in_coff=0, cin=Cin, B=B, H=H, W=W, wpack_dev=d_pack.data_ptr(), bias_dev=d_bias.data_ptr(),
                              out_dev=out.data_ptr(), out_pitch=rp, out_coff=0, cout_pad=rp, cout_store=rp, out_split=rp, out_coff2=0, out_f32=0,

@@ -26,14 +26,18 @@ def main():
     args = ap.parse_args()
     eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, use_tuning=False)
     names = eng.cfg_names()
-    bc = [int(n.split("_")[0].split("x")[1]) for n in names]
     x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8).cuda()
     ops = eng.program.ops
     conv_idx = [i for i, op in enumerate(ops) if op["kind"] == 1]
     best = {}
     times = {i: {} for i in conv_idx}
     for c, name in enumerate(names):
-        ok = [i for i in conv_idx if ops[i]["cout_pad"] % bc[c] == 0]
+        def fast(op):
+            ob = eng.program.bufs[op["out_buf"]]
+            al = all(op[k] % 8 == 0 for k in ("out_coff", "out_coff2", "out_split", "cout_store", "res_coff")) and ob["pitch"] % 8 == 0
+            return int((not ob["is_f32"]) and al)
+
+        ok = [i for i in conv_idx if eng.lib.vgh_conv_cfg_ok(c, ops[i]["ksize"], ops[i]["stride"], ops[i]["cout_pad"], fast(ops[i]), ops[i]["shuffle"])]
         if not ok:
             continue
         for i in conv_idx:
