@@ -35,6 +35,15 @@ __device__ __forceinline__ void bload_lds16(const void* base, unsigned voffset, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
+__device__ __forceinline__ int fastdiv(int n, unsigned m, unsigned s) { return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s); }
+
+// 9-bit (ky*3+kx) "tap inside the image" mask of a 3x3 window centred (pad 1) on (cy, cx); 1 bit for a 1x1 conv
+__device__ __forceinline__ unsigned tap_mask(int cy, int cx, int H, int W, int ksize) {
+    if (ksize == 1) return 1u;
+    const unsigned xm = (cx > 0 ? 1u : 0u) | 2u | (cx + 1 < W ? 4u : 0u);
+    return (cy > 0 ? xm : 0u) | (xm << 3) | (cy + 1 < H ? xm << 6 : 0u);
+}
+
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == VGH_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == VGH_ACT_SILU) return v / (1.0f + __expf(-v));
@@ -98,18 +107,13 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
         const int m = p0 + r;
         const bool valid = m < a.P;
         const int mm = valid ? m : 0;
-        const int b = mm / HoWo;
+        const int b = fastdiv(mm, a.div_howo_m, a.div_howo_s);
         const int rem = mm - b * HoWo;
-        const int oy = rem / a.Wo;
+        const int oy = fastdiv(rem, a.div_wo_m, a.div_wo_s);
         const int ox = rem - oy * a.Wo;
         const int cy = oy * a.stride, cx = ox * a.stride;  // centre tap (always inside the image)
         xoff[t] = 2u * (unsigned)(((b * a.H + cy) * a.W + cx) * (int)a.in_pitch + a.in_coff) + (((lane & 3) ^ ((lane >> 4) & 3))) * 16;
-        unsigned mask = 0;
-        for (int ky = 0; ky < a.ksize; ++ky)
-            for (int kx = 0; kx < a.ksize; ++kx) {
-                const int iy = cy + ky - a.pad, ix = cx + kx - a.pad;
-                if (valid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) mask |= 1u << (ky * a.ksize + kx);
-            }
+        const unsigned mask = valid ? tap_mask(cy, cx, a.H, a.W, a.ksize) : 0u;
         xmask[t] = mask;
     }
     constexpr unsigned OOB = 0xFFFFFFF0u;  // >= num_records: the buffer range check returns zeros
@@ -244,6 +248,7 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    if (a.ablate & 8) return;  // perf experiments only
     const int half4 = (lane >> 5) * 4;
     if constexpr (EPI == 1) {
         // Fast path (bf16 out, every channel offset a multiple of 8): each wave transposes its accumulators through a
@@ -693,6 +698,13 @@ const CfgEntry g_cfgs[] = {
     CFGR(128, 128, 32, 64, 1, 2),  // 44  8 waves
     CFGR(128, 128, 32, 64, 1, 3),  // 45
     CFGR(512, 64, 64, 64, 1, 2),   // 46  8 waves
+    CFGR(256, 128, 128, 64, 1, 2), // 47  4 waves, 128x64 wave tiles (8 MFMA tiles / wave)
+    CFGR(256, 128, 128, 64, 1, 3), // 48
+    CFGR(256, 128, 64, 128, 1, 2), // 49  4 waves, 64x128 wave tiles
+    CFGR(256, 64, 128, 64, 1, 2),  // 50  2 waves
+    CFGR(512, 128, 128, 64, 1, 2), // 51  8 waves, 128x64 wave tiles
+    CFGR(256, 256, 128, 64, 1, 2), // 52  8 waves
+    CFGR(256, 256, 64, 128, 1, 2), // 53  8 waves
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
@@ -740,8 +752,11 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     VGH_REQUIRE((int64_t)a.B * a.H * a.W * a.in_pitch * 2 < (1ll << 31), "conv: input tensor must stay below 2 GiB (32-bit buffer offsets); run the batch in chunks");
     VGH_REQUIRE(!a.shuffle || (a.shuffle_c % 4 == 0 && a.cout_pad >= 4 * a.shuffle_c && a.ksize == 1 && a.stride == 1), "conv: bad shuffle");
     if (a.P == 0) return VGH_OK;
+    VGH_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (1ll << 30), "conv: too many output pixels for one launch");
     static const int ablate = getenv("VGH_CONV_ABLATE") ? atoi(getenv("VGH_CONV_ABLATE")) : 0;  // perf experiments only
     const_cast<ConvArgs&>(a).ablate = ablate;
+    vgh_fastdiv_magic((unsigned)(a.Ho * a.Wo), &const_cast<ConvArgs&>(a).div_howo_m, &const_cast<ConvArgs&>(a).div_howo_s);
+    vgh_fastdiv_magic((unsigned)a.Wo, &const_cast<ConvArgs&>(a).div_wo_m, &const_cast<ConvArgs&>(a).div_wo_s);
     const bool al8 = a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_split % 8 == 0 && a.cout_store % 8 == 0 && a.out_pitch % 8 == 0 &&
                      (!a.res || (a.res_coff % 8 == 0 && a.res_pitch % 8 == 0)) && (!a.shuffle || a.shuffle_c % 8 == 0);
     const_cast<ConvArgs&>(a).fast_epi = (!a.out_f32 && al8 && !(ablate & 4)) ? 1 : 0;

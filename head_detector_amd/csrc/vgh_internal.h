@@ -55,6 +55,7 @@ struct ConvArgs {
     int P;          // B*Ho*Wo output pixels
     int nkb;        // ksize*ksize*cin/32
     int cblocks;    // cin/32
+    unsigned div_howo_m, div_howo_s, div_wo_m, div_wo_s;  // n / d == (umulhi(n, m) + n) >> s for n < 2^30 (filled by vgh_launch_conv)
     int fast_epi;   // 1: LDS-transposed 16-byte epilogue (bf16 out, 8-channel aligned offsets)
     int ablate;     // perf experiments: bit0 skip tile loads, bit1 skip MFMAs (results are garbage)
 };
@@ -64,6 +65,13 @@ int vgh_conv_pick_cfg(const ConvArgs& a);
 // host-side weight packing: dense [cout_pad][ks][ks][cin] f32 -> wpack bf16 image
 void vgh_pack_conv_weights_host(const float* w, int cout_pad, int ksize, int cin, uint16_t* dst);
 static inline size_t vgh_wpack_elems(int cout_pad, int ksize, int cin) { return (size_t)cout_pad * ksize * ksize * cin; }
+
+static inline void vgh_fastdiv_magic(unsigned d, unsigned* m, unsigned* s) {
+    unsigned sh = 0;
+    while ((1ull << sh) < d) ++sh;
+    *m = (unsigned)((((1ull << 32) * ((1ull << sh) - d)) / d) + 1);
+    *s = sh;
+}
 
 static inline uint16_t vgh_f32_to_bf16_host(float f) {
     uint32_t u;
