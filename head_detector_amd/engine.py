@@ -37,7 +37,8 @@ class Detections:
 
 class VGHeadsEngine:
     def __init__(self, variant: str = "vgg_heads_l", state_dict: Optional[Dict[str, np.ndarray]] = None, image_size: int = 640, max_batch: int = 1,
-                 device: Optional[int] = None, seed: int = 1, pre_nms_top_k: int = 1000, keep_top_k: int = 100, use_tuning: bool = True):
+                 device: Optional[int] = None, seed: int = 1, pre_nms_top_k: int = 1000, keep_top_k: int = 100, use_tuning: bool = True,
+                 arena_batch: Optional[int] = None):
         if variant not in arch.VARIANTS:
             raise ValueError(f"unknown model variant {variant!r}; known: {sorted(arch.VARIANTS)}")
         if not torch.cuda.is_available():
@@ -50,13 +51,17 @@ class VGHeadsEngine:
             state_dict = arch.random_state_dict(variant, seed)  # synthetic weights of the exact architecture
         self.program = arch.build_program(variant, state_dict, image_size)
         P = self.program
+        # the conv loader addresses an input tensor with 32-bit byte offsets: keep every arena tensor below 2 GiB by running
+        # large batches through the network in chunks (post-network stages always see the whole batch)
+        per_image = max(bf["h"] * bf["w"] * bf["pitch"] * (4 if bf["is_f32"] else 2) for bf in P.bufs)
+        self.arena_batch = max(1, min(max_batch, ((1 << 31) - 1) // per_image, arena_batch or max_batch))
         w, b = P.arrays()
         bufs = (_lib.BufDesc * len(P.bufs))(*[_lib.BufDesc(bf["h"], bf["w"], bf["pitch"], bf["is_f32"]) for bf in P.bufs])
         fields = [f for f, _ in _lib.OpDesc._fields_ if f != "reserved"]
         ops = (_lib.OpDesc * len(P.ops))(*[_lib.OpDesc(**{f: (op[f] if f != "in_buf" else max(op[f], 0)) for f in fields}) for op in P.ops])
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.vgh_net_create(self.device_index, image_size, max_batch, bufs, len(P.bufs), ops, len(P.ops), _lib.ptr(w), w.size, _lib.ptr(b), b.size, C.byref(h)))
+            _lib.check(self.lib.vgh_net_create(self.device_index, image_size, self.arena_batch, bufs, len(P.bufs), ops, len(P.ops), _lib.ptr(w), w.size, _lib.ptr(b), b.size, C.byref(h)))
         self._net = h
         self.stream = torch.cuda.Stream(device=self.device)
         self.A = sum(lv["h"] * lv["w"] for lv in P.levels)
@@ -141,8 +146,10 @@ class VGHeadsEngine:
         return B, fmt
 
     def forward_net(self, images: torch.Tensor, use_graph: bool = False) -> int:
-        """Backbone + neck + heads: leaves the fp32 prediction buffers inside the arena. Returns B."""
+        """Backbone + neck + heads for one arena-sized batch: leaves the fp32 prediction buffers inside the arena. Returns B."""
         B, fmt = self._check_images(images)
+        if B > self.arena_batch:
+            raise ValueError(f"forward_net handles at most arena_batch={self.arena_batch} images; use forward_candidates() for larger batches")
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         if use_graph:
             key = (images.data_ptr(), B, fmt)
@@ -156,28 +163,38 @@ class VGHeadsEngine:
             _lib.check(self.lib.vgh_net_forward(self._net, images.data_ptr(), fmt, B, self._sp()))
         return B
 
-    def candidates(self, B: int):
-        """K6 + K7 + K6b on the engine stream: boxes/scores for all anchors, top-k, gather + FLAME fix-up."""
+    def candidates(self, B: int, at: int = 0):
+        """K6 + K7 + K6b on the engine stream for the B images currently in the arena: boxes/scores for all anchors, top-k,
+        gather + FLAME fix-up; results land in rows [at, at+B) of the batch-level candidate tensors."""
         lv = self._levels_arr(B)
         P = self.program
         sp = self._sp()
-        _lib.check(self.lib.vgh_head_decode(lv, len(P.levels), B, _lib.ptr(self.boxes_all), _lib.ptr(self.scores_all), sp))
-        _lib.check(self.lib.vgh_topk(_lib.ptr(self.scores_all), B, self.A, self.pre_k, _lib.ptr(self.idx), _lib.ptr(self.cand_scores), sp))
-        _lib.check(self.lib.vgh_gather_candidates(lv, len(P.levels), B, self.A, P.shape_c, P.expr_c, _lib.ptr(self.boxes_all), _lib.ptr(self.idx), self.pre_k,
-                                                  _lib.ptr(self.cand_boxes), _lib.ptr(self.cand_flame), sp))
+        ba, sa, ix = self.boxes_all[at:], self.scores_all[at:], self.idx[at:]
+        cs, cb, cf = self.cand_scores[at:], self.cand_boxes[at:], self.cand_flame[at:]
+        _lib.check(self.lib.vgh_head_decode(lv, len(P.levels), B, _lib.ptr(ba), _lib.ptr(sa), sp))
+        _lib.check(self.lib.vgh_topk(_lib.ptr(sa), B, self.A, self.pre_k, _lib.ptr(ix), _lib.ptr(cs), sp))
+        _lib.check(self.lib.vgh_gather_candidates(lv, len(P.levels), B, self.A, P.shape_c, P.expr_c, _lib.ptr(ba), _lib.ptr(ix), self.pre_k, _lib.ptr(cb), _lib.ptr(cf), sp))
+
+    def forward_candidates(self, images: torch.Tensor, use_graph: bool = False) -> int:
+        """Network + candidate stages for a batch of any size <= max_batch, in arena-sized chunks."""
+        B = images.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
+        for i in range(0, B, self.arena_batch):
+            n = self.forward_net(images[i : i + self.arena_batch], use_graph and B <= self.arena_batch)
+            self.candidates(n, at=i)
+        return B
 
     def model(self, images: torch.Tensor, use_graph: bool = False):
         """Drop-in for ``self.model(image)`` (detector.py:58-59)."""
-        B = self.forward_net(images, use_graph)
-        self.candidates(B)
+        B = self.forward_candidates(images, use_graph)
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self.cand_boxes[:B], self.cand_scores[:B].unsqueeze(-1), self.cand_flame[:B]
 
     def detect(self, images: torch.Tensor, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
                unpad: Optional[torch.Tensor] = None, use_graph: bool = False) -> Detections:
         """net -> top-k -> NMS (every image) -> optional FLAME decode of every surviving head."""
-        B = self.forward_net(images, use_graph)
-        self.candidates(B)
+        B = self.forward_candidates(images, use_graph)
         sp = self._sp()
         _lib.check(self.lib.vgh_nms(_lib.ptr(self.cand_boxes), _lib.ptr(self.cand_scores), B, self.pre_k, float(confidence_threshold), float(iou_threshold), self.keep_k,
                                     _lib.ptr(self.keep_idx), _lib.ptr(self.counts), sp))

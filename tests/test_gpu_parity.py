@@ -488,3 +488,47 @@ def test_detect_pipeline_and_facade(gpu_lib, flame_model):
     # empty result path (detector must not fail when nothing passes the threshold; flame.py:186-189)
     empty = det(img, confidence_threshold=1.1)
     assert empty.heads == []
+
+
+def test_batch_chunking_is_invisible(gpu_lib):
+    """Batches whose tensors would cross the 2 GiB / 32-bit-offset limit run through the network in arena-sized chunks;
+    forced here with a tiny arena: results must be bit-identical to the unchunked run."""
+    from head_detector_amd.engine import VGHeadsEngine
+
+    S, B = 128, 5
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).to(_dev())
+    a = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=2, use_tuning=False)
+    b = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=2, use_tuning=False, arena_batch=2)
+    assert a.arena_batch == 5 and b.arena_batch == 2
+    ra = [t.clone() for t in a.model(x)]
+    rb = [t.clone() for t in b.model(x)]
+    for u, v in zip(ra, rb):
+        assert torch.equal(u, v)
+    da, db = a.detect(x, confidence_threshold=float(ra[1][:, 5, 0].min())), b.detect(x, confidence_threshold=float(ra[1][:, 5, 0].min()))
+    assert torch.equal(da.counts, db.counts) and torch.equal(da.boxes, db.boxes)
+    a.close()
+    b.close()
+
+
+def test_1280_crowd_config_shapes(gpu_lib, flame_model):
+    """BASELINE config 5 geometry: 1280x1280 -> 33 600 anchors, top-k 1000, crowd NMS keeps up to 100 heads per image."""
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+    from oracle import postproc_oracle as po
+
+    eng = VGHeadsEngine("vgg_heads_l", image_size=1280, max_batch=2, seed=1)
+    assert eng.A == 33600
+    x = torch.randint(0, 256, (2, 1280, 1280, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(_dev())
+    boxes, scores, flame = eng.model(x)
+    assert boxes.shape == (2, 1000, 4) and torch.isfinite(flame).all()
+    ref_idx = po.stable_topk(eng.scores_all[0].cpu(), 1000)
+    assert torch.equal(eng.idx[0].cpu().long(), ref_idx)
+    conf = float(scores[:, 400, 0].max())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=256)
+    det = eng.detect(x, confidence_threshold=conf, flame=fl)
+    ref = po.postprocess_batched(boxes.cpu(), scores.cpu(), flame.cpu(), conf, 0.5)
+    for b in range(2):
+        n = int(det.counts[b])
+        assert n == ref[b][0].shape[0] and torch.equal(det.boxes[b, :n].cpu(), ref[b][0])
+    assert det.vertices_3d.shape[0] == int(det.counts.sum())
+    eng.close()

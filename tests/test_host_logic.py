@@ -158,3 +158,75 @@ def test_product_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_trcd_ingest_roundtrip(tmp_path):
+    """N1: a TorchScript archive shaped like the released .trcd (module tree under `model.`, exportable_mesh_model.py:421-427)
+    -> detector.load_weights -> fold: the state dict survives bit-exactly and folds without complaint."""
+    from head_detector_amd.detector import load_weights
+
+    variant = "vgg_heads_m"
+    sd = arch.random_state_dict(variant, 2)
+    oracle = _oracle_with(variant, sd)
+
+    class Pipeline(torch.nn.Module):  # ConvertableCompletePipelineModel keeps the network under `.model`
+        def __init__(self, m):
+            super().__init__()
+            self.model = m
+
+        def forward(self, x):
+            return self.model.neck(*self.model.backbone(x))
+
+    ts = torch.jit.trace(Pipeline(oracle), torch.zeros(1, 3, 64, 64), check_trace=False)
+    path = str(tmp_path / "vgg_heads_m.trcd")
+    ts.save(path)
+    got = load_weights(path)
+    keys = set(sd)
+    assert keys <= set(got), sorted(keys - set(got))[:5]
+    for k in keys:
+        assert np.array_equal(got[k], sd[k]), k
+    folded = arch.fold_state_dict(variant, got)
+    assert "backbone.stem.conv" in folded and folded["heads.head3.reg_pred"][0].shape == (68, 192, 1, 1)
+
+
+def test_flame_pickle_ingest(tmp_path):
+    """N1: FLAME pickle semantics of head_detector/flame.py:18-24,75-95 -- latin1 pickle, chumpy-wrapped arrays, scipy-sparse
+    J_regressor, posedirs reshaped [V*3, P] then transposed, parents from kintree_table[0] with parents[0] = -1."""
+    import pickle
+    import sys
+    import types
+
+    import scipy.sparse as sp
+
+    from head_detector_amd.flame import FLAMELayer
+    from head_detector_amd.synthetic import synthetic_flame_model
+    from oracle import flame_oracle as fo
+
+    m = synthetic_flame_model(seed=5, V=97, NB=400, NJ=5)
+    mod = types.ModuleType("chumpy")
+    sub = types.ModuleType("chumpy.ch")
+
+    class Ch:  # minimal stand-in for chumpy.ch.Ch: numeric payload in `.x`
+        def __init__(self, x):
+            self.x = x
+
+    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
+    sub.Ch = Ch
+    sys.modules["chumpy"], sys.modules["chumpy.ch"] = mod, sub
+    try:
+        blob = dict(m)
+        blob["v_template"] = Ch(m["v_template"])
+        blob["shapedirs"] = Ch(m["shapedirs"])
+        blob["J_regressor"] = sp.csc_matrix(m["J_regressor"])
+        path = str(tmp_path / "generic_model.pkl")
+        with open(path, "wb") as f:
+            pickle.dump(blob, f, protocol=2)
+    finally:
+        del sys.modules["chumpy"], sys.modules["chumpy.ch"]
+    layer = FLAMELayer(flame_path=path)  # must not need chumpy installed
+    ref = fo.FlameConstants(m, torch.float32)
+    for name in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+        assert torch.equal(getattr(layer, name), getattr(ref, name)), name
+    assert layer.parents.tolist() == [-1, 0, 1, 1, 1] and layer.faces_tensor.shape == (9976, 3)
+    with pytest.raises(FileNotFoundError):
+        FLAMELayer(flame_path=str(tmp_path / "missing.pkl"))
