@@ -178,8 +178,8 @@ def random_state_dict(variant: str, seed: int = 1) -> Dict[str, np.ndarray]:
         # cls bias prior of YoloHeadsDFLHead._initialize_biases (yolo_head_dfl_head.py:188-190); modest logit spread
         sd[f"heads.head{lv + 1}.cls_pred.bias"][:] = -math.log((1 - 1e-2) / 1e-2)
         sd[f"heads.head{lv + 1}.cls_pred.weight"] *= np.float32(0.02)
-        for k in list(sd):  # keep scale = exp(x)/0.05, translation, 6D rotation, jaw in a sane range
-            if re.fullmatch(rf"heads\.head{lv + 1}\.flame_(scale|translation|rotation|jaw)_pred\.\d+\.(weight|bias)", k):
+        for k in list(sd):  # keep every raw FLAME prediction O(1) like a trained head's (scale = exp(x)/0.05, 3*tanh(x), ...)
+            if re.fullmatch(rf"heads\.head{lv + 1}\.flame_(scale|translation|rotation|jaw|shape|expression)_pred\.\d+\.(weight|bias)", k):
                 sd[k] = (sd[k] * 0.05).astype(np.float32)
     return sd
 
@@ -261,6 +261,7 @@ class Program:
     shape_c: int = 0
     expr_c: int = 0
     flops: float = 0.0  # algorithmic 2*MACs per image (fused-conv accounting)
+    precision: str = "bf16"
 
     def buf(self, name: str, h: int, w: int, pitch: int, f32: bool = False) -> int:
         self.bufs.append(dict(name=name, h=h, w=w, pitch=pitch, is_f32=int(f32)))
@@ -326,7 +327,9 @@ def _stack(parts: List[Tuple[np.ndarray, np.ndarray]], pad_to: int = 1) -> Tuple
     return np.concatenate(ws), np.concatenate(bs), offs
 
 
-def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640) -> Program:
+def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640, precision: str = "bf16") -> Program:
+    """precision: 'bf16' (throughput mode: bf16 activations/weights, fp32 accumulate) or 'fp32' (parity mode: no bf16 anywhere)."""
+    assert precision in ("bf16", "fp32")
     v = VARIANTS[variant]
     F = fold_state_dict(variant, sd)
     P = Program(variant=variant, image_size=image_size)
@@ -504,4 +507,8 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
         P.shape_c, P.expr_c = Sc, Ec
 
     P.flops = 2.0 * sum(o["macs"] for o in P.ops)
+    if precision == "fp32":
+        for bf in P.bufs:
+            bf["is_f32"] = 1
+    P.precision = precision
     return P

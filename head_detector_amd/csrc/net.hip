@@ -89,15 +89,22 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image, int fmt, i
     switch (d.kind) {
         case VGH_OP_STEM: {
             const vgh_buf_desc& ob = n->bufs[d.out_buf];
+            if (ob.is_f32)  // fp32 parity mode
+                return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)n->buf_ptr[d.out_buf], ob.pitch, d.out_coff, st);
             return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)n->buf_ptr[d.out_buf], ob.pitch, d.out_coff, st);
         }
         case VGH_OP_CONV: {
             ConvArgs a;
             if (int rc = net_conv_args(n, op, B, &a)) return rc;
+            if (n->bufs[d.in_buf].is_f32) {  // fp32 parity mode: dense fp32 weights, FMA kernel
+                VGH_REQUIRE(a.out_f32 && (d.res_buf < 0 || n->bufs[d.res_buf].is_f32), "net: fp32 conv needs fp32 output / residual buffers");
+                return vgh_launch_conv_f32(a, op.wf32, st);
+            }
             return vgh_launch_conv(a, d.force_cfg, st);
         }
         case VGH_OP_SPP_POOL: {
             const vgh_buf_desc& ib = n->bufs[d.in_buf];
+            if (ib.is_f32) return vgh_launch_spp_pool_f32((float*)n->buf_ptr[d.in_buf], ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
             return vgh_launch_spp_pool((uint16_t*)n->buf_ptr[d.in_buf], ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
         }
         default:
@@ -147,7 +154,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             const int64_t we = (int64_t)d.cout_pad * d.ksize * d.ksize * d.cin;
             VGH_REQUIRE(d.w_off >= 0 && d.w_off + we <= n_weights && d.b_off >= 0 && d.b_off + d.cout_pad <= n_biases, "net_create: op %d weight range", i);
             woff[i] = wbytes;
-            wbytes += align_up(we * 2, 256);
+            wbytes += align_up(we * (bufs[d.in_buf].is_f32 ? 4 : 2), 256);
             boff[i] = wbytes;
             wbytes += align_up((int64_t)d.cout_pad * 4, 256);
         } else if (d.kind == VGH_OP_STEM) {
@@ -162,7 +169,10 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     for (int i = 0; i < n_ops; ++i) {
         const vgh_op_desc& d = ops[i];
         if (d.kind == VGH_OP_CONV) {
-            vgh_pack_conv_weights_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint16_t*)(host.data() + woff[i]));
+            if (bufs[d.in_buf].is_f32)
+                memcpy(host.data() + woff[i], weights_host + d.w_off, (size_t)d.cout_pad * d.ksize * d.ksize * d.cin * 4);
+            else
+                vgh_pack_conv_weights_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint16_t*)(host.data() + woff[i]));
             memcpy(host.data() + boff[i], biases_host + d.b_off, (size_t)d.cout_pad * 4);
         } else if (d.kind == VGH_OP_STEM) {
             // host gives [48][3(ky)][3(kx)][3(ci)] -> device [27][48]
@@ -179,6 +189,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
         op.d = ops[i];
         if (ops[i].kind == VGH_OP_CONV) {
             op.wpack = (uint16_t*)(n->wblob + woff[i]);
+            op.wf32 = (float*)(n->wblob + woff[i]);  // same storage: bf16 image (throughput mode) or dense fp32 (parity mode)
             op.bias = (float*)(n->wblob + boff[i]);
         } else if (ops[i].kind == VGH_OP_STEM) {
             op.wf32 = (float*)(n->wblob + woff[i]);

@@ -84,4 +84,8 @@ static inline uint16_t vgh_f32_to_bf16_host(float f) {
 // ---- other launchers --------------------------------------------------------------------
 int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w /*[64][27] dev*/,
                     const float* bias /*[64] dev*/, uint16_t* out, int64_t out_pitch, int out_coff, hipStream_t stream);
+int vgh_launch_conv_f32(const ConvArgs& a, const float* wdense, hipStream_t stream);
+int vgh_launch_stem_f32(const void* image, int image_fmt, int B, int H, int W, const float* w, const float* bias, float* out, int64_t out_pitch, int out_coff,
+                        hipStream_t stream);
+int vgh_launch_spp_pool_f32(float* buf, int64_t pitch, int coff, int C, int B, int H, int W, hipStream_t stream);
 int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, int H, int W, hipStream_t stream);

@@ -38,7 +38,7 @@ class Detections:
 class VGHeadsEngine:
     def __init__(self, variant: str = "vgg_heads_l", state_dict: Optional[Dict[str, np.ndarray]] = None, image_size: int = 640, max_batch: int = 1,
                  device: Optional[int] = None, seed: int = 1, pre_nms_top_k: int = 1000, keep_top_k: int = 100, use_tuning: bool = True,
-                 arena_batch: Optional[int] = None):
+                 arena_batch: Optional[int] = None, precision: str = "bf16"):
         if variant not in arch.VARIANTS:
             raise ValueError(f"unknown model variant {variant!r}; known: {sorted(arch.VARIANTS)}")
         if not torch.cuda.is_available():
@@ -49,7 +49,8 @@ class VGHeadsEngine:
         self.device = torch.device("cuda", self.device_index)
         if state_dict is None:
             state_dict = arch.random_state_dict(variant, seed)  # synthetic weights of the exact architecture
-        self.program = arch.build_program(variant, state_dict, image_size)
+        self.precision = precision
+        self.program = arch.build_program(variant, state_dict, image_size, precision)
         P = self.program
         # the conv loader addresses an input tensor with 32-bit byte offsets: keep every arena tensor below 2 GiB by running
         # large batches through the network in chunks (post-network stages always see the whole batch)
@@ -82,7 +83,7 @@ class VGHeadsEngine:
         self.out_flame = torch.empty(B, kk, _lib.NUM_FLAME_PARAMS, **f32)
         self._levels = None
         self._graph_key = None
-        if use_tuning:
+        if use_tuning and precision == "bf16":
             self.load_tuning()
 
     # ---------------------------------------------------------------------------------------------------
