@@ -391,15 +391,16 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
 //   LDS        : X[2][(TH+2)*(TW+2) halo pixels][64 B] + W[2][3 taps][BC][64 B], both 16-B-chunk swizzled
 //   bytes/FLOP : (HP + 9*BC) * 64 B per 9*BP*BC*64 FLOP  ->  ~200 FLOP/B at 256 px x 128 couts (v1: 64-85)
 // =====================================================================================================
-template <int TW, int TH, int BC, int NW>
-__global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a, const int ntc, const int ntx, const int nty, const int total_tiles,
-                                                                const int chunk) {
-    constexpr int NPX = TW * TH, NG = (NPX + 31) / 32, TJ = NG / NW, TI = BC / 32;
+template <int TW, int TH, int BC, int NWP, int NWC>
+__global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const ConvArgs a, const int ntc, const int ntx, const int nty, const int total_tiles,
+                                                                        const int chunk) {
+    constexpr int NW = NWP * NWC;
+    constexpr int NPX = TW * TH, NG = (NPX + 31) / 32, TJ = NG / NWP, TI = BC / 32 / NWC, WC = BC / NWC;
     constexpr int HW = TW + 2, HP = HW * (TH + 2), HPU = (HP + 15) / 16;
     constexpr int XBYTES = HPU * 1024, WTAP = BC * 64, WSTEP = 3 * WTAP;
-    constexpr int XUW = (HPU + NW - 1) / NW;   // halo units (16 pixels) staged per wave per channel block
+    constexpr int XUW = (HPU + NW - 1) / NW;  // halo units (16 pixels = 1 KiB) staged per wave per channel block
     constexpr int WU = 3 * BC / 16, WUW = (WU + NW - 1) / NW;
-    static_assert(NG % NW == 0, "pixel groups must split evenly across waves");
+    static_assert(NG % NWP == 0 && (BC / 32) % NWC == 0, "tile must split evenly across the wave grid");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xbuf = smem;
     char* const wbuf = smem + 2 * XBYTES;
@@ -417,53 +418,63 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w % NWP, wc = w / NWP;
     const int lrow = lane & 31;
-    const int csel16 = (((lane & 3) ^ ((lane >> 4) & 3))) * 16;  // source-side swizzle: chunk = slot ^ ((halo_row>>2)&3)
+    constexpr unsigned OOB = 0xFFFFFFF0u;
 
-    // ---- halo loader state (fixed over the whole K loop; only the channel offset moves) ----
-    const char* xsrc[XUW];
+    // ---- halo loader state: one 32-bit offset per staged 16-pixel unit, fixed over the whole K loop (the channel block only
+    //      moves the descriptor base by 64 B); pixels outside the image / beyond the patch use an out-of-range offset = zeros
+    unsigned xoff[XUW];
 #pragma unroll
     for (int t = 0; t < XUW; ++t) {
         const int hp = (w + NW * t) * 16 + (lane >> 2);
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        xsrc[t] = ok ? (const char*)a.in + 2 * ((((int64_t)b * a.H + iy) * a.W + ix) * a.in_pitch + a.in_coff) + csel16 : nullptr;
+        // source-side swizzle: LDS slot (lane & 3) of halo pixel (hy, hx) holds channel chunk slot ^ ((hx >> 2) & 3)
+        xoff[t] = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * (int)a.in_pitch + a.in_coff) + (((lane & 3) ^ ((hx >> 2) & 3))) * 16 : OOB;
     }
-    const char* zsrc = (const char*)a.zeros + csel16;
-    const char* wlane = (const char*)a.wpack + (int64_t)c0 * 64 + lane * 16;
+    const char* const wbase = (const char*)a.wpack + (int64_t)c0 * 64;
+    const unsigned wvoff = lane * 16;
+    const unsigned wkstride = (unsigned)a.cout_pad * 64u;  // bytes between consecutive k-blocks of the packed weights
 
     auto load_x = [&](int cb, char* dst) {
+        const char* const xbase = (const char*)a.in + cb * 64;
 #pragma unroll
         for (int t = 0; t < XUW; ++t) {
             const int u = w + NW * t;
-            if (u < HPU) glds16(xsrc[t] ? xsrc[t] + cb * 64 : zsrc, dst + u * 1024);
+            if (HPU % NW == 0 || u < HPU) bload_lds16(xbase, xoff[t], 0, dst + u * 1024);
         }
     };
     auto load_w = [&](int cb, int ky, char* dst) {
 #pragma unroll
         for (int t = 0; t < WUW; ++t) {
             const int v = w + NW * t;  // wave-uniform
-            if (v < WU) {
+            if (WU % NW == 0 || v < WU) {
                 const int kx = v / (BC / 16), rb = v - kx * (BC / 16);
-                const int kb = (ky * 3 + kx) * a.cblocks + cb;
-                glds16(wlane + (int64_t)kb * a.cout_pad * 64 + rb * 1024, dst + kx * WTAP + rb * 1024);
+                const unsigned kb = (unsigned)((ky * 3 + kx) * a.cblocks + cb);
+                bload_lds16(wbase, wvoff + rb * 1024, kb * wkstride, dst + kx * WTAP + rb * 1024);
             }
         }
     };
 
-    // ---- fragment addressing ----
-    int r0[TJ];  // halo row of this lane's pixel at tap (0,0)
+    // ---- fragment addressing: the swizzle depends on the halo COLUMN only, so the kernel row ky is a wave-uniform LDS offset
+    //      and the per-lane byte offsets of all (kx, k16-half) combinations are computed once ----
+    const int hi = lane >> 5;
+    int boff[TJ][3][2];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        const int p = (w * TJ + j) * 32 + lrow;
+        const int p = (wp * TJ + j) * 32 + lrow;
         const int ty = p / TW, tx = p - ty * TW;
-        r0[j] = (p < NPX) ? ty * HW + tx : 0;
+        const int r00 = (p < NPX) ? ty * HW + tx : 0, hx0 = (p < NPX) ? tx : 0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi) ^ (((hx0 + kx) >> 2) & 3)) * 16);
     }
-    const int hi = lane >> 5;
     const int sw = (lane >> 2) & 3;
-    const int aoff0 = lrow * 64 + (((0 + hi) ^ sw) * 16);
-    const int aoff1 = lrow * 64 + (((2 + hi) ^ sw) * 16);
+    const int aoff0 = (wc * WC + lrow) * 64 + (((0 + hi) ^ sw) * 16);
+    const int aoff1 = (wc * WC + lrow) * 64 + (((2 + hi) ^ sw) * 16);
 
     f32x16_t acc[TI][TJ];
 #pragma unroll
@@ -477,11 +488,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a
         const int kx = sub >> 1, h = sub & 1;
 #pragma unroll
         for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8_t*)(Wt + kx * WTAP + i * 2048 + (h ? aoff1 : aoff0));
+        const char* Xk = X + ky * (HW * 64);
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int r = r0[j] + ky * HW + kx;
-            bfr[j] = *(const bf16x8_t*)(X + r * 64 + ((((h ? 2 : 0) + hi) ^ ((r >> 2) & 3)) * 16));
-        }
+        for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8_t*)(Xk + boff[j][kx][h]);
     };
     auto mma = [&](const bf16x8_t (&af)[TI], const bf16x8_t (&bfr)[TJ]) {
 #pragma unroll
@@ -527,28 +536,24 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a
         cb = ncb;
         ky = nky;
     }
+    if (a.ablate & 8) return;
 
     // ---- epilogue: LDS transpose -> 16-byte stores (same scheme as the fast path of the implicit-GEMM kernel) ----
-    constexpr int EP = BC + 4, CH = BC / 8, NIT = 32 * CH / 64;
+    constexpr int EP = WC + 4, CH = WC / 8, NIT = 32 * CH / 64;
     float* stg = (float*)smem + w * (32 * EP);
     const int half4 = hi * 4;
-    int ipx[NIT], ich[NIT];
-#pragma unroll
-    for (int t = 0; t < NIT; ++t) {
-        const int it = lane + 64 * t;
-        ipx[t] = it / CH;
-        ich[t] = it - ipx[t] * CH;
-    }
-    int64_t opix[TJ][NIT];  // output pixel index or -1
+    const int cw0 = c0 + wc * WC;
+    int opix[TJ][NIT];  // output pixel index (b*H + y)*W + x, or -1
 #pragma unroll
     for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
-            const int p = (w * TJ + j) * 32 + ipx[t];
+            const int it = lane + 64 * t;
+            const int p = (wp * TJ + j) * 32 + it / CH;
             const int ty = p / TW, tx = p - ty * TW;
             const int y = y0 + ty, x = x0 + tx;
-            const bool ok = p < NPX && y < a.H && x < a.W && (c0 + ich[t] * 8) < a.cout_store;
-            opix[j][t] = ok ? ((int64_t)b * a.H + y) * a.W + x : -1;
+            const bool ok = p < NPX && y < a.H && x < a.W && (cw0 + (it % CH) * 8) < a.cout_store;
+            opix[j][t] = ok ? (b * a.H + y) * a.W + x : -1;
         }
     bf16x8_t rres[TJ][NIT];
     if (a.res) {
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int t = 0; t < NIT; ++t)
-                if (opix[j][t] >= 0) rres[j][t] = *(const bf16x8_t*)(a.res + opix[j][t] * a.res_pitch + a.res_coff + c0 + ich[t] * 8);
+                if (opix[j][t] >= 0) rres[j][t] = *(const bf16x8_t*)(a.res + (int64_t)opix[j][t] * a.res_pitch + a.res_coff + cw0 + ((lane + 64 * t) % CH) * 8);
     }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = i * 32 + q * 8 + half4;
-                const f32x4_t bv = *(const f32x4_t*)(a.bias + c0 + cl);
+                const f32x4_t bv = *(const f32x4_t*)(a.bias + cw0 + cl);
                 f32x4_t v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][q * 4 + e] + bv[e], a.act);
@@ -577,7 +582,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
             if (opix[j][t] >= 0) {
-                const int px = ipx[t], ch = ich[t];
+                const int it = lane + 64 * t;
+                const int px = it / CH, ch = it - px * CH;
                 const f32x4_t v0 = *(const f32x4_t*)(stg + px * EP + ch * 8);
                 const f32x4_t v1 = *(const f32x4_t*)(stg + px * EP + ch * 8 + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -585,12 +591,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_patch_kernel(const ConvArgs a
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += a.alpha * (float)rres[j][t][e];
                 }
-                const int oc = c0 + ch * 8;
+                const int oc = cw0 + ch * 8;
                 const int ochan = (oc >= a.out_split) ? a.out_coff2 + (oc - a.out_split) : a.out_coff + oc;
                 bf16x8_t ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
-                *(bf16x8_t*)((uint16_t*)a.out + opix[j][t] * a.out_pitch + ochan) = ov;
+                *(bf16x8_t*)((uint16_t*)a.out + (int64_t)opix[j][t] * a.out_pitch + ochan) = ov;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -606,21 +612,21 @@ struct CfgEntry {
     void (*launch_patch)(const ConvArgs&, int, int, int, int, int, int, hipStream_t);
 };
 
-template <int TW, int TH, int BC, int NW>
+template <int TW, int TH, int BC, int NWP, int NWC>
 constexpr int patch_lds() {
     constexpr int HP = (TW + 2) * (TH + 2), HPU = (HP + 15) / 16;
-    constexpr int loop = 2 * HPU * 1024 + 2 * 3 * BC * 64, epi = NW * 32 * (BC + 4) * 4;
+    constexpr int loop = 2 * HPU * 1024 + 2 * 3 * BC * 64, epi = NWP * NWC * 32 * (BC / NWC + 4) * 4;
     return loop > epi ? loop : epi;
 }
 
-template <int TW, int TH, int BC, int NW>
+template <int TW, int TH, int BC, int NWP, int NWC>
 void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TW, TH, BC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NW>), dim3(chunk * 8), dim3(NW * 64), lds, st, a, ntc, ntx, nty, total, chunk);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>), dim3(chunk * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
 
 template <int BP, int BC, int WP, int WC, int KBS, int NST>
@@ -647,8 +653,8 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
     { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, 2), launch_cfg<BP, BC, WP, WC, KBS, 2>, 0, 0, 0, nullptr }
 #define CFGR(BP, BC, WP, WC, KBS, NST) \
     { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg<BP, BC, WP, WC, KBS, NST>, 0, 0, 0, nullptr }
-#define PCFG(TW, TH, BC, NW) \
-    { "p" #TH "x" #TW "x" #BC "_n" #NW, (TW) * (TH), BC, (NW) * 64, patch_lds<TW, TH, BC, NW>(), nullptr, 1, TW, TH, launch_patch_cfg<TW, TH, BC, NW> }
+#define PCFG(TW, TH, BC, NWP, NWC) \
+    { "p" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC>(), nullptr, 1, TW, TH, launch_patch_cfg<TW, TH, BC, NWP, NWC> }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -666,16 +672,16 @@ const CfgEntry g_cfgs[] = {
     CFG(64, 32, 32, 32, 1),    // 12 (2 waves)
     CFG(256, 128, 64, 128, 1), // 13
     CFG(128, 64, 32, 64, 2),   // 14
-    PCFG(16, 16, 64, 4),       // 15  256 px x 64
-    PCFG(16, 16, 128, 4),      // 16  256 px x 128, 1 wave/SIMD
-    PCFG(16, 16, 128, 8),      // 17  256 px x 128, 2 waves/SIMD
-    PCFG(16, 16, 96, 4),       // 18
-    PCFG(40, 8, 64, 5),        // 19  320 px (full-width rows of a 40-wide map)
-    PCFG(40, 8, 128, 5),       // 20
-    PCFG(40, 8, 96, 5),        // 21
-    PCFG(16, 8, 128, 4),       // 22  128 px x 128
-    PCFG(20, 8, 128, 5),       // 23  160 px (20-wide maps)
-    PCFG(16, 16, 32, 4),       // 24
+    PCFG(16, 16, 64, 4, 1),    // 15  256 px x 64: 4 waves x (64 px x 64)
+    PCFG(16, 16, 128, 4, 1),   // 16  256 px x 128, 1 wave/SIMD
+    PCFG(16, 16, 128, 4, 2),   // 17  256 px x 128: 8 waves x (64 px x 64)
+    PCFG(16, 16, 96, 4, 1),    // 18
+    PCFG(40, 8, 64, 5, 1),     // 19  320 px (full-width rows of a 40-wide map)
+    PCFG(40, 8, 128, 5, 2),    // 20  10 waves x (64 px x 64)
+    PCFG(40, 8, 96, 5, 1),     // 21
+    PCFG(32, 8, 128, 4, 2),    // 22  8 rows x 32 cols: conflict-free fragment reads, 8 waves x (64 px x 64)
+    PCFG(32, 8, 64, 4, 1),     // 23  4 waves x (64 px x 64)
+    PCFG(16, 16, 32, 4, 1),    // 24
     CFGR(128, 128, 64, 64, 1, 3),  // 25  counted-vmcnt rings
     CFGR(128, 128, 64, 64, 1, 4),  // 26
     CFGR(128, 64, 32, 64, 1, 4),   // 27
@@ -705,6 +711,13 @@ const CfgEntry g_cfgs[] = {
     CFGR(512, 128, 128, 64, 1, 2), // 51  8 waves, 128x64 wave tiles
     CFGR(256, 256, 128, 64, 1, 2), // 52  8 waves
     CFGR(256, 256, 64, 128, 1, 2), // 53  8 waves
+    PCFG(32, 8, 256, 4, 4),    // 54  256 px x 256: 16 waves x (64 px x 64)
+    PCFG(32, 16, 128, 8, 2),   // 55  512 px x 128: 16 waves
+    PCFG(32, 8, 96, 4, 1),     // 56
+    PCFG(32, 8, 64, 4, 2),     // 57  8 waves x (64 px x 32)
+    PCFG(16, 16, 256, 4, 4),   // 58
+    PCFG(20, 8, 128, 5, 2),    // 59  160 px (20-wide maps), 10 waves
+    PCFG(32, 4, 128, 4, 2),    // 60  128 px x 128, 8 waves x (32 px x 64)
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
