@@ -638,6 +638,10 @@ void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipSt
         attr_done = true;
     }
     const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64);
+    if (NST == 2 && (a.nkb + KBS - 1) / KBS == 1) {  // the whole K fits one stage: no second buffer -> more blocks per CU
+        const int one = KBS * (BP + BC) * 64, epi = (BP / WP) * (BC / WC) * 32 * (WC + 4) * 4;
+        lds = one > epi ? one : epi;
+    }
     if (a.fast_epi)
         hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>), grid, block, lds, st, a, ntc, total, chunk);
     else
@@ -718,6 +722,20 @@ const CfgEntry g_cfgs[] = {
     PCFG(16, 16, 256, 4, 4),   // 58
     PCFG(20, 8, 128, 5, 2),    // 59  160 px (20-wide maps), 10 waves
     PCFG(32, 4, 128, 4, 2),    // 60  128 px x 128, 8 waves x (32 px x 64)
+    CFG(128, 128, 64, 64, 3),  // 61  deep single-shot stages for short K (1x1 convs): K = 96 / 128 in ONE load round trip
+    CFG(128, 128, 64, 64, 4),  // 62
+    CFG(128, 64, 32, 64, 3),   // 63
+    CFG(128, 64, 32, 64, 4),   // 64
+    CFG(128, 96, 32, 96, 3),   // 65
+    CFG(128, 96, 32, 96, 4),   // 66
+    CFG(64, 64, 32, 32, 3),    // 67
+    CFG(64, 64, 32, 32, 4),    // 68
+    CFG(256, 64, 64, 64, 3),   // 69
+    CFG(64, 128, 32, 64, 3),   // 70
+    CFG(64, 128, 32, 64, 4),   // 71
+    CFG(128, 32, 32, 32, 4),   // 72
+    CFG(64, 96, 32, 96, 3),    // 73
+    CFG(256, 128, 64, 64, 3),  // 74  8 waves
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
