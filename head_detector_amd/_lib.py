@@ -9,7 +9,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvgh.so")
 
-VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL = 0, 1, 2
+VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
 VGH_IMG_F32_NCHW, VGH_IMG_U8_NHWC = 0, 1
 NUM_FLAME_PARAMS = 413
@@ -33,7 +33,7 @@ class OpDesc(C.Structure):
         ("w_off", C.c_int64),
         ("b_off", C.c_int64),
         ("force_cfg", C.c_int32),
-        ("reserved", C.c_int32),
+        ("lane", C.c_int32),
     ]
 
 

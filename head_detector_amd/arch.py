@@ -327,7 +327,7 @@ def _stack(parts: List[Tuple[np.ndarray, np.ndarray]], pad_to: int = 1) -> Tuple
     return np.concatenate(ws), np.concatenate(bs), offs
 
 
-def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640, precision: str = "bf16") -> Program:
+def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640, precision: str = "bf16", head_lanes: bool = False) -> Program:
     """precision: 'bf16' (throughput mode: bf16 activations/weights, fp32 accumulate) or 'fp32' (parity mode: no bf16 anywhere)."""
     assert precision in ("bf16", "fp32")
     v = VARIANTS[variant]
@@ -446,8 +446,14 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     csp("neck.neck4.blocks", View(n4cat, 0, o4 // 2 + o1), o4 // 2 + o1, View(p5b, 0, o4), n4, h4, False, px[5])
     p5 = View(p5b, 0, o4)
 
-    # ---------------- heads ----------------
+    # ---------------- heads: three independent branches.  head_lanes=True puts levels 1/2 on side HIP streams (VGH_OP_FORK);
+    # measured SLOWER on MI355X (M b32: 4577 vs 4960 img/s -- the tuned tiles already fill the chip and concurrent kernels
+    # thrash each other's L2), so it is off by default and kept only as an executor feature. ----
+    if head_lanes:
+    name="fork.heads", kind=3, in_buf=0, in_coff=0, cin=0, out_buf=0, out_coff=0, cout_pad=0, cout_store=0, out_split=0, out_coff2=0, res_buf=-1,
+                          res_coff=0, alpha=0.0, ksize=0, stride=0, act=0, shuffle=0, w_off=0, b_off=0, force_cfg=-1, lane=0, macs=0.0, gemm=(0, 0, 0)))
     for lv, (feat, stride) in enumerate(zip((p3, p4, p5), STRIDES)):
+        first_head_op = len(P.ops)
         d = head_dims(v, lv)
         p = f"heads.head{lv + 1}"
         r = S // stride
@@ -505,6 +511,9 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
         P.conv(f"{p}.flame_transform_pred.{nb}", View(cur, offs[2], 4 * trp), View(pred, 69 + Sc + Ec, 13), Wd, bd, 1, act=0, flops_macs=13 * tr)
         P.levels.append(dict(buf=pred, h=r, w=r, pitch=pred_pitch, stride=stride))
         P.shape_c, P.expr_c = Sc, Ec
+        if head_lanes:
+            for op in P.ops[first_head_op:]:
+                op["lane"] = lv
 
     P.flops = 2.0 * sum(o["macs"] for o in P.ops)
     if precision == "fp32":

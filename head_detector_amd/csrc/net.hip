@@ -36,6 +36,9 @@ struct vgh_net {
     uint16_t* zeros = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    static constexpr int kLanes = 4;  // lane 0 = the caller's stream
+    hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -107,6 +110,8 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image, int fmt, i
             if (ib.is_f32) return vgh_launch_spp_pool_f32((float*)n->buf_ptr[d.in_buf], ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
             return vgh_launch_spp_pool((uint16_t*)n->buf_ptr[d.in_buf], ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
         }
+        case VGH_OP_FORK:
+            return VGH_OK;  // handled by the executor
         default:
             VGH_REQUIRE(false, "net: unknown op kind %d", d.kind);
     }
@@ -143,6 +148,11 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     for (int i = 0; i < n_bufs; ++i) n->buf_ptr.push_back(n->arena + offs[i]);
     VGH_HIP(hipMalloc((void**)&n->zeros, 256));
     VGH_HIP(hipMemset(n->zeros, 0, 256));
+    VGH_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+    for (int l = 1; l < vgh_net::kLanes; ++l) {
+        VGH_HIP(hipStreamCreateWithFlags(&n->side[l], hipStreamNonBlocking));
+        VGH_HIP(hipEventCreateWithFlags(&n->ev_join[l], hipEventDisableTiming));
+    }
     // ---- weights: pack on the host, one upload ----
     int64_t wbytes = 0;
     std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0);
@@ -205,6 +215,11 @@ void vgh_net_destroy(vgh_net* n) {
     if (!n) return;
     if (n->graph_exec) hipGraphExecDestroy(n->graph_exec);
     if (n->graph) hipGraphDestroy(n->graph);
+    for (int l = 1; l < vgh_net::kLanes; ++l) {
+        if (n->side[l]) hipStreamDestroy(n->side[l]);
+        if (n->ev_join[l]) hipEventDestroy(n->ev_join[l]);
+    }
+    if (n->ev_fork) hipEventDestroy(n->ev_fork);
     hipFree(n->arena);
     hipFree(n->wblob);
     hipFree(n->zeros);
@@ -214,8 +229,34 @@ void vgh_net_destroy(vgh_net* n) {
 int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, void* stream) {
     VGH_REQUIRE(n && image_dev, "net_forward: null argument");
     VGH_REQUIRE(B >= 0 && B <= n->max_batch, "net_forward: B=%d exceeds max_batch=%d", B, n->max_batch);
-    for (const NetOp& op : n->ops)
-        if (int rc = net_run_op(n, op, image_dev, image_fmt, B, (hipStream_t)stream)) return rc;
+    // Independent branches (the three detection heads) run on side streams: a FORK op records an event on the main stream,
+    // the first op of a lane after it makes that lane's stream wait for the event, and every used lane is joined back into
+    // the main stream at the end (also valid under stream capture: the graph gets parallel branches).
+    hipStream_t main = (hipStream_t)stream;
+    bool pending[vgh_net::kLanes] = {false, false, false, false}, used[vgh_net::kLanes] = {false, false, false, false};
+    for (const NetOp& op : n->ops) {
+        if (op.d.kind == VGH_OP_FORK) {
+            VGH_HIP(hipEventRecord(n->ev_fork, main));
+            for (int l = 1; l < vgh_net::kLanes; ++l) pending[l] = true;
+            continue;
+        }
+        const int lane = (op.d.lane > 0 && op.d.lane < vgh_net::kLanes) ? op.d.lane : 0;
+        hipStream_t st = main;
+        if (lane > 0) {
+            st = n->side[lane];
+            if (pending[lane]) {
+                VGH_HIP(hipStreamWaitEvent(st, n->ev_fork, 0));
+                pending[lane] = false;
+            }
+            used[lane] = true;
+        }
+        if (int rc = net_run_op(n, op, image_dev, image_fmt, B, st)) return rc;
+    }
+    for (int l = 1; l < vgh_net::kLanes; ++l)
+        if (used[l]) {
+            VGH_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
+            VGH_HIP(hipStreamWaitEvent(main, n->ev_join[l], 0));
+        }
     return VGH_OK;
 }
 

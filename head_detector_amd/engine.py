@@ -58,8 +58,8 @@ class VGHeadsEngine:
         self.arena_batch = max(1, min(max_batch, ((1 << 31) - 1) // per_image, arena_batch or max_batch))
         w, b = P.arrays()
         bufs = (_lib.BufDesc * len(P.bufs))(*[_lib.BufDesc(bf["h"], bf["w"], bf["pitch"], bf["is_f32"]) for bf in P.bufs])
-        fields = [f for f, _ in _lib.OpDesc._fields_ if f != "reserved"]
-        ops = (_lib.OpDesc * len(P.ops))(*[_lib.OpDesc(**{f: (op[f] if f != "in_buf" else max(op[f], 0)) for f in fields}) for op in P.ops])
+        fields = [f for f, _ in _lib.OpDesc._fields_]
+        ops = (_lib.OpDesc * len(P.ops))(*[_lib.OpDesc(**{f: (op.get(f, 0) if f != "in_buf" else max(op[f], 0)) for f in fields}) for op in P.ops])
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.vgh_net_create(self.device_index, image_size, self.arena_batch, bufs, len(P.bufs), ops, len(P.ops), _lib.ptr(w), w.size, _lib.ptr(b), b.size, C.byref(h)))

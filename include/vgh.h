@@ -45,6 +45,8 @@ const char* vgh_last_error(void);
 #define VGH_OP_STEM 0     /* 3x3 s2 conv on the raw image, fused /255 + bias + ReLU (YoloNASStem)      */
 #define VGH_OP_CONV 1     /* implicit-GEMM conv k in {1,3}, stride in {1,2}, fused bias/act/residual    */
 #define VGH_OP_SPP_POOL 2 /* SPP max-pool 5/9/13 written next to its input (concat-by-offset)          */
+#define VGH_OP_FORK 3     /* fork point: ops with lane > 0 issued after it run on side HIP streams that wait for */
+                          /* everything enqueued on the main stream BEFORE this point; all lanes join at the end */
 
 typedef struct vgh_buf_desc {
     int32_t h, w;   /* spatial size per image */
@@ -65,7 +67,7 @@ typedef struct vgh_op_desc {
     int64_t w_off;                       /* offset (floats) of [cout_pad][k][k][cin] in `weights`      */
     int64_t b_off;                       /* offset (floats) of [cout_pad] in `biases`                  */
     int32_t force_cfg;                   /* -1: heuristic tile choice; else kernel config index        */
-    int32_t reserved;
+    int32_t lane;                        /* 0: main stream; 1..3: side stream (independent branch, see VGH_OP_FORK) */
 } vgh_op_desc;
 
 typedef struct vgh_net vgh_net;

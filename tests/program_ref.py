@@ -22,6 +22,8 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None):
     if w_all is None:
         w_all, b_all = P.arrays()
     kind = op["kind"]
+    if kind == 3:  # FORK: scheduling only
+        return
     if kind == 0:  # stem: exact fp32 conv on the image, ReLU, stored as bf16
         W = torch.from_numpy(w_all[op["w_off"] : op["w_off"] + 48 * 27].reshape(48, 3, 3, 3)).permute(0, 3, 1, 2).contiguous()
         b = torch.from_numpy(b_all[op["b_off"] : op["b_off"] + 48])
