@@ -450,7 +450,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     # measured SLOWER on MI355X (M b32: 4577 vs 4960 img/s -- the tuned tiles already fill the chip and concurrent kernels
     # thrash each other's L2), so it is off by default and kept only as an executor feature. ----
     if head_lanes:
-    name="fork.heads", kind=3, in_buf=0, in_coff=0, cin=0, out_buf=0, out_coff=0, cout_pad=0, cout_store=0, out_split=0, out_coff2=0, res_buf=-1,
+        P.ops.append(dict(name="fork.heads", kind=3, in_buf=0, in_coff=0, cin=0, out_buf=0, out_coff=0, cout_pad=0, cout_store=0, out_split=0, out_coff2=0, res_buf=-1,
                           res_coff=0, alpha=0.0, ksize=0, stride=0, act=0, shuffle=0, w_off=0, b_off=0, force_cfg=-1, lane=0, macs=0.0, gemm=(0, 0, 0)))
     for lv, (feat, stride) in enumerate(zip((p3, p4, p5), STRIDES)):
         first_head_op = len(P.ops)
