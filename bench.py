@@ -183,6 +183,10 @@ def main():
     if rank == 0:
         value = B * world * args.steps / dt
         conv_tflops = eng.flops_per_image * B / (net_ms * 1e-3) / 1e12
+        traffic = None  # HBM bytes per conv launch from the committed PMC pass (profiles/), only for the exact workload it was taken on
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_m32.json")
+        if os.path.exists(tpath) and args.variant == "vgg_heads_m" and B == 32 and S == 640:
+            traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
         line = {
             "metric": "images/sec at 640x640 (VGGHeads forward path: net -> top-k/NMS -> FLAME decode)",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,7 +196,7 @@ def main():
                        "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(eng.flops_per_image / 1e9, 2),
                        "graph": bool(args.graph), "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(net_ms, 3)},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(conv_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(conv_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "conv_igemm_kernel<*> (all launches of one forward; algorithmic 2*MACs / HIP-event time of the network part)"},
         }
         if world == 1 and not args.no_cpu_baseline:
