@@ -123,35 +123,32 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    heads_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+
     def step(i=None):
         if i is not None:
             ev0[i].record(eng.stream)  # HIP events on the stream the kernels are launched on
         eng.forward_net(images, use_graph=args.graph)
         if i is not None:
             ev1[i].record(eng.stream)
-        # post-network stages (detect() re-runs nothing: forward_net already done -> call the stages directly)
+        # post-network stages: decode/top-k/gather, then ONE library call for NMS + compaction + head list + FLAME decode of every
+        # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
         eng.candidates(B)
-        sp = eng._sp()
-        _lib.check(lib.vgh_nms(_lib.ptr(eng.cand_boxes), _lib.ptr(eng.cand_scores), B, eng.pre_k, conf, 0.5, eng.keep_k, _lib.ptr(eng.keep_idx), _lib.ptr(eng.counts), sp))
-        _lib.check(lib.vgh_compact(_lib.ptr(eng.cand_boxes), _lib.ptr(eng.cand_scores), _lib.ptr(eng.cand_flame), B, eng.pre_k, _lib.ptr(eng.keep_idx), eng.keep_k,
-                                   _lib.ptr(eng.out_boxes), _lib.ptr(eng.out_scores), _lib.ptr(eng.out_flame), sp))
+        det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad)
         with torch.cuda.stream(eng.stream):
-            valid = torch.arange(eng.keep_k, device=dev)[None, :] < eng.counts[:B, None]
-            params = eng.out_flame[:B][valid]
-            _, _, verts = flame.decode(params, unpad=unpad[valid.nonzero()[:, 0]], shape_live=eng.program.shape_c, expr_live=eng.program.expr_c, want_vertices=False)
-            out = gather_detections(eng.out_boxes[:B], eng.out_scores[:B], eng.out_flame[:B], eng.counts[:B], verts, dst=0) if world > 1 else None
-        return params.shape[0], out
+            heads_acc.add_(det.n_heads)
+            out = gather_detections(det.boxes, det.scores, det.flame_params, det.counts, det.vertices_3d, dst=0) if world > 1 else None
+        return out
 
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
+    heads_acc.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    heads = 0
     for i in range(args.steps):
-        n, _ = step(i)
-        heads += n
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -161,6 +158,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     net_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(args.steps, 1)
+    heads = int(heads_acc.item())
 
     per_layer = None
     if args.per_layer and rank == 0:

@@ -56,6 +56,23 @@ class HeadLevel(C.Structure):
     _fields_ = [("pred_dev", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("pitch", C.c_int32), ("stride", C.c_int32)]
 
 
+VGH_MAX_LEVELS = 4
+
+
+class DetectCfg(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("level_buf", C.c_int32 * VGH_MAX_LEVELS), ("level_h", C.c_int32 * VGH_MAX_LEVELS), ("level_w", C.c_int32 * VGH_MAX_LEVELS),
+                ("level_pitch", C.c_int32 * VGH_MAX_LEVELS), ("level_stride", C.c_int32 * VGH_MAX_LEVELS), ("shape_live", C.c_int32), ("expr_live", C.c_int32),
+                ("pre_k", C.c_int32), ("keep_k", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class DetectOut(C.Structure):
+    _fields_ = [("boxes_dev", C.c_void_p), ("scores_dev", C.c_void_p), ("flame_dev", C.c_void_p), ("counts_dev", C.c_void_p),
+                ("n_heads_dev", C.c_void_p), ("head_image_dev", C.c_void_p), ("head_capacity", C.c_int32), ("unpad_dev", C.c_void_p),
+                ("verts_dev", C.c_void_p), ("rot_dev", C.c_void_p), ("rpy_dev", C.c_void_p), ("proj_dev", C.c_void_p)]
+
+
+SCRATCH_BOXES_ALL, SCRATCH_SCORES_ALL, SCRATCH_TOPK_IDX, SCRATCH_KEEP_IDX, SCRATCH_HEAD_ROW = range(5)
+
 # every symbol include/vgh.h declares: (restype, argtypes)
 _P, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
@@ -70,6 +87,8 @@ SYMBOLS = {
     "vgh_net_buffer": (_P, [_P, _I]),
     "vgh_net_buffer_bytes": (_I64, [_P, _I]),
     "vgh_net_set_cfg": (_I, [_P, _I, _I]),
+    "vgh_net_max_batch": (_I, [_P]),
+    "vgh_net_image_size": (_I, [_P]),
     "vgh_conv2d": (_I, [C.POINTER(ConvCall), _P]),
     "vgh_pack_conv_weights": (_I, [_P, _I, _I, _I, _P]),
     "vgh_conv_num_cfgs": (_I, []),
@@ -83,6 +102,15 @@ SYMBOLS = {
     "vgh_flame_create": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, C.POINTER(_P)]),
     "vgh_flame_destroy": (None, [_P]),
     "vgh_flame_decode": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "vgh_flame_decode_indirect": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vgh_detector_create": (_I, [_P, _P, C.POINTER(DetectCfg), C.POINTER(_P)]),
+    "vgh_detector_destroy": (None, [_P]),
+    "vgh_detector_candidates": (_I, [_P, _P, _I, _I, _P]),
+    "vgh_detector_candidate_buffers": (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "vgh_detector_set_flame": (_I, [_P, _P]),
+    "vgh_detector_scratch": (_P, [_P, _I]),
+    "vgh_detector_select": (_I, [_P, _I, _F, _F, C.POINTER(DetectOut), _P]),
+    "vgh_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_flame_lbs": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vgh_stream_create": (_I, [_I, C.POINTER(_P)]),
     "vgh_stream_destroy": (_I, [_P]),

@@ -61,6 +61,12 @@ struct PrepArgs {
     float* rot_out;     // [n,9] or null
     float* joints_out;  // [n,NJ,3] or null
     int NB, NJ, Kp;
+    // indirect (fused detector) mode: head h reads params row head_row[h] and unpad row head_image[h];
+    // *n_dev is the live head count (blocks beyond it exit) -- no host round trip for the data-dependent n
+    const int32_t* head_row;
+    const int32_t* head_image;
+    const int32_t* n_dev;
+    float* rpy_out;  // [n,3] (roll, pitch, yaw) degrees or null: calculate_rpy, utils.py:146-151
 };
 
 // one wave per head
@@ -70,10 +76,13 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
     __shared__ float s_R[MAXJ * 9];
     __shared__ float s_pose[MAXJ * 3];
     const int h = blockIdx.x, lane = threadIdx.x;
+    if (a.n_dev && h >= *a.n_dev) return;
     const int NB = a.NB, NJ = a.NJ;
     float* coef = a.coef + (int64_t)h * a.Kp;
     float* hp = a.headpack + (int64_t)h * HP_SIZE;
-    const float* p = a.params ? a.params + (int64_t)h * VGH_NUM_FLAME_PARAMS : nullptr;
+    const int64_t prow = a.head_row ? a.head_row[h] : h;
+    const int64_t urow = a.head_image ? a.head_image[h] : h;
+    const float* p = a.params ? a.params + prow * VGH_NUM_FLAME_PARAMS : nullptr;
     // betas = [shape(300) | expression(100)]  (flame.py:132-140; FLAME_CONSTS widths make the padding empty)
     for (int l = lane; l < NB; l += 64) {
         const float v = p ? p[l] : a.betas[(int64_t)h * NB + l];
@@ -173,9 +182,37 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
         }
         hp[HP_S] = sc;
         for (int c = 0; c < 3; ++c) hp[HP_T + c] = t[c];
-        hp[HP_U + 0] = a.unpad ? a.unpad[(int64_t)h * 3 + 0] : 0.0f;
-        hp[HP_U + 1] = a.unpad ? a.unpad[(int64_t)h * 3 + 1] : 0.0f;
-        hp[HP_U + 2] = a.unpad ? a.unpad[(int64_t)h * 3 + 2] : 1.0f;
+        hp[HP_U + 0] = a.unpad ? a.unpad[urow * 3 + 0] : 0.0f;
+        hp[HP_U + 1] = a.unpad ? a.unpad[urow * 3 + 1] : 0.0f;
+        hp[HP_U + 2] = a.unpad ? a.unpad[urow * 3 + 2] : 1.0f;
+        if (a.rpy_out) {
+            // calculate_rpy (utils.py:146-151): Rotation.from_matrix(R^T).as_euler("xyz", degrees) in closed form.
+            // M = R^T = Rz(c) Ry(b) Rx(a) (extrinsic xyz): b = -asin(M20), a = atan2(M21, M22), c = atan2(M10, M00);
+            // at gimbal lock (|M20| = 1) scipy sets the third angle to 0 and folds it into the first.
+            const double m00 = R[0], m10 = R[1], m20 = R[2], m21 = R[5], m22 = R[8], m01 = R[3], m11 = R[4];
+            const double RAD = 57.29577951308232;
+            double ea, eb, ec;
+            const double cb = sqrt(m00 * m00 + m10 * m10);
+            eb = atan2(-m20, cb);
+            if (cb > 1e-7) {
+                ea = atan2(m21, m22);
+                ec = atan2(m10, m00);
+            } else {
+                ec = 0.0;
+                ea = (m20 < 0) ? atan2(m01, m11) : atan2(-m01, m11);
+            }
+            double ang[3] = {ec * RAD, ea * RAD - 180.0, eb * RAD};  // roll = a[2], pitch = a[0] - 180, yaw = a[1]
+            for (int c = 0; c < 3; ++c) {
+                double g = ang[c];  // limit_angle (utils.py:131-143)
+                if (g < -180.0) {
+                    const int q = (int)(g / 180.0);                      // int() truncates, // floors (q <= -1 here)
+                    const int fl = (q >= 0) ? q / 2 : -((-q + 1) / 2);
+                    g += -2.0 * (double)fl * 180.0;
+                }
+                if (g > 180.0) g -= 2.0 * (double)((((int)(g / 180.0)) + 1) / 2) * 180.0;
+                a.rpy_out[(int64_t)h * 3 + c] = (float)g;
+            }
+        }
     }
 }
 
@@ -187,6 +224,7 @@ struct VertArgs {
     const float* headpack;
     float* verts;  // [n][V][3] or null
     float* proj;   // [n][V][3] or null
+    const int32_t* n_dev;  // live head count on the device (fused detector) or null
     int n, V, Vp, NJ, Kp;
     int r0_begin, r0_end, r1_begin, r1_end, r2_begin, r2_end;  // k ranges (shape live, expr live, pose)
     float z_offset;
@@ -200,6 +238,10 @@ __global__ __launch_bounds__(256) void flame_vertex_kernel(VertArgs a) {
     float* s_hp = fsm + (size_t)a.Kp * HT; // [HT][HP_SIZE]
     const int tid = threadIdx.x;
     const int h0 = blockIdx.y * HT;
+    if (a.n_dev) {
+        a.n = min(a.n, *a.n_dev);
+        if (h0 >= a.n) return;
+    }
     for (int e = tid; e < a.Kp * HT; e += 256) {
         const int k = e / HT, hh = e - k * HT;
         s_coef[e] = (h0 + hh < a.n) ? a.coef[(int64_t)(h0 + hh) * a.Kp + k] : 0.0f;
@@ -322,6 +364,10 @@ int launch_vertex(const VertArgs& va, hipStream_t st) {
 
 int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (pa_in.n_dev && n > f->max_heads) {
+        vgh_set_error("flame decode (indirect): capacity %d exceeds max_heads %d", n, f->max_heads);
+        return VGH_ERR_INVALID;
+    }
     for (int done = 0; done < n; done += f->max_heads) {
         const int m = (n - done < f->max_heads) ? n - done : f->max_heads;
         PrepArgs pa = pa_in;
@@ -343,6 +389,7 @@ int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int e
         va.verts = verts ? verts + (int64_t)done * f->V * 3 : nullptr;
         va.proj = proj ? proj + (int64_t)done * f->V * 3 : nullptr;
         va.n = m;
+        va.n_dev = pa.n_dev;
         va.V = f->V;
         va.Vp = f->Vp;
         va.NJ = f->NJ;
@@ -363,7 +410,7 @@ int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int e
         va.z_offset = detector_mode ? 0.05f : 0.0f;  // MESH_OFFSET_Z, flame.py:34,164
         va.do_unpad = pa.unpad != nullptr;
         int rc;
-        if (m <= 2)
+        if (m <= 2 && !pa.n_dev)
             rc = launch_vertex<1>(va, st);
         else if (m <= 24)
             rc = launch_vertex<4>(va, st);
@@ -479,6 +526,35 @@ int vgh_flame_decode(vgh_flame* f, const float* params_dev, int n, int shape_liv
     pa.NJ = f->NJ;
     pa.Kp = f->Kp;
     return run_decode(f, pa, n, shape_live, expr_live, true, verts_dev, proj_dev, stream);
+}
+
+int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32_t* head_row_dev, const int32_t* head_image_dev, const int32_t* n_heads_dev,
+                              int capacity, int shape_live, int expr_live, const float* unpad_dev, float* verts_dev, float* rot_dev, float* rpy_dev,
+                              float* proj_dev, void* stream) {
+    VGH_REQUIRE(f, "flame_decode_indirect: null handle");
+    VGH_REQUIRE(f->NB == 400 && f->NJ == 5, "flame_decode_indirect: the 413-parameter layout needs NB=400, NJ=5 (FLAME_CONSTS, head_info.py:12-21)");
+    VGH_REQUIRE(shape_live >= 0 && shape_live <= 300 && expr_live >= 0 && expr_live <= 100, "flame_decode_indirect: live counts out of range");
+    VGH_REQUIRE(params_dev && head_row_dev && n_heads_dev, "flame_decode_indirect: null argument");
+    VGH_REQUIRE(!unpad_dev || head_image_dev, "flame_decode_indirect: unpad rows are indexed by head_image");
+    if (capacity <= 0) return VGH_OK;
+    PrepArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.params = params_dev;
+    pa.unpad = unpad_dev;
+    pa.J0 = f->J0;
+    pa.JS = f->JS;
+    pa.parents = f->parents;
+    pa.coef = f->coef;
+    pa.headpack = f->headpack;
+    pa.rot_out = rot_dev;
+    pa.rpy_out = rpy_dev;
+    pa.head_row = head_row_dev;
+    pa.head_image = head_image_dev;
+    pa.n_dev = n_heads_dev;
+    pa.NB = f->NB;
+    pa.NJ = f->NJ;
+    pa.Kp = f->Kp;
+    return run_decode(f, pa, capacity, shape_live, expr_live, true, verts_dev, proj_dev, stream);
 }
 
 int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream) {

@@ -307,6 +307,9 @@ int vgh_net_forward_graph(vgh_net* n, void* stream) {
 void* vgh_net_buffer(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_ptr.size()) ? n->buf_ptr[buf_id] : nullptr; }
 int64_t vgh_net_buffer_bytes(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_bytes.size()) ? n->buf_bytes[buf_id] : -1; }
 
+int vgh_net_max_batch(vgh_net* n) { return n ? n->max_batch : 0; }
+int vgh_net_image_size(vgh_net* n) { return n ? n->image_size : 0; }
+
 int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {
     VGH_REQUIRE(n && op_index >= 0 && op_index < (int)n->ops.size(), "net_set_cfg: bad op index");
     VGH_REQUIRE(cfg >= -1 && cfg < vgh_conv_num_cfgs(), "net_set_cfg: bad cfg");

@@ -16,7 +16,7 @@ scale is divided by the letterbox scale (detector.py:78-79); bbox via np.rint ->
 """
 from __future__ import annotations
 
-from typing import Any, Dict, List, Optional, Tuple, Union
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -25,7 +25,7 @@ from . import _lib
 from .detection_result import PredictionResult
 from .engine import VGHeadsEngine
 from .flame import FLAMELayer
-from .head_info import Bbox, FlameParams, HeadMetadata
+from .head_info import RPY, Bbox, FlameParams, HeadMetadata
 from .utils import calculate_rpy
 
 REPO_ID = "okupyn/vgg_heads"
@@ -48,17 +48,18 @@ def load_weights(path: str) -> Dict[str, np.ndarray]:
 
 class HeadDetector:
     def __init__(self, model: str = "vgg_heads_l", image_size: int = 640, *, weights: Optional[str] = None, flame_path: Optional[str] = None,
-                 flame_model: Optional[Dict[str, Any]] = None, seed: int = 1):
+                 flame_model: Optional[Dict[str, Any]] = None, seed: int = 1, max_batch: int = 1):
         if not torch.cuda.is_available():
             raise _lib.VghError("HeadDetector: no GPU visible. This package is the MI355X HIP path only; it does not fall back to the CPU.")
         self._image_size = image_size
         self._device = torch.device("cuda", torch.cuda.current_device())
-        self._flame = FLAMELayer(flame_path=flame_path, model=flame_model, device=self._device)
+        self._max_batch = max_batch
+        self._flame = FLAMELayer(flame_path=flame_path, model=flame_model, device=self._device, max_heads=max(1024, 100 * max_batch))
         self.model = self._read_model(model, weights, seed)
 
     def _read_model(self, model: str, weights: Optional[str], seed: int) -> VGHeadsEngine:
         sd = load_weights(weights) if weights is not None else None
-        return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=1, seed=seed)
+        return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=self._max_batch, seed=seed)
 
     # ---- host-side image handling (detector.py:32-56) ----------------------------------------------------
     def _convert_image(self, image) -> np.ndarray:
@@ -139,6 +140,44 @@ class HeadDetector:
         boxes, scores, flame_params = predictions
         boxes, scores, flame_params = nms(boxes, scores, flame_params, confidence_threshold=confidence_threshold)
         return self._parse_predictions(boxes, scores, flame_params, cache)
+
+    def detect_batch(self, images: Sequence[Union[str, "np.ndarray", Any]], confidence_threshold: float = 0.5) -> List[PredictionResult]:
+        """Batched twin of ``__call__`` (what yolo_heads_post_prediction_callback.py:41-99 does for a batch): every image goes
+        through ONE fused device call (vgh_detect: net -> top-k -> NMS per image -> FLAME decode + un-pad + head pose of every
+        survivor); only the final per-head Python objects are built on the host.  Needs ``max_batch >= len(images)``."""
+        if len(images) > self._max_batch:
+            raise ValueError(f"detect_batch: {len(images)} images exceed max_batch={self._max_batch} (pass max_batch= to HeadDetector)")
+        originals = [self._convert_image(im) for im in images]
+        if not originals:
+            return []
+        tensors, caches = zip(*[self._preprocess(im) for im in originals])
+        batch = torch.cat(tensors, 0).contiguous()
+        unpad = torch.tensor([[c["padding"][0], c["padding"][1], c["scale"]] for c in caches], dtype=torch.float32, device=self._device)
+        det = self.model.detect(batch, confidence_threshold=confidence_threshold, flame=self._flame, unpad=unpad)
+        counts = det.counts.cpu().numpy()
+        n = det.num_heads
+        verts = det.vertices_3d.cpu().numpy()
+        rpy = det.head_pose.cpu().numpy().astype(np.float64)
+        boxes, scores, params = det.boxes.cpu().numpy(), det.scores.cpu().numpy(), det.flame_params.cpu()
+        results, at = [], 0
+        S = self._image_size
+        for b, (orig, cache) in enumerate(zip(originals, caches)):
+            padding, scale = cache["padding"], cache["scale"]
+            heads = []
+            for i in range(int(counts[b])):
+                if at >= n:
+                    break  # head capacity exhausted (never with the default capacities)
+                bb = boxes[b, i].clip(0, S)
+                bb[[0, 2]] -= padding[0]
+                bb[[1, 3]] -= padding[1]
+                bb = np.rint(bb / scale).astype(int)
+                fp = FlameParams.from_3dmm(params[b, i].unsqueeze(0))
+                fp.scale = fp.scale / scale
+                heads.append(HeadMetadata(bbox=Bbox(x=bb[0], y=bb[1], w=bb[2] - bb[0], h=bb[3] - bb[1]), score=scores[b, i], flame_params=fp, vertices_3d=verts[at],
+                                          head_pose=RPY(roll=float(rpy[at, 0]), pitch=float(rpy[at, 1]), yaw=float(rpy[at, 2]))))
+                at += 1
+            results.append(PredictionResult(original_image=orig, heads=heads, faces=self._flame.faces))
+        return results
 
     def __call__(self, image: Union[str, "np.ndarray", Any], confidence_threshold: float = 0.5) -> PredictionResult:
         original_image = self._convert_image(image)

@@ -25,14 +25,51 @@ TUNING_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
 
 @dataclass
 class Detections:
-    """Fixed-capacity slabs on the GPU (+ per-head vertices for the valid heads, image-major order)."""
+    """Fixed-capacity slabs on the GPU + per-head outputs (valid heads only, image-major order).  Nothing here forces a
+    host synchronisation until ``num_heads`` / ``vertices_3d`` / ``head_image`` / ``head_pose`` are read: the per-head
+    tensors are capacity-sized on the device and the live count is a device scalar."""
 
     boxes: torch.Tensor  # [B, keep, 4] xyxy in network (padded-square) pixels
     scores: torch.Tensor  # [B, keep]
     flame_params: torch.Tensor  # [B, keep, 413]
     counts: torch.Tensor  # [B] int32
-    head_image: Optional[torch.Tensor] = None  # [n] image index of every valid head
-    vertices_3d: Optional[torch.Tensor] = None  # [n, V, 3] projected vertices (reproject_spatial_vertices(..., to_2d=False)[2])
+    n_heads: Optional[torch.Tensor] = None  # [1] int32 on the device: number of valid rows in the per-head tensors
+    head_image_cap: Optional[torch.Tensor] = None  # [capacity] int32
+    vertices_cap: Optional[torch.Tensor] = None  # [capacity, V, 3] projected (and un-padded) vertices
+    rpy_cap: Optional[torch.Tensor] = None  # [capacity, 3] roll, pitch, yaw (degrees)
+    _n: Optional[int] = None
+
+    @property
+    def num_heads(self) -> int:
+        if self._n is None:
+            self._n = int(self.n_heads.item()) if self.n_heads is not None else 0  # the one host sync
+        return self._n
+
+    @property
+    def head_image(self) -> Optional[torch.Tensor]:
+        """[n] image index of every valid head."""
+        return None if self.head_image_cap is None else self.head_image_cap[: self.num_heads].long()
+
+    @property
+    def vertices_3d(self) -> Optional[torch.Tensor]:
+        """[n, V, 3] = reproject_spatial_vertices(..., to_2d=False)[2] (un-padded when ``unpad`` was given)."""
+        return None if self.vertices_cap is None else self.vertices_cap[: self.num_heads]
+
+    @property
+    def head_pose(self) -> Optional[torch.Tensor]:
+        """[n, 3] (roll, pitch, yaw) degrees = calculate_rpy of every valid head."""
+        return None if self.rpy_cap is None else self.rpy_cap[: self.num_heads]
+
+
+def _alias(ptr: int, shape, typestr: str, device: torch.device) -> torch.Tensor:
+    """Zero-copy torch view of library-owned device memory (CUDA array interface)."""
+
+    class _Ext:
+        pass
+
+    e = _Ext()
+    e.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
+    return torch.as_tensor(e, device=device)
 
 
 class VGHeadsEngine:
@@ -70,17 +107,33 @@ class VGHeadsEngine:
         B, A, k, kk = max_batch, self.A, self.pre_k, keep_top_k
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
-        self.boxes_all = torch.empty(B, A, 4, **f32)
-        self.scores_all = torch.empty(B, A, **f32)
-        self.idx = torch.empty(B, k, **i32)
-        self.cand_scores = torch.empty(B, k, **f32)
-        self.cand_boxes = torch.empty(B, k, 4, **f32)
-        self.cand_flame = torch.empty(B, k, _lib.NUM_FLAME_PARAMS, **f32)
-        self.keep_idx = torch.empty(B, kk, **i32)
+        # the fused detector (csrc/detect.hip) owns the post-network scratch; torch sees it through zero-copy aliases
+        cfg = _lib.DetectCfg()
+        cfg.n_levels = len(P.levels)
+        for i, lv in enumerate(P.levels):
+            cfg.level_buf[i], cfg.level_h[i], cfg.level_w[i], cfg.level_pitch[i], cfg.level_stride[i] = lv["buf"], lv["h"], lv["w"], lv["pitch"], lv["stride"]
+        cfg.shape_live, cfg.expr_live, cfg.pre_k, cfg.keep_k, cfg.max_batch = P.shape_c, P.expr_c, k, kk, B
+        d = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.vgh_detector_create(self._net, None, C.byref(cfg), C.byref(d)))
+        self._det = d
+        self._flame_ref = None
+        pb, ps, pf = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.vgh_detector_candidate_buffers(self._det, C.byref(pb), C.byref(ps), C.byref(pf)))
+        self.cand_boxes = _alias(pb.value, (B, k, 4), "<f4", self.device)
+        self.cand_scores = _alias(ps.value, (B, k), "<f4", self.device)
+        self.cand_flame = _alias(pf.value, (B, k, _lib.NUM_FLAME_PARAMS), "<f4", self.device)
+        sc = lambda which: self.lib.vgh_detector_scratch(self._det, which)
+        self.boxes_all = _alias(sc(_lib.SCRATCH_BOXES_ALL), (B, A, 4), "<f4", self.device)
+        self.scores_all = _alias(sc(_lib.SCRATCH_SCORES_ALL), (B, A), "<f4", self.device)
+        self.idx = _alias(sc(_lib.SCRATCH_TOPK_IDX), (B, k), "<i4", self.device)
+        self.keep_idx = _alias(sc(_lib.SCRATCH_KEEP_IDX), (B, kk), "<i4", self.device)
         self.counts = torch.empty(B, **i32)
         self.out_boxes = torch.empty(B, kk, 4, **f32)
         self.out_scores = torch.empty(B, kk, **f32)
         self.out_flame = torch.empty(B, kk, _lib.NUM_FLAME_PARAMS, **f32)
+        self.n_heads = torch.zeros(1, **i32)
+        self._head_out = None  # (capacity, head_image, proj, rpy) allocated on first FLAME use
         self._levels = None
         self._graph_key = None
         if use_tuning and precision == "bf16":
@@ -88,6 +141,9 @@ class VGHeadsEngine:
 
     # ---------------------------------------------------------------------------------------------------
     def close(self):
+        if getattr(self, "_det", None) is not None:
+            self.lib.vgh_detector_destroy(self._det)
+            self._det = None
         if getattr(self, "_net", None) is not None:
             self.lib.vgh_net_destroy(self._net)
             self._net = None
@@ -120,12 +176,7 @@ class VGHeadsEngine:
         n = B * bf["h"] * bf["w"] * bf["pitch"]
         self.stream.synchronize()
 
-        class _Ext:  # zero-copy alias of arena memory through the CUDA array interface
-            pass
-
-        e = _Ext()
-        e.__cuda_array_interface__ = dict(shape=(n,), typestr="<f4" if bf["is_f32"] else "<i2", data=(int(self.lib.vgh_net_buffer(self._net, bid)), False), version=2)
-        t = torch.as_tensor(e, device=self.device)
+        t = _alias(self.lib.vgh_net_buffer(self._net, bid), (n,), "<f4" if bf["is_f32"] else "<i2", self.device)
         if not bf["is_f32"]:
             t = t.view(torch.bfloat16)
         return t.clone().view(B, bf["h"], bf["w"], bf["pitch"])
@@ -177,13 +228,14 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_gather_candidates(lv, len(P.levels), B, self.A, P.shape_c, P.expr_c, _lib.ptr(ba), _lib.ptr(ix), self.pre_k, _lib.ptr(cb), _lib.ptr(cf), sp))
 
     def forward_candidates(self, images: torch.Tensor, use_graph: bool = False) -> int:
-        """Network + candidate stages for a batch of any size <= max_batch, in arena-sized chunks."""
-        B = images.shape[0]
-        if B > self.max_batch:
-            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
-        for i in range(0, B, self.arena_batch):
-            n = self.forward_net(images[i : i + self.arena_batch], use_graph and B <= self.arena_batch)
-            self.candidates(n, at=i)
+        """Network + candidate stages for a batch of any size <= max_batch (arena-sized chunks): one vgh_detector_candidates call."""
+        B, fmt = self._check_images(images)
+        if use_graph and B <= self.arena_batch:
+            self.forward_net(images, True)
+            self.candidates(B)
+            return B
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        _lib.check(self.lib.vgh_detector_candidates(self._det, images.data_ptr(), fmt, B, self._sp()))
         return B
 
     def model(self, images: torch.Tensor, use_graph: bool = False):
@@ -192,25 +244,51 @@ class VGHeadsEngine:
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self.cand_boxes[:B], self.cand_scores[:B].unsqueeze(-1), self.cand_flame[:B]
 
-    def detect(self, images: torch.Tensor, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
-               unpad: Optional[torch.Tensor] = None, use_graph: bool = False) -> Detections:
-        """net -> top-k -> NMS (every image) -> optional FLAME decode of every surviving head."""
-        B = self.forward_candidates(images, use_graph)
-        sp = self._sp()
-        _lib.check(self.lib.vgh_nms(_lib.ptr(self.cand_boxes), _lib.ptr(self.cand_scores), B, self.pre_k, float(confidence_threshold), float(iou_threshold), self.keep_k,
-                                    _lib.ptr(self.keep_idx), _lib.ptr(self.counts), sp))
-        _lib.check(self.lib.vgh_compact(_lib.ptr(self.cand_boxes), _lib.ptr(self.cand_scores), _lib.ptr(self.cand_flame), B, self.pre_k, _lib.ptr(self.keep_idx), self.keep_k,
-                                        _lib.ptr(self.out_boxes), _lib.ptr(self.out_scores), _lib.ptr(self.out_flame), sp))
+    def _detect_out(self, B: int, flame: Optional[FLAMELayer], unpad: Optional[torch.Tensor]) -> Tuple["_lib.DetectOut", Detections]:
+        o = _lib.DetectOut()
+        o.boxes_dev, o.scores_dev, o.flame_dev, o.counts_dev = self.out_boxes.data_ptr(), self.out_scores.data_ptr(), self.out_flame.data_ptr(), self.counts.data_ptr()
         det = Detections(self.out_boxes[:B], self.out_scores[:B], self.out_flame[:B], self.counts[:B])
         if flame is not None:
-            with torch.cuda.stream(self.stream):
-                valid = torch.arange(self.keep_k, device=self.device)[None, :] < det.counts[:, None]
-                det.head_image = valid.nonzero()[:, 0]
-                params = det.flame_params[valid]  # [n,413], image-major (host sync: n is data dependent)
-                up = unpad[det.head_image] if unpad is not None else None
-                P = self.program
-                _, _, det.vertices_3d = flame.decode(params, unpad=up, shape_live=P.shape_c, expr_live=P.expr_c, want_vertices=False)
+            handle = flame._need_handle()
+            if self._flame_ref is not flame:
+                _lib.check(self.lib.vgh_detector_set_flame(self._det, handle))
+                self._flame_ref = flame
+            cap = min(self.max_batch * self.keep_k, flame.max_heads)
+            if self._head_out is None or self._head_out[0] != cap or self._head_out[2].shape[1] != flame.num_vertices:
+                self._head_out = (cap, torch.empty(cap, dtype=torch.int32, device=self.device), torch.empty(cap, flame.num_vertices, 3, dtype=torch.float32, device=self.device),
+                                  torch.empty(cap, 3, dtype=torch.float32, device=self.device))
+            cap, himg, proj, rpy = self._head_out
+            if unpad is not None:
+                if unpad.shape != (B, 3) or unpad.dtype != torch.float32 or not unpad.is_cuda or not unpad.is_contiguous():
+                    raise ValueError("unpad must be a contiguous float32 GPU tensor [B,3] = (pad_x, pad_y, scale) per image")
+                o.unpad_dev = unpad.data_ptr()
+            o.n_heads_dev, o.head_image_dev, o.head_capacity = self.n_heads.data_ptr(), himg.data_ptr(), cap
+            o.proj_dev, o.rpy_dev = proj.data_ptr(), rpy.data_ptr()
+            det.n_heads, det.head_image_cap, det.vertices_cap, det.rpy_cap = self.n_heads, himg, proj, rpy
+        return o, det
+
+    def detect(self, images: torch.Tensor, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
+               unpad: Optional[torch.Tensor] = None, use_graph: bool = False) -> Detections:
+        """net -> top-k -> NMS (every image) -> optional FLAME decode + head pose of every surviving head: ONE asynchronous
+        library call (vgh_detect); the data-dependent head count stays on the device (see ``Detections``).
+        ``unpad`` [B,3] = (pad_x, pad_y, scale) per image fuses detector.py:67-69."""
+        B, fmt = self._check_images(images)
+        o, det = self._detect_out(B, flame, unpad)
+        if use_graph and B <= self.arena_batch:
+            self.forward_candidates(images, True)
+            _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            _lib.check(self.lib.vgh_detect(self._det, images.data_ptr(), fmt, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return det
+
+    def select(self, B: int, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
+               unpad: Optional[torch.Tensor] = None) -> Detections:
+        """The post-candidate half of ``detect`` for the B images whose candidates are already in place
+        (after ``forward_candidates`` / ``forward_net`` + ``candidates``)."""
+        o, det = self._detect_out(B, flame, unpad)
+        _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         return det
 
     # ---------------------------------------------------------------------------------------------------

@@ -130,6 +130,14 @@ class FLAMELayer:
         except Exception:
             pass
 
+    @property
+    def max_heads(self) -> int:
+        return self._max_heads
+
+    @property
+    def num_vertices(self) -> int:
+        return int(self.v_template.shape[0])
+
     def _need_handle(self):
         if self._handle is None:
             if not torch.cuda.is_available():

@@ -86,6 +86,8 @@ int vgh_net_forward_graph(vgh_net* net, void* stream);
 void* vgh_net_buffer(vgh_net* net, int buf_id);         /* device pointer of an activation buffer   */
 int64_t vgh_net_buffer_bytes(vgh_net* net, int buf_id); /* bytes for max_batch                       */
 int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
+int vgh_net_max_batch(vgh_net* net);  /* images the activation arena was planned for */
+int vgh_net_image_size(vgh_net* net);
 
 /* Stand-alone conv launch on caller-owned device tensors (per-layer parity tests, micro-benchmarks).
  * `wpack_dev` must come from vgh_pack_conv_weights. */
@@ -176,9 +178,75 @@ void vgh_flame_destroy(vgh_flame* f);
 int vgh_flame_decode(vgh_flame* f, const float* params_dev, int n, int shape_live, int expr_live, const float* unpad_dev, float* verts_dev,
                      float* rot_dev, float* proj_dev, void* stream);
 
+/* vgh_flame_decode for a head list that lives on the device (no host round trip for the data-dependent n):
+ * head i (i < *n_heads_dev <= capacity <= max_heads) reads params_dev[head_row_dev[i]] and, if unpad_dev != NULL,
+ * unpad_dev[head_image_dev[i]] ([images,3]); outputs are compact rows i.  Kernels are launched at `capacity`
+ * and exit beyond the live count.  rpy_dev [capacity,3] = calculate_rpy (utils.py:146-151: scipy
+ * Rotation.from_matrix(R^T).as_euler("xyz", degrees) in closed form + limit_angle) as (roll, pitch, yaw). */
+int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32_t* head_row_dev, const int32_t* head_image_dev,
+                              const int32_t* n_heads_dev, int capacity, int shape_live, int expr_live, const float* unpad_dev, float* verts_dev,
+                              float* rot_dev, float* rpy_dev, float* proj_dev, void* stream);
+
 /* General FLAMELayer.forward core = smplx lbs(betas, full_pose): betas_dev [n,NB], pose_dev [n,3*NJ]
  * axis-angle per joint -> verts_dev [n,V,3] (NO z offset, NO global rotation), joints_dev [n,NJ,3] or NULL. */
 int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused detector: HeadDetector._process + the device-side arithmetic of _parse_predictions
+ * (head_detector/detector.py:54-90) for a whole batch behind one asynchronous call.
+ *   vgh_detector_candidates = `self.model(image)` (detector.py:58-59; VGGHeadDecodingModule.forward, yolo_heads.py:44-86):
+ *       fills the detector-owned candidate buffers boxes [max_batch,pre_k,4], scores [max_batch,pre_k], flame [max_batch,pre_k,413]
+ *       (vgh_detector_candidate_buffers returns their device pointers)
+ *   vgh_detector_select     = nms() for EVERY image (utils.py:159-194 / yolo_heads_post_prediction_callback.py:55-84) into the
+ *       caller's fixed-capacity slabs + the image-major head list + reproject_spatial_vertices / un-pad / calculate_rpy of
+ *       every survivor (detector.py:66-69,87)
+ *   vgh_detect              = both.
+ * Nothing is allocated after vgh_detector_create; all outputs are caller-owned device memory; every call is asynchronous
+ * on `stream`; a detector (like the net and FLAME handles it borrows) serves one stream at a time.
+ * ---------------------------------------------------------------------------------------------- */
+#define VGH_MAX_LEVELS 4
+typedef struct vgh_detect_cfg {
+    int32_t n_levels;
+    int32_t level_buf[VGH_MAX_LEVELS];    /* net buffer id of each level's fp32 prediction tensor (see vgh_head_level) */
+    int32_t level_h[VGH_MAX_LEVELS], level_w[VGH_MAX_LEVELS], level_pitch[VGH_MAX_LEVELS], level_stride[VGH_MAX_LEVELS];
+    int32_t shape_live, expr_live;        /* live shape / expression channels of the heads (L: 128/64, M: 64/32) */
+    int32_t pre_k, keep_k;                /* 1000 / 100 in the reference */
+    int32_t max_batch;                    /* may exceed the net's arena batch: processed in arena-sized chunks */
+} vgh_detect_cfg;
+
+typedef struct vgh_detect_out {
+    float* boxes_dev;        /* [B,keep_k,4] xyxy px in the padded S-space (rows >= count are zero) */
+    float* scores_dev;       /* [B,keep_k] */
+    float* flame_dev;        /* [B,keep_k,413] network layout */
+    int32_t* counts_dev;     /* [B] survivors per image */
+    /* per-head outputs, image-major compact rows; all optional, n_heads_dev mandatory if any is set */
+    int32_t* n_heads_dev;    /* [1] min(sum(counts), head_capacity) */
+    int32_t* head_image_dev; /* [head_capacity] image of each head or NULL */
+    int32_t head_capacity;   /* rows available in the per-head outputs; <= 0: B*keep_k */
+    const float* unpad_dev;  /* [B,3] (pad_x, pad_y, scale) per IMAGE or NULL (detector.py:67-69) */
+    float* verts_dev;        /* [head_capacity,5023,3] FLAMELayer.forward(zero_rot=True) or NULL */
+    float* rot_dev;          /* [head_capacity,3,3] or NULL */
+    float* rpy_dev;          /* [head_capacity,3] roll, pitch, yaw degrees or NULL */
+    float* proj_dev;         /* [head_capacity,5023,3] projected (and un-padded) vertices or NULL */
+} vgh_detect_out;
+
+typedef struct vgh_detector vgh_detector;
+/* `flame` may be NULL (then the FLAME outputs of vgh_detect_out must be NULL). The handles are borrowed, not owned. */
+int vgh_detector_create(vgh_net* net, vgh_flame* flame, const vgh_detect_cfg* cfg, vgh_detector** out);
+void vgh_detector_destroy(vgh_detector* d);
+int vgh_detector_candidates(vgh_detector* d, const void* images_dev, int image_fmt, int B, void* stream);
+int vgh_detector_candidate_buffers(vgh_detector* d, float** boxes_dev, float** scores_dev, float** flame_dev);
+int vgh_detector_set_flame(vgh_detector* d, vgh_flame* flame);
+/* detector-owned intermediates (parity tests / debugging): dense boxes [max_batch,A,4], dense scores [max_batch,A],
+ * top-k anchor indices [max_batch,pre_k] i32, NMS keep positions [max_batch,keep_k] i32, head rows [max_batch*keep_k] i32 */
+#define VGH_SCRATCH_BOXES_ALL 0
+#define VGH_SCRATCH_SCORES_ALL 1
+#define VGH_SCRATCH_TOPK_IDX 2
+#define VGH_SCRATCH_KEEP_IDX 3
+#define VGH_SCRATCH_HEAD_ROW 4
+void* vgh_detector_scratch(vgh_detector* d, int which);
+int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, vgh_detect_out* out, void* stream);
+int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, float conf_thr, float iou_thr, vgh_detect_out* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HIP-event helpers so Python can time work on the stream the kernels actually run on.

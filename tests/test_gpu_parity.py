@@ -600,3 +600,79 @@ def test_fp32_parity_mode_meets_north_star_tolerances(gpu_lib, variant, okey):
     swapped = float((idx != torch.stack([po_idx for po_idx in [torch.sort(os_[b, :, 0], descending=True, stable=True).indices[:k] for b in range(B)]])).float().mean())
     print(f"[fp32 parity mode] min IoU {float(iou.min()):.6f}, max FLAME rel err {float(rel.max()):.2e}, near-tie order swaps {swapped:.4f}")
     eng.close()
+
+
+def test_fused_detect_matches_staged_pipeline(gpu_lib, flame_model):
+    """vgh_detect (one asynchronous call, head count on the device) against the staged pipeline: oracle post-processing of the
+    engine's own candidates, direct FLAME decode of the survivors with the per-image un-pad, and scipy's calculate_rpy.
+    Also through the chunked path (arena smaller than the batch) and with a head capacity smaller than the survivors."""
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+    from oracle import flame_oracle as fo
+    from oracle import postproc_oracle as po
+
+    S, B = 256, 5
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(11)).to(_dev())
+    unpad = torch.tensor([[0.0, 12.0, 0.8], [7.0, 0.0, 1.25], [0.0, 0.0, 1.0], [3.0, 5.0, 0.5], [10.0, 20.0, 2.0]], device=_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=1024)
+    for arena in (None, 2):
+        eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=5, arena_batch=arena)
+        boxes, scores, flame = [t.clone() for t in eng.model(x)]
+        conf = float(scores[:, 30, 0].max())
+        det = eng.detect(x, confidence_threshold=conf, flame=fl, unpad=unpad)
+        ref = po.postprocess_batched(boxes.cpu(), scores.cpu(), flame.cpu(), conf, 0.5)
+        counts = det.counts.cpu().tolist()
+        assert counts == [r[0].shape[0] for r in ref] and sum(counts) >= B
+        assert det.num_heads == sum(counts)
+        assert det.head_image.cpu().tolist() == [b for b, c in enumerate(counts) for _ in range(c)]
+        params = torch.cat([r[2] for r in ref])
+        for b in range(B):
+            n = counts[b]
+            assert torch.equal(det.boxes[b, :n].cpu(), ref[b][0]) and torch.equal(det.flame_params[b, :n].cpu(), ref[b][2])
+        # FLAME: the indirect device-count path must be bit-identical to the direct decode of the same rows
+        _, rot, proj = fl.decode(params.to(_dev()), unpad=unpad[det.head_image], shape_live=eng.program.shape_c, expr_live=eng.program.expr_c, want_vertices=False)
+        assert torch.equal(det.vertices_3d, proj)
+        # and equal to the f64 oracle within the fp32 bar
+        _, _, q = fo.reproject(fo.FlameConstants(flame_model, torch.float64), params.double())
+        up = unpad[det.head_image].cpu().double()
+        q[:, :, 0] -= up[:, None, 0]
+        q[:, :, 1] -= up[:, None, 1]
+        q = q / up[:, None, 2:3]
+        assert float((det.vertices_3d.cpu().double() - q).abs().max()) < 2e-6 * max(1000.0, float(q.abs().max()))
+        # head pose: closed form in the kernel vs scipy (utils.py:146-151)
+        want = np.array([list(fo.calculate_rpy(p[403:409])) for p in params])
+        got = det.head_pose.cpu().numpy()
+        d = np.abs(((got - want) + 180.0) % 360.0 - 180.0)
+        assert d.max() < 2e-3, d.max()
+        eng.close()
+    # capacity smaller than the number of survivors: the list is truncated, never overrun
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=5)
+    small = FLAMELayer(model=flame_model, device=_dev(), max_heads=4)
+    det = eng.detect(x, confidence_threshold=conf, flame=small, unpad=unpad)
+    assert det.num_heads == 4 and torch.equal(det.vertices_3d, proj[:4])
+    eng.close()
+
+
+def test_detect_batch_facade_equals_single_image_calls(gpu_lib, flame_model):
+    """HeadDetector.detect_batch (fused device path for every image) returns, per image, what HeadDetector.__call__ returns."""
+    from head_detector_amd.detector import HeadDetector
+
+    det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, seed=4, max_batch=3)
+    rng = np.random.default_rng(1)
+    imgs = [rng.integers(0, 256, shape, dtype=np.uint8) for shape in ((240, 300, 3), (320, 320, 3), (400, 250, 3))]
+    image, _ = det._preprocess(imgs[0])
+    conf = float(det._process(image)[1][0, 15, 0])
+    singles = [det(im, confidence_threshold=conf) for im in imgs]
+    batch = det.detect_batch(imgs, confidence_threshold=conf)
+    assert len(batch) == 3 and sum(len(r.heads) for r in batch) >= 1
+    for one, many in zip(singles, batch):
+        assert len(one.heads) == len(many.heads)
+        for a, b in zip(one.heads, many.heads):
+            assert (a.bbox.x, a.bbox.y, a.bbox.w, a.bbox.h) == (b.bbox.x, b.bbox.y, b.bbox.w, b.bbox.h)
+            assert float(a.score) == float(b.score)
+            assert np.array_equal(a.vertices_3d, b.vertices_3d)
+            assert torch.equal(a.flame_params.to_3dmm_tensor(), b.flame_params.to_3dmm_tensor())
+            np.testing.assert_allclose(np.array(a.head_pose), np.array(b.head_pose), atol=2e-3)
+    assert det.detect_batch([]) == []
+    with pytest.raises(ValueError):
+        det.detect_batch(imgs + imgs)
