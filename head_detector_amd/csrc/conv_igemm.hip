@@ -49,6 +49,12 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == VGH_ACT_SILU) return v / (1.0f + __expf(-v));
     return v;
 }
+// Branch-free activation for the epilogues: with a runtime `act` inside the unrolled element loops hipcc emits a scalar
+// compare + branch PER ELEMENT.  ReLU / none become ONE v_max_f32 against a per-launch bound: 0 for ReLU, a quiet NaN for
+// "none" (IEEE maxNum(v, NaN) = v, so the value -- including a NaN accumulator -- passes through unchanged).  SiLU (unused by
+// the VGGHeads graphs) is applied afterwards under one wave-uniform branch per output vector.
+__device__ __forceinline__ float act_bound(int act) { return act == VGH_ACT_RELU ? 0.0f : __builtin_nanf(""); }
+__device__ __forceinline__ float silu_fn(float v) { return v / (1.0f + __expf(-v)); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -248,6 +254,7 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    const float act_lo = act_bound(a.act);
     if (a.ablate & 8) return;  // perf experiments only
     const int half4 = (lane >> 5) * 4;
     if constexpr (EPI == 1) {
@@ -290,7 +297,7 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
                     const f32x4_t bv = *(const f32x4_t*)(a.bias + c0 + wc * WC + cl);
                     f32x4_t v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][q * 4 + e] + bv[e], a.act);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][q * 4 + e] + bv[e], act_lo);
                     *(f32x4_t*)(stg + lrow * EP + cl) = v;
                 }
             }
@@ -305,6 +312,10 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
                     const f32x4_t v0 = *(const f32x4_t*)(stg + px * EP + ch * 8);
                     const f32x4_t v1 = *(const f32x4_t*)(stg + px * EP + ch * 8 + 4);
                     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (a.act == VGH_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = silu_fn(v[e]);
+                    }
                     int oc = c;
                     int64_t opix = m;
                     if (a.shuffle) {
@@ -352,7 +363,11 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
                 const f32x4_t bv = *(const f32x4_t*)(a.bias + c);
                 f32x4_t v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][q * 4 + e] + bv[e], a.act);
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][q * 4 + e] + bv[e], act_lo);
+                if (a.act == VGH_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_fn(v[e]);
+                }
                 int oc = c;
                 if (a.shuffle) {
                     const int d = c / a.shuffle_c;
@@ -392,7 +407,29 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
 //   bytes/FLOP : (HP + 9*BC) * 64 B per 9*BP*BC*64 FLOP  ->  ~200 FLOP/B at 256 px x 128 couts (v1: 64-85)
 // =====================================================================================================
 template <int TW, int TH, int BC, int NWP, int NWC>
-__global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const ConvArgs a, const int ntc, const int ntx, const int nty, const int total_tiles,
+constexpr int patch_lds() {
+    constexpr int HP = (TW + 2) * (TH + 2), HPU = (HP + 15) / 16;
+    constexpr int loop = 2 * HPU * 1024 + 2 * 3 * BC * 64, epi = NWP * NWC * 32 * (BC / NWC + 4) * 4;
+    return loop > epi ? loop : epi;
+}
+
+// waves per SIMD the register allocator must leave room for: the blocks that fit a CU by LDS (160 KiB) x waves per block over 4 SIMDs.
+// Without it hipcc sizes registers for ONE block per CU (e.g. 184 VGPRs for the 5-wave tile: the second resident block is lost).
+template <int TW, int TH, int BC, int NWP, int NWC>
+constexpr int patch_wps() {
+    constexpr int blocks = (160 * 1024) / patch_lds<TW, TH, BC, NWP, NWC>() < 1 ? 1 : (160 * 1024) / patch_lds<TW, TH, BC, NWP, NWC>();
+    // a block's waves are dealt to the SIMDs cyclically from a varying start, so with a wave count that is not a multiple of 4
+    // two resident blocks can stack their extra waves on the same SIMD: leave one more slot (5-wave tile at 144 VGPRs = 3 slots
+    // per SIMD ran one block per CU and lost 40 %)
+    constexpr int wps = (blocks * NWP * NWC + 3) / 4 + ((NWP * NWC) % 4 != 0 && blocks > 1 ? 1 : 0);
+    // 128 accumulator registers (TI*TJ = 8) cannot share a SIMD four ways
+    constexpr int acc = (BC / 32 / NWC) * (((TW * TH + 31) / 32) / NWP) * 16;
+    constexpr int cap = acc >= 128 ? 2 : 4;
+    return wps > cap ? cap : wps;
+}
+
+template <int TW, int TH, int BC, int NWP, int NWC>
+__global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())) void conv3x3_patch_kernel(const ConvArgs a, const int ntc, const int ntx, const int nty, const int total_tiles,
                                                                         const int chunk) {
     constexpr int NW = NWP * NWC;
     constexpr int NPX = TW * TH, NG = (NPX + 31) / 32, TJ = NG / NWP, TI = BC / 32 / NWC, WC = BC / NWC;
@@ -405,9 +442,26 @@ __global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const Con
     char* const xbuf = smem;
     char* const wbuf = smem + 2 * XBYTES;
 
-    const int bid = blockIdx.x;
-    int tile = (bid & 7) * chunk + (bid >> 3);
-    if (tile >= total_tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w % NWP, wc = w / NWP;
+    const int lrow = lane & 31, hi = lane >> 5;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    const unsigned wvoff = lane * 16;
+    const unsigned wkstride = (unsigned)a.cout_pad * 64u;  // bytes between consecutive k-blocks of the packed weights
+    int nx_mine = 0;  // halo-load instructions this wave issues per channel block (XUW or XUW-1: units are dealt round-robin)
+#pragma unroll
+    for (int t = 0; t < XUW; ++t) nx_mine += (HPU % NW == 0 || w + NW * t < HPU) ? 1 : 0;
+    const float act_lo = act_bound(a.act);
+
+    // ---- persistent block: XCD x owns the contiguous tile range [x*chunk, (x+1)*chunk) (3x3 halos of neighbouring tiles share
+    //      one L2); its gridDim/8 resident blocks stride through it.  Between tiles nothing is relaunched, and the output stores
+    //      of tile t drain from the memory pipeline while tile t+1 already loads and computes ----
+    const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
+    for (int local = blockIdx.x >> 3; local < chunk; local += gpx) {
+    int tile = xcd * chunk + local;
+    if (tile >= total_tiles) break;
     const int ctile = tile % ntc;
     tile /= ntc;
     const int txi = tile % ntx;
@@ -415,28 +469,25 @@ __global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const Con
     const int tyi = tile % nty;
     const int b = tile / nty;
     const int y0 = tyi * TH, x0 = txi * TW, c0 = ctile * BC;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wp = w % NWP, wc = w / NWP;
-    const int lrow = lane & 31;
-    constexpr unsigned OOB = 0xFFFFFFF0u;
+    // opaque per-tile copy of the lane id: everything per-lane below is derived from it, so hipcc re-materialises it per tile
+    // instead of hoisting tile-invariant sub-expressions out of the tile loop and keeping ~40 extra VGPRs alive (measured:
+    // 127 -> 184 VGPRs, i.e. the second resident block per CU was lost)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
 
     // ---- halo loader state: one 32-bit offset per staged 16-pixel unit, fixed over the whole K loop (the channel block only
     //      moves the descriptor base by 64 B); pixels outside the image / beyond the patch use an out-of-range offset = zeros
     unsigned xoff[XUW];
 #pragma unroll
     for (int t = 0; t < XUW; ++t) {
-        const int hp = (w + NW * t) * 16 + (lane >> 2);
+        const int hp = (w + NW * t) * 16 + (lane_t >> 2);
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         // source-side swizzle: LDS slot (lane & 3) of halo pixel (hy, hx) holds channel chunk slot ^ ((hx >> 2) & 3)
-        xoff[t] = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * (int)a.in_pitch + a.in_coff) + (((lane & 3) ^ ((hx >> 2) & 3))) * 16 : OOB;
+        xoff[t] = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * (int)a.in_pitch + a.in_coff) + (((lane_t & 3) ^ ((hx >> 2) & 3))) * 16 : OOB;
     }
     const char* const wbase = (const char*)a.wpack + (int64_t)c0 * 64;
-    const unsigned wvoff = lane * 16;
-    const unsigned wkstride = (unsigned)a.cout_pad * 64u;  // bytes between consecutive k-blocks of the packed weights
 
     auto load_x = [&](int cb, char* dst) {
         const char* const xbase = (const char*)a.in + cb * 64;
@@ -458,23 +509,25 @@ __global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const Con
         }
     };
 
-    // ---- fragment addressing: the swizzle depends on the halo COLUMN only, so the kernel row ky is a wave-uniform LDS offset
-    //      and the per-lane byte offsets of all (kx, k16-half) combinations are computed once ----
-    const int hi = lane >> 5;
+    // ---- fragment addressing: the swizzle depends on the halo COLUMN only, so the kernel row ky is a wave-uniform LDS offset and
+    //      the per-lane byte offsets of all (kx, k16-half) combinations are computed once per tile.  They are derived from an
+    //      opaque copy of the lane id so that hipcc re-materialises them per tile instead of keeping ~16 VGPRs alive across the
+    //      epilogue (hoisted, they pushed the 16-wave tiles over the 128-VGPR budget into scratch) ----
+    const int lrow_t = lane_t & 31, hi_t = lane_t >> 5;
     int boff[TJ][3][2];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
-        const int p = (wp * TJ + j) * 32 + lrow;
+        const int p = (wp * TJ + j) * 32 + lrow_t;
         const int ty = p / TW, tx = p - ty * TW;
         const int r00 = (p < NPX) ? ty * HW + tx : 0, hx0 = (p < NPX) ? tx : 0;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi) ^ (((hx0 + kx) >> 2) & 3)) * 16);
+            for (int h = 0; h < 2; ++h) boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi_t) ^ (((hx0 + kx) >> 2) & 3)) * 16);
     }
-    const int sw = (lane >> 2) & 3;
-    const int aoff0 = (wc * WC + lrow) * 64 + (((0 + hi) ^ sw) * 16);
-    const int aoff1 = (wc * WC + lrow) * 64 + (((2 + hi) ^ sw) * 16);
+    const int sw = (lane_t >> 2) & 3;
+    const int aoff0 = (wc * WC + lrow_t) * 64 + (((0 + hi_t) ^ sw) * 16);
+    const int aoff1 = (wc * WC + lrow_t) * 64 + (((2 + hi_t) ^ sw) * 16);
 
     f32x16_t acc[TI][TJ];
 #pragma unroll
@@ -498,7 +551,8 @@ __global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const Con
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     };
-    // 6 sub-steps (3 taps x 2 k16 halves) per step, fragment loads one sub-step ahead of the MFMAs
+    // 6 sub-steps (3 taps x 2 k16 halves) per step, fragment loads one sub-step ahead of the MFMAs (two sub-steps ahead with a
+    // third register set was measured: -15 % on the 5-wave tile, +6 % on p8x40x128 -> not kept)
     auto compute = [&](const char* X, const char* Wt, int ky) {
         bf16x8_t a0[TI], b0[TJ], a1[TI], b1[TJ];
         load_frags(X, Wt, ky, 0, a0, b0);
@@ -515,7 +569,9 @@ __global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const Con
         }
     };
 
-    // ---- main loop over (channel block, kernel row) steps; loads of step s+1 fly under the MFMAs of step s ----
+    // ---- main loop over (channel block, kernel row) steps.  Weights of step s+1 (L2-resident, short latency) are issued at the
+    //      start of step s; the halo patch of channel block cb+1 comes from HBM on first touch, so it is issued THREE steps ahead
+    //      (at ky = 0 of block cb: its buffer was released by the barrier that ended block cb-1) instead of one ----
     const int nsteps = a.cblocks * 3;
     load_x(0, xbuf);
     load_w(0, 0, wbuf);
@@ -527,44 +583,55 @@ __global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const Con
             nky = 0;
             ++ncb;
         }
-        if (s + 1 < nsteps && !(a.ablate & 1)) {
-            load_w(ncb, nky, wbuf + ((s + 1) & 1) * WSTEP);
-            if (nky == 0) load_x(ncb, xbuf + (ncb & 1) * XBYTES);
+        bool x_flying = false;
+        if (!(a.ablate & 1)) {
+            if (s + 1 < nsteps) load_w(ncb, nky, wbuf + ((s + 1) & 1) * WSTEP);
+            if (ky == 0 && cb + 1 < a.cblocks) {
+                load_x(cb + 1, xbuf + ((cb + 1) & 1) * XBYTES);
+                x_flying = true;
+            }
         }
         if (!(a.ablate & 2)) compute(xbuf + (cb & 1) * XBYTES, wbuf + (s & 1) * WSTEP, ky);
-        __syncthreads();
+        // the weights of step s+1 must have landed; the (younger) halo loads may stay in flight across this barrier:
+        // LDS-DMA loads retire in order, so "at most my own halo loads outstanding" == "my weight loads are done"
+        if (x_flying) {
+            if (nx_mine == XUW)
+                wait_vmcnt<XUW>();
+            else
+                wait_vmcnt<(XUW > 0 ? XUW - 1 : 0)>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         cb = ncb;
         ky = nky;
     }
-    if (a.ablate & 8) return;
+    if (a.ablate & 8) continue;
 
-    // ---- epilogue: LDS transpose -> 16-byte stores (same scheme as the fast path of the implicit-GEMM kernel) ----
+    // ---- epilogue: LDS transpose -> 16-byte stores (same scheme as the fast path of the implicit-GEMM kernel), one 32-pixel
+    //      group at a time; the residual vectors of a group are loaded before its transpose and consumed after it ----
     constexpr int EP = WC + 4, CH = WC / 8, NIT = 32 * CH / 64;
     float* stg = (float*)smem + w * (32 * EP);
-    const int half4 = hi * 4;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int half4 = (lane_e >> 5) * 4, lrow_e = lane_e & 31;
     const int cw0 = c0 + wc * WC;
-    int opix[TJ][NIT];  // output pixel index (b*H + y)*W + x, or -1
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int it = lane + 64 * t;
-            const int p = (wp * TJ + j) * 32 + it / CH;
-            const int ty = p / TW, tx = p - ty * TW;
-            const int y = y0 + ty, x = x0 + tx;
-            const bool ok = p < NPX && y < a.H && x < a.W && (cw0 + (it % CH) * 8) < a.cout_store;
-            opix[j][t] = ok ? (b * a.H + y) * a.W + x : -1;
-        }
-    bf16x8_t rres[TJ][NIT];
-    if (a.res) {
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int t = 0; t < NIT; ++t)
-                if (opix[j][t] >= 0) rres[j][t] = *(const bf16x8_t*)(a.res + (int64_t)opix[j][t] * a.res_pitch + a.res_coff + cw0 + ((lane + 64 * t) % CH) * 8);
-    }
+    const int pix00 = (b * a.H + y0) * a.W + x0;
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
+        int opix[NIT];  // output pixel index (b*H + y)*W + x, or -1
+        bf16x8_t rres[NIT];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int it = lane_e + 64 * t;
+            const int p = (wp * TJ + j) * 32 + it / CH;
+            const int ty = p / TW, tx = p - ty * TW;
+            const bool ok = p < NPX && y0 + ty < a.H && x0 + tx < a.W && (cw0 + (it % CH) * 8) < a.cout_store;
+            opix[t] = ok ? pix00 + ty * a.W + tx : -1;
+            if (a.res && ok) rres[t] = *(const bf16x8_t*)(a.res + (int64_t)opix[t] * a.res_pitch + a.res_coff + cw0 + (it % CH) * 8);
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -573,35 +640,44 @@ __global__ __launch_bounds__(NWP * NWC * 64) void conv3x3_patch_kernel(const Con
                 const f32x4_t bv = *(const f32x4_t*)(a.bias + cw0 + cl);
                 f32x4_t v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fn(acc[i][j][q * 4 + e] + bv[e], a.act);
-                *(f32x4_t*)(stg + lrow * EP + cl) = v;
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][q * 4 + e] + bv[e], act_lo);
+                *(f32x4_t*)(stg + lrow_e * EP + cl) = v;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
-            if (opix[j][t] >= 0) {
-                const int it = lane + 64 * t;
+            if (opix[t] >= 0) {
+                const int it = lane_e + 64 * t;
                 const int px = it / CH, ch = it - px * CH;
                 const f32x4_t v0 = *(const f32x4_t*)(stg + px * EP + ch * 8);
                 const f32x4_t v1 = *(const f32x4_t*)(stg + px * EP + ch * 8 + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (a.act == VGH_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = silu_fn(v[e]);
+                }
                 if (a.res) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += a.alpha * (float)rres[j][t][e];
+                    for (int e = 0; e < 8; ++e) v[e] += a.alpha * (float)rres[t][e];
                 }
                 const int oc = cw0 + ch * 8;
                 const int ochan = (oc >= a.out_split) ? a.out_coff2 + (oc - a.out_split) : a.out_coff + oc;
                 bf16x8_t ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
-                *(bf16x8_t*)((uint16_t*)a.out + (int64_t)opix[j][t] * a.out_pitch + ochan) = ov;
+                *(bf16x8_t*)((uint16_t*)a.out + (int64_t)opix[t] * a.out_pitch + ochan) = ov;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+    // every wave is done with its staging strip before the next tile's LDS-DMA loads overwrite the region
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    }  // tile loop
 }
 
 struct CfgEntry {
@@ -613,20 +689,22 @@ struct CfgEntry {
 };
 
 template <int TW, int TH, int BC, int NWP, int NWC>
-constexpr int patch_lds() {
-    constexpr int HP = (TW + 2) * (TH + 2), HPU = (HP + 15) / 16;
-    constexpr int loop = 2 * HPU * 1024 + 2 * 3 * BC * 64, epi = NWP * NWC * 32 * (BC / NWC + 4) * 4;
-    return loop > epi ? loop : epi;
-}
-
-template <int TW, int TH, int BC, int NWP, int NWC>
 void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
         (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>), dim3(chunk * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
+    // persistent grid: as many blocks per XCD as its 32 CUs keep resident (occupancy by LDS / registers), each looping over tiles
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, NWP * NWC * 64, lds) != hipSuccess || n < 1) n = 1;
+        per_cu = n;
+    }
+    static const int persist_env = getenv("VGH_PATCH_PERSIST") ? atoi(getenv("VGH_PATCH_PERSIST")) : 1;  // 0: one tile per block (A/B experiments)
+    const int gpx = persist_env ? (chunk < 32 * per_cu ? chunk : 32 * per_cu) : chunk;
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
 
 template <int BP, int BC, int WP, int WC, int KBS, int NST>
@@ -736,6 +814,8 @@ const CfgEntry g_cfgs[] = {
     CFG(128, 32, 32, 32, 4),   // 72
     CFG(64, 96, 32, 96, 3),    // 73
     CFG(256, 128, 64, 64, 3),  // 74  8 waves
+    PCFG(32, 16, 128, 4, 2),   // 75  512 px x 128: 8 waves x (128 px x 64): 6 fragment reads per 8 MFMAs
+    PCFG(32, 16, 64, 8, 1),    // 76  512 px x 64: 8 waves x (64 px x 64)
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
