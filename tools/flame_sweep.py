@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""FLAME decode alone (SURVEY 8(d) second headline metric): us per head at n in {1, 8, 64, 96, 1024, 8192}, through the C ABI
+(vgh_flame_decode via FLAMELayer.decode), synthetic constants seed 3, live coefficients of the M / L heads."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from head_detector_amd.flame import FLAMELayer  # noqa: E402
+from head_detector_amd.synthetic import synthetic_flame_model  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    fl = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=8192)
+    rows = []
+    for live, (sl, el) in (("M heads 64+32", (64, 32)), ("L heads 128+64", (128, 64)), ("all 300+100", (300, 100))):
+        for n in (1, 8, 64, 96, 1024, 8192):
+            p = torch.randn(n, 413, device=dev)
+            p[:, sl:300] = 0
+            p[:, 300 + el:400] = 0
+            unpad = torch.tensor([[3.0, 4.0, 1.25]], device=dev).expand(n, 3).contiguous()
+            for _ in range(3):
+                fl.decode(p, unpad=unpad, shape_live=sl, expr_live=el, want_vertices=False)
+            torch.cuda.synchronize()
+            it = 50 if n <= 1024 else 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(it):
+                fl.decode(p, unpad=unpad, shape_live=sl, expr_live=el, want_vertices=False)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / it
+            k = sl + el + 36
+            rows.append(dict(live=live, n=n, us_per_call=round(us, 2), us_per_head=round(us / n, 3), gflops=round(n * (2.0 * k * 15069 + 0.12e6 + 0.8e6) / us / 1e3, 1),
+                             out_GBps=round(n * 60276 / us / 1e3, 1)))
+            print(rows[-1])
+    if len(sys.argv) > 1:
+        json.dump(rows, open(sys.argv[1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
