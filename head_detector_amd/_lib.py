@@ -112,6 +112,9 @@ SYMBOLS = {
     "vgh_detector_select": (_I, [_P, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_flame_lbs": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "vgh_rasterize": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
+    "vgh_pncc_render": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P]),
+    "vgh_refined_head_bbox": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "vgh_stream_create": (_I, [_I, C.POINTER(_P)]),
     "vgh_stream_destroy": (_I, [_P]),
     "vgh_stream_sync": (_I, [_P]),

@@ -48,7 +48,8 @@ def load_weights(path: str) -> Dict[str, np.ndarray]:
 
 class HeadDetector:
     def __init__(self, model: str = "vgg_heads_l", image_size: int = 640, *, weights: Optional[str] = None, flame_path: Optional[str] = None,
-                 flame_model: Optional[Dict[str, Any]] = None, seed: int = 1, max_batch: int = 1):
+                 flame_model: Optional[Dict[str, Any]] = None, seed: int = 1, max_batch: int = 1,
+                 assets_dir: Optional[str] = None, mesh_assets=None):
         if not torch.cuda.is_available():
             raise _lib.VghError("HeadDetector: no GPU visible. This package is the MI355X HIP path only; it does not fall back to the CPU.")
         self._image_size = image_size
@@ -56,6 +57,12 @@ class HeadDetector:
         self._max_batch = max_batch
         self._flame = FLAMELayer(flame_path=flame_path, model=flame_model, device=self._device, max_heads=max(1024, 100 * max_batch))
         self.model = self._read_model(model, weights, seed)
+        # mesh assets of the reference (head_detector/assets) for PredictionResult.get_pncc(); user-supplied, optional
+        self._pncc = None
+        if mesh_assets is not None or assets_dir is not None:
+            from .pncc import PNCCProcessor
+
+            self._pncc = PNCCProcessor(mesh_assets if mesh_assets is not None else assets_dir)
 
     def _read_model(self, model: str, weights: Optional[str], seed: int) -> VGHeadsEngine:
         sd = load_weights(weights) if weights is not None else None
@@ -176,7 +183,7 @@ class HeadDetector:
                 heads.append(HeadMetadata(bbox=Bbox(x=bb[0], y=bb[1], w=bb[2] - bb[0], h=bb[3] - bb[1]), score=scores[b, i], flame_params=fp, vertices_3d=verts[at],
                                           head_pose=RPY(roll=float(rpy[at, 0]), pitch=float(rpy[at, 1]), yaw=float(rpy[at, 2]))))
                 at += 1
-            results.append(PredictionResult(original_image=orig, heads=heads, faces=self._flame.faces))
+            results.append(PredictionResult(original_image=orig, heads=heads, faces=self._flame.faces, pncc_processor=self._pncc))
         return results
 
     def __call__(self, image: Union[str, "np.ndarray", Any], confidence_threshold: float = 0.5) -> PredictionResult:
@@ -184,4 +191,4 @@ class HeadDetector:
         image, cache = self._preprocess(original_image)
         predictions = self._process(image)
         heads = self._postprocess(predictions, cache, confidence_threshold)
-        return PredictionResult(original_image=original_image, heads=heads, faces=self._flame.faces)
+        return PredictionResult(original_image=original_image, heads=heads, faces=self._flame.faces, pncc_processor=self._pncc)

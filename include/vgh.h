@@ -249,6 +249,26 @@ int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, v
 int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, float conf_thr, float iou_thr, vgh_detect_out* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Result-side consumers of the decoded meshes.
+ * vgh_rasterize = Sim3DR.rasterize(vertices, triangles, colors, bg=image, reverse) (head_detector/Sim3DR/Sim3DR.py:17-38 ->
+ *   _rasterize, head_detector/Sim3DR/lib/rasterize_kernel.cpp:219-293) with the binding's defaults alpha = 1 and a fresh
+ *   -1e8 depth buffer: z-buffer rasterisation of one mesh INTO image_dev (uint8 [H,W,channels], in/out), triangle order
+ *   semantics preserved (strictly deeper wins, ties to the earliest triangle); bit-identical to the reference's C++.
+ *   verts_dev [V,3] f32 (x, y in pixels, z = depth), tri_dev [ntri,3] i32, colors_dev [V,channels] f32,
+ *   zbuf_dev: caller-owned scratch of H*W uint64.
+ * vgh_pncc_render = PNCCProcessor.__call__ (head_detector/pncc_processor.py:66-73): zeroes image_dev [H,W,3], then paints
+ *   the heads in order (each with z negated and its own depth buffer; pixels whose painted colour is all-zero keep the
+ *   earlier content).  verts_dev [n_heads,V,3] are read, NOT modified (the reference negates z in place on the host array;
+ *   the Python facade reproduces that side effect).
+ * vgh_refined_head_bbox = refined_head_bbox (head_detector/utils.py:26-35) for every head: out_dev [n_heads,4] i32 (x,y,w,h).
+ * ---------------------------------------------------------------------------------------------- */
+int vgh_rasterize(const float* verts_dev, const int32_t* tri_dev, int ntri, const float* colors_dev, int channels, uint8_t* image_dev, int H, int W,
+                  int reverse, uint64_t* zbuf_dev, void* stream);
+int vgh_pncc_render(const float* verts_dev, int n_heads, int V, const int32_t* tri_dev, int ntri, const float* colors_dev, uint8_t* image_dev, int H, int W,
+                    uint64_t* zbuf_dev, void* stream);
+int vgh_refined_head_bbox(const float* verts_dev, int n_heads, int V, const int32_t* idx_dev, int n_idx, int32_t* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HIP-event helpers so Python can time work on the stream the kernels actually run on.
  * ---------------------------------------------------------------------------------------------- */
 int vgh_stream_create(int device, void** stream_out);

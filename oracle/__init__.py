@@ -17,6 +17,11 @@ Pinning status (see DESIGN.md "Oracle"):
                       published CPU algorithm restated; the surrounding glue
                       (head_detector/utils.py:159-194) is pinned by import.  "parity unpinned"
                       for the inner greedy loop.
+  * raster_oracle  -- Sim3DR rasteriser / PNCC composition / refined_head_bbox: PINNED.  The reference's only native
+                      code (head_detector/Sim3DR/lib/rasterize_kernel.cpp) compiles from its own two files, so
+                      ``oracle/build_ref.py`` builds it where it lies into ``oracle/_ref/libsim3dr_ref.so`` and the
+                      restatement is bit-identical to it; PNCCProcessor / refined_head_bbox vectors come from the
+                      reference's own Python run around that library (tests/golden/make_golden.py (f)).
   * net_oracle     -- super_gradients>=3.7 block definitions are absent and no weights are
                       reachable: architecture restated from the arch YAMLs + SG semantics.
                       "parity unpinned" (the reference's own test is ``assert True``,

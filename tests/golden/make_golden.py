@@ -14,6 +14,12 @@ What is real reference code here and what is stubbed:
                                   synthetic FLAME pickle (the licensed generic_model.pkl is absent)
   * yolo_head_training/tests/1.json  the reference's only numeric fixture, re-packed as float32 .npz
   * head_detector/assets/v_template.npy  data file, re-packed as float32
+  * head_detector/pncc_processor.py  imported with `head_detector.Sim3DR` := a module whose ``rasterize`` restates the 20-line
+                                  Python wrapper (Sim3DR.py:17-38) and calls the reference's OWN C++ `_rasterize`
+                                  (oracle/_ref/libsim3dr_ref.so, built from Sim3DR/lib/rasterize_kernel.cpp by oracle/build_ref.py)
+                                  -> real pncc(), compute_ncc_color_codes, PNCCProcessor.__init__/__call__ on SYNTHETIC mesh
+                                  assets (np.load patched inside that module; the reference's licensed mesh assets are not packed)
+  * head_detector/utils.py:refined_head_bbox  real function with HEAD_INDICES := synthetic subset
 No reference *source* is copied; the vectors are inputs + outputs only.
 """
 import importlib.util
@@ -159,6 +165,67 @@ def main():
     np.savez_compressed(
         os.path.join(OUT, "fixture_1json.npz"), params=np.array(d["3dmm_params"], dtype=np.float64), vertices_3d=np.array(d["3d_vertices"], dtype=np.float32),
         projected_vertices=np.array(d["projected_vertices"], dtype=np.float32), bbox=np.array(d["bbox"]), extended_bbox=np.array(d["extended_bbox"]),
+    )
+    # ---- (f) Sim3DR rasteriser + PNCC composition + refined_head_bbox -------------------------
+    from oracle import build_ref
+    from oracle import raster_oracle as ro
+
+    ref = build_ref.load()
+    assert ref is not None, "oracle/_ref could not be built"
+
+    def sim3dr_rasterize(vertices, triangles, colors, bg=None, height=None, width=None, channel=None, reverse=False):
+        if bg is not None:
+            height, width, channel = bg.shape
+        else:
+            bg = np.zeros((height, width, channel), dtype=np.uint8)
+        buffer = np.zeros((height, width), dtype=np.float32) - 1e8
+        if colors.dtype != np.float32:
+            colors = colors.astype(np.float32)
+        assert bg.flags.c_contiguous and vertices.flags.c_contiguous and vertices.dtype == np.float32 and triangles.dtype == np.int32
+        ref.ref_rasterize(bg.ctypes.data, vertices.ctypes.data, triangles.ctypes.data, colors.ctypes.data, buffer.ctypes.data, triangles.shape[0], height, width, channel, 1.0,
+                          int(reverse))
+        return bg
+
+    sim = types.ModuleType("head_detector.Sim3DR")
+    sim.rasterize = sim3dr_rasterize
+    sys.modules["head_detector.Sim3DR"] = sim
+    sys.modules["head_detector"].Sim3DR = sim
+    pp = _load("pncc_processor")
+    # single-mesh cases straight through the reference C++
+    cases = {}
+    for i, (seed, rev) in enumerate(((0, False), (5, True), (9, False))):
+        ver, tri, col = ro.random_mesh(seed, n_side=10 + seed, size=60 + 10 * seed, centre=(64 + 3 * seed, 50), depth_scale=30)
+        bg = np.random.default_rng(seed).integers(0, 256, (128, 160, 3), dtype=np.uint8)
+        cases.update({f"m{i}_ver": ver, f"m{i}_tri": tri, f"m{i}_col": col, f"m{i}_bg": bg, f"m{i}_rev": np.array(rev),
+                      f"m{i}_out": sim3dr_rasterize(ver, tri, col, bg=bg.copy(), reverse=rev)})
+    # PNCCProcessor on synthetic assets: a 14x14 grid "template", subset = all vertices but a border strip
+    rng = np.random.default_rng(21)
+    tver, ttri, _ = ro.random_mesh(21, n_side=14, size=1.0, centre=(0.0, 0.0), depth_scale=0.3)
+    subset = np.array([k for k in range(tver.shape[0]) if (k % 14) not in (0, 13)], dtype=np.int64)
+    fake = {"full_faces.npy": ttri.astype(np.int64), "v_template.npy": tver.astype(np.float64), "head_w_ears.npy": subset}
+    real_load = np.load
+    pp.np.load = lambda path, *a, **k: fake[os.path.basename(str(path))]
+    try:
+        proc = pp.PNCCProcessor()
+    finally:
+        pp.np.load = real_load
+    heads_v = []
+    for hseed, (cx, cy, sc) in enumerate(((60.0, 50.0, 70.0), (95.0, 60.0, 55.0), (70.0, 75.0, 40.0))):
+        v = tver.copy()
+        v[:, 0] = cx + sc * v[:, 0]
+        v[:, 1] = cy + sc * v[:, 1]
+        v[:, 2] = sc * v[:, 2] + rng.normal(0, 0.5, v.shape[0])
+        heads_v.append(v.astype(np.float32))
+    image = rng.integers(0, 256, (120, 150, 3), dtype=np.uint8)
+    heads = [types.SimpleNamespace(vertices_3d=v.copy()) for v in heads_v]
+    pncc_img = proc(image, heads)
+    hidx = np.array(sorted(rng.choice(tver.shape[0], 40, replace=False).tolist()))
+    utils.HEAD_INDICES = hidx
+    bb = [utils.refined_head_bbox(v) for v in heads_v]
+    np.savez_compressed(
+        os.path.join(OUT, "raster_ref.npz"), full_faces=fake["full_faces.npy"], v_template=fake["v_template.npy"], head_w_ears=subset,
+        pncc_triangles=proc.triangles, pncc_colors=proc.colors, heads=np.stack(heads_v), heads_after=np.stack([h.vertices_3d for h in heads]),
+        image_shape=np.array(image.shape), pncc=pncc_img, head_indices=hidx, bboxes=np.array([[b.x, b.y, b.w, b.h] for b in bb]), **cases,
     )
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

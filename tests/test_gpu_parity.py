@@ -676,3 +676,87 @@ def test_detect_batch_facade_equals_single_image_calls(gpu_lib, flame_model):
     assert det.detect_batch([]) == []
     with pytest.raises(ValueError):
         det.detect_batch(imgs + imgs)
+
+
+# ---- result-side consumers on the device: Sim3DR rasteriser, PNCC, refined_head_bbox -----------------------
+def test_rasterizer_bit_exact_vs_reference_vectors_and_oracle(gpu_lib):
+    """csrc/raster.hip through the C ABI (vgh_rasterize) against (i) images produced by the reference's own C++ (golden (f)),
+    (ii) the pinned oracle on fresh meshes incl. heavy clipping, degenerate triangles and a 1-channel image, (iii) the live
+    oracle/_ref build when present.  Bit-exact: integer/byte output."""
+    from head_detector_amd.pncc import rasterize
+    from oracle import build_ref
+    from oracle import raster_oracle as ro
+
+    g = golden("raster_ref.npz")
+    for i in range(3):
+        out = rasterize(g[f"m{i}_ver"], g[f"m{i}_tri"], g[f"m{i}_col"], bg=g[f"m{i}_bg"].copy(), reverse=bool(g[f"m{i}_rev"]))
+        assert np.array_equal(out, g[f"m{i}_out"]), f"golden mesh {i}"
+    ref = build_ref.load()
+    for seed in (41, 42, 43, 44):
+        ver, tri, col = ro.random_mesh(seed, n_side=8 + seed % 7, size=150 + 40 * (seed % 3), centre=(10 + 40 * (seed % 4), 30 + 20 * (seed % 3)), depth_scale=25)
+        tri = np.concatenate([tri, np.array([[0, 0, 1], [2, 2, 2]], dtype=np.int32)])  # degenerate triangles: zero area -> inverDeno = 0
+        bg = np.random.default_rng(seed).integers(0, 256, (90, 140, 3), dtype=np.uint8)
+        for rev in (False, True):
+            want = ro.rasterize(ver, tri, col, bg, reverse=rev)
+            assert np.array_equal(rasterize(ver, tri, col, bg=bg.copy(), reverse=rev), want), (seed, rev)
+            if ref is not None:
+                img, zb = bg.copy(), np.zeros((90, 140), dtype=np.float32) - 1e8
+                ref.ref_rasterize(img.ctypes.data, ver.ctypes.data, tri.ctypes.data, col.ctypes.data, zb.ctypes.data, tri.shape[0], 90, 140, 3, 1.0, int(rev))
+                assert np.array_equal(want, img)
+    ver, tri, col = ro.random_mesh(50)
+    out1 = rasterize(ver, tri, col[:, :1].copy(), height=128, width=128, channel=1)
+    assert np.array_equal(out1, ro.rasterize(ver, tri, col[:, :1], np.zeros((128, 128, 1), np.uint8)))
+    assert np.array_equal(rasterize(ver, tri[:0], col, bg=np.full((8, 8, 3), 7, np.uint8)), np.full((8, 8, 3), 7, np.uint8))  # empty mesh
+
+
+def test_pncc_processor_and_head_bbox_vs_reference_vectors(gpu_lib):
+    """PNCCProcessor (vgh_pncc_render) + refined_head_bbox (vgh_refined_head_bbox) against the outputs of the reference's own
+    pncc_processor.py / utils.py (golden (f)), including the in-place z negation and the empty-heads case."""
+    from types import SimpleNamespace
+
+    from head_detector_amd.pncc import MeshAssets, PNCCProcessor, compute_ncc_color_codes, refined_head_bbox
+
+    g = golden("raster_ref.npz")
+    assets = MeshAssets(g["full_faces"], g["v_template"], g["head_w_ears"], g["head_indices"])
+    proc = PNCCProcessor(assets)
+    assert np.array_equal(proc.triangles, g["pncc_triangles"]) and np.array_equal(proc.colors, g["pncc_colors"])
+    assert np.array_equal(compute_ncc_color_codes(g["v_template"], g["head_w_ears"]), g["pncc_colors"])
+    image = np.zeros(tuple(g["image_shape"]), dtype=np.uint8)
+    heads = [SimpleNamespace(vertices_3d=v.copy()) for v in g["heads"]]
+    img = proc(image, heads)
+    assert img.dtype == np.uint8 and np.array_equal(img, g["pncc"])
+    assert np.array_equal(np.stack([h.vertices_3d for h in heads]), g["heads_after"])
+    assert not proc(image, []).any()
+    boxes = refined_head_bbox(g["heads"], g["head_indices"])
+    assert [(b.x, b.y, b.w, b.h) for b in boxes] == [tuple(int(q) for q in bb) for bb in g["bboxes"]]
+    one = refined_head_bbox(g["heads"][1], g["head_indices"])
+    assert (one.x, one.y, one.w, one.h) == tuple(int(q) for q in g["bboxes"][1])
+
+
+def test_get_pncc_through_the_facade(gpu_lib, flame_model):
+    """HeadDetector(..., mesh_assets=...)(image).get_pncc() = the oracle's PNCC of the heads the detector returned; without
+    assets it raises FileNotFoundError (the reference would fail to np.load its bundled files the same way)."""
+    from head_detector_amd.detector import HeadDetector
+    from head_detector_amd.pncc import MeshAssets
+    from oracle import raster_oracle as ro
+
+    V = 5023
+    rng = np.random.default_rng(3)
+    faces = np.asarray(flame_model["f"]).astype(np.int64)
+    subset = np.sort(rng.choice(V, 3000, replace=False))
+    assets = MeshAssets(faces, np.asarray(flame_model["v_template"], dtype=np.float64), subset, subset[:500])
+    det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, seed=4, mesh_assets=assets)
+    img = rng.integers(0, 256, (300, 320, 3), dtype=np.uint8)
+    image, _ = det._preprocess(img)
+    conf = float(det._process(image)[1][0, 6, 0])
+    res = det(img, confidence_threshold=conf)
+    assert len(res.heads) >= 1
+    before = [h.vertices_3d.copy() for h in res.heads]
+    got = res.get_pncc()
+    tri = ro.pncc_triangles(faces, subset)
+    col = ro.compute_ncc_color_codes(np.asarray(flame_model["v_template"], dtype=np.float64), subset)
+    want = ro.pncc_image(img.shape, [v.copy() for v in before], tri, col)
+    assert got.shape == img.shape and np.array_equal(got, want)
+    assert all(np.array_equal(h.vertices_3d[:, 2], -b[:, 2]) for h, b in zip(res.heads, before))
+    with pytest.raises(FileNotFoundError):
+        HeadDetector("vgg_heads_m", 320, flame_model=flame_model, seed=4)(img, confidence_threshold=conf).get_pncc()

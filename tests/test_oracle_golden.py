@@ -1,6 +1,7 @@
 """CPU: pin the oracle (oracle/) against vectors produced by running the reference's own Python
 (tests/golden/make_golden.py) and against the reference's only known-answer fixture (tests/1.json)."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden
@@ -152,3 +153,46 @@ def test_ndfl_decode_anchor_order_and_permutation():
     assert torch.allclose(T[409:411], O[409:411] + 12.0) and T[411] == O[411] and torch.allclose(T[412], O[412] * 8)
     # level 2 single anchor index 20: stride 32 centre 16
     assert torch.allclose(flame[1, 20, 409:411], levels[2][2][1, 409:411, 0, 0] + 16.0)
+
+
+# ---- Sim3DR rasteriser / PNCC / refined_head_bbox ------------------------------------------------------
+def test_raster_oracle_reproduces_reference_outputs():
+    """oracle/raster_oracle.py against vectors produced by the reference's own C++ rasteriser and its own PNCCProcessor /
+    refined_head_bbox Python (tests/golden/make_golden.py (f)): bit-exact images, triangle filter, colour codes, boxes, and the
+    in-place z negation side effect."""
+    from oracle import raster_oracle as ro
+
+    g = golden("raster_ref.npz")
+    for i in range(3):
+        out = ro.rasterize(g[f"m{i}_ver"], g[f"m{i}_tri"], g[f"m{i}_col"], g[f"m{i}_bg"], reverse=bool(g[f"m{i}_rev"]))
+        assert np.array_equal(out, g[f"m{i}_out"]), f"mesh case {i}"
+        assert (out != g[f"m{i}_bg"]).any()
+    tri = ro.pncc_triangles(g["full_faces"], g["head_w_ears"])
+    assert np.array_equal(tri, g["pncc_triangles"]) and 0 < tri.shape[0] < g["full_faces"].shape[0]
+    col = ro.compute_ncc_color_codes(g["v_template"], g["head_w_ears"])
+    assert np.array_equal(col, g["pncc_colors"])
+    heads = [v.copy() for v in g["heads"]]
+    img = ro.pncc_image(tuple(g["image_shape"]), heads, tri, col)
+    assert np.array_equal(img, g["pncc"]) and img.any()
+    assert np.array_equal(np.stack(heads), g["heads_after"])  # z *= -1 in place, like the reference
+    for v, bb in zip(g["heads"], g["bboxes"]):
+        assert ro.refined_head_bbox(v, g["head_indices"]) == tuple(int(q) for q in bb)
+
+
+def test_raster_oracle_matches_live_reference_build():
+    """The same restatement against oracle/_ref/libsim3dr_ref.so (the reference's rasterize_kernel.cpp compiled by oracle/build_ref.py)
+    on fresh random meshes, clipped and unclipped, both row orders."""
+    from oracle import build_ref
+    from oracle import raster_oracle as ro
+
+    lib = build_ref.load()
+    if lib is None:
+        pytest.skip("neither /root/reference nor a prebuilt oracle/_ref/libsim3dr_ref.so is available")
+    for seed in (31, 32, 33):
+        ver, tri, col = ro.random_mesh(seed, n_side=9 + seed % 5, size=100 + 20 * (seed % 3), centre=(20 + 30 * (seed % 4), 70), depth_scale=25)
+        bg = np.random.default_rng(seed).integers(0, 256, (96, 128, 3), dtype=np.uint8)
+        for rev in (False, True):
+            img = bg.copy()
+            zb = np.zeros((96, 128), dtype=np.float32) - 1e8
+            lib.ref_rasterize(img.ctypes.data, ver.ctypes.data, tri.ctypes.data, col.ctypes.data, zb.ctypes.data, tri.shape[0], 96, 128, 3, 1.0, int(rev))
+            assert np.array_equal(ro.rasterize(ver, tri, col, bg, reverse=rev), img)
