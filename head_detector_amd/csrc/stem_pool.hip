@@ -15,16 +15,27 @@ constexpr int ST = 16;            // 16x16 output pixels per block
 constexpr int SIN = 2 * ST + 1;   // 33x33 input patch
 constexpr int STEM_CO = 48, STEM_CP = 64;
 
-template <int FMT>
-__global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ image, int H, int W, const float* __restrict__ wgt /*[27][48]*/,
+template <int FMT, int STAGE>
+__global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ image, int H, int W, const float* __restrict__ wgt /*[27][48]*/,
                                                    const float* __restrict__ bias /*[48]*/, uint16_t* __restrict__ out, int64_t out_pitch,
                                                    int out_coff) {
-    __shared__ float patch[3][SIN][SIN + 1];
+    // the 32 KiB output staging [pixel][chunk ^ (pixel & 7)] aliases the input patch (dead once every lane holds its 27 taps)
+    __shared__ __attribute__((aligned(16))) char smem_raw[STAGE ? 256 * 8 * 16 : 3 * SIN * (SIN + 1) * 4];
+    float (*patch)[SIN][SIN + 1] = (float (*)[SIN][SIN + 1]) smem_raw;
+    bf16x8_t* stage = (bf16x8_t*)smem_raw;
+    __shared__ float lut[256];  // u8 -> float(v) / 255.0f, the true (correctly rounded) division of detector.py:51, once per block
     const int Ho = H / 2, Wo = W / 2;
     const int b = blockIdx.z, ty = blockIdx.y * ST, tx = blockIdx.x * ST;
     const int tid = threadIdx.x;
+    if (FMT == VGH_IMG_U8_NHWC) lut[tid] = (float)tid / 255.0f;  // visible after the barrier that follows the load issue
     const int iy_base = ty * 2 - 1, ix_base = tx * 2 - 1;
-    for (int e = tid; e < 3 * SIN * SIN; e += 256) {
+    // fixed trip count + full unroll: all 13 loads of a lane are in flight together (as a rolled loop every iteration exposed
+    // one full memory round trip: 13 x ~1 us per block)
+    constexpr int NLD = (3 * SIN * SIN + 255) / 256;
+    float pv[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int e = tid + it * 256;
         int ci, r, c;
         if (FMT == VGH_IMG_F32_NCHW) {
             ci = e / (SIN * SIN);
@@ -39,18 +50,41 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ imag
         }
         const int iy = iy_base + r, ix = ix_base + c;
         float v = 0.0f;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        int q = -1;
+        if (e < 3 * SIN * SIN && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
             if (FMT == VGH_IMG_F32_NCHW)
                 v = ((const float*)image)[(((int64_t)b * 3 + ci) * H + iy) * W + ix];
             else
-                v = (float)((const uint8_t*)image)[(((int64_t)b * H + iy) * W + ix) * 3 + ci] / 255.0f;  // detector.py:51
+                q = ((const uint8_t*)image)[(((int64_t)b * H + iy) * W + ix) * 3 + ci];
+        }
+        pv[it] = (FMT == VGH_IMG_F32_NCHW) ? v : __int_as_float(q);
+    }
+    if (FMT == VGH_IMG_U8_NHWC) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int e = tid + it * 256;
+        if (e >= 3 * SIN * SIN) break;
+        int ci, r, c;
+        if (FMT == VGH_IMG_F32_NCHW) {
+            ci = e / (SIN * SIN);
+            const int rem = e - ci * SIN * SIN;
+            r = rem / SIN;
+            c = rem - r * SIN;
+        } else {
+            r = e / (SIN * 3);
+            const int rem = e - r * SIN * 3;
+            c = rem / 3;
+            ci = rem - c * 3;
+        }
+        float v = pv[it];
+        if (FMT == VGH_IMG_U8_NHWC) {
+            const int q = __float_as_int(pv[it]);
+            v = q >= 0 ? lut[q] : 0.0f;  // (float)u8 / 255.0f, detector.py:51
         }
         patch[ci][r][c] = v;
     }
     __syncthreads();
     const int ly = tid / ST, lx = tid % ST;
-    const int oy = ty + ly, ox = tx + lx;
-    if (oy >= Ho || ox >= Wo) return;
     float x[27];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -58,31 +92,63 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ imag
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) x[(ky * 3 + kx) * 3 + ci] = patch[ci][2 * ly + ky][2 * lx + kx];
-    uint16_t* op = out + (((int64_t)b * Ho + oy) * Wo + ox) * out_pitch + out_coff;
+    if (STAGE) __syncthreads();  // the patch is dead: its memory becomes the staging buffer
+    const int oy_l = ty + ly, ox_l = tx + lx;
+    const bool ok = oy_l < Ho && ox_l < Wo;
+    uint16_t* op = out + (((int64_t)b * Ho + oy_l) * Wo + ox_l) * out_pitch + out_coff;
+    // Results leave through an LDS transpose: a lane owns one pixel = 128 B (48 channels + 16 zero channels), so direct stores
+    // would touch 64 different cache lines with 16 B each per instruction (measured: 1.9 TB/s).  Staged as [pixel][8 chunks]
+    // (chunk slot XOR-swizzled by the pixel so the strided writes spread over the banks), 8 consecutive lanes then write
+    // one whole 128-B line.
+    // two output channels per instruction: <2 x float> fma = v_pk_fma_f32 (each lane an IEEE fma, bit-identical to fmaf)
 #pragma unroll
     for (int cg = 0; cg < STEM_CO / 16; ++cg) {
-        float acc[16];
+        f32x2_t acc[8];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+        for (int c = 0; c < 8; ++c) acc[c] = f32x2_t{0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
+            const f32x2_t xk = {x[k], x[k]};
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = fmaf(x[k], wgt[k * STEM_CO + cg * 16 + c], acc[c]);
+            for (int c = 0; c < 8; ++c) acc[c] = __builtin_elementwise_fma(xk, *(const f32x2_t*)(wgt + k * STEM_CO + cg * 16 + 2 * c), acc[c]);
         }
         bf16x8_t o0, o1;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            o0[c] = (__bf16)fmaxf(acc[c] + bias[cg * 16 + c], 0.0f);
-            o1[c] = (__bf16)fmaxf(acc[8 + c] + bias[cg * 16 + 8 + c], 0.0f);
+        for (int c = 0; c < 4; ++c) {
+            o0[2 * c] = (__bf16)fmaxf(acc[c][0] + bias[cg * 16 + 2 * c], 0.0f);
+            o0[2 * c + 1] = (__bf16)fmaxf(acc[c][1] + bias[cg * 16 + 2 * c + 1], 0.0f);
+            o1[2 * c] = (__bf16)fmaxf(acc[4 + c][0] + bias[cg * 16 + 8 + 2 * c], 0.0f);
+            o1[2 * c + 1] = (__bf16)fmaxf(acc[4 + c][1] + bias[cg * 16 + 8 + 2 * c + 1], 0.0f);
         }
-        *(bf16x8_t*)(op + cg * 16) = o0;
-        *(bf16x8_t*)(op + cg * 16 + 8) = o1;
+        if (STAGE) {
+            stage[tid * 8 + ((2 * cg) ^ (tid & 7))] = o0;
+            stage[tid * 8 + ((2 * cg + 1) ^ (tid & 7))] = o1;
+        } else if (ok) {
+            *(bf16x8_t*)(op + cg * 16) = o0;
+            *(bf16x8_t*)(op + cg * 16 + 8) = o1;
+        }
     }
     bf16x8_t z;
 #pragma unroll
     for (int c = 0; c < 8; ++c) z[c] = (__bf16)0.0f;
-    *(bf16x8_t*)(op + 48) = z;  // channels 48..63: exact zeros (K padding of the next conv)
-    *(bf16x8_t*)(op + 56) = z;
+    if (!STAGE) {
+        if (ok) {
+            *(bf16x8_t*)(op + 48) = z;  // channels 48..63: exact zeros (K padding of the next conv)
+            *(bf16x8_t*)(op + 56) = z;
+        }
+        return;
+    }
+    stage[tid * 8 + (6 ^ (tid & 7))] = z;
+    stage[tid * 8 + (7 ^ (tid & 7))] = z;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 256 + tid;
+        const int p = e >> 3, ch = e & 7;
+        const int oy = ty + (p / ST), ox = tx + (p % ST);
+        if (oy < Ho && ox < Wo)
+            *(bf16x8_t*)(out + (((int64_t)b * Ho + oy) * Wo + ox) * out_pitch + out_coff + ch * 8) = stage[p * 8 + (ch ^ (p & 7))];
+    }
 }
 
 // ---- SPP ---------------------------------------------------------------------------------------------
@@ -93,44 +159,48 @@ __device__ __forceinline__ bf16x8_t max8(bf16x8_t a, bf16x8_t b) {
     return r;
 }
 
-// one block = one image x CG channels; LDS ping-pong [H*W][CG] bf16
+// one block = one image x CG channels; LDS [H*W][CG] bf16 x 2.  A 5x5 max is separable: 5 taps along x into T, 5 taps along y
+// back into X (10 LDS reads per element instead of 25); pool9 / pool13 are the exact cascade pool5(pool5(.)) / pool5^3.
 __global__ __launch_bounds__(256) void spp_pool_kernel(uint16_t* __restrict__ buf, int64_t pitch, int coff, int C, int H, int W, int CG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int HW = H * W;
     const int cv = CG / 8;  // 16-byte vectors per pixel in this group
-    bf16x8_t* A = (bf16x8_t*)smem;
-    bf16x8_t* Bf = A + (size_t)HW * cv;
+    bf16x8_t* X = (bf16x8_t*)smem;
+    bf16x8_t* T = X + (size_t)HW * cv;
     const int b = blockIdx.y, cg0 = blockIdx.x * CG;
     uint16_t* base = buf + (int64_t)b * HW * pitch + coff + cg0;
     const int n = HW * cv;
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const int p = e / cv, v = e - p * cv;
-        A[e] = *(const bf16x8_t*)(base + (int64_t)p * pitch + v * 8);
+        X[e] = *(const bf16x8_t*)(base + (int64_t)p * pitch + v * 8);
     }
     __syncthreads();
-    bf16x8_t* src = A;
-    bf16x8_t* dst = Bf;
     for (int pass = 0; pass < 3; ++pass) {
         for (int e = threadIdx.x; e < n; e += blockDim.x) {
             const int p = e / cv, v = e - p * cv;
             const int y = p / W, x = p - y * W;
-            bf16x8_t m = src[e];
+            bf16x8_t m = X[e];
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if (dx != 0 && (unsigned)xx < (unsigned)W) m = max8(m, X[(y * W + xx) * cv + v]);
+            }
+            T[e] = m;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const int p = e / cv, v = e - p * cv;
+            const int y = p / W, x = p - y * W;
+            bf16x8_t m = T[e];
+#pragma unroll
             for (int dy = -2; dy <= 2; ++dy) {
                 const int yy = y + dy;
-                if ((unsigned)yy >= (unsigned)H) continue;
-                for (int dx = -2; dx <= 2; ++dx) {
-                    const int xx = x + dx;
-                    if ((unsigned)xx >= (unsigned)W) continue;
-                    m = max8(m, src[(yy * W + xx) * cv + v]);
-                }
+                if (dy != 0 && (unsigned)yy < (unsigned)H) m = max8(m, T[(yy * W + x) * cv + v]);
             }
-            dst[e] = m;
+            X[e] = m;
             *(bf16x8_t*)(base + (int64_t)p * pitch + (int64_t)(pass + 1) * C + v * 8) = m;
         }
         __syncthreads();
-        bf16x8_t* t = src;
-        src = dst;
-        dst = t;
     }
 }
 
@@ -142,10 +212,18 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
     VGH_REQUIRE(out_pitch % 8 == 0 && out_coff % 8 == 0, "stem: output alignment");
     if (B == 0) return VGH_OK;
     dim3 grid((W / 2 + ST - 1) / ST, (H / 2 + ST - 1) / ST, B);
-    if (image_fmt == VGH_IMG_F32_NCHW)
-        hipLaunchKernelGGL(stem_kernel<VGH_IMG_F32_NCHW>, grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
-    else if (image_fmt == VGH_IMG_U8_NHWC)
-        hipLaunchKernelGGL(stem_kernel<VGH_IMG_U8_NHWC>, grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
+    static const int stage = getenv("VGH_STEM_STAGE") ? atoi(getenv("VGH_STEM_STAGE")) : 1;  // A/B switch: 0 = direct per-lane stores
+    if (image_fmt == VGH_IMG_F32_NCHW) {
+        if (stage)
+            hipLaunchKernelGGL((stem_kernel<VGH_IMG_F32_NCHW, 1>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
+        else
+            hipLaunchKernelGGL((stem_kernel<VGH_IMG_F32_NCHW, 0>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
+    } else if (image_fmt == VGH_IMG_U8_NHWC) {
+        if (stage)
+            hipLaunchKernelGGL((stem_kernel<VGH_IMG_U8_NHWC, 1>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
+        else
+            hipLaunchKernelGGL((stem_kernel<VGH_IMG_U8_NHWC, 0>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
+    }
     else
         VGH_REQUIRE(false, "stem: unknown image format %d", image_fmt);
     VGH_HIP(hipGetLastError());
@@ -155,7 +233,7 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
 int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, int H, int W, hipStream_t stream) {
     VGH_REQUIRE(C % 8 == 0 && pitch % 8 == 0 && coff % 8 == 0, "spp: channel alignment");
     if (B == 0) return VGH_OK;
-    int CG = 32;
+    int CG = 16;  // 16 channels per block: B * C/16 blocks (768 for the M net at B = 32) of 25 KiB LDS at 20x20
     while (CG > 8 && ((size_t)2 * H * W * CG * 2 > 64 * 1024 || C % CG != 0)) CG /= 2;
     VGH_REQUIRE(C % CG == 0 && (size_t)2 * H * W * CG * 2 <= 160 * 1024, "spp: feature map %dx%d too large for the LDS tile", H, W);
     const size_t lds = (size_t)2 * H * W * CG * 2;
