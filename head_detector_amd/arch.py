@@ -21,6 +21,8 @@ import numpy as np
 
 BN_EPS = 1e-6  # arch yaml :139
 
+PRED_CLS_OFF, PRED_FLAME_OFF = 68, 72  # VGH_PRED_CLS_OFF / VGH_PRED_FLAME_OFF (include/vgh.h)
+
 VARIANTS: Dict[str, dict] = {
     # yolo_heads_l_arch_params.yaml:4-137
     "vgg_heads_l": dict(
@@ -460,7 +462,8 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
         fl, bb, nb = d["fl"], d["bbox"], d["blocks"]
         Sc, Ec, tr = d["shape_out"], d["expr_out"], d["tr_inter"]
         trp = _r32(tr)
-        pred_pitch = 69 + Sc + Ec + 13
+        FO = PRED_FLAME_OFF  # [reg 68 | cls 1 | 3 unused | shape | expr | rot 6 jaw 3 trans 3 scale 1]: 16-byte aligned segments
+        pred_pitch = (FO + Sc + Ec + 13 + 3) // 4 * 4
         pred = P.buf(f"{p}.pred", r, r, pred_pitch, f32=True)
         # stems: [pose | bbox]
         hs = P.buf(f"{p}.stems", r, r, fl + bb)
@@ -496,9 +499,9 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
             cur = nxt
         # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | shape | expr | rot6 | jaw3 | trans3 | scale1]
         W, b = F[f"{p}.flame_shape_pred.{nb}"]
-        P.conv(f"{p}.flame_shape_pred.{nb}", View(cur, offs[0], _r32(inters[0])), View(pred, 69, Sc), _ohwi(W, _r32(inters[0])), b, 1, act=0)
+        P.conv(f"{p}.flame_shape_pred.{nb}", View(cur, offs[0], _r32(inters[0])), View(pred, FO, Sc), _ohwi(W, _r32(inters[0])), b, 1, act=0)
         W, b = F[f"{p}.flame_expression_pred.{nb}"]
-        P.conv(f"{p}.flame_expression_pred.{nb}", View(cur, offs[1], _r32(inters[1])), View(pred, 69 + Sc, Ec), _ohwi(W, _r32(inters[1])), b, 1, act=0)
+        P.conv(f"{p}.flame_expression_pred.{nb}", View(cur, offs[1], _r32(inters[1])), View(pred, FO + Sc, Ec), _ohwi(W, _r32(inters[1])), b, 1, act=0)
         Wd = np.zeros((13, 1, 1, 4 * trp), dtype=np.float64)
         bd = np.zeros(13, dtype=np.float64)
         row = 0
@@ -508,7 +511,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
             bd[row : row + o_] = b
             row += o_
         assert offs[3] == offs[2] + trp and offs[5] == offs[2] + 3 * trp
-        P.conv(f"{p}.flame_transform_pred.{nb}", View(cur, offs[2], 4 * trp), View(pred, 69 + Sc + Ec, 13), Wd, bd, 1, act=0, flops_macs=13 * tr)
+        P.conv(f"{p}.flame_transform_pred.{nb}", View(cur, offs[2], 4 * trp), View(pred, FO + Sc + Ec, 13), Wd, bd, 1, act=0, flops_macs=13 * tr)
         P.levels.append(dict(buf=pred, h=r, w=r, pitch=pred_pitch, stride=stride))
         P.shape_c, P.expr_c = Sc, Ec
         if head_lanes:

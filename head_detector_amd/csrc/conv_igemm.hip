@@ -331,10 +331,24 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
                         for (int e = 0; e < 8; ++e) v[e] += a.alpha * (float)rres[j][t][e];
                     }
                     const int ochan = (oc >= a.out_split) ? a.out_coff2 + (oc - a.out_split) : a.out_coff + oc;
-                    bf16x8_t ov;
+                    if (a.out_f32) {
+                        // fp32 prediction buffers with 16-byte aligned channel offsets: two float4 stores per item, scalar tail
+                        // for the ragged last chunk (69 / 13 live channels)
+                        float* op = (float*)a.out + opix * a.out_pitch + ochan;
+                        if (c + 8 <= a.cout_store) {
+                            *(f32x4_t*)op = f32x4_t{v[0], v[1], v[2], v[3]};
+                            *(f32x4_t*)(op + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+                        } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
-                    *(bf16x8_t*)((uint16_t*)a.out + opix * a.out_pitch + ochan) = ov;
+                            for (int e = 0; e < 8; ++e)
+                                if (c + e < a.cout_store) op[e] = v[e];
+                        }
+                    } else {
+                        bf16x8_t ov;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
+                        *(bf16x8_t*)((uint16_t*)a.out + opix * a.out_pitch + ochan) = ov;
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -870,10 +884,12 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     vgh_fastdiv_magic((unsigned)a.Wo, &const_cast<ConvArgs&>(a).div_wo_m, &const_cast<ConvArgs&>(a).div_wo_s);
     const bool al8 = a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_split % 8 == 0 && a.cout_store % 8 == 0 && a.out_pitch % 8 == 0 &&
                      (!a.res || (a.res_coff % 8 == 0 && a.res_pitch % 8 == 0)) && (!a.shuffle || a.shuffle_c % 8 == 0);
-    const_cast<ConvArgs&>(a).fast_epi = (!a.out_f32 && al8 && !(ablate & 4)) ? 1 : 0;
+    // fp32 outputs (prediction buffers) take the transposed epilogue too when every pixel row starts 16-byte aligned
+    const bool al4f = a.out_f32 && a.out_coff % 4 == 0 && a.out_pitch % 4 == 0 && a.out_split >= a.cout_store && !a.res && !a.shuffle;
+    const_cast<ConvArgs&>(a).fast_epi = (((!a.out_f32 && al8) || al4f) && !(ablate & 4)) ? 1 : 0;
     int cfg = force_cfg >= 0 ? force_cfg : vgh_conv_pick_cfg(a);
     VGH_REQUIRE(cfg < kNumCfgs, "conv: cfg %d out of range", cfg);
-    if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi, a.shuffle)) {
+    if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) {
         VGH_REQUIRE(force_cfg < 0, "conv: cfg %s cannot run this conv (cout_pad=%d k=%d s=%d)", g_cfgs[cfg].name, a.cout_pad, a.ksize, a.stride);
         cfg = 4;
     }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void head_decode_kernel(Levels L, int B, int A
     o.z = (cx + d[2]) * st;
     o.w = (cy + d[3]) * st;
     *(float4*)(boxes + gid * 4) = o;
-    scores[gid] = 1.0f / (1.0f + expf(-pr[68]));
+    scores[gid] = 1.0f / (1.0f + expf(-pr[VGH_PRED_CLS_OFF]));
 }
 
 // ---- K7: per-image top-k via radix select on a 64-bit composite (score key, ~index) -------------
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void gather_kernel(Levels L, int A, int S, int 
     const float* pr = L.pred[l] + ((int64_t)b * hw + p) * L.pitch[l];
     const int ay = p / L.w[l], ax = p - ay * L.w[l];
     const float st = (float)L.stride[l];
-    const int o_shape = 69, o_expr = 69 + S, o_rot = 69 + S + E, o_jaw = o_rot + 6, o_tr = o_jaw + 3, o_sc = o_tr + 3;
+    const int o_shape = VGH_PRED_FLAME_OFF, o_expr = o_shape + S, o_rot = o_expr + E, o_jaw = o_rot + 6, o_tr = o_jaw + 3, o_sc = o_tr + 3;
     float* of = out_flame + ((int64_t)b * k + j) * VGH_NUM_FLAME_PARAMS;
     if (lane < 4) out_boxes[((int64_t)b * k + j) * 4 + lane] = boxes[((int64_t)b * A + a) * 4 + lane];
     for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) {
@@ -316,7 +316,7 @@ int vgh_gather_candidates(const vgh_head_level* levels, int n_levels, int B, int
     if (int rc = make_levels(levels, n_levels, &L)) return rc;
     VGH_REQUIRE(A == L.start[n_levels], "gather: A=%d does not match the levels (%d)", A, L.start[n_levels]);
     VGH_REQUIRE(shape_c >= 0 && shape_c <= 300 && expr_c >= 0 && expr_c <= 100, "gather: bad live channel counts");
-    for (int i = 0; i < n_levels; ++i) VGH_REQUIRE(levels[i].pitch >= 69 + shape_c + expr_c + 13, "gather: pitch too small");
+    for (int i = 0; i < n_levels; ++i) VGH_REQUIRE(levels[i].pitch >= VGH_PRED_FLAME_OFF + shape_c + expr_c + 13, "gather: pitch too small");
     if (B == 0 || k == 0) return VGH_OK;
     hipLaunchKernelGGL(gather_kernel, dim3(k, B), dim3(64), 0, (hipStream_t)stream, L, A, shape_c, expr_c, boxes_dev, idx_dev, k, out_boxes_dev,
                        out_flame_dev);

@@ -120,8 +120,11 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
  * Head decode: replaces YoloHeadsNDFLHeads.forward's tail (yolo_head_ndfl_heads.py:143-172) and the
  * activations of YoloHeadsDFLHead.forward (yolo_head_dfl_head.py:162-184).  `levels` describe the
  * fp32 NHWC prediction buffers written by the *_pred 1x1 convs, channel order per pixel:
- *   [reg 68 (side*17+bin) | cls 1 | shape S | expr E | rot 6 | jaw 3 | trans 3 | scale 1].
+ *   [reg 68 (side*17+bin) | cls 1 | 3 unused | shape S | expr E | rot 6 | jaw 3 | trans 3 | scale 1]
+ * (VGH_PRED_FLAME_OFF = 72: the three unused floats keep every segment 16-byte aligned so the *_pred convs store float4s).
  * ---------------------------------------------------------------------------------------------- */
+#define VGH_PRED_CLS_OFF 68
+#define VGH_PRED_FLAME_OFF 72
 typedef struct vgh_head_level {
     const float* pred_dev; /* [B, h*w, pitch] */
     int32_t h, w, pitch, stride;

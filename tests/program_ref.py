@@ -86,7 +86,7 @@ def head_outputs(P, bufs):
     S, E = P.shape_c, P.expr_c
     for lv in P.levels:
         t = bufs[lv["buf"]].permute(0, 3, 1, 2)
-        o = 69
+        o = 72  # VGH_PRED_FLAME_OFF: [reg 68 | cls 1 | 3 unused | shape | expr | rot jaw trans scale]
         raw = dict(shape=t[:, o : o + S], expr=t[:, o + S : o + S + E], rot=t[:, o + S + E : o + S + E + 6], jaw=t[:, o + S + E + 6 : o + S + E + 9],
                    trans=t[:, o + S + E + 9 : o + S + E + 12], scale=t[:, o + S + E + 12 : o + S + E + 13])
         out.append((t[:, :68], t[:, 68:69], raw))

@@ -174,13 +174,13 @@ def test_head_decode_and_gather_vs_oracle(gpu_lib, S_c, E_c):
 
     torch.manual_seed(S_c)
     B, sizes, strides = 2, [(20, 20), (10, 10), (5, 5)], (8, 16, 32)
-    pitch = 69 + S_c + E_c + 13 + 3
+    pitch = 72 + S_c + E_c + 13 + 3
     preds, olevels = [], []
     for h, w in sizes:
         t = torch.randn(B, h, w, pitch) * 1.5
         preds.append(t)
         nchw = t.permute(0, 3, 1, 2)
-        o = 69
+        o = 72  # VGH_PRED_FLAME_OFF
         fl = po.assemble_flame_channels(nchw[:, o : o + S_c], nchw[:, o + S_c : o + S_c + E_c], nchw[:, o + S_c + E_c : o + S_c + E_c + 6],
                                         nchw[:, o + S_c + E_c + 6 : o + S_c + E_c + 9], nchw[:, o + S_c + E_c + 9 : o + S_c + E_c + 12],
                                         nchw[:, o + S_c + E_c + 12 : o + S_c + E_c + 13])
@@ -351,6 +351,16 @@ def test_conv_epilogues(gpu_lib):
     out, ref, st, o0 = _run_conv(gpu_lib, x, W69, torch.randn(69, generator=g), 1, 1, act=0, out_f32=True, out_coff=5)
     _assert_close(out[..., 5 : 5 + 69], ref[..., :69], True, "f32 out")
     assert float((out[..., 5 + 69 :] + 768.0).abs().max()) == 0.0
+    # the same through the transposed float4 epilogue (16-byte aligned channel offset, as the network's prediction buffers):
+    # ragged 69 / 13 live channels, every tile config that can run a 1x1 conv; untouched floats keep the sentinel
+    for rows_ in (69, 13):
+        Wr, br = torch.randn(rows_, 1, 1, Cin, generator=g) * 0.1, torch.randn(rows_, generator=g)
+        for cfg in range(-1, gpu_lib.vgh_conv_num_cfgs()):
+            if cfg >= 0 and not gpu_lib.vgh_conv_cfg_ok(cfg, 1, 1, 96 if rows_ == 69 else 32, 0, 0):
+                continue
+            out, ref, st, o0 = _run_conv(gpu_lib, x, Wr, br, 1, 1, act=0, out_f32=True, out_coff=8, cfg=cfg)
+            _assert_close(out[..., 8 : 8 + rows_], ref[..., :rows_], True, f"f32 float4 epilogue rows={rows_} cfg={cfg}")
+            assert float((out[..., 8 + rows_ :] + 768.0).abs().max()) == 0.0 and float((out[..., :8] + 768.0).abs().max()) == 0.0
     # input view at a channel offset inside a wider (concat) buffer
     for cfg in (-1, 15, 16):
         out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, in_coff=32, in_pitch=160, cfg=cfg)
