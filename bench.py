@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--heads-per-image", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", default=None, help="write a per-op timing table (json) to this path")
+    ap.add_argument("--no-overlap", action="store_true", help="run NMS..FLAME decode on the network stream instead of the detector's side stream")
     ap.add_argument("--graph", action="store_true", help="replay the network through a captured hipGraph")
     args = ap.parse_args()
 
@@ -123,7 +124,9 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    heads_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+    n_heads_all = torch.zeros(max(args.steps, 1), dtype=torch.int32, device=dev)
+    # throughput mode: NMS .. FLAME decode of batch s run on the detector's side stream underneath the network of batch s+1
+    eng.set_overlap(not args.no_overlap and not args.graph)
 
     def step(i=None):
         if i is not None:
@@ -134,21 +137,23 @@ def main():
         # post-network stages: decode/top-k/gather, then ONE library call for NMS + compaction + head list + FLAME decode of every
         # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
         eng.candidates(B)
-        det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad)
-        with torch.cuda.stream(eng.stream):
-            heads_acc.add_(det.n_heads)
-            out = gather_detections(det.boxes, det.scores, det.flame_params, det.counts, det.vertices_3d, dst=0) if world > 1 else None
+        det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[(i if i is not None else 0) : (i if i is not None else 0) + 1])
+        out = None
+        if world > 1:  # the gather consumes this batch's results: join first (serialises the select of this step only)
+            eng.join()
+            with torch.cuda.stream(eng.stream):
+                out = gather_detections(det.boxes, det.scores, det.flame_params, det.counts, det.vertices_3d, dst=0)
         return out
 
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
-    heads_acc.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    eng.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -158,7 +163,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     net_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(args.steps, 1)
-    heads = int(heads_acc.item())
+    heads = int(n_heads_all.sum().item())
 
     per_layer = None
     if args.per_layer and rank == 0:
@@ -192,7 +197,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.variant} bf16 batch {B}/GPU @ {S}x{S}, u8 NHWC input resident in HBM, ~{heads / max(args.steps * B, 1):.2f} heads/img decoded",
                        "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(eng.flops_per_image / 1e9, 2),
-                       "graph": bool(args.graph), "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(net_ms, 3)},
+                       "graph": bool(args.graph), "overlap_post": not args.no_overlap and not args.graph, "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(net_ms, 3)},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "conv_igemm_kernel<*> (all launches of one forward; algorithmic 2*MACs / HIP-event time of the network part)"},

@@ -87,6 +87,7 @@ SYMBOLS = {
     "vgh_net_buffer": (_P, [_P, _I]),
     "vgh_net_buffer_bytes": (_I64, [_P, _I]),
     "vgh_net_set_cfg": (_I, [_P, _I, _I]),
+    "vgh_net_set_pred_guard": (_I, [_P, _P]),
     "vgh_net_max_batch": (_I, [_P]),
     "vgh_net_image_size": (_I, [_P]),
     "vgh_conv2d": (_I, [C.POINTER(ConvCall), _P]),
@@ -106,10 +107,13 @@ SYMBOLS = {
     "vgh_detector_create": (_I, [_P, _P, C.POINTER(DetectCfg), C.POINTER(_P)]),
     "vgh_detector_destroy": (None, [_P]),
     "vgh_detector_candidates": (_I, [_P, _P, _I, _I, _P]),
+    "vgh_detector_decode_candidates": (_I, [_P, _I, _I, _P]),
     "vgh_detector_candidate_buffers": (_I, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "vgh_detector_set_flame": (_I, [_P, _P]),
     "vgh_detector_scratch": (_P, [_P, _I]),
     "vgh_detector_select": (_I, [_P, _I, _F, _F, C.POINTER(DetectOut), _P]),
+    "vgh_detector_set_overlap": (_I, [_P, _I]),
+    "vgh_detector_join": (_I, [_P, _P]),
     "vgh_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_flame_lbs": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "vgh_rasterize": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),

@@ -26,6 +26,11 @@ struct vgh_detector {
     int32_t* keep_idx = nullptr;   // [max_batch, keep_k]
     int32_t* head_row = nullptr;   // [max_batch * keep_k]
     int32_t* head_image = nullptr; // [max_batch * keep_k]
+    // overlap mode: the select half (NMS .. FLAME decode: small, latency-bound kernels) runs on a detector-owned side stream,
+    // concurrently with the network of the NEXT batch on the caller's stream
+    bool overlap = false, side_pending = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_net = nullptr, ev_cand = nullptr, ev_side = nullptr;
 };
 
 namespace {
@@ -127,6 +132,14 @@ void vgh_detector_destroy(vgh_detector* d) {
     hipFree(d->keep_idx);
     hipFree(d->head_row);
     hipFree(d->head_image);
+    if (d->side) {
+        hipStreamSynchronize(d->side);
+        hipStreamDestroy(d->side);
+    }
+    if (d->net) vgh_net_set_pred_guard(d->net, nullptr);
+    if (d->ev_net) hipEventDestroy(d->ev_net);
+    if (d->ev_cand) hipEventDestroy(d->ev_cand);
+    if (d->ev_side) hipEventDestroy(d->ev_side);
     delete d;
 }
 
@@ -134,8 +147,21 @@ int vgh_detector_candidates(vgh_detector* d, const void* images_dev, int image_f
     VGH_REQUIRE(d && images_dev, "detector_candidates: null argument");
     VGH_REQUIRE(B >= 1 && B <= d->cfg.max_batch, "detector_candidates: batch %d outside 1..%d", B, d->cfg.max_batch);
     VGH_REQUIRE(image_fmt == VGH_IMG_F32_NCHW || image_fmt == VGH_IMG_U8_NHWC, "detector_candidates: unknown image format %d", image_fmt);
-    const vgh_detect_cfg& c = d->cfg;
     const size_t img_bytes = (size_t)d->S * d->S * 3 * (image_fmt == VGH_IMG_F32_NCHW ? 4 : 1);
+    // arena-sized chunks (the conv kernels address < 2 GiB per tensor; the arena is planned for arena_batch images)
+    for (int at = 0; at < B; at += d->arena_batch) {
+        const int n = (B - at < d->arena_batch) ? B - at : d->arena_batch;
+        int rc = vgh_net_forward(d->net, (const char*)images_dev + (size_t)at * img_bytes, image_fmt, n, stream);
+        if (rc) return rc;
+        if ((rc = vgh_detector_decode_candidates(d, n, at, stream))) return rc;
+    }
+    return VGH_OK;
+}
+
+int vgh_detector_decode_candidates(vgh_detector* d, int n, int at, void* stream) {
+    VGH_REQUIRE(d, "detector_decode_candidates: null handle");
+    VGH_REQUIRE(n >= 1 && at >= 0 && at + n <= d->cfg.max_batch && n <= d->arena_batch, "detector_decode_candidates: rows [%d,%d) outside the buffers", at, at + n);
+    const vgh_detect_cfg& c = d->cfg;
     vgh_head_level lv[VGH_MAX_LEVELS];
     for (int l = 0; l < c.n_levels; ++l) {
         lv[l].pred_dev = (const float*)vgh_net_buffer(d->net, c.level_buf[l]);
@@ -144,19 +170,25 @@ int vgh_detector_candidates(vgh_detector* d, const void* images_dev, int image_f
         lv[l].pitch = c.level_pitch[l];
         lv[l].stride = c.level_stride[l];
     }
-    // arena-sized chunks (the conv kernels address < 2 GiB per tensor; the arena is planned for arena_batch images)
-    for (int at = 0; at < B; at += d->arena_batch) {
-        const int n = (B - at < d->arena_batch) ? B - at : d->arena_batch;
-        int rc = vgh_net_forward(d->net, (const char*)images_dev + (size_t)at * img_bytes, image_fmt, n, stream);
-        if (rc) return rc;
-        float* ba = d->boxes_all + (size_t)at * d->A * 4;
-        float* sa = d->scores_all + (size_t)at * d->A;
-        int32_t* ix = d->idx + (size_t)at * c.pre_k;
-        if ((rc = vgh_head_decode(lv, c.n_levels, n, ba, sa, stream))) return rc;
-        if ((rc = vgh_topk(sa, n, d->A, c.pre_k, ix, d->cand_scores + (size_t)at * c.pre_k, stream))) return rc;
-        if ((rc = vgh_gather_candidates(lv, c.n_levels, n, d->A, c.shape_live, c.expr_live, ba, ix, c.pre_k, d->cand_boxes + (size_t)at * c.pre_k * 4,
-                                        d->cand_flame + (size_t)at * c.pre_k * VGH_NUM_FLAME_PARAMS, stream)))
-            return rc;
+    void* st = stream;
+    if (d->overlap) {  // predictions ready on `stream` -> side stream (ordered after everything queued there, incl. the last select)
+        VGH_HIP(hipEventRecord(d->ev_net, (hipStream_t)stream));
+        VGH_HIP(hipStreamWaitEvent(d->side, d->ev_net, 0));
+        st = d->side;
+    }
+    float* ba = d->boxes_all + (size_t)at * d->A * 4;
+    float* sa = d->scores_all + (size_t)at * d->A;
+    int32_t* ix = d->idx + (size_t)at * c.pre_k;
+    int rc;
+    if ((rc = vgh_head_decode(lv, c.n_levels, n, ba, sa, st))) return rc;
+    if ((rc = vgh_topk(sa, n, d->A, c.pre_k, ix, d->cand_scores + (size_t)at * c.pre_k, st))) return rc;
+    if ((rc = vgh_gather_candidates(lv, c.n_levels, n, d->A, c.shape_live, c.expr_live, ba, ix, c.pre_k, d->cand_boxes + (size_t)at * c.pre_k * 4,
+                                    d->cand_flame + (size_t)at * c.pre_k * VGH_NUM_FLAME_PARAMS, st)))
+        return rc;
+    if (d->overlap) {  // the next forward may run its backbone / neck now, but must not overwrite the predictions before this point
+        VGH_HIP(hipEventRecord(d->ev_cand, d->side));
+        if ((rc = vgh_net_set_pred_guard(d->net, d->ev_cand))) return rc;
+        d->side_pending = true;
     }
     return VGH_OK;
 }
@@ -187,10 +219,7 @@ int vgh_detector_set_flame(vgh_detector* d, vgh_flame* flame) {
     return VGH_OK;
 }
 
-int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, vgh_detect_out* o, void* stream) {
-    VGH_REQUIRE(d && o, "detector_select: null argument");
-    VGH_REQUIRE(B >= 1 && B <= d->cfg.max_batch, "detector_select: batch %d outside 1..%d", B, d->cfg.max_batch);
-    VGH_REQUIRE(o->boxes_dev && o->scores_dev && o->flame_dev && o->counts_dev, "detector_select: boxes/scores/flame/counts outputs are mandatory");
+static int select_on(vgh_detector* d, int B, float conf_thr, float iou_thr, vgh_detect_out* o, void* stream) {
     const vgh_detect_cfg& c = d->cfg;
     int rc;
     if ((rc = vgh_nms(d->cand_boxes, d->cand_scores, B, c.pre_k, conf_thr, iou_thr, c.keep_k, d->keep_idx, o->counts_dev, stream))) return rc;
@@ -209,6 +238,43 @@ int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, v
     VGH_REQUIRE(d->flame, "detector_select: per-head FLAME outputs requested but the detector was created without a FLAME handle");
     return vgh_flame_decode_indirect(d->flame, o->flame_dev, d->head_row, himg, o->n_heads_dev, capacity, c.shape_live, c.expr_live, o->unpad_dev, o->verts_dev,
                                      o->rot_dev, o->rpy_dev, o->proj_dev, stream);
+}
+
+int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, vgh_detect_out* o, void* stream) {
+    VGH_REQUIRE(d && o, "detector_select: null argument");
+    VGH_REQUIRE(B >= 1 && B <= d->cfg.max_batch, "detector_select: batch %d outside 1..%d", B, d->cfg.max_batch);
+    VGH_REQUIRE(o->boxes_dev && o->scores_dev && o->flame_dev && o->counts_dev, "detector_select: boxes/scores/flame/counts outputs are mandatory");
+    if (!d->overlap) return select_on(d, B, conf_thr, iou_thr, o, stream);
+    // overlap mode: the candidates were produced on the side stream; the select simply follows them there
+    const int rc = select_on(d, B, conf_thr, iou_thr, o, d->side);
+    d->side_pending = true;
+    return rc;
+}
+
+int vgh_detector_set_overlap(vgh_detector* d, int enable) {
+    VGH_REQUIRE(d, "detector_set_overlap: null handle");
+    if (enable && !d->side) {
+        VGH_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+        VGH_HIP(hipEventCreateWithFlags(&d->ev_net, hipEventDisableTiming));
+        VGH_HIP(hipEventCreateWithFlags(&d->ev_cand, hipEventDisableTiming));
+        VGH_HIP(hipEventCreateWithFlags(&d->ev_side, hipEventDisableTiming));
+    }
+    if (!enable && d->side) {
+        VGH_HIP(hipStreamSynchronize(d->side));
+        vgh_net_set_pred_guard(d->net, nullptr);
+        d->side_pending = false;
+    }
+    d->overlap = enable != 0;
+    return VGH_OK;
+}
+
+int vgh_detector_join(vgh_detector* d, void* stream) {
+    VGH_REQUIRE(d, "detector_join: null handle");
+    if (d->overlap && d->side && d->side_pending) {
+        VGH_HIP(hipEventRecord(d->ev_side, d->side));
+        VGH_HIP(hipStreamWaitEvent((hipStream_t)stream, d->ev_side, 0));
+    }
+    return VGH_OK;
 }
 
 int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, float conf_thr, float iou_thr, vgh_detect_out* o, void* stream) {

@@ -39,6 +39,9 @@ struct vgh_net {
     static constexpr int kLanes = 4;  // lane 0 = the caller's stream
     hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    // optional guard (borrowed event): the first op that writes an fp32 prediction buffer waits for it, so a consumer of the
+    // PREVIOUS forward's predictions may still be running on another stream while this forward's backbone / neck execute
+    hipEvent_t pred_guard = nullptr;
 };
 
 static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -234,7 +237,15 @@ int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
     // the main stream at the end (also valid under stream capture: the graph gets parallel branches).
     hipStream_t main = (hipStream_t)stream;
     bool pending[vgh_net::kLanes] = {false, false, false, false}, used[vgh_net::kLanes] = {false, false, false, false};
+    bool guard_pending = n->pred_guard != nullptr;
     for (const NetOp& op : n->ops) {
+        if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32) {
+            // every stream that may run a prediction conv waits (main; the lanes inherit it through the fork / their own wait)
+            VGH_HIP(hipStreamWaitEvent(main, n->pred_guard, 0));
+            for (int l = 1; l < vgh_net::kLanes; ++l)
+                if (n->side[l]) VGH_HIP(hipStreamWaitEvent(n->side[l], n->pred_guard, 0));
+            guard_pending = false;
+        }
         if (op.d.kind == VGH_OP_FORK) {
             VGH_HIP(hipEventRecord(n->ev_fork, main));
             for (int l = 1; l < vgh_net::kLanes; ++l) pending[l] = true;
@@ -280,6 +291,7 @@ int vgh_net_profile(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
 
 int vgh_net_capture(vgh_net* n, const void* image_dev, int image_fmt, int B, void* stream) {
     VGH_REQUIRE(n && stream, "net_capture: needs a non-null stream");
+    VGH_REQUIRE(!n->pred_guard, "net_capture: a prediction guard event is set (detector overlap mode); graph replay cannot honour it");
     hipStream_t st = (hipStream_t)stream;
     if (n->graph_exec) {
         hipGraphExecDestroy(n->graph_exec);
@@ -300,12 +312,19 @@ int vgh_net_capture(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
 
 int vgh_net_forward_graph(vgh_net* n, void* stream) {
     VGH_REQUIRE(n && n->graph_exec, "net_forward_graph: call vgh_net_capture first");
+    VGH_REQUIRE(!n->pred_guard, "net_forward_graph: a prediction guard event is set (detector overlap mode); use vgh_net_forward");
     VGH_HIP(hipGraphLaunch(n->graph_exec, (hipStream_t)stream));
     return VGH_OK;
 }
 
 void* vgh_net_buffer(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_ptr.size()) ? n->buf_ptr[buf_id] : nullptr; }
 int64_t vgh_net_buffer_bytes(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_bytes.size()) ? n->buf_bytes[buf_id] : -1; }
+
+int vgh_net_set_pred_guard(vgh_net* n, void* event) {
+    VGH_REQUIRE(n, "net_set_pred_guard: null handle");
+    n->pred_guard = (hipEvent_t)event;
+    return VGH_OK;
+}
 
 int vgh_net_max_batch(vgh_net* n) { return n ? n->max_batch : 0; }
 int vgh_net_image_size(vgh_net* n) { return n ? n->image_size : 0; }

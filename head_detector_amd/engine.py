@@ -204,6 +204,8 @@ class VGHeadsEngine:
             raise ValueError(f"forward_net handles at most arena_batch={self.arena_batch} images; use forward_candidates() for larger batches")
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         if use_graph:
+            if getattr(self, "_overlap", False):
+                raise ValueError("hipGraph replay cannot honour the prediction-buffer guard of overlap mode: use one or the other")
             key = (images.data_ptr(), B, fmt)
             if self._graph_key != key:
                 _lib.check(self.lib.vgh_net_forward(self._net, images.data_ptr(), fmt, B, self._sp()))  # warm: lazy attributes before capture
@@ -215,17 +217,22 @@ class VGHeadsEngine:
             _lib.check(self.lib.vgh_net_forward(self._net, images.data_ptr(), fmt, B, self._sp()))
         return B
 
+    def set_overlap(self, enable: bool = True):
+        """Throughput mode (vgh_detector_set_overlap): ``select`` / the select half of ``detect`` run on a detector-owned side
+        stream underneath the next batch's network.  Call ``join()`` before reading a batch's outputs."""
+        _lib.check(self.lib.vgh_detector_set_overlap(self._det, int(bool(enable))))
+        self._overlap = bool(enable)
+
+    def join(self):
+        """Make the engine stream (and the caller's current stream) wait for the last queued select."""
+        _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
     def candidates(self, B: int, at: int = 0):
-        """K6 + K7 + K6b on the engine stream for the B images currently in the arena: boxes/scores for all anchors, top-k,
-        gather + FLAME fix-up; results land in rows [at, at+B) of the batch-level candidate tensors."""
-        lv = self._levels_arr(B)
-        P = self.program
-        sp = self._sp()
-        ba, sa, ix = self.boxes_all[at:], self.scores_all[at:], self.idx[at:]
-        cs, cb, cf = self.cand_scores[at:], self.cand_boxes[at:], self.cand_flame[at:]
-        _lib.check(self.lib.vgh_head_decode(lv, len(P.levels), B, _lib.ptr(ba), _lib.ptr(sa), sp))
-        _lib.check(self.lib.vgh_topk(_lib.ptr(sa), B, self.A, self.pre_k, _lib.ptr(ix), _lib.ptr(cs), sp))
-        _lib.check(self.lib.vgh_gather_candidates(lv, len(P.levels), B, self.A, P.shape_c, P.expr_c, _lib.ptr(ba), _lib.ptr(ix), self.pre_k, _lib.ptr(cb), _lib.ptr(cf), sp))
+        """K6 + K7 + K6b for the B images currently in the arena (vgh_detector_decode_candidates): boxes/scores for all anchors,
+        top-k, gather + FLAME fix-up; results land in rows [at, at+B) of the batch-level candidate tensors.  In overlap mode
+        they are queued on the detector's side stream (``join()`` before reading them)."""
+        _lib.check(self.lib.vgh_detector_decode_candidates(self._det, B, at, self._sp()))
 
     def forward_candidates(self, images: torch.Tensor, use_graph: bool = False) -> int:
         """Network + candidate stages for a batch of any size <= max_batch (arena-sized chunks): one vgh_detector_candidates call."""
@@ -238,13 +245,18 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_detector_candidates(self._det, images.data_ptr(), fmt, B, self._sp()))
         return B
 
+    def _join_if_overlap(self):
+        if getattr(self, "_overlap", False):
+            _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))
+
     def model(self, images: torch.Tensor, use_graph: bool = False):
         """Drop-in for ``self.model(image)`` (detector.py:58-59)."""
         B = self.forward_candidates(images, use_graph)
+        self._join_if_overlap()
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self.cand_boxes[:B], self.cand_scores[:B].unsqueeze(-1), self.cand_flame[:B]
 
-    def _detect_out(self, B: int, flame: Optional[FLAMELayer], unpad: Optional[torch.Tensor]) -> Tuple["_lib.DetectOut", Detections]:
+    def _detect_out(self, B: int, flame: Optional[FLAMELayer], unpad: Optional[torch.Tensor], n_heads_out: Optional[torch.Tensor] = None) -> Tuple["_lib.DetectOut", Detections]:
         o = _lib.DetectOut()
         o.boxes_dev, o.scores_dev, o.flame_dev, o.counts_dev = self.out_boxes.data_ptr(), self.out_scores.data_ptr(), self.out_flame.data_ptr(), self.counts.data_ptr()
         det = Detections(self.out_boxes[:B], self.out_scores[:B], self.out_flame[:B], self.counts[:B])
@@ -262,9 +274,10 @@ class VGHeadsEngine:
                 if unpad.shape != (B, 3) or unpad.dtype != torch.float32 or not unpad.is_cuda or not unpad.is_contiguous():
                     raise ValueError("unpad must be a contiguous float32 GPU tensor [B,3] = (pad_x, pad_y, scale) per image")
                 o.unpad_dev = unpad.data_ptr()
-            o.n_heads_dev, o.head_image_dev, o.head_capacity = self.n_heads.data_ptr(), himg.data_ptr(), cap
+            nh = self.n_heads if n_heads_out is None else n_heads_out
+            o.n_heads_dev, o.head_image_dev, o.head_capacity = nh.data_ptr(), himg.data_ptr(), cap
             o.proj_dev, o.rpy_dev = proj.data_ptr(), rpy.data_ptr()
-            det.n_heads, det.head_image_cap, det.vertices_cap, det.rpy_cap = self.n_heads, himg, proj, rpy
+            det.n_heads, det.head_image_cap, det.vertices_cap, det.rpy_cap = nh, himg, proj, rpy
         return o, det
 
     def detect(self, images: torch.Tensor, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
@@ -280,14 +293,17 @@ class VGHeadsEngine:
         else:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             _lib.check(self.lib.vgh_detect(self._det, images.data_ptr(), fmt, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
+        if getattr(self, "_overlap", False):
+            _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))  # detect() keeps stream-ordered semantics
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return det
 
     def select(self, B: int, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
-               unpad: Optional[torch.Tensor] = None) -> Detections:
+               unpad: Optional[torch.Tensor] = None, n_heads_out: Optional[torch.Tensor] = None) -> Detections:
         """The post-candidate half of ``detect`` for the B images whose candidates are already in place
-        (after ``forward_candidates`` / ``forward_net`` + ``candidates``)."""
-        o, det = self._detect_out(B, flame, unpad)
+        (after ``forward_candidates`` / ``forward_net`` + ``candidates``).  In overlap mode it is queued on the detector's side
+        stream: ``join()`` before reading the result.  ``n_heads_out`` [1] int32: where to write the head count."""
+        o, det = self._detect_out(B, flame, unpad, n_heads_out)
         _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         return det
 

@@ -86,6 +86,9 @@ int vgh_net_forward_graph(vgh_net* net, void* stream);
 void* vgh_net_buffer(vgh_net* net, int buf_id);         /* device pointer of an activation buffer   */
 int64_t vgh_net_buffer_bytes(vgh_net* net, int buf_id); /* bytes for max_batch                       */
 int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
+/* Borrowed HIP event (or NULL): the first op of the next forwards that writes a prediction buffer waits for it on its stream.
+ * Lets a consumer of the previous forward's predictions run on another stream underneath this forward's backbone / neck. */
+int vgh_net_set_pred_guard(vgh_net* net, void* event);
 int vgh_net_max_batch(vgh_net* net);  /* images the activation arena was planned for */
 int vgh_net_image_size(vgh_net* net);
 
@@ -238,6 +241,10 @@ typedef struct vgh_detector vgh_detector;
 int vgh_detector_create(vgh_net* net, vgh_flame* flame, const vgh_detect_cfg* cfg, vgh_detector** out);
 void vgh_detector_destroy(vgh_detector* d);
 int vgh_detector_candidates(vgh_detector* d, const void* images_dev, int image_fmt, int B, void* stream);
+/* The post-network half of vgh_detector_candidates alone (box/score decode, top-k, gather) for the n images currently in the
+ * net's prediction buffers -> candidate rows [at, at+n).  With vgh_net_forward before it, this is what vgh_detector_candidates
+ * does per arena-sized chunk; separate so a caller can bracket the network with its own events. */
+int vgh_detector_decode_candidates(vgh_detector* d, int n, int at, void* stream);
 int vgh_detector_candidate_buffers(vgh_detector* d, float** boxes_dev, float** scores_dev, float** flame_dev);
 int vgh_detector_set_flame(vgh_detector* d, vgh_flame* flame);
 /* detector-owned intermediates (parity tests / debugging): dense boxes [max_batch,A,4], dense scores [max_batch,A],
@@ -250,6 +257,15 @@ int vgh_detector_set_flame(vgh_detector* d, vgh_flame* flame);
 void* vgh_detector_scratch(vgh_detector* d, int which);
 int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, vgh_detect_out* out, void* stream);
 int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, float conf_thr, float iou_thr, vgh_detect_out* out, void* stream);
+/* Throughput mode.  With overlap enabled the select half (NMS, compaction, head list, FLAME decode: small latency-bound
+ * kernels, ~0.3 ms per batch) AND the candidate half (decode, top-k, gather) are queued on a detector-owned side stream, so
+ * they run underneath the NETWORK OF THE NEXT BATCH queued on the caller's stream; the next forward waits (vgh_net_set_pred_guard)
+ * only before it overwrites the prediction buffers.  Ordering rules: the candidates / outputs of call s are complete once
+ * `vgh_detector_join(det, stream)` has been ordered after it (it makes `stream` wait for everything queued on the side
+ * stream); the caller must not reuse the vgh_detect_out buffers of call s for call s+1 unless it joined in between (or does
+ * not read them). */
+int vgh_detector_set_overlap(vgh_detector* d, int enable);
+int vgh_detector_join(vgh_detector* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Result-side consumers of the decoded meshes.

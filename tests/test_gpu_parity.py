@@ -770,3 +770,46 @@ def test_get_pncc_through_the_facade(gpu_lib, flame_model):
     assert all(np.array_equal(h.vertices_3d[:, 2], -b[:, 2]) for h, b in zip(res.heads, before))
     with pytest.raises(FileNotFoundError):
         HeadDetector("vgg_heads_m", 320, flame_model=flame_model, seed=4)(img, confidence_threshold=conf).get_pncc()
+
+
+def test_overlap_mode_is_race_free_and_identical(gpu_lib, flame_model):
+    """Throughput mode (vgh_detector_set_overlap): the select half of batch s runs on the detector's side stream while the network
+    of batch s+1 runs on the engine stream.  Results must be bit-identical to the stream-ordered mode, also when the next batch's
+    network + candidate stages are queued before the previous select is consumed."""
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    S, B = 256, 4
+    g = torch.Generator().manual_seed(23)
+    xa = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(_dev())
+    xb = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=1024)
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=5)
+    conf = float(eng.model(xa)[1][:, 25, 0].max())
+
+    def snap(det):
+        return [t.clone() for t in (det.boxes, det.scores, det.flame_params, det.counts, det.vertices_3d, det.head_pose, det.head_image)]
+
+    ref_a, ref_b = snap(eng.detect(xa, confidence_threshold=conf, flame=fl)), snap(eng.detect(xb, confidence_threshold=conf, flame=fl))
+    assert int(ref_a[3].sum()) > 0 and not torch.equal(ref_a[0], ref_b[0])
+    eng.set_overlap(True)
+    for _ in range(3):
+        eng.forward_net(xa)
+        eng.candidates(B)
+        da = eng.select(B, confidence_threshold=conf, flame=fl)  # side stream
+        eng.forward_net(xb)                                      # next batch's network queued while select(a) may still run
+        eng.candidates(B)                                        # waits for select(a) before refilling the candidate buffers
+        eng.join()
+        got_a = snap(da)
+        db = eng.select(B, confidence_threshold=conf, flame=fl)
+        eng.join()
+        got_b = snap(db)
+        for r, q in zip(ref_a, got_a):
+            assert torch.equal(r, q)
+        for r, q in zip(ref_b, got_b):
+            assert torch.equal(r, q)
+    # detect() keeps its stream-ordered contract in overlap mode
+    for r, q in zip(ref_a, snap(eng.detect(xa, confidence_threshold=conf, flame=fl))):
+        assert torch.equal(r, q)
+    eng.set_overlap(False)
+    eng.close()
