@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--heads-per-image", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-layer", default=None, help="write a per-op timing table (json) to this path")
+    ap.add_argument("--split", type=int, default=2, help="independent sub-batches per forward on the net's lane streams (1 = off)")
     ap.add_argument("--no-overlap", action="store_true", help="run NMS..FLAME decode on the network stream instead of the detector's side stream")
     ap.add_argument("--graph", action="store_true", help="replay the network through a captured hipGraph")
     args = ap.parse_args()
@@ -127,6 +128,7 @@ def main():
     n_heads_all = torch.zeros(max(args.steps, 1), dtype=torch.int32, device=dev)
     # throughput mode: NMS .. FLAME decode of batch s run on the detector's side stream underneath the network of batch s+1
     eng.set_overlap(not args.no_overlap and not args.graph)
+    eng.set_split(1 if args.graph else max(1, min(4, args.split)))
 
     def step(i=None):
         if i is not None:
@@ -197,7 +199,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.variant} bf16 batch {B}/GPU @ {S}x{S}, u8 NHWC input resident in HBM, ~{heads / max(args.steps * B, 1):.2f} heads/img decoded",
                        "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(eng.flops_per_image / 1e9, 2),
-                       "graph": bool(args.graph), "overlap_post": not args.no_overlap and not args.graph, "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(net_ms, 3)},
+                       "graph": bool(args.graph), "overlap_post": not args.no_overlap and not args.graph, "batch_split": 1 if args.graph else max(1, min(4, args.split)), "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(net_ms, 3)},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "conv_igemm_kernel<*> (all launches of one forward; algorithmic 2*MACs / HIP-event time of the network part)"},

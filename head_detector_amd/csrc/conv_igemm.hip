@@ -420,9 +420,22 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
 //   LDS        : X[2][(TH+2)*(TW+2) halo pixels][64 B] + W[2][3 taps][BC][64 B], both 16-B-chunk swizzled
 //   bytes/FLOP : (HP + 9*BC) * 64 B per 9*BP*BC*64 FLOP  ->  ~200 FLOP/B at 256 px x 128 couts (v1: 64-85)
 // =====================================================================================================
+// LDS layout of the halo patch, per tile width: row pitch (halo pixels) and the 16-byte-chunk swizzle
+//     slot = chunk ^ (((hx >> SH) + ROW * hy) & 3)
+// chosen (exhaustive search over pitches / shifts / row terms against the ds_read_b128 lane groups {0-3,12-15,20-27}, ...) so
+// that the tap-shifted B-fragment reads of every 32-pixel MFMA group are bank-conflict free:
+//     TW = 16: pitch 18, SH 1           TW = 32: pitch 34, SH 2           TW = 40: pitch 44 (2 padding pixels), SH 2, ROW 2
+// (TW = 20 would need pitch 24 with ROW 1, whose kernel-row dependence is not an XOR: it keeps 2-way conflicts.)
+template <int TW>
+struct PatchLayout {
+    static constexpr int HW = (TW == 40) ? 44 : TW + 2;
+    static constexpr int SH = (TW == 16) ? 1 : 2;
+    static constexpr int ROW = (TW == 40) ? 2 : 0;
+};
+
 template <int TW, int TH, int BC, int NWP, int NWC>
 constexpr int patch_lds() {
-    constexpr int HP = (TW + 2) * (TH + 2), HPU = (HP + 15) / 16;
+    constexpr int HP = PatchLayout<TW>::HW * (TH + 2), HPU = (HP + 15) / 16;
     constexpr int loop = 2 * HPU * 1024 + 2 * 3 * BC * 64, epi = NWP * NWC * 32 * (BC / NWC + 4) * 4;
     return loop > epi ? loop : epi;
 }
@@ -447,7 +460,8 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
                                                                         const int chunk) {
     constexpr int NW = NWP * NWC;
     constexpr int NPX = TW * TH, NG = (NPX + 31) / 32, TJ = NG / NWP, TI = BC / 32 / NWC, WC = BC / NWC;
-    constexpr int HW = TW + 2, HP = HW * (TH + 2), HPU = (HP + 15) / 16;
+    constexpr int HW = PatchLayout<TW>::HW, HP = HW * (TH + 2), HPU = (HP + 15) / 16;
+    constexpr int SWZ_SH = PatchLayout<TW>::SH, SWZ_ROW = PatchLayout<TW>::ROW;
     constexpr int XBYTES = HPU * 1024, WTAP = BC * 64, WSTEP = 3 * WTAP;
     constexpr int XUW = (HPU + NW - 1) / NW;  // halo units (16 pixels = 1 KiB) staged per wave per channel block
     constexpr int WU = 3 * BC / 16, WUW = (WU + NW - 1) / NW;
@@ -497,9 +511,10 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
         const int hp = (w + NW * t) * 16 + (lane_t >> 2);
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        // source-side swizzle: LDS slot (lane & 3) of halo pixel (hy, hx) holds channel chunk slot ^ ((hx >> 2) & 3)
-        xoff[t] = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * (int)a.in_pitch + a.in_coff) + (((lane_t & 3) ^ ((hx >> 2) & 3))) * 16 : OOB;
+        const bool ok = hp < HP && hx < TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        // source-side swizzle: LDS slot (lane & 3) of halo pixel (hy, hx) holds channel chunk slot ^ swz(hy, hx)
+        const int swz = ((hx >> SWZ_SH) + SWZ_ROW * hy) & 3;
+        xoff[t] = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * (int)a.in_pitch + a.in_coff) + (((lane_t & 3) ^ swz)) * 16 : OOB;
     }
     const char* const wbase = (const char*)a.wpack + (int64_t)c0 * 64;
 
@@ -537,7 +552,8 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi_t) ^ (((hx0 + kx) >> 2) & 3)) * 16);
+            for (int h = 0; h < 2; ++h)  // swizzle of halo row ty (kernel row 0); rows ty+1 / ty+2 differ by ROW*ky, see load_frags
+                boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi_t) ^ ((((hx0 + kx) >> SWZ_SH) + SWZ_ROW * (p < NPX ? ty : 0)) & 3)) * 16);
     }
     const int sw = (lane_t >> 2) & 3;
     const int aoff0 = (wc * WC + lrow_t) * 64 + (((0 + hi_t) ^ sw) * 16);
@@ -556,8 +572,10 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
 #pragma unroll
         for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8_t*)(Wt + kx * WTAP + i * 2048 + (h ? aoff1 : aoff0));
         const char* Xk = X + ky * (HW * 64);
+        // ROW = 2: the swizzle of halo row ty + ky is that of row ty plus 2*ky (mod 4) = bit 1 flipped for ky = 1 = byte offset ^ 32
+        const int kyx = (SWZ_ROW == 2 && (ky & 1)) ? 32 : 0;
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8_t*)(Xk + boff[j][kx][h]);
+        for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8_t*)(Xk + (boff[j][kx][h] ^ kyx));
     };
     auto mma = [&](const bf16x8_t (&af)[TI], const bf16x8_t (&bfr)[TJ]) {
 #pragma unroll

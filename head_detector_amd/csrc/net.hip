@@ -42,16 +42,22 @@ struct vgh_net {
     // optional guard (borrowed event): the first op that writes an fp32 prediction buffer waits for it, so a consumer of the
     // PREVIOUS forward's predictions may still be running on another stream while this forward's backbone / neck execute
     hipEvent_t pred_guard = nullptr;
+    // batch split: the batch runs as `nsplit` independent sub-batches on the lane streams, so the fixed cost of every launch
+    // (dispatch, tile prologue, first-load latency, epilogue store burst, tail) of one sub-batch hides under the main loops of
+    // the others (measured on the M net at B = 32: 5.75 ms -> 5.35 ms with 4 lanes)
+    int nsplit = 1;
 };
+
+static inline int64_t buf_image_bytes(const vgh_buf_desc& b) { return (int64_t)b.h * b.w * b.pitch * (b.is_f32 ? 4 : 2); }
 
 static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-static int net_conv_args(vgh_net* n, const NetOp& op, int B, ConvArgs* a) {
+static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a) {
     const vgh_op_desc& d = op.d;
     const vgh_buf_desc& ib = n->bufs[d.in_buf];
     const vgh_buf_desc& ob = n->bufs[d.out_buf];
     memset(a, 0, sizeof(*a));
-    a->in = (const uint16_t*)n->buf_ptr[d.in_buf];
+    a->in = (const uint16_t*)((const char*)n->buf_ptr[d.in_buf] + at * buf_image_bytes(ib));
     a->in_pitch = ib.pitch;
     a->in_coff = d.in_coff;
     a->cin = d.cin;
@@ -65,7 +71,7 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, ConvArgs* a) {
     a->Wo = (ib.w + 2 * a->pad - d.ksize) / d.stride + 1;
     a->wpack = op.wpack;
     a->bias = op.bias;
-    a->out = n->buf_ptr[d.out_buf];
+    a->out = (char*)n->buf_ptr[d.out_buf] + at * buf_image_bytes(ob);
     a->out_pitch = ob.pitch;
     a->out_coff = d.out_coff;
     a->out_coff2 = d.out_coff2;
@@ -73,7 +79,7 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, ConvArgs* a) {
     a->cout_pad = d.cout_pad;
     a->cout_store = d.cout_store;
     a->out_f32 = ob.is_f32;
-    a->res = d.res_buf >= 0 ? (const uint16_t*)n->buf_ptr[d.res_buf] : nullptr;
+    a->res = d.res_buf >= 0 ? (const uint16_t*)((const char*)n->buf_ptr[d.res_buf] + at * buf_image_bytes(n->bufs[d.res_buf])) : nullptr;
     a->res_pitch = d.res_buf >= 0 ? n->bufs[d.res_buf].pitch : 0;
     a->res_coff = d.res_coff;
     a->alpha = d.alpha;
@@ -90,18 +96,21 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, ConvArgs* a) {
     return VGH_OK;
 }
 
-static int net_run_op(vgh_net* n, const NetOp& op, const void* image, int fmt, int B, hipStream_t st) {
+// runs one op for the `B` images starting at batch row `at` (image pointer and every activation buffer offset accordingly)
+static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, int B, int at, hipStream_t st) {
     const vgh_op_desc& d = op.d;
+    const void* image = (const char*)image0 + (int64_t)at * n->image_size * n->image_size * 3 * (fmt == VGH_IMG_F32_NCHW ? 4 : 1);
+    auto bp = [&](int id) { return (char*)n->buf_ptr[id] + at * buf_image_bytes(n->bufs[id]); };
     switch (d.kind) {
         case VGH_OP_STEM: {
             const vgh_buf_desc& ob = n->bufs[d.out_buf];
             if (ob.is_f32)  // fp32 parity mode
-                return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)n->buf_ptr[d.out_buf], ob.pitch, d.out_coff, st);
-            return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)n->buf_ptr[d.out_buf], ob.pitch, d.out_coff, st);
+                return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)bp(d.out_buf), ob.pitch, d.out_coff, st);
+            return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)bp(d.out_buf), ob.pitch, d.out_coff, st);
         }
         case VGH_OP_CONV: {
             ConvArgs a;
-            if (int rc = net_conv_args(n, op, B, &a)) return rc;
+            if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
             if (n->bufs[d.in_buf].is_f32) {  // fp32 parity mode: dense fp32 weights, FMA kernel
                 VGH_REQUIRE(a.out_f32 && (d.res_buf < 0 || n->bufs[d.res_buf].is_f32), "net: fp32 conv needs fp32 output / residual buffers");
                 return vgh_launch_conv_f32(a, op.wf32, st);
@@ -110,13 +119,40 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image, int fmt, i
         }
         case VGH_OP_SPP_POOL: {
             const vgh_buf_desc& ib = n->bufs[d.in_buf];
-            if (ib.is_f32) return vgh_launch_spp_pool_f32((float*)n->buf_ptr[d.in_buf], ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
-            return vgh_launch_spp_pool((uint16_t*)n->buf_ptr[d.in_buf], ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
+            if (ib.is_f32) return vgh_launch_spp_pool_f32((float*)bp(d.in_buf), ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
+            return vgh_launch_spp_pool((uint16_t*)bp(d.in_buf), ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
         }
         case VGH_OP_FORK:
             return VGH_OK;  // handled by the executor
         default:
             VGH_REQUIRE(false, "net: unknown op kind %d", d.kind);
+    }
+    return VGH_OK;
+}
+
+// The batch as nsplit independent sub-batches, one per lane stream (lane 0 = the caller's stream); launches are interleaved
+// op by op so the lanes advance together.
+static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, int B, hipStream_t main) {
+    const int L = n->nsplit < B ? n->nsplit : B;
+    int at[vgh_net::kLanes + 1];
+    at[0] = 0;
+    for (int l = 0; l < L; ++l) at[l + 1] = at[l] + B / L + (l < B % L ? 1 : 0);
+    VGH_HIP(hipEventRecord(n->ev_fork, main));
+    for (int l = 1; l < L; ++l) VGH_HIP(hipStreamWaitEvent(n->side[l], n->ev_fork, 0));
+    bool guard_pending = n->pred_guard != nullptr;
+    for (const NetOp& op : n->ops) {
+        if (op.d.kind == VGH_OP_FORK) continue;  // head lanes are not combined with the batch split
+        if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32) {
+            VGH_HIP(hipStreamWaitEvent(main, n->pred_guard, 0));
+            for (int l = 1; l < L; ++l) VGH_HIP(hipStreamWaitEvent(n->side[l], n->pred_guard, 0));
+            guard_pending = false;
+        }
+        for (int l = 0; l < L; ++l)
+            if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l])) return rc;
+    }
+    for (int l = 1; l < L; ++l) {
+        VGH_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
+        VGH_HIP(hipStreamWaitEvent(main, n->ev_join[l], 0));
     }
     return VGH_OK;
 }
@@ -236,6 +272,7 @@ int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
     // the first op of a lane after it makes that lane's stream wait for the event, and every used lane is joined back into
     // the main stream at the end (also valid under stream capture: the graph gets parallel branches).
     hipStream_t main = (hipStream_t)stream;
+    if (n->nsplit > 1 && B > 1) return net_forward_split(n, image_dev, image_fmt, B, main);
     bool pending[vgh_net::kLanes] = {false, false, false, false}, used[vgh_net::kLanes] = {false, false, false, false};
     bool guard_pending = n->pred_guard != nullptr;
     for (const NetOp& op : n->ops) {
@@ -261,7 +298,7 @@ int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
             }
             used[lane] = true;
         }
-        if (int rc = net_run_op(n, op, image_dev, image_fmt, B, st)) return rc;
+        if (int rc = net_run_op(n, op, image_dev, image_fmt, B, 0, st)) return rc;
     }
     for (int l = 1; l < vgh_net::kLanes; ++l)
         if (used[l]) {
@@ -279,8 +316,26 @@ int vgh_net_profile(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
     std::vector<hipEvent_t> ev(m + 1);
     for (auto& e : ev) VGH_HIP(hipEventCreate(&e));
     VGH_HIP(hipEventRecord(ev[0], st));
+    const int L = (n->nsplit > 1 && B > 1) ? (n->nsplit < B ? n->nsplit : B) : 1;
     for (size_t i = 0; i < m; ++i) {
-        if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, B, st)) return rc;
+        if (L == 1) {
+            if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, B, 0, st)) return rc;
+        } else {
+            // batch-split mode: the op's sub-batches run concurrently on the lane streams, as in vgh_net_forward
+            VGH_HIP(hipEventRecord(n->ev_fork, st));
+            int at = 0;
+            for (int l = 0; l < L; ++l) {
+                const int nb = B / L + (l < B % L ? 1 : 0);
+                hipStream_t ls = l == 0 ? st : n->side[l];
+                if (l > 0) VGH_HIP(hipStreamWaitEvent(ls, n->ev_fork, 0));
+                if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, nb, at, ls)) return rc;
+                if (l > 0) {
+                    VGH_HIP(hipEventRecord(n->ev_join[l], ls));
+                    VGH_HIP(hipStreamWaitEvent(st, n->ev_join[l], 0));
+                }
+                at += nb;
+            }
+        }
         VGH_HIP(hipEventRecord(ev[i + 1], st));
     }
     VGH_HIP(hipEventSynchronize(ev[m]));
@@ -319,6 +374,13 @@ int vgh_net_forward_graph(vgh_net* n, void* stream) {
 
 void* vgh_net_buffer(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_ptr.size()) ? n->buf_ptr[buf_id] : nullptr; }
 int64_t vgh_net_buffer_bytes(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_bytes.size()) ? n->buf_bytes[buf_id] : -1; }
+
+int vgh_net_set_split(vgh_net* n, int nsplit) {
+    VGH_REQUIRE(n, "net_set_split: null handle");
+    VGH_REQUIRE(nsplit >= 1 && nsplit <= vgh_net::kLanes, "net_set_split: 1..%d lanes", vgh_net::kLanes);
+    n->nsplit = nsplit;
+    return VGH_OK;
+}
 
 int vgh_net_set_pred_guard(vgh_net* n, void* event) {
     VGH_REQUIRE(n, "net_set_pred_guard: null handle");

@@ -136,7 +136,9 @@ class VGHeadsEngine:
         self._head_out = None  # (capacity, head_image, proj, rpy) allocated on first FLAME use
         self._levels = None
         self._graph_key = None
-        if use_tuning and precision == "bf16":
+        self._use_tuning = bool(use_tuning and precision == "bf16")
+        self.nsplit = 1
+        if self._use_tuning:
             self.load_tuning()
 
     # ---------------------------------------------------------------------------------------------------
@@ -216,6 +218,13 @@ class VGHeadsEngine:
         else:
             _lib.check(self.lib.vgh_net_forward(self._net, images.data_ptr(), fmt, B, self._sp()))
         return B
+
+    def set_split(self, nsplit: int = 1):
+        """vgh_net_set_split: run each batch as ``nsplit`` independent sub-batches on the net's lane streams (throughput mode)."""
+        _lib.check(self.lib.vgh_net_set_split(self._net, int(nsplit)))
+        self.nsplit = int(nsplit)
+        if self._use_tuning:
+            self.load_tuning()  # the table may hold tile choices measured in this split mode
 
     def set_overlap(self, enable: bool = True):
         """Throughput mode (vgh_detector_set_overlap): ``select`` / the select half of ``detect`` run on a detector-owned side
@@ -338,15 +347,16 @@ class VGHeadsEngine:
         for i, op in enumerate(self.program.ops):
             if op["kind"] != 1:
                 continue
-            key = tuning_key(op, self.max_batch)
-            name = table.get(key)
+            key = tuning_key(op, self.max_batch, getattr(self, "nsplit", 1))
+            name = table.get(key, table.get(tuning_key(op, self.max_batch)))
             if name in names:
                 self.set_cfg(i, names[name])
                 applied += 1
         return applied
 
 
-def tuning_key(op: dict, batch: int) -> str:
+def tuning_key(op: dict, batch: int, nsplit: int = 1) -> str:
     m, n, k = op["gemm"]
     bucket = 1 if batch <= 2 else (8 if batch <= 16 else 32)
-    return f"b{bucket}_m{m}_n{n}_k{k}_ks{op['ksize']}_s{op['stride']}"
+    lanes = f"x{nsplit}" if nsplit > 1 else ""  # tile choices measured with the batch split over `nsplit` lane streams
+    return f"b{bucket}{lanes}_m{m}_n{n}_k{k}_ks{op['ksize']}_s{op['stride']}"

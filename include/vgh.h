@@ -86,6 +86,11 @@ int vgh_net_forward_graph(vgh_net* net, void* stream);
 void* vgh_net_buffer(vgh_net* net, int buf_id);         /* device pointer of an activation buffer   */
 int64_t vgh_net_buffer_bytes(vgh_net* net, int buf_id); /* bytes for max_batch                       */
 int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
+/* Batch split (1..4, default 1): vgh_net_forward runs the batch as `nsplit` independent sub-batches on net-owned lane streams
+ * (forked from / joined into `stream`), so that the fixed cost of every launch -- dispatch, tile prologue and first-load
+ * latency, epilogue store burst, tail -- of one sub-batch hides under the main loops of the others.  Results are identical
+ * (images are independent; every op keeps its tile configuration). */
+int vgh_net_set_split(vgh_net* net, int nsplit);
 /* Borrowed HIP event (or NULL): the first op of the next forwards that writes a prediction buffer waits for it on its stream.
  * Lets a consumer of the previous forward's predictions run on another stream underneath this forward's backbone / neck. */
 int vgh_net_set_pred_guard(vgh_net* net, void* event);

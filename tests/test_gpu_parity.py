@@ -813,3 +813,39 @@ def test_overlap_mode_is_race_free_and_identical(gpu_lib, flame_model):
         assert torch.equal(r, q)
     eng.set_overlap(False)
     eng.close()
+
+
+def test_batch_split_lanes_are_invisible(gpu_lib, flame_model):
+    """vgh_net_set_split: the batch as 2 / 3 / 4 independent sub-batches on the net's lane streams (uneven sizes included) must give
+    bit-identical activations, candidates and detections to the single-stream run -- also combined with overlap mode."""
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    S, B = 192, 7
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(31)).to(_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=1024)
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=6, use_tuning=False)  # same tile choice in every mode
+    ref = [t.clone() for t in eng.model(x)]
+    conf = float(ref[1][:, 12, 0].max())
+    d0 = eng.detect(x, confidence_threshold=conf, flame=fl)
+    ref_det = [t.clone() for t in (d0.boxes, d0.counts, d0.vertices_3d, d0.head_pose)]
+    names = [bf["name"] for bf in eng.program.bufs]
+    probe = [names[len(names) // 3], names[-1]]
+    ref_bufs = [eng.buffer(nm, B) for nm in probe]
+    for ns in (2, 3, 4):
+        eng.set_split(ns)
+        for overlap in (False, True):
+            eng.set_overlap(overlap)
+            got = eng.model(x)
+            for r, q in zip(ref, got):
+                assert torch.equal(r, q), (ns, overlap)
+            for nm, r in zip(probe, ref_bufs):
+                assert torch.equal(eng.buffer(nm, B), r), (ns, nm)
+            d = eng.detect(x, confidence_threshold=conf, flame=fl)
+            for r, q in zip(ref_det, (d.boxes, d.counts, d.vertices_3d, d.head_pose)):
+                assert torch.equal(r, q), (ns, overlap)
+    # a batch smaller than the number of lanes
+    eng.set_split(4)
+    assert all(torch.equal(r[:2], q) for r, q in zip(ref, eng.model(x[:2].contiguous())))
+    eng.set_overlap(False)
+    eng.close()

@@ -21,10 +21,13 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--image-size", type=int, default=640)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--split", type=int, default=1, help="measure with the batch split over this many lane streams (vgh_net_set_split)")
     ap.add_argument("--out", default=os.path.join(TUNING_DIR, "conv_cfg.json"))
     ap.add_argument("--report", default=None)
     args = ap.parse_args()
     eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, use_tuning=False)
+    if args.split > 1:
+        eng.set_split(args.split)
     names = eng.cfg_names()
     x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8).cuda()
     ops = eng.program.ops
@@ -47,7 +50,7 @@ def main():
             times[i][name] = min(r[i]["ms"] for r in runs)
     table, report = {}, []
     for i in conv_idx:
-        key = tuning_key(ops[i], args.batch)
+        key = tuning_key(ops[i], args.batch, args.split)
         w = min(times[i], key=times[i].get)
         if key not in best or times[i][w] < best[key][1]:
             best[key] = (w, times[i][w])
@@ -59,7 +62,7 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(old, open(args.out, "w"), indent=0, sort_keys=True)
     tot = sum(r["ms"] for r in report)
-    print(f"{args.variant} B={args.batch}: sum of best conv times {tot:.3f} ms -> {eng.flops_per_image * args.batch / tot / 1e9:.1f} TFLOP/s over convs; {len(table)} shapes")
+    print(f"{args.variant} B={args.batch} split={args.split}: sum of best conv times {tot:.3f} ms -> {eng.flops_per_image * args.batch / tot / 1e9:.1f} TFLOP/s over convs; {len(table)} shapes")
     if args.report:
         json.dump(report, open(args.report, "w"), indent=0)
     eng.close()
