@@ -140,14 +140,7 @@ static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, i
     VGH_HIP(hipEventRecord(n->ev_fork, main));
     for (int l = 1; l < L; ++l) VGH_HIP(hipStreamWaitEvent(n->side[l], n->ev_fork, 0));
     bool guard_pending = n->pred_guard != nullptr;
-    static const bool sequential = getenv("VGH_SPLIT_SEQ") && atoi(getenv("VGH_SPLIT_SEQ")) != 0;
-    if (sequential && guard_pending) {
-        VGH_HIP(hipStreamWaitEvent(main, n->pred_guard, 0));
-        for (int l = 1; l < L; ++l) VGH_HIP(hipStreamWaitEvent(n->side[l], n->pred_guard, 0));
-        guard_pending = false;
-    }
     for (const NetOp& op : n->ops) {
-        if (sequential) break;
         if (op.d.kind == VGH_OP_FORK) continue;  // head lanes are not combined with the batch split
         if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32) {
             VGH_HIP(hipStreamWaitEvent(main, n->pred_guard, 0));
@@ -156,14 +149,6 @@ static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, i
         }
         for (int l = 0; l < L; ++l)
             if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l])) return rc;
-        if (sequential) break;
-    }
-    if (sequential) {  // experiment switch (VGH_SPLIT_SEQ=1): queue each lane's whole program in turn instead of op by op
-        for (int l = 0; l < L; ++l)
-            for (const NetOp& op : n->ops) {
-                if (op.d.kind == VGH_OP_FORK) continue;
-                if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l])) return rc;
-            }
     }
     for (int l = 1; l < L; ++l) {
         VGH_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
