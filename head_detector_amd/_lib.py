@@ -120,6 +120,7 @@ SYMBOLS = {
     "vgh_rasterize": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "vgh_pncc_render": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P]),
     "vgh_refined_head_bbox": (_I, [_P, _I, _I, _P, _I, _P, _P]),
+    "vgh_letterbox": (_I, [_P, _I, _I, _I, _I64, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vgh_stream_create": (_I, [_I, C.POINTER(_P)]),
     "vgh_stream_destroy": (_I, [_P]),
     "vgh_stream_sync": (_I, [_P]),

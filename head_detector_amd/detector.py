@@ -9,8 +9,8 @@ Differences that are forced, not chosen:
     There is no network here, so ``weights`` is a path to a user-supplied .trcd / state_dict, or None for
     seeded synthetic weights of the same architecture (throughput / plumbing only);
   * FLAME constants: ``flame_path`` / ``flame_model`` as in FLAMELayer (user-supplied licensed asset);
-  * letterbox resize: cv2.INTER_LANCZOS4 (detector.py:47) when cv2 is importable, else PIL LANCZOS
-    (not bit-identical to OpenCV's fixed-point kernel).
+  * letterbox resize: cv2.INTER_LANCZOS4 + constant border (detector.py:47-50) restated as a HIP kernel (letterbox.py); cv2 is
+    not needed at run time (and is absent here: that stage is "parity unpinned").
 Preserved quirks: nms() looks at image 0 only; FlameParams.translation is left in padded-640 space while
 scale is divided by the letterbox scale (detector.py:78-79); bbox via np.rint -> int; z is divided by scale too.
 """
@@ -84,28 +84,13 @@ class HeadDetector:
         return image
 
     def _transform_image(self, image: np.ndarray) -> Tuple[torch.Tensor, Tuple[int, int], float]:
-        S = self._image_size
-        h, w = image.shape[:2]
-        if h > w:
-            new_h, new_w = S, int(w * S / h)
-        else:
-            new_h, new_w = int(h * S / w), S
-        scale = S / max(image.shape[:2])
-        if (new_h, new_w) != (h, w):
-            try:
-                import cv2
+        """detector.py:40-52 on the GPU (head_detector_amd.letterbox): LANCZOS4 resize in OpenCV's 8-bit fixed-point arithmetic,
+        the (127, 0, 0) constant border of ``copyMakeBorder(..., value=127)``; the u8 -> float /255 conversion (detector.py:51)
+        is fused into the stem kernel, so the network input is the u8 NHWC canvas."""
+        from .letterbox import letterbox
 
-                image = cv2.resize(image, (new_w, new_h), interpolation=cv2.INTER_LANCZOS4)
-            except ImportError:
-                from PIL import Image
-
-                image = np.array(Image.fromarray(image).resize((new_w, new_h), Image.LANCZOS))
-        pad_w, pad_h = S - image.shape[1], S - image.shape[0]
-        canvas = np.full((S, S, 3), 127, dtype=np.uint8)  # cv2.copyMakeBorder(..., BORDER_CONSTANT, value=127)
-        canvas[pad_h // 2 : pad_h // 2 + image.shape[0], pad_w // 2 : pad_w // 2 + image.shape[1]] = image[..., :3]
-        # the u8 -> float /255 conversion (detector.py:51) is fused into the stem kernel
-        image_input = torch.from_numpy(canvas).to(self._device).unsqueeze(0).contiguous()
-        return image_input, (pad_w // 2, pad_h // 2), scale
+        canvas, padding, scale = letterbox(image, self._image_size, self._device)
+        return canvas.unsqueeze(0), padding, scale
 
     def _preprocess(self, image: np.ndarray):
         image, padding, scale = self._transform_image(image)

@@ -293,6 +293,18 @@ int vgh_pncc_render(const float* verts_dev, int n_heads, int V, const int32_t* t
 int vgh_refined_head_bbox(const float* verts_dev, int n_heads, int V, const int32_t* idx_dev, int n_idx, int32_t* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Letterbox: HeadDetector._transform_image (head_detector/detector.py:40-52) on the device:
+ * cv2.resize(..., INTER_LANCZOS4) in OpenCV's 8-bit fixed-point arithmetic (8x8 taps, short weights scaled by 2048, int32
+ * accumulation, (v + 2^21) >> 22, edge replication) + cv2.copyMakeBorder(BORDER_CONSTANT) into the u8 NHWC canvas [S,S,3] that
+ * vgh_net_forward(VGH_IMG_U8_NHWC) consumes.  The caller supplies the per-axis tables exactly as resize.cpp builds them
+ * (head_detector_amd/letterbox.py: xofs/yofs = floor source coordinate, alpha/beta = [n][8] fixed-point weights) and the
+ * placement of the resized image; src is u8 [src_h, src_w, src_channels >= 3] with the given row pitch; pad_rgb is HOST memory.
+ * ---------------------------------------------------------------------------------------------- */
+int vgh_letterbox(const uint8_t* src_dev, int src_h, int src_w, int src_channels, int64_t src_pitch_bytes, const int32_t* xofs_dev,
+                  const int16_t* alpha_dev, const int32_t* yofs_dev, const int16_t* beta_dev, int new_w, int new_h, int pad_x, int pad_y,
+                  const uint8_t* pad_rgb, uint8_t* dst_dev, int S, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HIP-event helpers so Python can time work on the stream the kernels actually run on.
  * ---------------------------------------------------------------------------------------------- */
 int vgh_stream_create(int device, void** stream_out);

@@ -22,6 +22,8 @@ Pinning status (see DESIGN.md "Oracle"):
                       ``oracle/build_ref.py`` builds it where it lies into ``oracle/_ref/libsim3dr_ref.so`` and the
                       restatement is bit-identical to it; PNCCProcessor / refined_head_bbox vectors come from the
                       reference's own Python run around that library (tests/golden/make_golden.py (f)).
+  * letterbox_oracle -- cv2.resize(INTER_LANCZOS4) + copyMakeBorder (opencv-python, requirements.txt, version unpinned) are
+                      absent: OpenCV's published 8-bit fixed-point algorithm restated.  "parity unpinned".
   * net_oracle     -- super_gradients>=3.7 block definitions are absent and no weights are
                       reachable: architecture restated from the arch YAMLs + SG semantics.
                       "parity unpinned" (the reference's own test is ``assert True``,

@@ -849,3 +849,30 @@ def test_batch_split_lanes_are_invisible(gpu_lib, flame_model):
     assert all(torch.equal(r[:2], q) for r, q in zip(ref, eng.model(x[:2].contiguous())))
     eng.set_overlap(False)
     eng.close()
+
+
+def test_letterbox_kernel_vs_oracle(gpu_lib):
+    """vgh_letterbox (LANCZOS4 fixed-point resize + constant border on the GPU) against oracle/letterbox_oracle.py, bit-exact:
+    landscape / portrait / square, up- and down-scaling, the identity size, a 4-channel source, extreme aspect ratios.
+    (Both restate OpenCV's published algorithm; cv2 itself is absent => this stage is parity-unpinned against the reference.)"""
+    from head_detector_amd.letterbox import geometry, letterbox
+    from oracle import letterbox_oracle as lo
+
+    rng = np.random.default_rng(5)
+    for (h, w), S in (((480, 600), 640), ((600, 480), 640), ((640, 640), 640), ((97, 1300), 640), ((1080, 1920), 640), ((333, 200), 320), ((64, 64), 256),
+                      ((720, 1280), 1280)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if (h, w) == (333, 200):
+            img[50:80, 20:90] = 255  # saturated block next to a black one: the negative Lanczos lobes must clamp, not wrap
+            img[80:110, 20:90] = 0
+        want, pad, scale = lo.transform_image(img, S)
+        got, gpad, gscale = letterbox(img, S, _dev())
+        assert gpad == pad and gscale == scale and geometry(h, w, S)[2:4] == pad
+        assert np.array_equal(got.cpu().numpy(), want), (h, w, S)
+    rgba = rng.integers(0, 256, (100, 150, 4), dtype=np.uint8)
+    got, _, _ = letterbox(rgba, 128, _dev())
+    assert np.array_equal(got.cpu().numpy(), lo.transform_image(rgba, 128)[0])
+    same = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)
+    assert np.array_equal(letterbox(same, 128, _dev())[0].cpu().numpy(), same)  # identity size: exact copy
+    with pytest.raises(ValueError):
+        letterbox(same.astype(np.float32), 128, _dev())
