@@ -230,3 +230,34 @@ def test_flame_pickle_ingest(tmp_path):
     assert layer.parents.tolist() == [-1, 0, 1, 1, 1] and layer.faces_tensor.shape == (9976, 3)
     with pytest.raises(FileNotFoundError):
         FLAMELayer(flame_path=str(tmp_path / "missing.pkl"))
+
+
+def test_c_abi_argument_validation_reports_errors_without_a_gpu():
+    """Every entry point validates its arguments before touching the device: a bad call returns a negative code and leaves a
+    message in vgh_last_error() (never throws, never computes on the CPU).  Exercised here without a GPU."""
+    import ctypes as C
+
+    from head_detector_amd import _lib
+
+    lib = _lib.load()
+
+    def err(rc):
+        assert rc < 0
+        return lib.vgh_last_error().decode()
+
+    assert "null" in err(lib.vgh_net_forward(None, None, 0, 1, None))
+    assert "null" in err(lib.vgh_flame_decode(None, None, 1, 300, 100, None, None, None, None, None))
+    fake = 0x1000  # non-null placeholders: validation fails before any of them would be dereferenced
+    geo = dict(B=1, H=8, W=8, in_dev=fake, wpack_dev=fake, bias_dev=fake, out_dev=fake, in_pitch=64, out_pitch=64, cout_store=64, out_split=64)
+    # vgh_conv2d looks at the current device first: without a GPU that is the (loud) error, with one the shape check is
+    m = err(lib.vgh_conv2d(C.byref(_lib.ConvCall(cin=48, cout_pad=64, ksize=3, stride=1, **geo)), None))
+    assert "cin=48" in m or "no ROCm-capable device" in m
+    m = err(lib.vgh_conv2d(C.byref(_lib.ConvCall(cin=32, cout_pad=64, ksize=5, stride=1, **geo)), None))
+    assert "ksize=5" in m or "no ROCm-capable device" in m
+    assert "null" in err(lib.vgh_rasterize(None, None, 3, None, 3, None, 8, 8, 0, None, None))
+    assert "null" in err(lib.vgh_letterbox(None, 4, 4, 3, 12, None, None, None, None, 4, 4, 0, 0, None, None, 8, None))
+    assert "null" in err(lib.vgh_detector_create(None, None, None, None))
+    assert "1..4" in err(lib.vgh_net_set_split(C.c_void_p(1), 9)) or "null" in lib.vgh_last_error().decode()
+    with pytest.raises(_lib.VghError, match="libvgh error"):
+        _lib.check(lib.vgh_net_forward(None, None, 0, 1, None))
+    assert lib.vgh_conv_num_cfgs() > 70 and lib.vgh_conv_cfg_name(19).decode().startswith("p8x40")
