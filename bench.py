@@ -202,7 +202,7 @@ def main():
                        "graph": bool(args.graph), "overlap_post": not args.no_overlap and not args.graph, "batch_split": 1 if args.graph else max(1, min(4, args.split)), "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(net_ms, 3)},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "conv_igemm_kernel<*> (all launches of one forward; algorithmic 2*MACs / HIP-event time of the network part)"},
+                         "kernel": "conv_igemm_kernel<*> + conv3x3_patch_kernel<*> (all launches of one forward: algorithmic 2*MACs / HIP-event time of the network part; traffic = PMC HBM bytes per launch, mean over the 120 conv + stem launches of a single-lane forward)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.variant, S, flame_model)
