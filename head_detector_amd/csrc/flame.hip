@@ -75,11 +75,17 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
     __shared__ float s_J[MAXJ * 3];
     __shared__ float s_R[MAXJ * 9];
     __shared__ float s_pose[MAXJ * 3];
+    __shared__ float s_tail[16];   // params[400..412]: jaw 3 | rot6 | trans 3 | scale 1
+    __shared__ int s_par[MAXJ];
+    __shared__ float s_unpad[3];
+    __shared__ float s_hp[HP_SIZE];  // the head pack is assembled here and leaves as one coalesced store
     const int h = blockIdx.x, lane = threadIdx.x;
     if (a.n_dev && h >= *a.n_dev) return;
     const int NB = a.NB, NJ = a.NJ;
     float* coef = a.coef + (int64_t)h * a.Kp;
-    float* hp = a.headpack + (int64_t)h * HP_SIZE;
+    float* const hpg = a.headpack + (int64_t)h * HP_SIZE;
+    float* const hp = s_hp;
+    for (int e = lane; e < HP_SIZE; e += 64) s_hp[e] = 0.0f;
     const int64_t prow = a.head_row ? a.head_row[h] : h;
     const int64_t urow = a.head_image ? a.head_image[h] : h;
     const float* p = a.params ? a.params + prow * VGH_NUM_FLAME_PARAMS : nullptr;
@@ -89,6 +95,11 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
         s_beta[l] = v;
         coef[l] = v;
     }
+    // everything the serial tail needs comes in with this first wave of loads (it used to fetch these one dependent global
+    // load at a time from lane 0: a dozen L2 round trips)
+    if (p && lane < 13) s_tail[lane] = p[400 + lane];
+    if (lane < NJ) s_par[lane] = a.parents[lane];
+    if (lane < 3) s_unpad[lane] = a.unpad ? a.unpad[urow * 3 + lane] : (lane == 2 ? 1.0f : 0.0f);
     // full_pose = [global 0 | neck 0 | jaw | eyes 0]  (flame.py:141-148)
     if (lane < NJ * 3) {
         float v;
@@ -99,14 +110,28 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
         s_pose[lane] = v;
     }
     __syncthreads();
-    // joints: J = J0 + JS beta
-    for (int o = 0; o < NJ * 3; ++o) {
-        float s = 0.0f;
-        const float* js = a.JS + (int64_t)o * NB;
-        for (int l = lane; l < NB; l += 64) s = fmaf(js[l], s_beta[l], s);
+    // joints: J = J0 + JS beta.  All 3*NJ dot products advance together (their loads are independent and stay in flight; one
+    // output at a time exposed a full memory round trip per output: ~40 us per launch, all latency).  Per output the
+    // arithmetic is unchanged: lane-strided fmaf chain in ascending l, then the xor butterfly.
+    {
+        float s[MAXJ * 3];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) s_J[o] = a.J0[o] + s;
+        for (int o = 0; o < MAXJ * 3; ++o) s[o] = 0.0f;
+        for (int l = lane; l < NB; l += 64) {
+            const float bl = s_beta[l];
+#pragma unroll
+            for (int o = 0; o < MAXJ * 3; ++o)
+                if (o < NJ * 3) s[o] = fmaf(a.JS[(int64_t)o * NB + l], bl, s[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < MAXJ * 3; ++o) {
+            if (o < NJ * 3) {
+                float v = s[o];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) s_J[o] = a.J0[o] + v;
+            }
+        }
     }
     // smplx batch_rodrigues per joint
     if (lane < NJ) {
@@ -133,7 +158,7 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
         // batch_rigid_transform: chain along parents, A_j = [Rg_j | tg_j - Rg_j J_j]
         float Rg[MAXJ][9], tg[MAXJ][3];
         for (int j = 0; j < NJ; ++j) {
-            const int par = a.parents[j];
+            const int par = s_par[j];
             float rel[3];
             for (int c = 0; c < 3; ++c) rel[c] = s_J[j * 3 + c] - (j > 0 ? s_J[par * 3 + c] : 0.0f);
             if (j == 0) {
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
         float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         float sc = 1.0f, t[3] = {0, 0, 0};
         if (p) {
-            const float* v = p + 403;
+            const float* v = s_tail + 3;
             float b1[3], b3[3], b2[3];
             float n1 = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
             for (int c = 0; c < 3; ++c) b1[c] = v[c] / n1;
@@ -173,8 +198,8 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
                 R[r * 3 + 1] = b2[r];
                 R[r * 3 + 2] = b3[r];
             }
-            sc = fmaxf(p[412], 1e-8f);  // torch.clamp(scale, 1e-8)
-            for (int c = 0; c < 3; ++c) t[c] = p[409 + c];
+            sc = fmaxf(s_tail[12], 1e-8f);  // torch.clamp(scale, 1e-8)
+            for (int c = 0; c < 3; ++c) t[c] = s_tail[9 + c];
         }
         for (int e = 0; e < 9; ++e) {
             hp[HP_R + e] = R[e];
@@ -182,9 +207,9 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
         }
         hp[HP_S] = sc;
         for (int c = 0; c < 3; ++c) hp[HP_T + c] = t[c];
-        hp[HP_U + 0] = a.unpad ? a.unpad[urow * 3 + 0] : 0.0f;
-        hp[HP_U + 1] = a.unpad ? a.unpad[urow * 3 + 1] : 0.0f;
-        hp[HP_U + 2] = a.unpad ? a.unpad[urow * 3 + 2] : 1.0f;
+        hp[HP_U + 0] = s_unpad[0];
+        hp[HP_U + 1] = s_unpad[1];
+        hp[HP_U + 2] = s_unpad[2];
         if (a.rpy_out) {
             // calculate_rpy (utils.py:146-151): Rotation.from_matrix(R^T).as_euler("xyz", degrees) in closed form.
             // M = R^T = Rz(c) Ry(b) Rx(a) (extrinsic xyz): b = -asin(M20), a = atan2(M21, M22), c = atan2(M10, M00);
@@ -214,6 +239,8 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
             }
         }
     }
+    __syncthreads();
+    for (int e = lane; e < HP_SIZE; e += 64) hpg[e] = s_hp[e];
 }
 
 struct VertArgs {
@@ -233,6 +260,7 @@ struct VertArgs {
 
 template <int HT>
 __global__ __launch_bounds__(256) void flame_vertex_kernel(VertArgs a) {
+    constexpr int UNR = HT >= 8 ? 4 : 8;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* s_coef = fsm;                   // [Kp][HT]
     float* s_hp = fsm + (size_t)a.Kp * HT; // [HT][HP_SIZE]
@@ -268,7 +296,8 @@ __global__ __launch_bounds__(256) void flame_vertex_kernel(VertArgs a) {
     }
     auto run = [&](int kb, int ke) {
         const float* bp = a.basis + (int64_t)kb * 3 * plane + v0;
-#pragma unroll 2
+        // the basis stream is pure latency at small n (one block per 1024 vertices): keep UNR k-planes (3 x 16 B each) in flight
+#pragma unroll UNR
         for (int k = kb; k < ke; ++k, bp += 3 * plane) {
             const f32x4_t bx = *(const f32x4_t*)(bp);
             const f32x4_t by = *(const f32x4_t*)(bp + plane);
