@@ -101,6 +101,8 @@ SYMBOLS = {
     "vgh_gather_candidates": (_I, [C.POINTER(HeadLevel), _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "vgh_nms": (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P]),
     "vgh_compact": (_I, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "vgh_topk_nms_workspace_bytes": (_I64, [_I, _I, _I, _I]),
+    "vgh_topk_nms": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vgh_flame_create": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, C.POINTER(_P)]),
     "vgh_flame_destroy": (None, [_P]),
     "vgh_flame_decode": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -264,6 +264,37 @@ __global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ b
         for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) of[o * VGH_NUM_FLAME_PARAMS + c] = flame[s * VGH_NUM_FLAME_PARAMS + c];
 }
 
+// rows of boxes [B,n,4] picked by idx [B,k] -> sorted boxes [B,k,4]
+__global__ __launch_bounds__(256) void gather_boxes_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ idx, int n, int k, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (j >= k) return;
+    const int src = idx[(int64_t)b * k + j];
+    const f32x4_t v = *(const f32x4_t*)(boxes + ((int64_t)b * n + src) * 4);
+    *(f32x4_t*)(out + ((int64_t)b * k + j) * 4) = v;
+}
+
+// survivors of the NMS (positions into the top-k order) -> rows of the ORIGINAL tensors: src = idx[b][keep[b][j]]
+__global__ __launch_bounds__(64) void compact_indirect_kernel(const float* __restrict__ boxes, const float* __restrict__ flame, int flame_w, int n,
+                                                              const int32_t* __restrict__ idx, const float* __restrict__ sorted_scores, int k,
+                                                              const int32_t* __restrict__ keep_idx, int keep_k, float* __restrict__ ob, float* __restrict__ os,
+                                                              float* __restrict__ of) {
+    const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int pos = keep_idx[(int64_t)b * keep_k + j];
+    const int64_t o = (int64_t)b * keep_k + j;
+    if (pos < 0) {
+        if (lane < 4) ob[o * 4 + lane] = 0.0f;
+        if (lane == 0) os[o] = 0.0f;
+        if (of)
+            for (int c = lane; c < flame_w; c += 64) of[o * flame_w + c] = 0.0f;
+        return;
+    }
+    const int64_t s = (int64_t)b * n + idx[(int64_t)b * k + pos];
+    if (lane < 4) ob[o * 4 + lane] = boxes[s * 4 + lane];
+    if (lane == 0) os[o] = sorted_scores[(int64_t)b * k + pos];
+    if (of)
+        for (int c = lane; c < flame_w; c += 64) of[o * flame_w + c] = flame[s * flame_w + c];
+}
+
 int make_levels(const vgh_head_level* levels, int n_levels, Levels* L) {
     VGH_REQUIRE(n_levels >= 1 && n_levels <= MAX_LEVELS, "head: n_levels=%d out of range", n_levels);
     L->n = n_levels;
@@ -340,6 +371,40 @@ int vgh_compact(const float* boxes_dev, const float* scores_dev, const float* fl
     if (B == 0) return VGH_OK;
     hipLaunchKernelGGL(compact_kernel, dim3(keep_k, B), dim3(64), 0, (hipStream_t)stream, boxes_dev, scores_dev, flame_dev, n_in, keep_idx_dev, keep_k,
                        out_boxes_dev, out_scores_dev, out_flame_dev);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
+int64_t vgh_topk_nms_workspace_bytes(int B, int n, int pre_k, int keep_k) {
+    const int64_t k = pre_k < n ? pre_k : n;
+    return (int64_t)B * (k * 4 /*idx*/ + k * 4 /*sorted scores*/ + k * 16 /*sorted boxes*/ + (int64_t)keep_k * 4 /*keep*/) + 256;
+}
+
+int vgh_topk_nms(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int flame_width, int B, int n, float conf_thr, float iou_thr, int pre_k,
+                 int keep_k, void* workspace_dev, float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, int32_t* counts_dev, void* stream) {
+    VGH_REQUIRE(boxes_dev && scores_dev && workspace_dev && out_boxes_dev && out_scores_dev && counts_dev, "topk_nms: null argument");
+    VGH_REQUIRE((flame_dev == nullptr) == (out_flame_dev == nullptr) && (!flame_dev || flame_width > 0), "topk_nms: flame input / output must both be given or both be NULL");
+    VGH_REQUIRE(B >= 0 && n >= 1 && pre_k >= 1 && keep_k >= 1, "topk_nms: bad sizes");
+    const int k = pre_k < n ? pre_k : n;
+    VGH_REQUIRE(k <= 1024, "topk_nms: min(pre_k, n) = %d exceeds the 1024 candidates the NMS kernel holds", k);
+    if (B == 0) return VGH_OK;
+    VGH_REQUIRE(((uintptr_t)workspace_dev & 15) == 0, "topk_nms: workspace must be 16-byte aligned");
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    char* ws = (char*)workspace_dev;
+    const size_t o_ssc = al16((size_t)B * k * 4), o_sbx = al16(o_ssc + (size_t)B * k * 4), o_keep = o_sbx + (size_t)B * k * 16;
+    int32_t* idx = (int32_t*)ws;
+    float* ssc = (float*)(ws + o_ssc);
+    float* sbx = (float*)(ws + o_sbx);
+    int32_t* keep = (int32_t*)(ws + o_keep);
+    int rc;
+    // utils.py:174-185: score >= conf filter and top-k are one stable descending sort (ties by ascending index); the conf filter
+    // is the prefix test inside vgh_nms
+    if ((rc = vgh_topk(scores_dev, B, n, k, idx, ssc, stream))) return rc;
+    hipLaunchKernelGGL(gather_boxes_kernel, dim3((k + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, boxes_dev, (const int32_t*)idx, n, k, sbx);
+    VGH_HIP(hipGetLastError());
+    if ((rc = vgh_nms(sbx, ssc, B, k, conf_thr, iou_thr, keep_k, keep, counts_dev, stream))) return rc;
+    hipLaunchKernelGGL(compact_indirect_kernel, dim3(keep_k, B), dim3(64), 0, (hipStream_t)stream, boxes_dev, flame_dev, flame_width, n, (const int32_t*)idx,
+                       (const float*)ssc, k, (const int32_t*)keep, keep_k, out_boxes_dev, out_scores_dev, out_flame_dev);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }

@@ -65,27 +65,18 @@ def nms_batched(boxes_xyxy: torch.Tensor, scores: torch.Tensor, flame_params: to
     boxes = boxes_xyxy.detach().float().contiguous()
     sc = scores.detach().float().reshape(B, n).contiguous()
     fl = flame_params.detach().float().contiguous()
-    st = _stream_ptr()
-    k = min(top_k, n, 1024)
-    if top_k > 1024 and n > 1024:
+    if fl.shape[2] != _lib.NUM_FLAME_PARAMS:
+        raise ValueError(f"Invalid number of parameters. Expected: {_lib.NUM_FLAME_PARAMS}. Got: {fl.shape[2]}.")
+    if min(top_k, n) > 1024:
         raise _lib.VghError("nms: top_k > 1024 is not supported by the HIP kernel")
-    # descending order with ties by ascending index (what the kernel's prefix conf-filter needs); for the network
-    # output this is a re-sort of an already sorted list.
-    idx = torch.empty(B, k, dtype=torch.int32, device=dev)
-    ssc = torch.empty(B, k, dtype=torch.float32, device=dev)
-    _lib.check(lib.vgh_topk(_lib.ptr(sc), B, n, k, _lib.ptr(idx), _lib.ptr(ssc), st))
-    li = idx.long()
-    sboxes = torch.gather(boxes, 1, li[:, :, None].expand(B, k, 4)).contiguous()
-    keep_idx = torch.empty(B, keep_top_k, dtype=torch.int32, device=dev)
-    counts = torch.empty(B, dtype=torch.int32, device=dev)
-    _lib.check(lib.vgh_nms(_lib.ptr(sboxes), _lib.ptr(ssc), B, k, float(confidence_threshold), float(iou_threshold), keep_top_k, _lib.ptr(keep_idx), _lib.ptr(counts), st))
-    sfl = torch.gather(fl, 1, li[:, :, None].expand(B, k, fl.shape[2])).contiguous()
+    # one library call (vgh_topk_nms): stable top-k, conf filter, greedy NMS, keep-k, rows gathered from the original tensors
+    ws = torch.empty(int(lib.vgh_topk_nms_workspace_bytes(B, n, top_k, keep_top_k)), dtype=torch.uint8, device=dev)
     ob = torch.empty(B, keep_top_k, 4, dtype=torch.float32, device=dev)
     os_ = torch.empty(B, keep_top_k, dtype=torch.float32, device=dev)
     of = torch.empty(B, keep_top_k, fl.shape[2], dtype=torch.float32, device=dev)
-    if fl.shape[2] != _lib.NUM_FLAME_PARAMS:
-        raise ValueError(f"Invalid number of parameters. Expected: {_lib.NUM_FLAME_PARAMS}. Got: {fl.shape[2]}.")
-    _lib.check(lib.vgh_compact(_lib.ptr(sboxes), _lib.ptr(ssc), _lib.ptr(sfl), B, k, _lib.ptr(keep_idx), keep_top_k, _lib.ptr(ob), _lib.ptr(os_), _lib.ptr(of), st))
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.vgh_topk_nms(_lib.ptr(boxes), _lib.ptr(sc), _lib.ptr(fl), fl.shape[2], B, n, float(confidence_threshold), float(iou_threshold), int(top_k), int(keep_top_k),
+                                _lib.ptr(ws), _lib.ptr(ob), _lib.ptr(os_), _lib.ptr(of), _lib.ptr(counts), _stream_ptr()))
     return ob, os_, of, counts
 
 

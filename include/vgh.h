@@ -164,6 +164,15 @@ int vgh_nms(const float* boxes_dev /*[B,n_in,4]*/, const float* scores_dev /*[B,
 int vgh_compact(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int B, int n_in, const int32_t* keep_idx_dev,
                 int keep_k, float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, void* stream);
 
+/* The whole of nms() (head_detector/utils.py:159-194; batched twin yolo_heads_post_prediction_callback.py:55-84) for EVERY image
+ * on arbitrary (unsorted) inputs: conf filter, top-k (pre_k), greedy NMS, first keep_k survivors, gathered from the ORIGINAL
+ * tensors -- boxes [B,n,4], scores [B,n], flame [B,n,flame_width] (or NULL) -> slabs [B,keep_k,{4,1,flame_width}] + counts [B].
+ * min(pre_k, n) <= 1024.  workspace_dev: caller-owned, 16-byte aligned, vgh_topk_nms_workspace_bytes(...) bytes. */
+int64_t vgh_topk_nms_workspace_bytes(int B, int n, int pre_k, int keep_k);
+int vgh_topk_nms(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int flame_width, int B, int n, float conf_thr, float iou_thr,
+                 int pre_k, int keep_k, void* workspace_dev, float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, int32_t* counts_dev,
+                 void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * FLAME: replaces FLAMELayer (head_detector/flame.py:37-169) + smplx.lbs.lbs + rot_mat_from_6dof
  * (utils.py:120-128) + reproject_spatial_vertices (flame.py:179-208) + the vertex un-pad/un-scale of
