@@ -169,7 +169,11 @@ def main():
 
     per_layer = None
     if args.per_layer and rank == 0:
+        eng.join()
+        ns = eng.nsplit
+        eng.set_split(1)  # per-op events make sense on one stream only: the table is the single-stream view of every op
         per_layer = eng.profile_ops(images)
+        eng.set_split(ns)
         json.dump(per_layer, open(args.per_layer, "w"), indent=0)
 
     # FLAME decode alone (second headline metric): us per head at n = 96
