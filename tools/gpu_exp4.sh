@@ -4,6 +4,7 @@ mkdir -p gpurun_out
 L=gpurun_out/exp4.log
 : > $L
 echo "== mfma peak calibration" >> $L
+[ -x tools/micro/mfma_peak ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/micro/mfma_peak tools/micro/mfma_peak.hip
 for bpc in 1 2 4; do ./tools/micro/mfma_peak $bpc 20000 0.01 >> $L 2>&1; done
 ./tools/micro/mfma_peak 2 20000 0 >> $L 2>&1
 PC="15,17,19,20,22,23,55,57,60,75,76"

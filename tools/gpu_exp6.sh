@@ -4,6 +4,7 @@ mkdir -p gpurun_out
 L=gpurun_out/exp6.log
 : > $L
 echo "== hbm calibration" >> $L
+[ -x tools/micro/hbm_peak ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/micro/hbm_peak tools/micro/hbm_peak.hip
 ./tools/micro/hbm_peak >> $L 2>&1
 echo "== flame sweep" >> $L
 python tools/flame_sweep.py gpurun_out/flame_sweep.json >> $L 2>&1
