@@ -876,3 +876,54 @@ def test_letterbox_kernel_vs_oracle(gpu_lib):
     assert np.array_equal(letterbox(same, 128, _dev())[0].cpu().numpy(), same)  # identity size: exact copy
     with pytest.raises(ValueError):
         letterbox(same.astype(np.float32), 128, _dev())
+
+
+def test_full_size_batch_independence_property(gpu_lib, flame_model):
+    """BASELINE configs[1] geometry (VGGHeads_M, B = 32 @ 640x640, tuned tiles, two lanes + overlap): the oracle cannot run this
+    size in seconds, so parity rests on a size-independent property -- images are independent, hence every image's candidates
+    and detections in the full batch equal those of the same image run alone (same engine, same tile choices), bit for bit."""
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    B, S = 32, 640
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(77)).to(_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=B * 100)
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=1)
+    eng.set_split(2)
+    eng.set_overlap(True)
+    boxes, scores, flame = [t.clone() for t in eng.model(x)]
+    assert torch.isfinite(boxes).all() and torch.isfinite(flame).all()
+    conf = float(scores[:, 3, 0].min())
+    det = eng.detect(x, confidence_threshold=conf, flame=fl)
+    counts = det.counts.cpu().tolist()
+    full = (det.boxes.clone(), det.flame_params.clone(), det.vertices_3d.clone(), det.head_image.clone())
+    assert min(counts) >= 1
+    for i in (0, 13, 31):
+        b1, s1, f1 = eng.model(x[i : i + 1].contiguous())
+        assert torch.equal(b1[0], boxes[i]) and torch.equal(s1[0], scores[i]) and torch.equal(f1[0], flame[i])
+        d1 = eng.detect(x[i : i + 1].contiguous(), confidence_threshold=conf, flame=fl)
+        n = counts[i]
+        assert int(d1.counts[0]) == n and torch.equal(d1.boxes[0, :n], full[0][i, :n]) and torch.equal(d1.flame_params[0, :n], full[1][i, :n])
+        assert torch.equal(d1.vertices_3d, full[2][full[3] == i])
+    eng.set_overlap(False)
+    eng.close()
+
+
+def test_flame_decode_large_n_equals_chunks(gpu_lib, flame_model):
+    """FLAME decode at crowd scale (n = 8192 heads, BASELINE config 5) equals the same heads decoded in chunks of 1000 (different
+    HT tile variants and launch shapes must not change a single bit), and every vertex is finite."""
+    from head_detector_amd.flame import FLAMELayer
+
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=8192)
+    n = 8192
+    p = torch.randn(n, 413, generator=torch.Generator().manual_seed(9)).to(_dev())
+    p[:, 128:300] = 0
+    p[:, 364:400] = 0
+    unpad = torch.tensor([[5.0, 7.0, 1.5]], device=_dev()).expand(n, 3).contiguous()
+    _, rot, proj = fl.decode(p, unpad=unpad, shape_live=128, expr_live=64, want_vertices=False)
+    assert torch.isfinite(proj).all()
+    for a in range(0, n, 1000):
+        _, r2, q2 = fl.decode(p[a : a + 1000].contiguous(), unpad=unpad[a : a + 1000].contiguous(), shape_live=128, expr_live=64, want_vertices=False)
+        assert torch.equal(q2, proj[a : a + 1000]) and torch.equal(r2, rot[a : a + 1000])
+    _, _, q1 = fl.decode(p[4242:4243].contiguous(), unpad=unpad[:1].contiguous(), shape_live=128, expr_live=64, want_vertices=False)
+    assert torch.equal(q1[0], proj[4242])  # HT = 1 variant
