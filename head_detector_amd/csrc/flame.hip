@@ -258,8 +258,10 @@ struct VertArgs {
     int do_unpad;
 };
 
-template <int HT>
-__global__ __launch_bounds__(256) void flame_vertex_kernel(VertArgs a) {
+// BT = threads per block: 256 normally; 64 when the grid would otherwise be a handful of blocks (n <= ~50 heads), so that the
+// basis stream is pulled by 4x as many CUs.  The per-lane arithmetic is identical in every (HT, BT) variant.
+template <int HT, int BT>
+__global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a) {
     constexpr int UNR = HT >= 8 ? 4 : 8;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* s_coef = fsm;                   // [Kp][HT]
@@ -270,16 +272,16 @@ __global__ __launch_bounds__(256) void flame_vertex_kernel(VertArgs a) {
         a.n = min(a.n, *a.n_dev);
         if (h0 >= a.n) return;
     }
-    for (int e = tid; e < a.Kp * HT; e += 256) {
+    for (int e = tid; e < a.Kp * HT; e += BT) {
         const int k = e / HT, hh = e - k * HT;
         s_coef[e] = (h0 + hh < a.n) ? a.coef[(int64_t)(h0 + hh) * a.Kp + k] : 0.0f;
     }
-    for (int e = tid; e < HT * HP_SIZE; e += 256) {
+    for (int e = tid; e < HT * HP_SIZE; e += BT) {
         const int hh = e / HP_SIZE;
         s_hp[e] = (h0 + hh < a.n) ? a.headpack[(int64_t)(h0 + hh) * HP_SIZE + (e - hh * HP_SIZE)] : 0.0f;
     }
     __syncthreads();
-    const int v0 = (blockIdx.x * 256 + tid) * 4;
+    const int v0 = (blockIdx.x * BT + tid) * 4;
     if (v0 >= a.Vp) return;
     const int64_t plane = a.Vp;
     f32x4_t acc[HT][3];
@@ -385,8 +387,12 @@ template <int HT>
 int launch_vertex(const VertArgs& va, hipStream_t st) {
     const size_t lds = ((size_t)va.Kp * HT + (size_t)HT * HP_SIZE) * sizeof(float);
     const int quads = va.Vp / 4;
-    dim3 grid((quads + 255) / 256, (va.n + HT - 1) / HT);
-    hipLaunchKernelGGL(flame_vertex_kernel<HT>, grid, dim3(256), lds, st, va);
+    const int groups = (va.n + HT - 1) / HT;
+    if (((quads + 255) / 256) * groups < 32) {  // a handful of blocks (n <= ~24 heads): quarter-size blocks put 4x as many CUs on the basis stream
+        hipLaunchKernelGGL((flame_vertex_kernel<HT, 64>), dim3((quads + 63) / 64, groups), dim3(64), lds, st, va);
+    } else {
+        hipLaunchKernelGGL((flame_vertex_kernel<HT, 256>), dim3((quads + 255) / 256, groups), dim3(256), lds, st, va);
+    }
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
