@@ -196,3 +196,25 @@ def test_raster_oracle_matches_live_reference_build():
             zb = np.zeros((96, 128), dtype=np.float32) - 1e8
             lib.ref_rasterize(img.ctypes.data, ver.ctypes.data, tri.ctypes.data, col.ctypes.data, zb.ctypes.data, tri.shape[0], 96, 128, 3, 1.0, int(rev))
             assert np.array_equal(ro.rasterize(ver, tri, col, bg, reverse=rev), img)
+
+
+def test_letterbox_oracle_sanity_against_pil_lanczos():
+    """oracle/letterbox_oracle.py is parity-unpinned against cv2 (absent).  As an independent sanity check of the sampling geometry
+    (pixel-centre alignment, tap order, fixed-point scaling) it must stay within 2 grey levels of PIL's Lanczos filter on a smooth
+    image -- a different kernel (a = 3 vs OpenCV's 8-tap a = 4), so not a parity claim -- and geometry / border must match
+    detector.py:41-50."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    from oracle import letterbox_oracle as lo
+
+    yy, xx = np.mgrid[0:200, 0:300]
+    img = np.stack([127 + 100 * np.sin(xx / 17.0) * np.cos(yy / 23.0), xx * 255 / 299, yy * 255 / 199], -1).astype(np.uint8)
+    for nw, nh in ((450, 300), (640, 427), (150, 100)):
+        a = lo.resize_lanczos4(img, nw, nh).astype(int)
+        b = np.array(PIL_Image.fromarray(img).resize((nw, nh), PIL_Image.LANCZOS)).astype(int)
+        assert np.abs(a - b).max() <= 2 and np.abs(a - b).mean() < 0.6
+    canvas, pad, scale = lo.transform_image(img, 640)
+    assert canvas.shape == (640, 640, 3) and pad == (0, (640 - int(200 * 640 / 300)) // 2) and scale == 640 / 300
+    assert tuple(canvas[0, 0]) == (127, 0, 0) and tuple(canvas[-1, -1]) == (127, 0, 0)
+    assert np.array_equal(lo.resize_lanczos4(img, 300, 200), img)
+    tab = lo.resize_tables(300, 640)[1].astype(int).sum(1)
+    assert tab.min() >= 2044 and tab.max() <= 2052  # weights sum to ~2048 (no sum correction in cv::resize)
