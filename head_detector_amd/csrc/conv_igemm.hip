@@ -863,8 +863,26 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
 }
 const char* vgh_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].name : "?"; }
 
-int vgh_conv_pick_cfg(const ConvArgs& a) {
-    // Heuristic fallback; a measured per-layer table (tuning/*.json) overrides it through force_cfg.
+namespace {
+// Tile choice for shapes without a measured entry in tuning/conv_cfg.json: a class table distilled from the per-op tuning
+// reports (tools/gen_heuristic.py).  Class = (kernel size, stride, pixel-count bucket, largest of {128,96,64,32} dividing
+// cout, cout > 128, K bucket, output width divisible by 40 / 32 / 16).
+struct HeurRow {
+    int ks, st, pb, nd, nb, kb, wo;
+    const char* name;
+};
+const HeurRow g_heur[] = {
+#include "conv_heur_table.inc"
+};
+constexpr int kNumHeur = sizeof(g_heur) / sizeof(g_heur[0]);
+
+int cfg_by_name(const char* name) {
+    for (int i = 0; i < kNumCfgs; ++i)
+        if (strcmp(g_cfgs[i].name, name) == 0) return i;
+    return -1;
+}
+
+int pick_size_only(const ConvArgs& a) {  // last resort: largest plain implicit-GEMM tile that still fills the chip
     const int cp = a.cout_pad;
     const int64_t P = a.P;
     auto tiles = [&](int cfg) { return ((P + g_cfgs[cfg].BP - 1) / g_cfgs[cfg].BP) * (int64_t)(cp / g_cfgs[cfg].BC); };
@@ -874,14 +892,40 @@ int vgh_conv_pick_cfg(const ConvArgs& a) {
     if (cp % 96 == 0) cand[n++] = 2;
     if (cp % 64 == 0) cand[n++] = 1;
     cand[n++] = 4;
-    int best = cand[0];
-    // prefer the largest tile that still fills the chip (>= 2 blocks per CU), else fall to smaller tiles
     for (int i = 0; i < n; ++i)
         if (tiles(cand[i]) >= 512) return cand[i];
     if (cp % 128 == 0 && tiles(5) >= 256) return 5;
     if (cp % 64 == 0) return 6;
     if (cp % 32 == 0) return (P >= 128 * 512) ? 4 : 11;
-    return best;
+    return cand[0];
+}
+}  // namespace
+
+int vgh_conv_pick_cfg(const ConvArgs& a) {
+    // A measured per-layer table (tuning/*.json) overrides this through force_cfg.
+    static int row_cfg[kNumHeur];
+    static bool resolved = false;
+    if (!resolved) {
+        for (int i = 0; i < kNumHeur; ++i) row_cfg[i] = cfg_by_name(g_heur[i].name);
+        resolved = true;
+    }
+    const int64_t P = a.P;
+    const int N = a.cout_pad, K = a.nkb * 32;
+    const int pb = P < 8192 ? 0 : P < 40000 ? 1 : P < 160000 ? 2 : P < 600000 ? 3 : 4;
+    const int nd = N % 128 == 0 ? 128 : N % 96 == 0 ? 96 : N % 64 == 0 ? 64 : 32;
+    const int nb = N > 128, kb = K <= 128 ? 0 : K <= 512 ? 1 : 2;
+    const int wo = (a.ksize == 3 && a.stride == 1) ? ((a.Wo % 40 == 0 && a.Wo % 32 != 0) | ((a.Wo % 32 == 0) << 1) | ((a.Wo % 16 == 0) << 2)) : 0;
+    int best = -1, best_d = 1 << 30;
+    for (int i = 0; i < kNumHeur; ++i) {
+        const HeurRow& r = g_heur[i];
+        if (r.ks != a.ksize || r.st != a.stride || row_cfg[i] < 0) continue;
+        const int d = 4 * abs(r.pb - pb) + 8 * (r.nd != nd) + 2 * (r.nb != nb) + abs(r.kb - kb) + 3 * (r.wo != wo);
+        if (d < best_d && vgh_conv_cfg_ok(row_cfg[i], a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) {
+            best_d = d;
+            best = row_cfg[i];
+        }
+    }
+    return best >= 0 ? best : pick_size_only(a);
 }
 
 int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
