@@ -7,7 +7,8 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvgh.so")
+# VGH_LIB_PATH: load another build of the library (tools/ use it for the -DVGH_EXPERIMENTS build, which is never shipped)
+LIB_PATH = os.environ.get("VGH_LIB_PATH") or os.path.join(HERE, "libvgh.so")
 
 VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
@@ -96,6 +97,7 @@ SYMBOLS = {
     "vgh_conv_num_cfgs": (_I, []),
     "vgh_conv_cfg_name": (C.c_char_p, [_I]),
     "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),
+    "vgh_conv_set_max_blocks_per_xcd": (_I, [_I]),
     "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),
     "vgh_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "vgh_gather_candidates": (_I, [C.POINTER(HeadLevel), _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),

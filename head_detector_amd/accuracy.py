@@ -1,0 +1,101 @@
+"""Deviation of the bf16 throughput mode from the fp32 parity mode of the SAME engine (same folded weights, same
+images, same post-network kernels): what north_star's "bbox IoU >= 0.999, FLAME params / vertices within 1e-4" bar reads on
+the path ``bench.py`` times.  The fp32 mode itself is held to that bar against the unfused fp32 oracle by
+``tests/test_gpu_parity.py::test_fp32_parity_mode_meets_north_star_tolerances``; this module needs no oracle.
+
+Detections are matched BY ANCHOR: the fp32 engine's NMS survivors (head_detector/utils.py:159-194 semantics) are looked up at the
+same anchor indices in the bf16 engine's outputs, so a near-tie that reorders candidates does not masquerade as a box error.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import arch
+from .engine import VGHeadsEngine
+from .flame import FLAMELayer
+
+
+def _iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    lt, rb = torch.maximum(a[..., :2], b[..., :2]), torch.minimum(a[..., 2:], b[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    ua = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter
+    return inter / ua
+
+
+def bf16_vs_fp32(variant: str, image_size: int = 640, batch: int = 2, flame: Optional[FLAMELayer] = None, weight_seed: int = 1, image_seed: int = 0,
+                 split: int = 2, heads_per_image: float = 8.0) -> Dict[str, float]:
+    """Runs both precision modes on ``batch`` seeded u8 images and returns the deviation of the bf16 mode (tuned tiles, ``split``
+    lane streams: the benchmark configuration) on the detections the fp32 mode keeps."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sd = arch.random_state_dict(variant, weight_seed)
+    x = torch.randint(0, 256, (batch, image_size, image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(image_seed)).to(dev)
+    e16 = VGHeadsEngine(variant, state_dict=sd, image_size=image_size, max_batch=batch)
+    e16.set_split(split)
+    e32 = VGHeadsEngine(variant, state_dict=sd, image_size=image_size, max_batch=batch, precision="fp32")
+    try:
+        _, s32, f32 = [t.clone() for t in e32.model(x)]
+        idx32, dense_b32, dense_s32 = e32.idx[:batch].clone().long(), e32.boxes_all[:batch].clone(), e32.scores_all[:batch].clone()
+        _, _, f16 = [t.clone() for t in e16.model(x)]
+        idx16, dense_b16, dense_s16 = e16.idx[:batch].clone().long(), e16.boxes_all[:batch].clone(), e16.scores_all[:batch].clone()
+        # confidence threshold giving ~heads_per_image fp32 survivors per image (the random-weight network's scores are arbitrary)
+        lo, hi = float(s32.min()), float(s32.max())
+        conf = hi
+        for _ in range(30):
+            conf = 0.5 * (lo + hi)
+            n = float(e32.detect(x, confidence_threshold=conf).counts.float().mean())
+            if abs(n - heads_per_image) < 0.5:
+                break
+            lo, hi = (conf, hi) if n > heads_per_image else (lo, conf)
+        det32 = e32.detect(x, confidence_threshold=conf)
+        counts32 = det32.counts.clone().long().cpu()
+        keep32 = e32.keep_idx[:batch].clone().long().cpu()
+        det16 = e16.detect(x, confidence_threshold=conf)
+        counts16 = det16.counts.clone().long().cpu()
+        keep16 = e16.keep_idx[:batch].clone().long().cpu()
+        idx32c, idx16c = idx32.cpu(), idx16.cpu()
+        P = e16.program
+        S_c, E_c = P.shape_c, P.expr_c
+        live = torch.tensor(list(range(S_c)) + list(range(300, 300 + E_c)) + list(range(400, 412)))
+        ious, dpar, dlog, p16_rows, p32_rows = [], [], [], [], []
+        missing, same_keep, total = 0, 0, 0
+        for b in range(batch):
+            pos32 = keep32[b, : int(counts32[b])]
+            anchors = idx32c[b, pos32]
+            kept16 = set(idx16c[b, keep16[b, : int(counts16[b])]].tolist())
+            where16 = {int(a): i for i, a in enumerate(idx16c[b].tolist())}
+            for p32, a in zip(pos32.tolist(), anchors.tolist()):
+                total += 1
+                same_keep += int(a in kept16)
+                ious.append(float(_iou(dense_b16[b, a], dense_b32[b, a])))
+                if a not in where16:
+                    missing += 1
+                    continue
+                r16, r32 = f16[b, where16[a]], f32[b, p32]
+                dpar.append(float((r16[live] - r32[live]).abs().max()))
+                dlog.append(float((torch.log(r16[412]) - torch.log(r32[412])).abs()))
+                p16_rows.append(r16)
+                p32_rows.append(r32)
+        out = {
+            "variant": variant, "image_size": image_size, "batch": batch, "kept_fp32": total, "conf": round(conf, 6),
+            "iou_min": round(min(ious), 6) if ious else None, "iou_median": round(float(np.median(ious)), 6) if ious else None,
+            "dense_iou_min": round(float(_iou(dense_b16, dense_b32).min()), 6),
+            "dense_score_max_abs_err": float((dense_s16 - dense_s32).abs().max()),
+            "param_max_abs_err_live": max(dpar) if dpar else None,  # shape / expression / rot6 / jaw / translation (px), scale excluded
+            "log_scale_max_abs_err": max(dlog) if dlog else None,
+            "kept_by_both_frac": round(same_keep / max(total, 1), 4), "missing_in_bf16_topk": missing,
+        }
+        if flame is not None and p16_rows:
+            v16, _, pr16 = flame.decode(torch.stack(p16_rows), shape_live=S_c, expr_live=E_c)
+            v32, _, pr32 = flame.decode(torch.stack(p32_rows), shape_live=S_c, expr_live=E_c)
+            d = (v16 - v32).norm(dim=-1)  # FLAME metric space (|v| ~ 0.2 m), unrotated: what "vertices within 1e-4" is stated on
+            dp = (pr16 - pr32).norm(dim=-1)
+            out.update({"vertex_l2_metric_max": float(d.max()), "vertex_l2_metric_mean": float(d.mean()),
+                        "vertex_l2_px_max": float(dp.max()), "vertex_l2_px_mean": float(dp.mean())})
+        return out
+    finally:
+        e16.close()
+        e32.close()

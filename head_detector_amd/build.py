@@ -28,17 +28,26 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = True) -> str:
+LIB_EXP = os.path.join(HERE, "libvgh_exp.so")  # -DVGH_EXPERIMENTS build (work-skipping switches, env-var knobs): tools/ only
+
+
+def build_lib(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+    if experiments:
+        return _build(LIB_EXP, ["-DVGH_EXPERIMENTS"], "build_exp", verbose)
     if not force and not needs_build():
         return LIB
+    return _build(LIB, [], "build", verbose)
+
+
+def _build(LIB: str, extra, objdir: str, verbose: bool) -> str:
     hipcc = _hipcc()
     objs, procs = [], []
     t0 = time.time()
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:
@@ -67,4 +76,4 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build_lib(force="--force" in sys.argv)
+    build_lib(force="--force" in sys.argv, experiments="--experiments" in sys.argv)

@@ -18,10 +18,16 @@
 //   weights (vgh_pack_conv_weights_host).
 #include <stdlib.h>
 
+#include <atomic>
+#include <type_traits>
+
 #include "vgh_internal.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 #define AS1 __attribute__((address_space(1)))
 #define AS3 __attribute__((address_space(3)))
+#define AS4 __attribute__((address_space(4)))
 
 namespace {
 
@@ -223,8 +229,8 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
         for (int s = 0; s < nsteps; ++s) {
             char* cur = smem + (s & 1) * STAGE;
             char* nxt = smem + ((s + 1) & 1) * STAGE;
-            if (s + 1 < nsteps && !(a.ablate & 1)) stage_load(nxt);
-            if (!(a.ablate & 2)) stage_compute(cur);
+            if (s + 1 < nsteps && !VGH_ABLATE(a, 1)) stage_load(nxt);
+            if (!VGH_ABLATE(a, 2)) stage_compute(cur);
             __syncthreads();
         }
     } else {
@@ -244,8 +250,8 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
             asm volatile("" ::: "memory");
             int nb = buf + NST - 1;
             if (nb >= NST) nb -= NST;
-            if (s + NST - 1 < nsteps && !(a.ablate & 1)) stage_load(smem + nb * STAGE);
-            if (!(a.ablate & 2)) stage_compute(smem + buf * STAGE);
+            if (s + NST - 1 < nsteps && !VGH_ABLATE(a, 1)) stage_load(smem + nb * STAGE);
+            if (!VGH_ABLATE(a, 2)) stage_compute(smem + buf * STAGE);
             if (++buf == NST) buf = 0;
         }
         wait_vmcnt<0>();
@@ -255,7 +261,7 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
 
     // ---- epilogue ---------------------------------------------------------------------------------
     const float act_lo = act_bound(a.act);
-    if (a.ablate & 8) return;  // perf experiments only
+    if (VGH_ABLATE(a, 8)) return;
     const int half4 = (lane >> 5) * 4;
     if constexpr (EPI == 1) {
         // Fast path (bf16 out, every channel offset a multiple of 8): each wave transposes its accumulators through a
@@ -616,14 +622,14 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
             ++ncb;
         }
         bool x_flying = false;
-        if (!(a.ablate & 1)) {
+        if (!VGH_ABLATE(a, 1)) {
             if (s + 1 < nsteps) load_w(ncb, nky, wbuf + ((s + 1) & 1) * WSTEP);
             if (ky == 0 && cb + 1 < a.cblocks) {
                 load_x(cb + 1, xbuf + ((cb + 1) & 1) * XBYTES);
                 x_flying = true;
             }
         }
-        if (!(a.ablate & 2)) compute(xbuf + (cb & 1) * XBYTES, wbuf + (s & 1) * WSTEP, ky);
+        if (!VGH_ABLATE(a, 2)) compute(xbuf + (cb & 1) * XBYTES, wbuf + (s & 1) * WSTEP, ky);
         // the weights of step s+1 must have landed; the (younger) halo loads may stay in flight across this barrier:
         // LDS-DMA loads retire in order, so "at most my own halo loads outstanding" == "my weight loads are done"
         if (x_flying) {
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
         cb = ncb;
         ky = nky;
     }
-    if (a.ablate & 8) continue;
+    if (VGH_ABLATE(a, 8)) continue;
 
     // ---- epilogue: LDS transpose -> 16-byte stores (same scheme as the fast path of the implicit-GEMM kernel), one 32-pixel
     //      group at a time; the residual vectors of a group are loaded before its transpose and consumed after it ----
@@ -712,40 +718,440 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
     }  // tile loop
 }
 
+// =====================================================================================================
+// Patch kernel v3 ("q" tiles): the tile mathematics of conv3x3_patch_kernel, re-pipelined ACROSS the tiles of the
+// persistent block.  Per-launch profiles of v2 (profiles/r01_pmc_patch.txt) showed three phases that add up
+// instead of overlapping: ~35 us of MFMA work, ~10 us of tile prologues (address math + the first HBM round trip, every
+// block of the chip at once) and ~14 us of epilogues (every block storing its tile at once).  v3:
+//   * the first halo patch and weight stage of tile t+1 are issued during the LAST channel block of tile t, into the
+//     ring slots tile t no longer needs, so a tile starts with its operands already in LDS;
+//   * LDS is two regions [halo | weights]; tile t's last step leaves one region free for the epilogue staging while the
+//     other region is being filled for tile t+1 (the region parity simply keeps running across tiles);
+//   * output stores go through a buffer descriptor with an out-of-range offset for masked-off lanes, so every wave
+//     issues EXACTLY NS stores per tile: the next tile waits `vmcnt(NS)` -- "my prefetched operands landed" -- and the
+//     stores of tile t drain underneath the first steps of tile t+1 (vmcnt retires loads and stores in issue order);
+//   * blocks in odd resident slots of a CU start `stagger` sleeps late, so that co-resident blocks (and the two halves
+//     of the chip) are not in their store burst / operand-fetch phase at the same moment.
+// =====================================================================================================
+template <int TW, int TH, int BC, int NWP, int NWC>
+struct Patch3 {
+    static constexpr int NW = NWP * NWC;
+    static constexpr int NPX = TW * TH, NG = (NPX + 31) / 32, TJ = NG / NWP, TI = BC / 32 / NWC, WC = BC / NWC;
+    static constexpr int HW = PatchLayout<TW>::HW, HP = HW * (TH + 2), HPU = (HP + 15) / 16;
+    static constexpr int XBYTES = HPU * 1024, WTAP = BC * 64, WSTEP = 3 * WTAP;
+    static constexpr int R = XBYTES + WSTEP;          // one region: halo patch of a channel block + one kernel row of weights
+    static constexpr int EP = WC + 4, CH = WC / 8;    // staged fp32 row (+16 B: conflict-free ds_write_b128), 16-byte output chunks per pixel
+    static constexpr int STRIP = (NW * 32 * EP * 4 <= R) ? 32 : 16;  // pixels staged per pass: whole MFMA groups when they fit a region
+    static constexpr int STG = NW * STRIP * EP * 4;
+    static constexpr int RS = ((R > STG ? R : STG) + 1023) / 1024 * 1024;
+    static constexpr int LDS = 2 * RS;
+    static constexpr int NITS = STRIP * CH / 64;      // 16-byte items per lane per pass
+    static constexpr int NS = TJ * (32 / STRIP) * NITS;  // output stores per wave per tile (exact: masked lanes store out of range)
+    static_assert(NG % NWP == 0 && (BC / 32) % NWC == 0, "tile must split evenly across the wave grid");
+    static_assert((STRIP * CH) % 64 == 0, "staging pass must be whole wave instructions");
+    static constexpr int blocks_per_cu() { return (160 * 1024) / LDS < 1 ? 1 : (160 * 1024) / LDS; }
+    static constexpr int wps() {
+        constexpr int blocks = blocks_per_cu();
+        constexpr int w0 = (blocks * NW + 3) / 4 + ((NW % 4 != 0 && blocks > 1) ? 1 : 0);
+        constexpr int acc = TI * TJ * 16;
+        constexpr int cap = acc >= 128 ? 2 : 4;
+        return w0 > cap ? cap : w0;
+    }
+};
+
+template <int TW, int TH, int BC, int NWP, int NWC>
+__global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps())) void conv3x3_patch3_kernel(const ConvArgs a, const int ntc, const int ntx, const int nty,
+                                                                                                               const int total_tiles, const int chunk) {
+    using G = Patch3<TW, TH, BC, NWP, NWC>;
+    constexpr int NW = G::NW, NPX = G::NPX, TJ = G::TJ, TI = G::TI, WC = G::WC;
+    constexpr int HW = G::HW, HP = G::HP, HPU = G::HPU;
+    constexpr int SWZ_SH = PatchLayout<TW>::SH, SWZ_ROW = PatchLayout<TW>::ROW;
+    constexpr int XBYTES = G::XBYTES, WTAP = G::WTAP, RS = G::RS;
+    constexpr int XUW = (HPU + NW - 1) / NW;
+    constexpr int WU = 3 * BC / 16, WUW = (WU + NW - 1) / NW;
+    constexpr int EP = G::EP, CH = G::CH, STRIP = G::STRIP, NITS = G::NITS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w % NWP, wc = w / NWP;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
+    int local = blockIdx.x >> 3;
+    if (local >= chunk || xcd * chunk + local >= total_tiles) return;
+    // de-phase the co-resident blocks of a CU (the dispatcher deals consecutive blocks of an XCD to its 32 CUs in turn, so block
+    // `local` and block `local + 32` share a CU; placement only affects speed)
+    if (a.stagger > 0 && ((local >> 5) & 1))
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+
+    const unsigned wvoff = lane * 16;
+    const unsigned wkstride = (unsigned)a.cout_pad * 64u;
+    int nx_mine = 0;
+#pragma unroll
+    for (int t = 0; t < XUW; ++t) nx_mine += (HPU % NW == 0 || w + NW * t < HPU) ? 1 : 0;
+    const float act_lo = act_bound(a.act);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x80000000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.in), 0, 0x80000000, 0x00020000);
+
+    auto decode = [&](int loc, int& b, int& y0, int& x0, int& c0) {
+        int tile = xcd * chunk + loc;
+        const int ctile = tile % ntc;
+        tile /= ntc;
+        const int txi = tile % ntx;
+        tile /= ntx;
+        const int tyi = tile % nty;
+        b = tile / nty;
+        y0 = tyi * TH;
+        x0 = txi * TW;
+        c0 = ctile * BC;
+    };
+    // halo loader offsets of a tile: one 32-bit offset per staged 16-pixel unit, fixed over the K loop; out-of-image -> OOB = zeros
+    auto calc_xoff = [&](int b, int y0, int x0, unsigned (&xo)[XUW]) {
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));  // re-materialise per tile instead of keeping tile-invariant sub-expressions live
+#pragma unroll
+        for (int t = 0; t < XUW; ++t) {
+            const int hp = (w + NW * t) * 16 + (lane_t >> 2);
+            const int hy = hp / HW, hx = hp - hy * HW;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool ok = hp < HP && hx < TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int swz = ((hx >> SWZ_SH) + SWZ_ROW * hy) & 3;
+            xo[t] = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * (int)a.in_pitch + a.in_coff) + (((lane_t & 3) ^ swz)) * 16 : OOB;
+        }
+    };
+    auto load_x = [&](const unsigned (&xo)[XUW], int cb, char* dst) {
+        const char* const xbase = (const char*)a.in + cb * 64;
+#pragma unroll
+        for (int t = 0; t < XUW; ++t) {
+            const int u = w + NW * t;
+            if (HPU % NW == 0 || u < HPU) bload_lds16(xbase, xo[t], 0, dst + u * 1024);
+        }
+    };
+    auto load_w = [&](const char* wbase, int cb, int ky, char* dst) {
+#pragma unroll
+        for (int t = 0; t < WUW; ++t) {
+            const int v = w + NW * t;  // wave-uniform
+            if (WU % NW == 0 || v < WU) {
+                const int kx = v / (BC / 16), rb = v - kx * (BC / 16);
+                const unsigned kb = (unsigned)((ky * 3 + kx) * a.cblocks + cb);
+                bload_lds16(wbase, wvoff + rb * 1024, kb * wkstride, dst + kx * WTAP + rb * 1024);
+            }
+        }
+    };
+
+    int b, y0, x0, c0;
+    decode(local, b, y0, x0, c0);
+    unsigned xoff[XUW];
+    calc_xoff(b, y0, x0, xoff);
+    const char* wbase = (const char*)a.wpack + (int64_t)c0 * 64;
+    load_x(xoff, 0, smem);
+    load_w(wbase, 0, 0, smem + XBYTES);
+    int par = 0;  // region holding channel block 0 / step 0 of the current tile
+    bool first = true;
+    const int C = a.cblocks, nsteps = 3 * C;
+
+    while (true) {
+        const int nlocal = local + gpx;
+        const bool has_next = nlocal < chunk && xcd * chunk + nlocal < total_tiles;
+        int nb = 0, ny0 = 0, nx0 = 0, nc0 = 0;
+        if (has_next) decode(nlocal, nb, ny0, nx0, nc0);
+        const char* const wbase_n = (const char*)a.wpack + (int64_t)nc0 * 64;
+        unsigned xoff_n[XUW];
+
+        // ---- fragment addressing of this tile (see conv3x3_patch_kernel) ----
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        const int lrow_t = lane_t & 31, hi_t = lane_t >> 5;
+        int boff[TJ][3][2];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int p = (wp * TJ + j) * 32 + lrow_t;
+            const int ty = p / TW, tx = p - ty * TW;
+            const int r00 = (p < NPX) ? ty * HW + tx : 0, hx0 = (p < NPX) ? tx : 0;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi_t) ^ ((((hx0 + kx) >> SWZ_SH) + SWZ_ROW * (p < NPX ? ty : 0)) & 3)) * 16);
+        }
+        const int sw = (lane_t >> 2) & 3;
+        const int aoff0 = (wc * WC + lrow_t) * 64 + (((0 + hi_t) ^ sw) * 16);
+        const int aoff1 = (wc * WC + lrow_t) * 64 + (((2 + hi_t) ^ sw) * 16);
+
+        // the accumulators start at the bias (the C input of the first MFMA of each chain).  It arrives by SCALAR loads (the wave's
+        // couts are wave-uniform; the two half-waves own alternate groups of 4): no VGPRs held across tiles and, above all, no vector
+        // loads in the epilogue whose waits would drain the previous strip's stores (vmcnt is one in-order queue)
+        f32x16_t acc[TI][TJ];
+        {
+            const AS4 f32x4_t* const bp = (const AS4 f32x4_t*)(a.bias + c0 + wc * WC);
+            const bool upper = hi_t != 0;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4_t lo = bp[i * 8 + q * 2], up = bp[i * 8 + q * 2 + 1];
+                    asm volatile("" : "+s"(lo), "+s"(up));  // keep them scalar: hipcc would fold the select into a per-lane address
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = upper ? up[e] : lo[e];
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) acc[i][j][q * 4 + e] = bv;
+                    }
+                }
+        }
+
+        auto load_frags = [&](const char* X, const char* Wt, int ky, int sub, bf16x8_t (&af)[TI], bf16x8_t (&bfr)[TJ]) {
+            const int kx = sub >> 1, h = sub & 1;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *(const bf16x8_t*)(Wt + kx * WTAP + i * 2048 + (h ? aoff1 : aoff0));
+            const char* Xk = X + ky * (HW * 64);
+            const int kyx = (SWZ_ROW == 2 && (ky & 1)) ? 32 : 0;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bfr[j] = *(const bf16x8_t*)(Xk + (boff[j][kx][h] ^ kyx));
+        };
+        auto mma = [&](const bf16x8_t (&af)[TI], const bf16x8_t (&bfr)[TJ]) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        };
+        auto compute = [&](const char* X, const char* Wt, int ky) {
+            bf16x8_t a0[TI], b0[TJ], a1[TI], b1[TJ];
+            load_frags(X, Wt, ky, 0, a0, b0);
+#pragma unroll
+            for (int sub = 0; sub < 6; sub += 2) {
+                load_frags(X, Wt, ky, sub + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sub + 2 < 6) load_frags(X, Wt, ky, sub + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // ---- operands of step 0 landed (they are older than the NS stores of the previous tile's epilogue); every wave has
+        //      finished that epilogue, so its staging region may be overwritten by this tile's loads ----
+        if (first)
+            wait_vmcnt<0>();
+        else
+            wait_vmcnt<G::NS>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        int cb = 0, ky = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            int ncb = cb, nky = ky + 1;
+            if (nky == 3) {
+                nky = 0;
+                ++ncb;
+            }
+            char* const wnext = smem + ((par + s + 1) & 1) * RS + XBYTES;
+            bool x_flying = false;
+            if (!VGH_ABLATE(a, 1)) {
+                if (s + 1 < nsteps)
+                    load_w(wbase, ncb, nky, wnext);
+                else if (has_next)
+                    load_w(wbase_n, 0, 0, wnext);  // (par + nsteps) & 1 == (par + C) & 1: the region tile t+1 starts in
+                if (ky == 0) {
+                    if (cb + 1 < C) {
+                        load_x(xoff, cb + 1, smem + ((par + cb + 1) & 1) * RS);
+                        x_flying = true;
+                    } else if (has_next) {
+                        calc_xoff(nb, ny0, nx0, xoff_n);
+                        load_x(xoff_n, 0, smem + ((par + C) & 1) * RS);
+                        x_flying = true;
+                    }
+                }
+            }
+            if (!VGH_ABLATE(a, 2)) compute(smem + ((par + cb) & 1) * RS, smem + ((par + s) & 1) * RS + XBYTES, ky);
+            if (s + 1 < nsteps) {  // the weights of step s+1 must have landed; younger halo loads may stay in flight
+                if (x_flying) {
+                    if (nx_mine == XUW)
+                        wait_vmcnt<XUW>();
+                    else
+                        wait_vmcnt<(XUW > 0 ? XUW - 1 : 0)>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cb = ncb;
+            ky = nky;
+        }
+
+        // ---- epilogue: fp32 -> LDS strip -> 16-byte buffer stores; the strip lives in the region the last step just released.
+        //      Straight-line code: store offsets and the residual tile (buffer loads, out-of-range lanes read zeros) are produced
+        //      up front, so hipcc's own vmcnt bookkeeping stays counted and no load wait ever drains the stores before it ----
+        if (!VGH_ABLATE(a, 8)) {
+            float* stg = (float*)(smem + ((par + C - 1) & 1) * RS) + w * (STRIP * EP);
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int half4 = (lane_e >> 5) * 4, lrow_e = lane_e & 31;
+            const int cw0 = c0 + wc * WC;
+            const int pix00 = (b * a.H + y0) * a.W + x0;
+            constexpr int PASSES = 32 / STRIP;
+            auto run = [&](auto res_tag) {
+                constexpr bool HAS_RES = decltype(res_tag)::value;
+                unsigned soff[TJ][PASSES][NITS];
+                u32x4_t rres[HAS_RES ? TJ : 1][PASSES][NITS];
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int hp = 0; hp < PASSES; ++hp)
+#pragma unroll
+                        for (int t = 0; t < NITS; ++t) {
+                            const int it = lane_e + 64 * t;
+                            const int pl = it / CH, ch = it - pl * CH;
+                            const int p = (wp * TJ + j) * 32 + hp * STRIP + pl;
+                            const int ty = p / TW, tx = p - ty * TW;
+                            const int oc = cw0 + ch * 8;
+                            const bool ok = p < NPX && y0 + ty < a.H && x0 + tx < a.W && oc < a.cout_store;
+                            const int opix = pix00 + ty * a.W + tx;
+                            const int ochan = (oc >= a.out_split) ? a.out_coff2 + (oc - a.out_split) : a.out_coff + oc;
+                            soff[j][hp][t] = ok ? 2u * (unsigned)(opix * (int)a.out_pitch + ochan) : OOB;
+                            if constexpr (HAS_RES)
+                                rres[j][hp][t] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? 2u * (unsigned)(opix * (int)a.res_pitch + a.res_coff + oc) : OOB, 0, 0);
+                        }
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+#pragma unroll
+                    for (int hp = 0; hp < PASSES; ++hp) {
+                        if (STRIP == 32 || (lrow_e >> 4) == hp) {
+#pragma unroll
+                            for (int i = 0; i < TI; ++i) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    f32x4_t v;  // the bias is already inside the accumulator (it was the MFMA chain's C input)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][q * 4 + e], act_lo);
+                                    *(f32x4_t*)(stg + (lrow_e & (STRIP - 1)) * EP + i * 32 + q * 8 + half4) = v;
+                                }
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int t = 0; t < NITS; ++t) {
+                            const int it = lane_e + 64 * t;
+                            const int pl = it / CH, ch = it - pl * CH;
+                            const f32x4_t v0 = *(const f32x4_t*)(stg + pl * EP + ch * 8);
+                            const f32x4_t v1 = *(const f32x4_t*)(stg + pl * EP + ch * 8 + 4);
+                            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            if (a.act == VGH_ACT_SILU) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = silu_fn(v[e]);
+                            }
+                            if constexpr (HAS_RES) {
+                                const bf16x8_t rv = __builtin_bit_cast(bf16x8_t, rres[j][hp][t]);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += a.alpha * (float)rv[e];
+                            }
+                            bf16x8_t ov;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), orsrc, soff[j][hp][t], 0, 0);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            };
+            if (a.res)
+                run(std::true_type{});
+            else
+                run(std::false_type{});
+        }
+        if (!has_next) break;
+        local = nlocal;
+        b = nb;
+        y0 = ny0;
+        x0 = nx0;
+        c0 = nc0;
+        wbase = wbase_n;
+#pragma unroll
+        for (int t = 0; t < XUW; ++t) xoff[t] = xoff_n[t];
+        par = (par + C) & 1;
+        first = false;
+    }
+}
+
 struct CfgEntry {
     const char* name;
     int BP, BC, threads, lds;
     void (*launch)(const ConvArgs&, int, int, int, int, hipStream_t);
-    int patch, TW, TH;  // patch != 0: conv3x3_patch_kernel (3x3, stride 1, fast epilogue only), tile TH x TW
+    int patch, TW, TH;  // patch != 0: conv3x3_patch_kernel (1) / conv3x3_patch3_kernel (2): 3x3, stride 1, fast epilogue only, tile TH x TW
     void (*launch_patch)(const ConvArgs&, int, int, int, int, int, int, hipStream_t);
 };
 
+// Per-device launch state: the >64 KiB dynamic-LDS opt-in and the occupancy query act on the CURRENT device, so they are cached
+// per device id (a second engine on another GPU of the same process needs its own opt-in).  Racing threads compute the same value.
+constexpr int kMaxDevices = 16;
+static int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
+template <typename K>
+static int patch_blocks_per_cu(K kernel, int threads, int lds, std::atomic<int> (&cache)[kMaxDevices]) {
+    const int dev = current_device();
+    int n = cache[dev].load(std::memory_order_acquire);
+    if (n == 0) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kernel, threads, lds) != hipSuccess || n < 1) n = 1;
+        cache[dev].store(n, std::memory_order_release);
+    }
+    return n;
+}
+
+static std::atomic<int> g_max_blocks_per_xcd{0};
+
+static int persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int per_cu) {
+    // as many blocks per XCD as its 32 CUs keep resident, each looping over tiles; with the batch split over lane streams every
+    // lane's kernel takes its share of the slots so that kernels of different lanes are co-resident (and out of phase)
+    int slots = 32 * per_cu / (a.grid_share > 1 ? a.grid_share : 1);
+    if (slots < 32) slots = 32;
+    const int cap = g_max_blocks_per_xcd.load(std::memory_order_relaxed);
+    if (cap > 0 && slots > cap) slots = cap;
+#ifdef VGH_EXPERIMENTS
+    static const int persist_env = getenv("VGH_PATCH_PERSIST") ? atoi(getenv("VGH_PATCH_PERSIST")) : 1;  // 0: one tile per block
+    if (!persist_env) return chunk;
+#endif
+    return chunk < slots ? chunk : slots;
+}
+
 template <int TW, int TH, int BC, int NWP, int NWC>
 void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
-    // persistent grid: as many blocks per XCD as its 32 CUs keep resident (occupancy by LDS / registers), each looping over tiles
-    static int per_cu = 0;
-    if (per_cu == 0) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, NWP * NWC * 64, lds) != hipSuccess || n < 1) n = 1;
-        per_cu = n;
-    }
-    static const int persist_env = getenv("VGH_PATCH_PERSIST") ? atoi(getenv("VGH_PATCH_PERSIST")) : 1;  // 0: one tile per block (A/B experiments)
-    const int gpx = persist_env ? (chunk < 32 * per_cu ? chunk : 32 * per_cu) : chunk;
+    static std::atomic<int> per_cu[kMaxDevices];
+    const int n = patch_blocks_per_cu(conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, NWP * NWC * 64, lds, per_cu);
+    const int gpx = persistent_blocks_per_xcd(a, chunk, n);
     hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
+}
+
+template <int TW, int TH, int BC, int NWP, int NWC>
+void launch_patch3_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
+    static std::atomic<int> per_cu[kMaxDevices];
+    const int n = patch_blocks_per_cu(conv3x3_patch3_kernel<TW, TH, BC, NWP, NWC>, NWP * NWC * 64, lds, per_cu);
+    const int gpx = persistent_blocks_per_xcd(a, chunk, n);
+    hipLaunchKernelGGL((conv3x3_patch3_kernel<TW, TH, BC, NWP, NWC>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
 
 template <int BP, int BC, int WP, int WC, int KBS, int NST>
 void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
+    static std::atomic<int> attr_done[kMaxDevices];
+    if (lds > 64 * 1024) {
+        const int dev = current_device();
+        if (!attr_done[dev].load(std::memory_order_acquire)) {
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_done[dev].store(1, std::memory_order_release);
+        }
     }
     const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64);
     if (NST == 2 && (a.nkb + KBS - 1) / KBS == 1) {  // the whole K fits one stage: no second buffer -> more blocks per CU
@@ -769,6 +1175,9 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
     { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg<BP, BC, WP, WC, KBS, NST>, 0, 0, 0, nullptr }
 #define PCFG(TW, TH, BC, NWP, NWC) \
     { "p" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC>(), nullptr, 1, TW, TH, launch_patch_cfg<TW, TH, BC, NWP, NWC> }
+
+#define QCFG(TW, TH, BC, NWP, NWC) \
+    { "q" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, Patch3<TW, TH, BC, NWP, NWC>::LDS, nullptr, 2, TW, TH, launch_patch3_cfg<TW, TH, BC, NWP, NWC> }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -848,12 +1257,35 @@ const CfgEntry g_cfgs[] = {
     CFG(256, 128, 64, 64, 3),  // 74  8 waves
     PCFG(32, 16, 128, 4, 2),   // 75  512 px x 128: 8 waves x (128 px x 64): 6 fragment reads per 8 MFMAs
     PCFG(32, 16, 64, 8, 1),    // 76  512 px x 64: 8 waves x (64 px x 64)
+    // cross-tile pipelined patch kernels (v3), same tile shapes as their "p" twins
+    QCFG(16, 16, 64, 4, 1),    // 77
+    QCFG(16, 16, 128, 4, 2),   // 78
+    QCFG(16, 16, 96, 4, 1),    // 79
+    QCFG(32, 8, 96, 4, 1),     // 80
+    QCFG(32, 8, 64, 4, 1),     // 81
+    QCFG(32, 8, 128, 4, 2),    // 82
+    QCFG(40, 8, 64, 5, 1),     // 83
+    QCFG(40, 8, 128, 5, 2),    // 84
+    QCFG(16, 16, 256, 4, 4),   // 85
+    QCFG(32, 8, 256, 4, 4),    // 86
+    QCFG(16, 16, 32, 4, 1),    // 87
+    QCFG(20, 8, 128, 5, 2),    // 88
+    QCFG(32, 16, 128, 4, 2),   // 89  512 px x 128: 8 waves x (128 px x 64)
+    QCFG(16, 16, 128, 4, 1),   // 90
+    QCFG(32, 8, 64, 4, 2),     // 91
+    QCFG(32, 4, 128, 4, 2),    // 92
+    QCFG(40, 8, 96, 5, 1),     // 93
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
 }  // namespace
 
 int vgh_conv_num_cfgs() { return kNumCfgs; }
+int vgh_conv_set_max_blocks_per_xcd(int blocks) {
+    VGH_REQUIRE(blocks >= 0, "conv_set_max_blocks_per_xcd: negative");
+    g_max_blocks_per_xcd.store(blocks, std::memory_order_relaxed);
+    return VGH_OK;
+}
 int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle) {
     if (cfg < 0 || cfg >= kNumCfgs) return 0;
     const CfgEntry& e = g_cfgs[cfg];
@@ -940,7 +1372,15 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     VGH_REQUIRE(!a.shuffle || (a.shuffle_c % 4 == 0 && a.cout_pad >= 4 * a.shuffle_c && a.ksize == 1 && a.stride == 1), "conv: bad shuffle");
     if (a.P == 0) return VGH_OK;
     VGH_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (1ll << 30), "conv: too many output pixels for one launch");
-    static const int ablate = getenv("VGH_CONV_ABLATE") ? atoi(getenv("VGH_CONV_ABLATE")) : 0;  // perf experiments only
+#ifdef VGH_EXPERIMENTS
+    static const int ablate = getenv("VGH_CONV_ABLATE") ? atoi(getenv("VGH_CONV_ABLATE")) : 0;
+    static const int stagger_env = getenv("VGH_STAGGER") ? atoi(getenv("VGH_STAGGER")) : -1;
+    static const int share_env = getenv("VGH_GRID_SHARE") ? atoi(getenv("VGH_GRID_SHARE")) : -1;
+    if (stagger_env >= 0) const_cast<ConvArgs&>(a).stagger = stagger_env;
+    if (share_env >= 1) const_cast<ConvArgs&>(a).grid_share = share_env;
+#else
+    constexpr int ablate = 0;
+#endif
     const_cast<ConvArgs&>(a).ablate = ablate;
     vgh_fastdiv_magic((unsigned)(a.Ho * a.Wo), &const_cast<ConvArgs&>(a).div_howo_m, &const_cast<ConvArgs&>(a).div_howo_s);
     vgh_fastdiv_magic((unsigned)a.Wo, &const_cast<ConvArgs&>(a).div_wo_m, &const_cast<ConvArgs&>(a).div_wo_s);
@@ -957,6 +1397,9 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     }
     const CfgEntry& e = g_cfgs[cfg];
     if (e.patch) {
+        if (e.patch == 2)  // output / residual addressed with 32-bit buffer offsets (exact store count needs out-of-range masking)
+            VGH_REQUIRE((int64_t)a.P * a.out_pitch * 2 < (1ll << 31) && (!a.res || (int64_t)a.P * a.res_pitch * 2 < (1ll << 31)),
+                        "conv: output / residual tensor must stay below 2 GiB for cfg %s; run the batch in chunks", e.name);
         const int ntc = a.cout_pad / e.BC, ntx = (a.W + e.TW - 1) / e.TW, nty = (a.H + e.TH - 1) / e.TH;
         const int64_t total = (int64_t)a.B * nty * ntx * ntc;
         VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");

@@ -97,7 +97,7 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
 }
 
 // runs one op for the `B` images starting at batch row `at` (image pointer and every activation buffer offset accordingly)
-static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, int B, int at, hipStream_t st) {
+static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, int B, int at, hipStream_t st, int share = 1) {
     const vgh_op_desc& d = op.d;
     const void* image = (const char*)image0 + (int64_t)at * n->image_size * n->image_size * 3 * (fmt == VGH_IMG_F32_NCHW ? 4 : 1);
     auto bp = [&](int id) { return (char*)n->buf_ptr[id] + at * buf_image_bytes(n->bufs[id]); };
@@ -111,6 +111,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
         case VGH_OP_CONV: {
             ConvArgs a;
             if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
+            a.grid_share = share;
             if (n->bufs[d.in_buf].is_f32) {  // fp32 parity mode: dense fp32 weights, FMA kernel
                 VGH_REQUIRE(a.out_f32 && (d.res_buf < 0 || n->bufs[d.res_buf].is_f32), "net: fp32 conv needs fp32 output / residual buffers");
                 return vgh_launch_conv_f32(a, op.wf32, st);
@@ -148,7 +149,7 @@ static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, i
             guard_pending = false;
         }
         for (int l = 0; l < L; ++l)
-            if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l])) return rc;
+            if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l], L)) return rc;
     }
     for (int l = 1; l < L; ++l) {
         VGH_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
@@ -328,7 +329,7 @@ int vgh_net_profile(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
                 const int nb = B / L + (l < B % L ? 1 : 0);
                 hipStream_t ls = l == 0 ? st : n->side[l];
                 if (l > 0) VGH_HIP(hipStreamWaitEvent(ls, n->ev_fork, 0));
-                if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, nb, at, ls)) return rc;
+                if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, nb, at, ls, L)) return rc;
                 if (l > 0) {
                     VGH_HIP(hipEventRecord(n->ev_join[l], ls));
                     VGH_HIP(hipStreamWaitEvent(st, n->ev_join[l], 0));

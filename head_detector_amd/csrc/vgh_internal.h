@@ -58,8 +58,17 @@ struct ConvArgs {
     int cblocks;    // cin/32
     unsigned div_howo_m, div_howo_s, div_wo_m, div_wo_s;  // n / d == (umulhi(n, m) + n) >> s for n < 2^30 (filled by vgh_launch_conv)
     int fast_epi;   // 1: LDS-transposed 16-byte epilogue (bf16 out, 8-channel aligned offsets)
-    int ablate;     // perf experiments: bit0 skip tile loads, bit1 skip MFMAs (results are garbage)
+    int stagger;    // persistent patch kernels: odd resident-slot blocks start this many ~0.5 us sleeps late (de-phases co-resident blocks)
+    int grid_share; // persistent patch kernels: take 1/grid_share of the CU slots (the executor's other lane streams own the rest)
+    int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
 };
+
+// Work-skipping switches exist only in the experiments build (tools/, never the shipped libvgh.so)
+#ifdef VGH_EXPERIMENTS
+#define VGH_ABLATE(a, bit) ((a).ablate & (bit))
+#else
+#define VGH_ABLATE(a, bit) 0
+#endif
 
 int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);
 int vgh_conv_pick_cfg(const ConvArgs& a);

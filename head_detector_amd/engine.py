@@ -338,7 +338,9 @@ class VGHeadsEngine:
 
     def load_tuning(self, path: Optional[str] = None) -> int:
         """Apply a measured per-layer tile table: {gemm-shape key: cfg name}. Missing file -> heuristic choice."""
-        path = path or os.path.join(TUNING_DIR, "conv_cfg.json")
+        if path is not None:
+            self._tuning_path = path  # remembered: set_split() re-applies the same table for its lane-count keys
+        path = getattr(self, "_tuning_path", None) or os.path.join(TUNING_DIR, "conv_cfg.json")
         if not os.path.exists(path):
             return 0
         table = json.load(open(path))

@@ -123,6 +123,9 @@ int vgh_conv_num_cfgs(void);
 const char* vgh_conv_cfg_name(int cfg);
 /* 1 if tile configuration `cfg` can run a conv of this kind (tuning tools). */
 int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle);
+/* Cap on the persistent 3x3 kernels' grid: at most `blocks` workgroups per XCD (0 = as many as stay resident, the default).
+ * Process-wide.  Leaves CUs to other work; the parity tests use it to drive many tiles through one workgroup. */
+int vgh_conv_set_max_blocks_per_xcd(int blocks);
 
 /* ------------------------------------------------------------------------------------------------
  * Head decode: replaces YoloHeadsNDFLHeads.forward's tail (yolo_head_ndfl_heads.py:143-172) and the

@@ -320,6 +320,34 @@ def test_conv_all_configs_vs_torch(gpu_lib, case):
     assert tested >= 2
 
 
+@pytest.mark.parametrize("cin,res", [(64, False), (64, True), (32, True), (96, False)])
+def test_conv_persistent_multi_tile(gpu_lib, cin, res):
+    """Halo-patch kernels with MANY tiles per workgroup (grid capped to 2 workgroups per XCD): the tile loop of the "p" kernels and
+    the cross-tile pipeline of the "q" kernels (operands of tile t+1 prefetched under tile t, region parity running across tiles,
+    counted store waits, cout-tile changes between consecutive tiles of a workgroup, ragged last tiles)."""
+    g = torch.Generator().manual_seed(11 + cin)
+    B, H, W, Cout = 3, 40, 56, 128
+    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).float()
+    Wt = torch.randn(Cout, 3, 3, cin, generator=g) * (1.5 / np.sqrt(9 * cin)) * (1.0 + 0.5 * torch.arange(Cout).float()[:, None, None, None] / Cout)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).float() if res else None
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    tested = 0
+    try:
+        for cap in (2, 5):
+            assert gpu_lib.vgh_conv_set_max_blocks_per_xcd(cap) == 0
+            for cfg, name in enumerate(names):
+                if name[0] not in "pq" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, Cout, 1, 0):
+                    continue
+                out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, cfg=cfg, res=r, alpha=0.37 if res else 0.0)
+                _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"multi-tile cfg={name} cap={cap} cin={cin} res={res}")
+                assert float((out[..., :o0] + 768.0).abs().max()) == 0.0 and float((out[..., o0 + st :] + 768.0).abs().max()) == 0.0, f"{name}: wrote outside its channels"
+                tested += 1
+    finally:
+        gpu_lib.vgh_conv_set_max_blocks_per_xcd(0)
+    assert tested >= 20
+
+
 def test_conv_epilogues(gpu_lib):
     g = torch.Generator().manual_seed(5)
     B, H, W, Cin, Cout = 2, 12, 12, 64, 128

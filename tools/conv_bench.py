@@ -17,14 +17,20 @@ from head_detector_amd import _lib  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="32,80,80,128,128,3,1", help="B,H,W,Cin,Cout,k,stride")
-    ap.add_argument("--cfgs", default="all")
+    ap.add_argument("--shape", default=["32,80,80,128,128,3,1"], nargs="+", help="B,H,W,Cin,Cout,k,stride (several allowed)")
+    ap.add_argument("--cfgs", default="all", help="all | comma-separated indices or names")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--res", action="store_true")
     args = ap.parse_args()
-    B, H, W, Cin, Cout, k, stride = map(int, args.shape.split(","))
     lib = _lib.load()
+    for shape in args.shape:
+        run_shape(lib, args, shape)
+
+
+def run_shape(lib, args, shape):
+    B, H, W, Cin, Cout, k, stride = map(int, shape.split(","))
     dev = torch.device("cuda", 0)
+    print(f"== shape {shape}{' +res' if args.res else ''}")
     rp = (Cout + 31) // 32 * 32
     w = (np.random.default_rng(0).standard_normal((rp, k, k, Cin)) * 0.05).astype(np.float32)
     pack = np.zeros(w.size, dtype=np.uint16)
@@ -36,7 +42,7 @@ def main():
     out = torch.empty(B, Ho, Wo, rp, device=dev, dtype=torch.bfloat16)
     res = torch.randn(B, Ho, Wo, rp, device=dev).to(torch.bfloat16) if args.res else None
     names = [lib.vgh_conv_cfg_name(i).decode() for i in range(lib.vgh_conv_num_cfgs())]
-    cfgs = range(len(names)) if args.cfgs == "all" else [int(c) for c in args.cfgs.split(",")]
+    cfgs = range(len(names)) if args.cfgs == "all" else [int(c) if c.lstrip("-").isdigit() else names.index(c) for c in args.cfgs.split(",") if c.lstrip("-").isdigit() or c in names]
     flops = 2.0 * B * Ho * Wo * Cout * k * k * Cin
     st = torch.cuda.current_stream().cuda_stream
     for c in cfgs:
