@@ -493,9 +493,12 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
     //      one L2); its gridDim/8 resident blocks stride through it.  Between tiles nothing is relaunched, and the output stores
     //      of tile t drain from the memory pipeline while tile t+1 already loads and computes ----
     const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
+    int trace_no = -1;
     for (int local = blockIdx.x >> 3; local < chunk; local += gpx) {
     int tile = xcd * chunk + local;
     if (tile >= total_tiles) break;
+    ++trace_no;
+    VGH_MARK(a, trace_no, 0);
     const int ctile = tile % ntc;
     tile /= ntc;
     const int txi = tile % ntx;
@@ -593,6 +596,20 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
     // third register set was measured: -15 % on the 5-wave tile, +6 % on p8x40x128 -> not kept)
     auto compute = [&](const char* X, const char* Wt, int ky) {
         bf16x8_t a0[TI], b0[TJ], a1[TI], b1[TJ];
+#ifdef VGH_EXPERIMENTS
+        if (VGH_ABLATE(a, 32)) {  // MFMAs on whatever the registers hold: the loop without its LDS fragment traffic
+#pragma unroll
+            for (int i = 0; i < TI; ++i) asm volatile("" : "=v"(a0[i]), "=v"(a1[i]));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) asm volatile("" : "=v"(b0[j]), "=v"(b1[j]));
+#pragma unroll
+            for (int sub = 0; sub < 6; sub += 2) {
+                mma(a0, b0);
+                mma(a1, b1);
+            }
+            return;
+        }
+#endif
         load_frags(X, Wt, ky, 0, a0, b0);
 #pragma unroll
         for (int sub = 0; sub < 6; sub += 2) {
@@ -614,6 +631,7 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
     load_x(0, xbuf);
     load_w(0, 0, wbuf);
     __syncthreads();
+    VGH_MARK(a, trace_no, 1);
     int cb = 0, ky = 0;
     for (int s = 0; s < nsteps; ++s) {
         int ncb = cb, nky = ky + 1;
@@ -641,11 +659,12 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
             wait_vmcnt<0>();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!VGH_ABLATE(a, 16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         cb = ncb;
         ky = nky;
     }
+    VGH_MARK(a, trace_no, 2);
     if (VGH_ABLATE(a, 8)) continue;
 
     // ---- epilogue: LDS transpose -> 16-byte stores (same scheme as the fast path of the implicit-GEMM kernel), one 32-pixel
@@ -715,6 +734,7 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    VGH_MARK(a, trace_no, 3);
     }  // tile loop
 }
 
@@ -769,7 +789,8 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
     constexpr int XBYTES = G::XBYTES, WTAP = G::WTAP, RS = G::RS;
     constexpr int XUW = (HPU + NW - 1) / NW;
     constexpr int WU = 3 * BC / 16, WUW = (WU + NW - 1) / NW;
-    constexpr int EP = G::EP, CH = G::CH, STRIP = G::STRIP, NITS = G::NITS;
+    constexpr int EP = G::EP, CH = G::CH, STRIP = G::STRIP, NITS = G::NITS, PASSES = 32 / G::STRIP;
+    static_assert(XUW <= 8 && G::NS <= 16, "per-lane flag words hold 4 bits per halo unit / 2 bits per store");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -777,11 +798,14 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
     const int wp = w % NWP, wc = w / NWP;
     constexpr unsigned OOB = 0xFFFFFFF0u;
 
-    const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
-    int local = blockIdx.x >> 3;
-    if (local >= chunk || xcd * chunk + local >= total_tiles) return;
-    // de-phase the co-resident blocks of a CU (the dispatcher deals consecutive blocks of an XCD to its 32 CUs in turn, so block
-    // `local` and block `local + 32` share a CU; placement only affects speed)
+    // ---- this block's CONTIGUOUS run of tiles inside its XCD's chunk (cout tile fastest, then x, y, image): consecutive tiles
+    //      differ by scalar increments, so nothing per-lane is recomputed between tiles ----
+    const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3, local = blockIdx.x >> 3;
+    const int lo = (int)(((int64_t)local * chunk) / gpx), hi_ = (int)(((int64_t)(local + 1) * chunk) / gpx);
+    int tile = xcd * chunk + lo;
+    const int tile_end = (xcd * chunk + hi_ < total_tiles) ? xcd * chunk + hi_ : total_tiles;
+    if (tile >= tile_end) return;
+    // de-phase the co-resident blocks of a CU (block `local` and block `local + 32` of an XCD share a CU; speed only)
     if (a.stagger > 0 && ((local >> 5) & 1))
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
 
@@ -791,37 +815,94 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
 #pragma unroll
     for (int t = 0; t < XUW; ++t) nx_mine += (HPU % NW == 0 || w + NW * t < HPU) ? 1 : 0;
     const float act_lo = act_bound(a.act);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x80000000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.in), 0, 0x80000000, 0x00020000);
+    const int C = a.cblocks, nsteps = 3 * C;
+    const int hr = a.H - (nty - 1) * TH, wr = a.W - (ntx - 1) * TW;  // rows / columns of the last (possibly ragged) tile row / column
 
-    auto decode = [&](int loc, int& b, int& y0, int& x0, int& c0) {
-        int tile = xcd * chunk + loc;
-        const int ctile = tile % ntc;
-        tile /= ntc;
-        const int txi = tile % ntx;
-        tile /= ntx;
-        const int tyi = tile % nty;
-        b = tile / nty;
-        y0 = tyi * TH;
-        x0 = txi * TW;
-        c0 = ctile * BC;
-    };
-    // halo loader offsets of a tile: one 32-bit offset per staged 16-pixel unit, fixed over the K loop; out-of-image -> OOB = zeros
-    auto calc_xoff = [&](int b, int y0, int x0, unsigned (&xo)[XUW]) {
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));  // re-materialise per tile instead of keeping tile-invariant sub-expressions live
+    // ---- per-lane constants of the whole launch ----
+    // halo loader: byte offset of each staged 16-pixel unit relative to the halo origin (y0-1, x0-1) of a tile (+ the source-side
+    // swizzle), and 4 flag bits per unit: halo pixel lies in the {top row, rows past the last tile's ragged end, left column,
+    // columns past the ragged end}; a tile at the matching image border masks those lanes (out-of-range offset = zeros)
+    unsigned xrel[XUW], xflags = 0;
 #pragma unroll
-        for (int t = 0; t < XUW; ++t) {
-            const int hp = (w + NW * t) * 16 + (lane_t >> 2);
-            const int hy = hp / HW, hx = hp - hy * HW;
-            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-            const bool ok = hp < HP && hx < TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int swz = ((hx >> SWZ_SH) + SWZ_ROW * hy) & 3;
-            xo[t] = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * (int)a.in_pitch + a.in_coff) + (((lane_t & 3) ^ swz)) * 16 : OOB;
+    for (int t = 0; t < XUW; ++t) {
+        const int hp = (w + NW * t) * 16 + (lane >> 2);
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const bool ok = hp < HP && hx < TW + 2;
+        const int swz = ((hx >> SWZ_SH) + SWZ_ROW * hy) & 3;
+        xrel[t] = ok ? 2u * (unsigned)((hy * a.W + hx) * (int)a.in_pitch) + (((lane & 3) ^ swz)) * 16 : OOB;
+        xflags |= (unsigned)((hy == 0 ? 1 : 0) | (hy > hr ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx > wr ? 8 : 0)) << (4 * t);
+    }
+    // fragment byte offsets (see conv3x3_patch_kernel): swizzle of the halo column only, kernel row = scalar LDS offset
+    const int lrow = lane & 31, hi = lane >> 5;
+    int boff[TJ][3][2];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int p = (wp * TJ + j) * 32 + lrow;
+        const int ty = p / TW, tx = p - ty * TW;
+        const int r00 = (p < NPX) ? ty * HW + tx : 0, hx0 = (p < NPX) ? tx : 0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi) ^ ((((hx0 + kx) >> SWZ_SH) + SWZ_ROW * (p < NPX ? ty : 0)) & 3)) * 16);
+    }
+    const int sw = (lane >> 2) & 3;
+    const int aoff0 = (wc * WC + lrow) * 64 + (((0 + hi) ^ sw) * 16);
+    const int aoff1 = (wc * WC + lrow) * 64 + (((2 + hi) ^ sw) * 16);
+    // epilogue: byte offsets of this lane's 16-byte items relative to the tile origin (output and residual pitches), 2 flag bits per
+    // item: pixel beyond the ragged last tile column / row
+    unsigned orel[TJ][PASSES][NITS], rrel[TJ][PASSES][NITS], oflags = 0;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int hp = 0; hp < PASSES; ++hp)
+#pragma unroll
+            for (int t = 0; t < NITS; ++t) {
+                const int it = lane + 64 * t;
+                const int pl = it / CH, ch = it - pl * CH;
+                const int p = (wp * TJ + j) * 32 + hp * STRIP + pl;
+                const int ty = p / TW, tx = p - ty * TW;
+                orel[j][hp][t] = p < NPX ? 2u * (unsigned)((ty * a.W + tx) * (int)a.out_pitch + ch * 8) : OOB;
+                rrel[j][hp][t] = p < NPX ? 2u * (unsigned)((ty * a.W + tx) * (int)a.res_pitch + ch * 8) : OOB;
+                oflags |= (unsigned)((tx >= wr ? 1 : 0) | (ty >= hr ? 2 : 0)) << (2 * ((j * PASSES + hp) * NITS + t));
+            }
+    const int half4 = hi * 4;
+
+    // ---- tile coordinates: decoded once, then advanced with scalar increments ----
+    int ct, txi, tyi, b;
+    {
+        int q = tile;
+        ct = q % ntc;
+        q /= ntc;
+        txi = q % ntx;
+        q /= ntx;
+        tyi = q % nty;
+        b = q / nty;
+    }
+    auto advance = [&](int& ct_, int& tx_, int& ty_, int& b_) {
+        if (++ct_ == ntc) {
+            ct_ = 0;
+            if (++tx_ == ntx) {
+                tx_ = 0;
+                if (++ty_ == nty) {
+                    ty_ = 0;
+                    ++b_;
+                }
+            }
         }
     };
-    auto load_x = [&](const unsigned (&xo)[XUW], int cb, char* dst) {
-        const char* const xbase = (const char*)a.in + cb * 64;
+    // halo offsets of a tile: the launch constants, masked where the tile touches an image border
+    auto tile_xoff = [&](int tx_, int ty_, unsigned (&xo)[XUW]) {
+        const unsigned m = (ty_ == 0 ? 1u : 0u) | (ty_ == nty - 1 ? 2u : 0u) | (tx_ == 0 ? 4u : 0u) | (tx_ == ntx - 1 ? 8u : 0u);
+        const unsigned bad = xflags & (m * 0x11111111u);
+#pragma unroll
+        for (int t = 0; t < XUW; ++t) xo[t] = ((bad >> (4 * t)) & 15u) ? OOB : xrel[t];
+    };
+    auto halo_base = [&](int tx_, int ty_, int b_) {  // (y0 - 1, x0 - 1) of the tile; may lie before the tensor for masked lanes only
+        return (const char*)a.in + 2 * (((int64_t)(b_ * a.H + ty_ * TH - 1) * a.W + (tx_ * TW - 1)) * a.in_pitch + a.in_coff);
+    };
+    auto load_x = [&](const char* hbase, const unsigned (&xo)[XUW], int cb, char* dst) {
+        const char* const xbase = hbase + cb * 64;
 #pragma unroll
         for (int t = 0; t < XUW; ++t) {
             const int u = w + NW * t;
@@ -840,44 +921,26 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
         }
     };
 
-    int b, y0, x0, c0;
-    decode(local, b, y0, x0, c0);
     unsigned xoff[XUW];
-    calc_xoff(b, y0, x0, xoff);
-    const char* wbase = (const char*)a.wpack + (int64_t)c0 * 64;
-    load_x(xoff, 0, smem);
+    tile_xoff(txi, tyi, xoff);
+    const char* hbase = halo_base(txi, tyi, b);
+    const char* wbase = (const char*)a.wpack + (int64_t)(ct * BC) * 64;
+    load_x(hbase, xoff, 0, smem);
     load_w(wbase, 0, 0, smem + XBYTES);
     int par = 0;  // region holding channel block 0 / step 0 of the current tile
     bool first = true;
-    const int C = a.cblocks, nsteps = 3 * C;
+    int trace_no = -1;
 
     while (true) {
-        const int nlocal = local + gpx;
-        const bool has_next = nlocal < chunk && xcd * chunk + nlocal < total_tiles;
-        int nb = 0, ny0 = 0, nx0 = 0, nc0 = 0;
-        if (has_next) decode(nlocal, nb, ny0, nx0, nc0);
-        const char* const wbase_n = (const char*)a.wpack + (int64_t)nc0 * 64;
+        ++trace_no;
+        VGH_MARK(a, trace_no, 0);
+        const bool has_next = tile + 1 < tile_end;
+        int nct = ct, ntxi = txi, ntyi = tyi, nb = b;
+        advance(nct, ntxi, ntyi, nb);
+        const char* const wbase_n = (const char*)a.wpack + (int64_t)(nct * BC) * 64;
+        const char* const hbase_n = halo_base(ntxi, ntyi, nb);
         unsigned xoff_n[XUW];
-
-        // ---- fragment addressing of this tile (see conv3x3_patch_kernel) ----
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        const int lrow_t = lane_t & 31, hi_t = lane_t >> 5;
-        int boff[TJ][3][2];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int p = (wp * TJ + j) * 32 + lrow_t;
-            const int ty = p / TW, tx = p - ty * TW;
-            const int r00 = (p < NPX) ? ty * HW + tx : 0, hx0 = (p < NPX) ? tx : 0;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    boff[j][kx][h] = (r00 + kx) * 64 + (((2 * h + hi_t) ^ ((((hx0 + kx) >> SWZ_SH) + SWZ_ROW * (p < NPX ? ty : 0)) & 3)) * 16);
-        }
-        const int sw = (lane_t >> 2) & 3;
-        const int aoff0 = (wc * WC + lrow_t) * 64 + (((0 + hi_t) ^ sw) * 16);
-        const int aoff1 = (wc * WC + lrow_t) * 64 + (((2 + hi_t) ^ sw) * 16);
+        const int c0 = ct * BC;
 
         // the accumulators start at the bias (the C input of the first MFMA of each chain).  It arrives by SCALAR loads (the wave's
         // couts are wave-uniform; the two half-waves own alternate groups of 4): no VGPRs held across tiles and, above all, no vector
@@ -885,16 +948,16 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
         f32x16_t acc[TI][TJ];
         {
             const AS4 f32x4_t* const bp = (const AS4 f32x4_t*)(a.bias + c0 + wc * WC);
-            const bool upper = hi_t != 0;
+            const bool upper = hi != 0;
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4_t lo = bp[i * 8 + q * 2], up = bp[i * 8 + q * 2 + 1];
-                    asm volatile("" : "+s"(lo), "+s"(up));  // keep them scalar: hipcc would fold the select into a per-lane address
+                    f32x4_t lo4 = bp[i * 8 + q * 2], up4 = bp[i * 8 + q * 2 + 1];
+                    asm volatile("" : "+s"(lo4), "+s"(up4));  // keep them scalar: hipcc would fold the select into a per-lane address
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float bv = upper ? up[e] : lo[e];
+                        const float bv = upper ? up4[e] : lo4[e];
 #pragma unroll
                         for (int j = 0; j < TJ; ++j) acc[i][j][q * 4 + e] = bv;
                     }
@@ -941,6 +1004,7 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        VGH_MARK(a, trace_no, 1);
 
         int cb = 0, ky = 0;
         for (int s = 0; s < nsteps; ++s) {
@@ -958,11 +1022,11 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
                     load_w(wbase_n, 0, 0, wnext);  // (par + nsteps) & 1 == (par + C) & 1: the region tile t+1 starts in
                 if (ky == 0) {
                     if (cb + 1 < C) {
-                        load_x(xoff, cb + 1, smem + ((par + cb + 1) & 1) * RS);
+                        load_x(hbase, xoff, cb + 1, smem + ((par + cb + 1) & 1) * RS);
                         x_flying = true;
                     } else if (has_next) {
-                        calc_xoff(nb, ny0, nx0, xoff_n);
-                        load_x(xoff_n, 0, smem + ((par + C) & 1) * RS);
+                        tile_xoff(ntxi, ntyi, xoff_n);
+                        load_x(hbase_n, xoff_n, 0, smem + ((par + C) & 1) * RS);
                         x_flying = true;
                     }
                 }
@@ -985,44 +1049,40 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
             ky = nky;
         }
 
+        VGH_MARK(a, trace_no, 2);
         // ---- epilogue: fp32 -> LDS strip -> 16-byte buffer stores; the strip lives in the region the last step just released.
-        //      Straight-line code: store offsets and the residual tile (buffer loads, out-of-range lanes read zeros) are produced
-        //      up front, so hipcc's own vmcnt bookkeeping stays counted and no load wait ever drains the stores before it ----
+        //      Straight-line code: offsets are launch constants, only the descriptor bases move with the tile; the residual tile
+        //      arrives by buffer loads issued up front (out-of-range lanes read zeros), so hipcc's own vmcnt bookkeeping stays
+        //      counted and no load wait ever drains the stores before it ----
         if (!VGH_ABLATE(a, 8)) {
             float* stg = (float*)(smem + ((par + C - 1) & 1) * RS) + w * (STRIP * EP);
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));
-            const int half4 = (lane_e >> 5) * 4, lrow_e = lane_e & 31;
             const int cw0 = c0 + wc * WC;
-            const int pix00 = (b * a.H + y0) * a.W + x0;
-            constexpr int PASSES = 32 / STRIP;
+            const int ochan0 = (cw0 >= a.out_split) ? a.out_coff2 + (cw0 - a.out_split) : a.out_coff + cw0;
+            const int64_t pix00 = (int64_t)(b * a.H + tyi * TH) * a.W + txi * TW;
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)a.out + 2 * (pix00 * a.out_pitch + ochan0), 0, 0x80000000, 0x00020000);
+            const unsigned em = (txi == ntx - 1 && wr < TW ? 1u : 0u) | (tyi == nty - 1 && hr < TH ? 2u : 0u);
+            const unsigned ebad = oflags & (em * 0x55555555u);
             auto run = [&](auto res_tag) {
                 constexpr bool HAS_RES = decltype(res_tag)::value;
-                unsigned soff[TJ][PASSES][NITS];
                 u32x4_t rres[HAS_RES ? TJ : 1][PASSES][NITS];
+                if constexpr (HAS_RES) {
+                    const __amdgpu_buffer_rsrc_t rrsrc =
+                        __builtin_amdgcn_make_buffer_rsrc((char*)a.res + 2 * (pix00 * a.res_pitch + a.res_coff + cw0), 0, 0x80000000, 0x00020000);
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
+                    for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                    for (int hp = 0; hp < PASSES; ++hp)
+                        for (int hp = 0; hp < PASSES; ++hp)
 #pragma unroll
-                        for (int t = 0; t < NITS; ++t) {
-                            const int it = lane_e + 64 * t;
-                            const int pl = it / CH, ch = it - pl * CH;
-                            const int p = (wp * TJ + j) * 32 + hp * STRIP + pl;
-                            const int ty = p / TW, tx = p - ty * TW;
-                            const int oc = cw0 + ch * 8;
-                            const bool ok = p < NPX && y0 + ty < a.H && x0 + tx < a.W && oc < a.cout_store;
-                            const int opix = pix00 + ty * a.W + tx;
-                            const int ochan = (oc >= a.out_split) ? a.out_coff2 + (oc - a.out_split) : a.out_coff + oc;
-                            soff[j][hp][t] = ok ? 2u * (unsigned)(opix * (int)a.out_pitch + ochan) : OOB;
-                            if constexpr (HAS_RES)
-                                rres[j][hp][t] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ok ? 2u * (unsigned)(opix * (int)a.res_pitch + a.res_coff + oc) : OOB, 0, 0);
-                        }
+                            for (int t = 0; t < NITS; ++t) {
+                                const bool bad = (ebad >> (2 * ((j * PASSES + hp) * NITS + t))) & 3u;
+                                rres[j][hp][t] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, bad ? OOB : rrel[j][hp][t], 0, 0);
+                            }
+                }
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
 #pragma unroll
                     for (int hp = 0; hp < PASSES; ++hp) {
-                        if (STRIP == 32 || (lrow_e >> 4) == hp) {
+                        if (STRIP == 32 || (lrow >> 4) == hp) {
 #pragma unroll
                             for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -1030,7 +1090,7 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
                                     f32x4_t v;  // the bias is already inside the accumulator (it was the MFMA chain's C input)
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][q * 4 + e], act_lo);
-                                    *(f32x4_t*)(stg + (lrow_e & (STRIP - 1)) * EP + i * 32 + q * 8 + half4) = v;
+                                    *(f32x4_t*)(stg + (lrow & (STRIP - 1)) * EP + i * 32 + q * 8 + half4) = v;
                                 }
                             }
                         }
@@ -1038,7 +1098,7 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int t = 0; t < NITS; ++t) {
-                            const int it = lane_e + 64 * t;
+                            const int it = lane + 64 * t;
                             const int pl = it / CH, ch = it - pl * CH;
                             const f32x4_t v0 = *(const f32x4_t*)(stg + pl * EP + ch * 8);
                             const f32x4_t v1 = *(const f32x4_t*)(stg + pl * EP + ch * 8 + 4);
@@ -1055,7 +1115,8 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
                             bf16x8_t ov;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), orsrc, soff[j][hp][t], 0, 0);
+                            const bool bad = (ebad >> (2 * ((j * PASSES + hp) * NITS + t))) & 3u;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ov), orsrc, bad ? OOB : orel[j][hp][t], 0, 0);
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_wave_barrier();
@@ -1067,13 +1128,15 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
             else
                 run(std::false_type{});
         }
+        VGH_MARK(a, trace_no, 3);
         if (!has_next) break;
-        local = nlocal;
+        ++tile;
+        ct = nct;
+        txi = ntxi;
+        tyi = ntyi;
         b = nb;
-        y0 = ny0;
-        x0 = nx0;
-        c0 = nc0;
         wbase = wbase_n;
+        hbase = hbase_n;
 #pragma unroll
         for (int t = 0; t < XUW; ++t) xoff[t] = xoff_n[t];
         par = (par + C) & 1;
@@ -1280,6 +1343,13 @@ constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
 }  // namespace
 
+#ifdef VGH_EXPERIMENTS
+static unsigned long long* g_trace = nullptr;
+extern "C" int vgh_conv_set_trace(void* dev_buffer) {
+    g_trace = (unsigned long long*)dev_buffer;
+    return VGH_OK;
+}
+#endif
 int vgh_conv_num_cfgs() { return kNumCfgs; }
 int vgh_conv_set_max_blocks_per_xcd(int blocks) {
     VGH_REQUIRE(blocks >= 0, "conv_set_max_blocks_per_xcd: negative");
@@ -1376,6 +1446,7 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     static const int ablate = getenv("VGH_CONV_ABLATE") ? atoi(getenv("VGH_CONV_ABLATE")) : 0;
     static const int stagger_env = getenv("VGH_STAGGER") ? atoi(getenv("VGH_STAGGER")) : -1;
     static const int share_env = getenv("VGH_GRID_SHARE") ? atoi(getenv("VGH_GRID_SHARE")) : -1;
+    const_cast<ConvArgs&>(a).trace = g_trace;
     if (stagger_env >= 0) const_cast<ConvArgs&>(a).stagger = stagger_env;
     if (share_env >= 1) const_cast<ConvArgs&>(a).grid_share = share_env;
 #else
@@ -1395,11 +1466,16 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
         VGH_REQUIRE(force_cfg < 0, "conv: cfg %s cannot run this conv (cout_pad=%d k=%d s=%d)", g_cfgs[cfg].name, a.cout_pad, a.ksize, a.stride);
         cfg = 4;
     }
+    if (g_cfgs[cfg].patch == 2 && !(a.cout_store == a.cout_pad && (a.out_split >= a.cout_pad || a.out_split % g_cfgs[cfg].BC == 0))) {
+        // the pipelined kernel stores whole cout tiles into ONE output segment: ragged channel counts run on its "p" twin
+        char twin[48];
+        snprintf(twin, sizeof(twin), "p%s", g_cfgs[cfg].name + 1);
+        const int t = cfg_by_name(twin);
+        VGH_REQUIRE(t >= 0, "conv: cfg %s has no fallback tile", g_cfgs[cfg].name);
+        cfg = t;
+    }
     const CfgEntry& e = g_cfgs[cfg];
     if (e.patch) {
-        if (e.patch == 2)  // output / residual addressed with 32-bit buffer offsets (exact store count needs out-of-range masking)
-            VGH_REQUIRE((int64_t)a.P * a.out_pitch * 2 < (1ll << 31) && (!a.res || (int64_t)a.P * a.res_pitch * 2 < (1ll << 31)),
-                        "conv: output / residual tensor must stay below 2 GiB for cfg %s; run the batch in chunks", e.name);
         const int ntc = a.cout_pad / e.BC, ntx = (a.W + e.TW - 1) / e.TW, nty = (a.H + e.TH - 1) / e.TH;
         const int64_t total = (int64_t)a.B * nty * ntx * ntc;
         VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");

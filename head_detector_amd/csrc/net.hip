@@ -149,7 +149,7 @@ static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, i
             guard_pending = false;
         }
         for (int l = 0; l < L; ++l)
-            if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l], L)) return rc;
+            if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l])) return rc;
     }
     for (int l = 1; l < L; ++l) {
         VGH_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
@@ -329,7 +329,7 @@ int vgh_net_profile(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
                 const int nb = B / L + (l < B % L ? 1 : 0);
                 hipStream_t ls = l == 0 ? st : n->side[l];
                 if (l > 0) VGH_HIP(hipStreamWaitEvent(ls, n->ev_fork, 0));
-                if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, nb, at, ls, L)) return rc;
+                if (int rc = net_run_op(n, n->ops[i], image_dev, image_fmt, nb, at, ls)) return rc;
                 if (l > 0) {
                     VGH_HIP(hipEventRecord(n->ev_join[l], ls));
                     VGH_HIP(hipStreamWaitEvent(st, n->ev_join[l], 0));

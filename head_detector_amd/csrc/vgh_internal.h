@@ -61,13 +61,24 @@ struct ConvArgs {
     int stagger;    // persistent patch kernels: odd resident-slot blocks start this many ~0.5 us sleeps late (de-phases co-resident blocks)
     int grid_share; // persistent patch kernels: take 1/grid_share of the CU slots (the executor's other lane streams own the rest)
     int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
+    unsigned long long* trace;  // -DVGH_EXPERIMENTS builds only: per-(block, tile) phase timestamps (s_memtime), or nullptr
 };
+#define VGH_TRACE_TILES 16  // tiles recorded per block
+#define VGH_TRACE_MARKS 4   // marks per tile: tile top, operands landed, K loop done, epilogue done
 
 // Work-skipping switches exist only in the experiments build (tools/, never the shipped libvgh.so)
 #ifdef VGH_EXPERIMENTS
 #define VGH_ABLATE(a, bit) ((a).ablate & (bit))
+#define VGH_MARK(a, tile_no, k)                                                                                                      \
+    do {                                                                                                                             \
+        if ((a).trace && threadIdx.x == 0 && (tile_no) < VGH_TRACE_TILES)                                                            \
+            (a).trace[((size_t)blockIdx.x * VGH_TRACE_TILES + (tile_no)) * VGH_TRACE_MARKS + (k)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
 #else
 #define VGH_ABLATE(a, bit) 0
+#define VGH_MARK(a, tile_no, k) \
+    do {                        \
+    } while (0)
 #endif
 
 int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);

@@ -21,8 +21,10 @@ def main():
     ap.add_argument("--cfgs", default="all", help="all | comma-separated indices or names")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--res", action="store_true")
+    ap.add_argument("--max-blocks", type=int, default=0, help="vgh_conv_set_max_blocks_per_xcd (32 = one workgroup per CU)")
     args = ap.parse_args()
     lib = _lib.load()
+    _lib.check(lib.vgh_conv_set_max_blocks_per_xcd(args.max_blocks))
     for shape in args.shape:
         run_shape(lib, args, shape)
 
