@@ -20,6 +20,8 @@ What is real reference code here and what is stubbed:
                                   -> real pncc(), compute_ncc_color_codes, PNCCProcessor.__init__/__call__ on SYNTHETIC mesh
                                   assets (np.load patched inside that module; the reference's licensed mesh assets are not packed)
   * head_detector/utils.py:refined_head_bbox  real function with HEAD_INDICES := synthetic subset
+  * head_detector/detection_result.py  imported as-is (cv2 stubbed: only the draw helpers touch it) -> real MeshSaver /
+                                  PredictionResult.save_meshes on the synthetic faces: the OBJ bytes are the fixture (mesh_obj.npz)
 No reference *source* is copied; the vectors are inputs + outputs only.
 """
 import importlib.util
@@ -227,6 +229,20 @@ def main():
         pncc_triangles=proc.triangles, pncc_colors=proc.colors, heads=np.stack(heads_v), heads_after=np.stack([h.vertices_3d for h in heads]),
         image_shape=np.array(image.shape), pncc=pncc_img, head_indices=hidx, bboxes=np.array([[b.x, b.y, b.w, b.h] for b in bb]), **cases,
     )
+    # ---- (g) PredictionResult.save_meshes / MeshSaver (detection_result.py:22-35,73-78): the OBJ text the reference writes ------
+    _load("draw_utils")  # cv2 is only touched inside the draw functions
+    det = _load("detection_result")
+    det.np.load = lambda path, *a, **k: fake[os.path.basename(str(path))]
+    try:
+        pr = det.PredictionResult(image, [types.SimpleNamespace(vertices_3d=v.copy()) for v in heads_v[:2]])
+    finally:
+        det.np.load = real_load
+    with tempfile.TemporaryDirectory() as d:
+        pr.save_meshes(os.path.join(d, "meshes"))
+        names = sorted(os.listdir(os.path.join(d, "meshes")))
+        texts = [open(os.path.join(d, "meshes", n), "rb").read() for n in names]
+    np.savez_compressed(os.path.join(OUT, "mesh_obj.npz"), faces=fake["full_faces.npy"], heads=np.stack(heads_v[:2]), names=np.array(names),
+                        obj0=np.frombuffer(texts[0], dtype=np.uint8), obj1=np.frombuffer(texts[1], dtype=np.uint8))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -47,7 +47,14 @@ from oracle import postproc_oracle as po  # noqa: E402
 # ------------------------------------------------------------------------------------------------------
 # inert shells for the absent third-party packages
 # ------------------------------------------------------------------------------------------------------
-class _Inert:
+class _InertMeta(type):
+    def __getattr__(cls, name):  # class-level constants of enums etc. (e.g. DetectionOutputFormatMode.BATCH_FORMAT in a default argument)
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Inert()
+
+
+class _Inert(metaclass=_InertMeta):
     """Usable as a base class, an instance, a decorator factory and a decorator."""
 
     def __init__(self, *a, **k):
@@ -68,7 +75,7 @@ class _ShellModule(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__"):
             raise AttributeError(name)
-        cls = type(name, (_Inert,), {})  # a distinct class per name (several may appear in one bases list)
+        cls = _InertMeta(name, (_Inert,), {})  # a distinct class per name (several may appear in one bases list)
         setattr(self, name, cls)
         return cls
 
@@ -125,7 +132,10 @@ def _install_shells():
     import super_gradients.training.utils as sgtu
     import super_gradients.training.utils.bbox_utils as sgbb
     import omegaconf
+    import super_gradients.training.models.detection_models.pp_yolo_e.pp_yolo_head as ppy
 
+    # only feeds YoloHeadsRawOutputs (loss-side anchors), which nothing on the inference path reads
+    ppy.generate_anchors_for_grid_cell = lambda feats, strides, scale, offset: (None, None, None, None)
     sgm.ConvBNReLU = lambda cin, cout, kernel_size, stride, padding, groups=1, bias=False: net_oracle.ConvBNReLU(cin, cout, kernel_size, stride, padding)
     sgm.QARepVGGBlock = net_oracle.QARepVGGBlock
     sgb.BaseDetectionModule = BaseDetectionModule

@@ -32,7 +32,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = gather_detections(*_make(rank), dst=0)
     if rank == 0:
-        q.put({k: getattr(out, k) for k in ("boxes", "scores", "flame_params", "counts", "vertices_3d", "head_image")})
+        # by value (numpy): a torch tensor travels through the queue as a file descriptor served by THIS process, which may have
+        # exited by the time the parent asks for it
+        q.put({k: getattr(out, k).numpy() for k in ("boxes", "scores", "flame_params", "counts", "vertices_3d", "head_image")})
     else:
         assert out is None
     dist.barrier()
@@ -46,7 +48,7 @@ def test_gather_detections_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = {k: torch.from_numpy(v) for k, v in q.get(timeout=120).items()}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

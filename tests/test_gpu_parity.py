@@ -206,6 +206,65 @@ def test_head_decode_and_gather_vs_oracle(gpu_lib, S_c, E_c):
     assert float(of[..., S_c:300].abs().max()) == 0.0 and float(of[..., 300 + E_c : 400].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("tag", ["l", "m"])
+def test_post_network_kernels_vs_reference_run_fixture(gpu_lib, flame_model, tag):
+    """The HIP post-network kernels against tests/golden/head_decode.npz = outputs of the reference's OWN YoloHeadsDFLHead /
+    YoloHeadsNDFLHeads / VGGHeadDecodingModule / YoloHeadsPostPredictionCallback (make_golden_heads.py), fed with the reference's
+    raw per-level head outputs: vgh_head_decode, vgh_topk, vgh_gather_candidates (activations, padding, fix-up, permutation),
+    the facade's nms_batched (vgh_topk_nms) and the FLAME decode of the survivors."""
+    from conftest import golden
+    from head_detector_amd import _lib
+    from head_detector_amd import utils as hu
+    from head_detector_amd.flame import FLAMELayer
+    from oracle import flame_oracle as fo
+
+    g = golden("head_decode.npz")
+    t = lambda k: torch.from_numpy(g[f"{tag}_{k}"])  # noqa: E731
+    B, strides = 2, (8, 16, 32)
+    S_c, E_c = g[f"{tag}_raw0_shape"].shape[1], g[f"{tag}_raw0_expression"].shape[1]
+    pitch = (72 + S_c + E_c + 13 + 3) // 4 * 4
+    preds, sizes = [], []
+    for lv in range(3):
+        reg = t(f"reg{lv}")
+        h, w = reg.shape[2:]
+        sizes.append((h, w))
+        buf = torch.zeros(B, h, w, pitch)
+        parts = [reg, t(f"cls{lv}"), torch.zeros(B, 3, h, w)] + [t(f"raw{lv}_{n}") for n in ("shape", "expression", "rotation", "jaw", "translation", "scale")]
+        buf[..., : 72 + S_c + E_c + 13] = torch.cat(parts, 1).permute(0, 2, 3, 1)
+        preds.append(buf.to(_dev()).contiguous())
+    lv_arr = (_lib.HeadLevel * 3)(*[_lib.HeadLevel(preds[i].data_ptr(), sizes[i][0], sizes[i][1], pitch, strides[i]) for i in range(3)])
+    A = sum(h * w for h, w in sizes)
+    boxes = torch.empty(B, A, 4, device=_dev())
+    scores = torch.empty(B, A, device=_dev())
+    _lib.check(gpu_lib.vgh_head_decode(lv_arr, 3, B, _lib.ptr(boxes), _lib.ptr(scores), _sp()))
+    assert (boxes.cpu() - t("boxes")).abs().max() < 2e-4  # px
+    assert (scores.cpu() - t("scores")[..., 0]).abs().max() < 2e-6
+    # row a7: top-k of the reference's scores -> the same candidates in the same order
+    k = g[f"{tag}_cand_scores"].shape[1]
+    ref_scores = t("scores")[..., 0].contiguous().to(_dev())
+    idx = torch.empty(B, k, dtype=torch.int32, device=_dev())
+    top = torch.empty(B, k, device=_dev())
+    _lib.check(gpu_lib.vgh_topk(_lib.ptr(ref_scores), B, A, k, _lib.ptr(idx), _lib.ptr(top), _sp()))
+    assert torch.equal(top.cpu(), t("cand_scores")[..., 0])
+    ob = torch.empty(B, k, 4, device=_dev())
+    of = torch.empty(B, k, 413, device=_dev())
+    _lib.check(gpu_lib.vgh_gather_candidates(lv_arr, 3, B, A, S_c, E_c, _lib.ptr(boxes), _lib.ptr(idx), k, _lib.ptr(ob), _lib.ptr(of), _sp()))
+    assert (ob.cpu() - t("cand_boxes")).abs().max() < 2e-4
+    d = (of.cpu() - t("cand_flame")).abs() / (t("cand_flame").abs() + 1.0)
+    assert d.max() < 1e-5, d.max()
+    assert float(of[..., S_c:300].abs().max()) == 0.0 and float(of[..., 300 + E_c : 400].abs().max()) == 0.0
+    # batched twin of nms(): the reference's decoded tensors in, its survivors out -- bit-exact decisions, rows copied verbatim
+    rb, rs, rf, cnt = hu.nms_batched(t("boxes").to(_dev()), t("scores").to(_dev()), t("flame").to(_dev()), float(g[f"{tag}_post_conf"]), 0.5, top_k=30, keep_top_k=10)
+    fl = FLAMELayer(model=fo.synthetic_flame_model(seed=3), device=_dev(), max_heads=64)
+    for i in range(B):
+        n = int(cnt[i])
+        assert n == int(g[f"{tag}_post_counts"][i])
+        assert torch.equal(rb[i, :n].cpu(), t(f"post{i}_boxes")) and torch.equal(rs[i, :n].cpu(), t(f"post{i}_scores")) and torch.equal(rf[i, :n].cpu(), t(f"post{i}_params"))
+        _, _, proj = fl.decode(rf[i, :n])
+        ref = t(f"post{i}_v3d")
+        assert (proj[:, ::97].cpu() - ref).abs().max() <= 2e-4 * ref.abs().max()
+
+
 # ======================================================================================================
 # implicit-GEMM conv (K2/K3/K4), per configuration
 # ======================================================================================================
@@ -251,6 +310,8 @@ def _run_conv(lib, x, W, b, k, stride, act=1, res=None, alpha=0.0, split=None, o
     y = F.conv2d(xr, wr, None, stride=stride, padding=k // 2) + bp[None, :, None, None]
     if act == 1:
         y = torch.relu(y)
+    elif act == 2:
+        y = F.silu(y)
     y = y.permute(0, 2, 3, 1)
     if shuffle:
         Cc = rp // 4
@@ -346,6 +407,32 @@ def test_conv_persistent_multi_tile(gpu_lib, cin, res):
     finally:
         gpu_lib.vgh_conv_set_max_blocks_per_xcd(0)
     assert tested >= 20
+
+
+def test_conv_silu_epilogue(gpu_lib):
+    """VGH_ACT_SILU (north_star's "BN/SiLU fusion"; the VGGHeads graphs themselves are all-ReLU): x * sigmoid(x) with the hardware
+    exp (__expf, ~2 ulp fp32 -- far below the bf16 output rounding, and within 1e-6 relative on the fp32 store path) in every
+    epilogue family: LDS-transposed and general implicit-GEMM epilogues, fp32 store, residual after the activation, the halo-patch
+    kernels ("p") and the pipelined ones ("q")."""
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Cin, Cout = 2, 24, 24, 64, 128
+    x = torch.randn(B, H, W, Cin, generator=g)
+    Wt = torch.randn(Cout, 3, 3, Cin, generator=g) * 0.08
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, H, W, Cout, generator=g)
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    picks = [-1] + [names.index(n) for n in ("128x128_w64x64_k1", "256x128_w64x64_k1_r3", "p16x16x64_n4x1", "q16x16x64_n4x1", "p8x32x64_n4x2", "q16x16x128_n4x2")]
+    for cfg in picks:
+        for r, alpha in ((None, 0.0), (res, 0.3)):
+            out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, act=2, cfg=cfg, res=r, alpha=alpha)
+            _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"silu cfg={cfg} res={r is not None}")
+    for cfg in picks[:3]:  # general epilogue (8-byte aligned offset) and the fp32 store path
+        out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, act=2, cfg=cfg, out_coff=4)
+        _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"silu general epilogue cfg={cfg}")
+    W1 = torch.randn(69, 1, 1, Cin, generator=g) * 0.1
+    out, ref, st, o0 = _run_conv(gpu_lib, x, W1, torch.randn(69, generator=g), 1, 1, act=2, out_f32=True, out_coff=8)
+    _assert_close(out[..., o0 : o0 + st], ref[..., :st], True, "silu fp32 store")
+    assert ((out[..., o0 : o0 + st] - ref[..., :st]).abs() / (ref[..., :st].abs() + 1e-3)).max() < 2e-2  # bf16 inputs dominate; __expf is invisible
 
 
 def test_conv_epilogues(gpu_lib):
@@ -906,17 +993,20 @@ def test_letterbox_kernel_vs_oracle(gpu_lib):
         letterbox(same.astype(np.float32), 128, _dev())
 
 
-def test_full_size_batch_independence_property(gpu_lib, flame_model):
-    """BASELINE configs[1] geometry (VGGHeads_M, B = 32 @ 640x640, tuned tiles, two lanes + overlap): the oracle cannot run this
-    size in seconds, so parity rests on a size-independent property -- images are independent, hence every image's candidates
-    and detections in the full batch equal those of the same image run alone (same engine, same tile choices), bit for bit."""
+@pytest.mark.parametrize("variant,B,probe", [("vgg_heads_m", 32, (0, 13, 31)), ("vgg_heads_l", 64, (0, 31, 63)), ("vgg_heads_l", 8, (0, 5, 7))],
+                         ids=["m32", "l64", "l8"])
+def test_full_size_batch_independence_property(gpu_lib, flame_model, variant, B, probe):
+    """BASELINE configs[1] (VGGHeads_M, B = 32) and configs[2] (VGGHeads_L, B = 64 + FLAME decode: the benchmark line) at 640x640
+    with the tuned tile tables, two lanes + overlap, plus the b8 tile bucket: the oracle cannot run these sizes in seconds, so
+    parity rests on a size-independent property -- images are independent, hence every image's candidates and detections in the
+    full batch equal those of the same image run alone (same engine, same tile choices), bit for bit."""
     from head_detector_amd.engine import VGHeadsEngine
     from head_detector_amd.flame import FLAMELayer
 
-    B, S = 32, 640
+    S = 640
     x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(77)).to(_dev())
     fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=B * 100)
-    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=1)
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=1)
     eng.set_split(2)
     eng.set_overlap(True)
     boxes, scores, flame = [t.clone() for t in eng.model(x)]
@@ -926,7 +1016,7 @@ def test_full_size_batch_independence_property(gpu_lib, flame_model):
     counts = det.counts.cpu().tolist()
     full = (det.boxes.clone(), det.flame_params.clone(), det.vertices_3d.clone(), det.head_image.clone())
     assert min(counts) >= 1
-    for i in (0, 13, 31):
+    for i in probe:
         b1, s1, f1 = eng.model(x[i : i + 1].contiguous())
         assert torch.equal(b1[0], boxes[i]) and torch.equal(s1[0], scores[i]) and torch.equal(f1[0], flame[i])
         d1 = eng.detect(x[i : i + 1].contiguous(), confidence_threshold=conf, flame=fl)
@@ -935,6 +1025,27 @@ def test_full_size_batch_independence_property(gpu_lib, flame_model):
         assert torch.equal(d1.vertices_3d, full[2][full[3] == i])
     eng.set_overlap(False)
     eng.close()
+
+
+def test_bf16_mode_accuracy_vs_fp32_mode(gpu_lib, flame_model):
+    """North_star states "bbox IoU >= 0.999, FLAME params / vertices within 1e-4" for the reference's fp32 path; the engine meets it
+    in fp32 parity mode (test_fp32_parity_mode_meets_north_star_tolerances).  The bf16 THROUGHPUT mode -- the one bench.py times:
+    tuned tiles, two lane streams -- cannot (bf16 storage through ~190 layers), so its deviation from the fp32 mode is measured
+    on the benchmark geometry and held to explicit numbers (random weights; matched by anchor on the fp32 mode's NMS survivors)."""
+    from head_detector_amd.accuracy import bf16_vs_fp32
+    from head_detector_amd.flame import FLAMELayer
+
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=256)
+    for variant, B, split in (("vgg_heads_m", 2, 2), ("vgg_heads_l", 1, 1)):
+        r = bf16_vs_fp32(variant, 640, B, fl, split=split)
+        print(f"[bf16 vs fp32 mode] {r}")
+        assert r["kept_fp32"] >= 4 and r["missing_in_bf16_topk"] == 0
+        assert r["iou_median"] >= 0.999 and r["iou_min"] >= 0.90  # median meets the bar; a near-tie DFL bin can move one box by a few %
+        assert r["dense_score_max_abs_err"] < 2e-3
+        assert r["param_max_abs_err_live"] < 0.5  # translation is in pixels (|t| ~ 640): 0.5 px
+        assert r["log_scale_max_abs_err"] < 5e-2
+        assert r["vertex_l2_metric_mean"] < 2e-3 and r["vertex_l2_metric_max"] < 2e-2  # metres in FLAME space (|v| ~ 0.2)
+        assert r["kept_by_both_frac"] >= 0.6
 
 
 def test_flame_decode_large_n_equals_chunks(gpu_lib, flame_model):

@@ -261,3 +261,23 @@ def test_c_abi_argument_validation_reports_errors_without_a_gpu():
     with pytest.raises(_lib.VghError, match="libvgh error"):
         _lib.check(lib.vgh_net_forward(None, None, 0, 1, None))
     assert lib.vgh_conv_num_cfgs() > 70 and lib.vgh_conv_cfg_name(19).decode().startswith("p8x40")
+
+
+def test_save_meshes_matches_reference_obj_bytes(tmp_path):
+    """PredictionResult.save_meshes writes byte-for-byte what the reference's MeshSaver / save_meshes wrote for the same vertices and
+    triangles (tests/golden/mesh_obj.npz, produced by running head_detector/detection_result.py:22-35,73-78)."""
+    import types
+
+    from conftest import golden
+    from head_detector_amd.detection_result import PredictionResult
+
+    g = golden("mesh_obj.npz")
+    heads = [types.SimpleNamespace(vertices_3d=v) for v in g["heads"]]
+    pr = PredictionResult(np.zeros((4, 4, 3), dtype=np.uint8), heads, faces=g["faces"])
+    pr.save_meshes(str(tmp_path / "meshes"))
+    names = sorted(os.listdir(tmp_path / "meshes"))
+    assert names == [str(n) for n in g["names"]]
+    for i, n in enumerate(names):
+        assert open(tmp_path / "meshes" / n, "rb").read() == g[f"obj{i}"].tobytes()
+    with pytest.raises(ValueError):
+        PredictionResult(np.zeros((4, 4, 3), dtype=np.uint8), heads).save_meshes(str(tmp_path / "none"))
