@@ -72,6 +72,17 @@ class DetectOut(C.Structure):
                 ("verts_dev", C.c_void_p), ("rot_dev", C.c_void_p), ("rpy_dev", C.c_void_p), ("proj_dev", C.c_void_p)]
 
 
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("pack_path", C.c_char_p), ("max_batch", C.c_int32), ("pre_nms_top_k", C.c_int32), ("keep_top_k", C.c_int32),
+                ("max_heads", C.c_int32), ("batch_split", C.c_int32), ("overlap", C.c_int32)]
+
+
+class CtxInfo(C.Structure):
+    _fields_ = [("variant", C.c_char * 32), ("image_size", C.c_int32), ("max_batch", C.c_int32), ("arena_batch", C.c_int32), ("num_anchors", C.c_int32),
+                ("pre_nms_top_k", C.c_int32), ("keep_top_k", C.c_int32), ("num_vertices", C.c_int32), ("shape_live", C.c_int32), ("expr_live", C.c_int32),
+                ("precision", C.c_int32), ("flops_per_image", C.c_double)]
+
+
 SCRATCH_BOXES_ALL, SCRATCH_SCORES_ALL, SCRATCH_TOPK_IDX, SCRATCH_KEEP_IDX, SCRATCH_HEAD_ROW = range(5)
 
 # every symbol include/vgh.h declares: (restype, argtypes)
@@ -121,6 +132,15 @@ SYMBOLS = {
     "vgh_detector_join": (_I, [_P, _P]),
     "vgh_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_flame_lbs": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "vgh_create": (_I, [C.POINTER(Config), C.POINTER(_P)]),
+    "vgh_destroy": (None, [_P]),
+    "vgh_ctx_last_error": (C.c_char_p, [_P]),
+    "vgh_ctx_get_info": (_I, [_P, C.POINTER(CtxInfo)]),
+    "vgh_ctx_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),
+    "vgh_ctx_join": (_I, [_P, _P]),
+    "vgh_ctx_net": (_P, [_P]),
+    "vgh_ctx_flame": (_P, [_P]),
+    "vgh_ctx_detector": (_P, [_P]),
     "vgh_rasterize": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "vgh_pncc_render": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P]),
     "vgh_refined_head_bbox": (_I, [_P, _I, _I, _P, _I, _P, _P]),

@@ -6,8 +6,9 @@
 
 Differences that are forced, not chosen:
   * weights: the reference downloads ``okupyn/vgg_heads/<model>.trcd`` from the HF hub (detector.py:25-30).
-    There is no network here, so ``weights`` is a path to a user-supplied .trcd / state_dict, or None for
-    seeded synthetic weights of the same architecture (throughput / plumbing only);
+    There is no network here, so ``weights`` is a path to a user-supplied .trcd / state_dict (default: ``<model>.trcd`` next
+    to this package; a missing file raises, naming it), or the explicit opt-in ``"synthetic"`` for seeded random weights of the
+    same architecture (throughput / plumbing only);
   * FLAME constants: ``flame_path`` / ``flame_model`` as in FLAMELayer (user-supplied licensed asset);
   * letterbox resize: cv2.INTER_LANCZOS4 + constant border (detector.py:47-50) restated as a HIP kernel (letterbox.py); cv2 is
     not needed at run time (and is absent here: that stage is "parity unpinned").
@@ -16,6 +17,9 @@ scale is divided by the letterbox scale (detector.py:78-79); bbox via np.rint ->
 """
 from __future__ import annotations
 
+import os
+import re
+import warnings
 from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -33,17 +37,38 @@ REPO_ID = "okupyn/vgg_heads"
 
 def load_weights(path: str) -> Dict[str, np.ndarray]:
     """state_dict of a released TorchScript archive (.trcd) or of a torch checkpoint -> {name: ndarray} with the
-    ``model.`` prefix of ConvertableCompletePipelineModel stripped (exportable_mesh_model.py:421-427)."""
+    ``model.`` prefix of ConvertableCompletePipelineModel stripped (exportable_mesh_model.py:421-427).  A training checkpoint's
+    EMA weights win over the raw ones (they are what the export pipeline serialises)."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
     try:
         sd = torch.jit.load(path, map_location="cpu").state_dict()
-    except Exception:
-        obj = torch.load(path, map_location="cpu")
-        sd = obj.get("net", obj.get("ema_net", obj)) if isinstance(obj, dict) else obj.state_dict()
+    except (RuntimeError, ValueError) as jit_err:  # not a TorchScript archive: a plain checkpoint?
+        try:
+            obj = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as ckpt_err:
+            raise ValueError(f"{path}: neither a TorchScript archive ({str(jit_err).splitlines()[0]}) nor a torch checkpoint ({ckpt_err})") from ckpt_err
+        if isinstance(obj, dict):
+            sd = obj.get("ema_net", obj.get("net", obj))
+        else:
+            sd = obj.state_dict()
     out = {}
     for k, v in sd.items():
         k = k[len("model."):] if k.startswith("model.") else k
         out[k] = v.detach().float().numpy()
     return out
+
+
+def weight_manifest_diff(variant: str, sd: Dict[str, np.ndarray]) -> Dict[str, list]:
+    """Keys / shapes of ``sd`` against the architecture reconstructed from the arch yaml: the first contact with a
+    real released blob should fail HERE, with the whole difference, not with a KeyError somewhere inside the fold."""
+    from . import arch
+
+    want = {k: v.shape for k, v in arch.random_state_dict(variant, 0).items()}
+    ignore = re.compile(r"(num_batches_tracked|rbr_reparam\.|anchor_points|stride_tensor|proj_conv|max_batch)")
+    have = {k: tuple(np.asarray(v).shape) for k, v in sd.items() if not ignore.search(k)}
+    return {"missing": sorted(k for k in want if k not in have), "unexpected": sorted(k for k in have if k not in want),
+            "shape": sorted(f"{k}: expected {tuple(want[k])}, got {have[k]}" for k in want if k in have and tuple(want[k]) != have[k])}
 
 
 class HeadDetector:
@@ -65,7 +90,25 @@ class HeadDetector:
             self._pncc = PNCCProcessor(mesh_assets if mesh_assets is not None else assets_dir)
 
     def _read_model(self, model: str, weights: Optional[str], seed: int) -> VGHeadsEngine:
-        sd = load_weights(weights) if weights is not None else None
+        """detector.py:25-30 downloads ``okupyn/vgg_heads/<model>.trcd``; without a network the archive is a user-supplied file:
+        ``weights`` = its path (default: ``<model>.trcd`` next to this package).  ``weights="synthetic"`` is the explicit opt-in for
+        seeded random weights of the same architecture (plumbing / throughput work) -- never a silent default."""
+        if weights is None:
+            cand = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{model}.trcd")
+            if not os.path.exists(cand):
+                raise FileNotFoundError(
+                    f"HeadDetector: no weights for {model!r}. The reference fetches {REPO_ID}/{model}.trcd from the Hugging Face hub (head_detector/detector.py:25-30); "
+                    f"there is no network here: pass weights=<path to {model}.trcd> (or place it at {cand}), or weights='synthetic' for seeded random weights "
+                    "of the same architecture (throughput / plumbing only: the detections are meaningless).")
+            weights = cand
+        if weights == "synthetic":
+            warnings.warn(f"HeadDetector({model!r}): seeded SYNTHETIC weights (seed {seed}) -- detections are meaningless; supply the released {model}.trcd for real use", stacklevel=3)
+            sd = None
+        else:
+            sd = load_weights(weights)
+            diff = weight_manifest_diff(model, sd)
+            if any(diff.values()):
+                raise ValueError(f"{weights} does not match the {model} architecture this engine lowers:\n" + "\n".join(f"  {k}: {v[:12]}{' ...' if len(v) > 12 else ''}" for k, v in diff.items() if v))
         return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=self._max_batch, seed=seed)
 
     # ---- host-side image handling (detector.py:32-56) ----------------------------------------------------

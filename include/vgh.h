@@ -285,6 +285,42 @@ int vgh_detector_set_overlap(vgh_detector* d, int enable);
 int vgh_detector_join(vgh_detector* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Whole-pipeline context from ONE pack file: replaces HeadDetector.__init__ (head_detector/detector.py:19-30: hub download,
+ * torch.jit.load of the .trcd, FLAMELayer()) and, with vgh_ctx_detect, HeadDetector._process + the device arithmetic of
+ * _parse_predictions for a whole batch (detector.py:54-90) -- no Python at run time.  The pack (.vghpack, written by
+ * `python -m head_detector_amd.pack <variant> <weights.trcd | seed:N> <generic_model.pkl | seed:N> out.vghpack`) holds the
+ * lowered op program, the folded fp32 weights, the per-op tile choices (by name) and the FLAME constants, behind a versioned
+ * header.  A context owns its net / FLAME / detector handles; it is NOT thread-safe: one context per (device, stream).
+ * vgh_ctx_last_error(ctx) returns the message of the last failed call ON THAT CONTEXT (vgh_last_error() stays thread-local).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vgh_config {
+    int32_t device;
+    const char* pack_path;
+    int32_t max_batch;                 /* images per vgh_ctx_detect call (processed in arena-sized chunks when tensors would pass 2 GiB) */
+    int32_t pre_nms_top_k, keep_top_k; /* 0: the reference's 1000 / 100 */
+    int32_t max_heads;                 /* FLAME decode capacity; 0: max_batch * keep_top_k */
+    int32_t batch_split;               /* vgh_net_set_split (0 / 1: off) */
+    int32_t overlap;                   /* vgh_detector_set_overlap: results complete after vgh_ctx_join */
+} vgh_config;
+typedef struct vgh_ctx_info {
+    char variant[32];
+    int32_t image_size, max_batch, arena_batch, num_anchors, pre_nms_top_k, keep_top_k, num_vertices, shape_live, expr_live, precision;
+    double flops_per_image;
+} vgh_ctx_info;
+typedef struct vgh_ctx vgh_ctx;
+int vgh_create(const vgh_config* cfg, vgh_ctx** out);
+void vgh_destroy(vgh_ctx* ctx);
+const char* vgh_ctx_last_error(const vgh_ctx* ctx);
+int vgh_ctx_get_info(const vgh_ctx* ctx, vgh_ctx_info* info);
+/* = vgh_detect on the context's detector (outputs: caller-owned device slabs, see vgh_detect_out). */
+int vgh_ctx_detect(vgh_ctx* ctx, const void* images_dev, int image_fmt, int B, float conf_thr, float iou_thr, vgh_detect_out* out, void* stream);
+int vgh_ctx_join(vgh_ctx* ctx, void* stream);
+/* borrowed handles (for callers that mix the context with the fine-grained entry points above) */
+vgh_net* vgh_ctx_net(vgh_ctx* ctx);
+vgh_flame* vgh_ctx_flame(vgh_ctx* ctx);
+vgh_detector* vgh_ctx_detector(vgh_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
  * Result-side consumers of the decoded meshes.
  * vgh_rasterize = Sim3DR.rasterize(vertices, triangles, colors, bg=image, reverse) (head_detector/Sim3DR/Sim3DR.py:17-38 ->
  *   _rasterize, head_detector/Sim3DR/lib/rasterize_kernel.cpp:219-293) with the binding's defaults alpha = 1 and a fresh

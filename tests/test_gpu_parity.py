@@ -1,6 +1,7 @@
 """GPU (-m gpu): parity of every HIP kernel, called through the C ABI, against the CPU oracle / golden vectors.
 Integer / index results must be bit-exact; floating point within the tolerance written next to each check."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -583,7 +584,7 @@ def test_detect_pipeline_and_facade(gpu_lib, flame_model):
     from oracle import flame_oracle as fo
     from oracle import postproc_oracle as po
 
-    det = HeadDetector("vgg_heads_m", 640, flame_model=flame_model, seed=4)
+    det = HeadDetector("vgg_heads_m", 640, flame_model=flame_model, weights="synthetic", seed=4)
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, (480, 600, 3), dtype=np.uint8)  # letterboxed: scale 640/600, pad (0, 64)
     image, cache = det._preprocess(img)
@@ -782,7 +783,7 @@ def test_detect_batch_facade_equals_single_image_calls(gpu_lib, flame_model):
     """HeadDetector.detect_batch (fused device path for every image) returns, per image, what HeadDetector.__call__ returns."""
     from head_detector_amd.detector import HeadDetector
 
-    det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, seed=4, max_batch=3)
+    det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, max_batch=3)
     rng = np.random.default_rng(1)
     imgs = [rng.integers(0, 256, shape, dtype=np.uint8) for shape in ((240, 300, 3), (320, 320, 3), (400, 250, 3))]
     image, _ = det._preprocess(imgs[0])
@@ -870,7 +871,7 @@ def test_get_pncc_through_the_facade(gpu_lib, flame_model):
     faces = np.asarray(flame_model["f"]).astype(np.int64)
     subset = np.sort(rng.choice(V, 3000, replace=False))
     assets = MeshAssets(faces, np.asarray(flame_model["v_template"], dtype=np.float64), subset, subset[:500])
-    det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, seed=4, mesh_assets=assets)
+    det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, mesh_assets=assets)
     img = rng.integers(0, 256, (300, 320, 3), dtype=np.uint8)
     image, _ = det._preprocess(img)
     conf = float(det._process(image)[1][0, 6, 0])
@@ -884,7 +885,7 @@ def test_get_pncc_through_the_facade(gpu_lib, flame_model):
     assert got.shape == img.shape and np.array_equal(got, want)
     assert all(np.array_equal(h.vertices_3d[:, 2], -b[:, 2]) for h, b in zip(res.heads, before))
     with pytest.raises(FileNotFoundError):
-        HeadDetector("vgg_heads_m", 320, flame_model=flame_model, seed=4)(img, confidence_threshold=conf).get_pncc()
+        HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4)(img, confidence_threshold=conf).get_pncc()
 
 
 def test_overlap_mode_is_race_free_and_identical(gpu_lib, flame_model):
@@ -1046,6 +1047,74 @@ def test_bf16_mode_accuracy_vs_fp32_mode(gpu_lib, flame_model):
         assert r["log_scale_max_abs_err"] < 5e-2
         assert r["vertex_l2_metric_mean"] < 2e-3 and r["vertex_l2_metric_max"] < 2e-2  # metres in FLAME space (|v| ~ 0.2)
         assert r["kept_by_both_frac"] >= 0.6
+
+
+def test_c_only_create_and_detect(gpu_lib, flame_model, tmp_path):
+    """the pipeline from a pack file behind `vgh_create(config)` with no Python in the loop.  tests/c_abi_smoke.c is
+    compiled by plain gcc against include/vgh.h + libvgh.so, builds a context from a .vghpack written by head_detector_amd.pack and
+    runs one vgh_ctx_detect; its raw outputs must equal the Python engine's (same folded weights, same tile choices) bit for bit.
+    Also: the context created through ctypes, a missing pack and an oversize batch fail with messages (per-context error)."""
+    import subprocess
+
+    from conftest import ROOT
+    from head_detector_amd import _lib, arch, pack
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    variant, S, B = "vgg_heads_m", 320, 3
+    sd = arch.random_state_dict(variant, 13)
+    P = arch.build_program(variant, sd, S)
+    names = {i: "256x128_w64x64_k1_r3" for i, op in enumerate(P.ops) if op["kind"] == 1 and op["cout_pad"] % 128 == 0 and i % 2 == 0}
+    path = str(tmp_path / "m320.vghpack")
+    pack.write_pack(path, P, flame_model, names, B)
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    x.numpy().tofile(str(tmp_path / "images.u8"))
+    unpad = torch.tensor([[3.0 * i, 5.0, 1.0 + 0.25 * i] for i in range(B)], device=_dev())
+    # Python path with the same tile choices
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=B * 100)
+    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, use_tuning=False)
+    for i, n in names.items():
+        eng.set_cfg(i, eng.cfg_names().index(n))
+    _, sc, _ = eng.model(x.to(_dev()))
+    conf = float(sc[:, 6, 0].min())
+    det = eng.detect(x.to(_dev()), confidence_threshold=conf, flame=fl, unpad=unpad)
+    n_py = det.num_heads
+    assert n_py >= B
+    # C path
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.join(ROOT, "head_detector_amd")
+    cc = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi_smoke.c"),
+          "-o", exe, "-L" + libdir, "-lvgh", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cc, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe, path, str(tmp_path / "images.u8"), str(B), repr(conf), str(tmp_path / "c")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
+    rd = lambda name, dt: np.fromfile(str(tmp_path / f"c.{name}"), dtype=dt)  # noqa: E731
+    counts = rd("counts", np.int32)
+    assert np.array_equal(counts, det.counts.cpu().numpy()) and int(rd("n_heads", np.int32)[0]) == n_py
+    kk = eng.keep_k
+    cb, cs, cf = rd("boxes", np.float32).reshape(B, kk, 4), rd("scores", np.float32).reshape(B, kk), rd("flame", np.float32).reshape(B, kk, 413)
+    for i in range(B):
+        n = int(counts[i])
+        assert np.array_equal(cb[i, :n], det.boxes[i, :n].cpu().numpy()) and np.array_equal(cs[i, :n], det.scores[i, :n].cpu().numpy())
+        assert np.array_equal(cf[i, :n], det.flame_params[i, :n].cpu().numpy())
+    V = fl.num_vertices
+    assert np.array_equal(rd("head_image", np.int32)[:n_py], det.head_image.cpu().numpy().astype(np.int32))
+    assert np.array_equal(rd("proj", np.float32).reshape(-1, V, 3)[:n_py], det.vertices_3d.cpu().numpy())
+    assert np.array_equal(rd("rpy", np.float32).reshape(-1, 3)[:n_py], det.head_pose.cpu().numpy())
+    eng.close()
+    # the same context through ctypes + per-context error text
+    cfg = _lib.Config(device=torch.cuda.current_device(), pack_path=path.encode(), max_batch=B)
+    h = C.c_void_p()
+    _lib.check(gpu_lib.vgh_create(C.byref(cfg), C.byref(h)))
+    info = _lib.CtxInfo()
+    _lib.check(gpu_lib.vgh_ctx_get_info(h, C.byref(info)))
+    assert (info.variant.decode(), info.image_size, info.num_vertices, info.keep_top_k, info.shape_live) == (variant, S, V, 100, 64)
+    o = _lib.DetectOut()
+    assert gpu_lib.vgh_ctx_detect(h, x.to(_dev()).data_ptr(), _lib.VGH_IMG_U8_NHWC, B + 5, 0.5, 0.5, C.byref(o), None) != 0
+    assert b"max_batch" in gpu_lib.vgh_ctx_last_error(h) or b"B=" in gpu_lib.vgh_ctx_last_error(h)
+    gpu_lib.vgh_destroy(h)
+    bad = _lib.Config(device=0, pack_path=str(tmp_path / "images.u8").encode(), max_batch=1)
+    assert gpu_lib.vgh_create(C.byref(bad), C.byref(h)) != 0 and b"not a readable" in gpu_lib.vgh_last_error()
 
 
 def test_flame_decode_large_n_equals_chunks(gpu_lib, flame_model):

@@ -281,3 +281,62 @@ def test_save_meshes_matches_reference_obj_bytes(tmp_path):
         assert open(tmp_path / "meshes" / n, "rb").read() == g[f"obj{i}"].tobytes()
     with pytest.raises(ValueError):
         PredictionResult(np.zeros((4, 4, 3), dtype=np.uint8), heads).save_meshes(str(tmp_path / "none"))
+
+
+def test_weight_manifest_diff_names_every_mismatch():
+    """N1 / ADVICE: a released blob whose parameters are renamed or re-shaped must fail with the whole difference up front."""
+    from head_detector_amd.detector import weight_manifest_diff
+
+    sd = arch.random_state_dict("vgg_heads_m", 3)
+    assert not any(weight_manifest_diff("vgg_heads_m", sd).values())
+    sd["backbone.stem.conv.post_bn.num_batches_tracked"] = np.zeros(())  # bookkeeping buffers of a real archive are ignored
+    assert not any(weight_manifest_diff("vgg_heads_m", sd).values())
+    bad = dict(sd)
+    bad["backbone.stage1.downsample.rbr_reparam.weight"] = np.zeros((96, 48, 3, 3), np.float32)  # fused twin kept by SG: ignored
+    del bad["heads.head1.cls_pred.bias"]
+    bad["heads.head2.reg_pred.weight"] = np.zeros((68, 5, 1, 1), np.float32)
+    bad["neck.neck9.extra"] = np.zeros(3, np.float32)
+    d = weight_manifest_diff("vgg_heads_m", bad)
+    assert d["missing"] == ["heads.head1.cls_pred.bias"] and d["unexpected"] == ["neck.neck9.extra"] and len(d["shape"]) == 1 and "heads.head2.reg_pred.weight" in d["shape"][0]
+    assert len(weight_manifest_diff("vgg_heads_l", sd)["shape"]) > 10  # an M archive offered as L
+
+
+def test_pack_file_round_trip(tmp_path):
+    """.vghpack (head_detector_amd/pack.py): header fields, section sizes and the per-op tile names survive a write/read cycle; the
+    op / buffer records use the C layout of include/vgh.h (what csrc/ctx.hip freads)."""
+    import ctypes as C
+
+    from head_detector_amd import pack
+    from head_detector_amd.synthetic import synthetic_flame_model
+
+    P = arch.build_program("vgg_heads_m", arch.random_state_dict("vgg_heads_m", 7), 128)
+    assert pack.tile_names_for(P, 32, 2) == {}  # the measured table holds 640 / 1280 geometries only
+    P640 = arch.build_program("vgg_heads_m", arch.random_state_dict("vgg_heads_m", 7), 640)
+    n640 = pack.tile_names_for(P640, 32, 2)
+    assert len(n640) > 100 and all(P640.ops[i]["kind"] == 1 for i in n640)
+    names = {i: ("256x128_w64x64_k1_r3" if i % 2 else "q16x16x64_n4x1") for i, op in enumerate(P.ops) if op["kind"] == 1 and i % 3}
+    fm = synthetic_flame_model(seed=3)
+    path = str(tmp_path / "m.vghpack")
+    n = pack.write_pack(path, P, fm, names, 32)
+    h = pack.read_header(path)
+    assert (h["variant"], h["image_size"], h["n_ops"], h["n_bufs"], h["n_levels"], h["shape_c"], h["expr_c"], h["has_flame"], h["tune_batch"]) == \
+        ("vgg_heads_m", 128, len(P.ops), len(P.bufs), 3, 64, 32, 1, 32)
+    assert (h["V"], h["NB"], h["NJ"]) == (5023, 400, 5) and abs(h["flops_per_image"] - P.flops) < 1
+    assert C.sizeof(_lib.OpDesc) == 96 and C.sizeof(_lib.BufDesc) == 16
+    w, b = P.arrays()
+    flame_bytes = 4 * (5023 * 3 + 5023 * 3 * 400 + 36 * 3 * 5023 + 5 * 5023 + 5 + 5023 * 5) + 4 * 3 * h["F"]
+    assert n == 128 + 16 * len(P.bufs) + (96 + 32) * len(P.ops) + 20 * 3 + 4 * (w.size + b.size) + flame_bytes
+    raw = open(path, "rb").read()
+    off = 128 + 16 * len(P.bufs)
+    ops = (_lib.OpDesc * len(P.ops)).from_buffer_copy(raw[off : off + 96 * len(P.ops)])
+    assert [o.cout_pad for o in ops] == [op["cout_pad"] for op in P.ops] and [o.w_off for o in ops] == [op["w_off"] for op in P.ops]
+    tn = np.frombuffer(raw[off + 96 * len(P.ops) : off + 128 * len(P.ops)], dtype="S32")
+    assert {i: t.decode() for i, t in enumerate(tn) if t} == names
+    woff = off + 128 * len(P.ops) + 60
+    assert np.array_equal(np.frombuffer(raw[woff : woff + 4 * w.size], dtype=np.float32), w)
+    with pytest.raises(ValueError):
+        open(tmp_path / "junk", "wb").write(b"x" * 200)
+        pack.read_header(str(tmp_path / "junk"))
+    # CLI
+    pack.main(["vgg_heads_m", "seed:7", "none", str(tmp_path / "cli.vghpack"), "--image-size", "128", "--batch", "32"])
+    assert pack.read_header(str(tmp_path / "cli.vghpack"))["has_flame"] == 0
