@@ -69,37 +69,40 @@ struct PrepArgs {
     float* rpy_out;  // [n,3] (roll, pitch, yaw) degrees or null: calculate_rpy, utils.py:146-151
 };
 
-// one wave per head
-__global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
-    __shared__ float s_beta[1024];
-    __shared__ float s_J[MAXJ * 3];
-    __shared__ float s_R[MAXJ * 9];
-    __shared__ float s_pose[MAXJ * 3];
-    __shared__ float s_tail[16];   // params[400..412]: jaw 3 | rot6 | trans 3 | scale 1
-    __shared__ int s_par[MAXJ];
-    __shared__ float s_unpad[3];
-    __shared__ float s_hp[HP_SIZE];  // the head pack is assembled here and leaves as one coalesced store
-    const int h = blockIdx.x, lane = threadIdx.x;
-    if (a.n_dev && h >= *a.n_dev) return;
+// Per-wave LDS scratch of the per-head prologue
+struct PrepScratch {
+    float beta[1024];
+    float J[MAXJ * 3];
+    float R[MAXJ * 9];
+    float pose[MAXJ * 3];
+    float tail[16];  // params[400..412]: jaw 3 | rot6 | trans 3 | scale 1
+    int par[MAXJ];
+    float unpad[4];
+    float Rg[MAXJ * 9], tg[MAXJ * 3];  // global rotations / translations of the kinematic chain
+};
+
+// Everything the vertex kernel needs for head h, computed by ONE wave: blend coefficients [betas | pose features] -> coef[k * cstride],
+// the 5 skinning transforms + 6D rotation + clamp(scale) + translation + un-pad triple -> hp[HP_SIZE] (LDS).  `emit`: also write
+// the caller-visible per-head outputs (rotation matrix, joints, roll/pitch/yaw).  The arithmetic is the same wherever it runs
+// (stand-alone prologue kernel for large batches, or the vertex kernel's own prologue for small ones).
+__device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, PrepScratch& S, float* coef, int cstride, float* hp, bool emit) {
+// every rounding is spelled out (explicit fmaf where a fused multiply-add is meant): the function is inlined into several kernels and
+// must not be contracted differently from one to the next, or a head's vertices would depend on the batch it is decoded in
+#pragma clang fp contract(off)
     const int NB = a.NB, NJ = a.NJ;
-    float* coef = a.coef + (int64_t)h * a.Kp;
-    float* const hpg = a.headpack + (int64_t)h * HP_SIZE;
-    float* const hp = s_hp;
-    for (int e = lane; e < HP_SIZE; e += 64) s_hp[e] = 0.0f;
+    for (int e = lane; e < HP_SIZE; e += 64) hp[e] = 0.0f;
     const int64_t prow = a.head_row ? a.head_row[h] : h;
     const int64_t urow = a.head_image ? a.head_image[h] : h;
     const float* p = a.params ? a.params + prow * VGH_NUM_FLAME_PARAMS : nullptr;
     // betas = [shape(300) | expression(100)]  (flame.py:132-140; FLAME_CONSTS widths make the padding empty)
     for (int l = lane; l < NB; l += 64) {
         const float v = p ? p[l] : a.betas[(int64_t)h * NB + l];
-        s_beta[l] = v;
-        coef[l] = v;
+        S.beta[l] = v;
+        coef[(int64_t)l * cstride] = v;
     }
-    // everything the serial tail needs comes in with this first wave of loads (it used to fetch these one dependent global
-    // load at a time from lane 0: a dozen L2 round trips)
-    if (p && lane < 13) s_tail[lane] = p[400 + lane];
-    if (lane < NJ) s_par[lane] = a.parents[lane];
-    if (lane < 3) s_unpad[lane] = a.unpad ? a.unpad[urow * 3 + lane] : (lane == 2 ? 1.0f : 0.0f);
+    if (p && lane < 13) S.tail[lane] = p[400 + lane];
+    if (lane < NJ) S.par[lane] = a.parents[lane];
+    if (lane < 3) S.unpad[lane] = a.unpad ? a.unpad[urow * 3 + lane] : (lane == 2 ? 1.0f : 0.0f);
     // full_pose = [global 0 | neck 0 | jaw | eyes 0]  (flame.py:141-148)
     if (lane < NJ * 3) {
         float v;
@@ -107,18 +110,18 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
             v = (lane >= 6 && lane < 9) ? p[400 + lane - 6] : 0.0f;
         else
             v = a.pose[(int64_t)h * NJ * 3 + lane];
-        s_pose[lane] = v;
+        S.pose[lane] = v;
     }
-    __syncthreads();
-    // joints: J = J0 + JS beta.  All 3*NJ dot products advance together (their loads are independent and stay in flight; one
-    // output at a time exposed a full memory round trip per output: ~40 us per launch, all latency).  Per output the
-    // arithmetic is unchanged: lane-strided fmaf chain in ascending l, then the xor butterfly.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // joints: J = J0 + JS beta.  All 3*NJ dot products advance together (independent loads in flight); per output a lane-strided
+    // fmaf chain in ascending l, then the xor butterfly.
     {
         float s[MAXJ * 3];
 #pragma unroll
         for (int o = 0; o < MAXJ * 3; ++o) s[o] = 0.0f;
         for (int l = lane; l < NB; l += 64) {
-            const float bl = s_beta[l];
+            const float bl = S.beta[l];
 #pragma unroll
             for (int o = 0; o < MAXJ * 3; ++o)
                 if (o < NJ * 3) s[o] = fmaf(a.JS[(int64_t)o * NB + l], bl, s[o]);
@@ -129,13 +132,13 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
                 float v = s[o];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if (lane == 0) s_J[o] = a.J0[o] + v;
+                if (lane == 0) S.J[o] = a.J0[o] + v;
             }
         }
     }
     // smplx batch_rodrigues per joint
     if (lane < NJ) {
-        const float rx0 = s_pose[lane * 3 + 0], ry0 = s_pose[lane * 3 + 1], rz0 = s_pose[lane * 3 + 2];
+        const float rx0 = S.pose[lane * 3 + 0], ry0 = S.pose[lane * 3 + 1], rz0 = S.pose[lane * 3 + 2];
         const float ex = rx0 + 1e-8f, ey = ry0 + 1e-8f, ez = rz0 + 1e-8f;
         const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
         const float rx = rx0 / angle, ry = ry0 / angle, rz = rz0 / angle;
@@ -147,43 +150,51 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) KK[r * 3 + c] = K[r * 3 + 0] * K[0 * 3 + c] + K[r * 3 + 1] * K[1 * 3 + c] + K[r * 3 + 2] * K[2 * 3 + c];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) s_R[lane * 9 + e] = ((e % 4 == 0) ? 1.0f : 0.0f) + sn * K[e] + (1.0f - cs) * KK[e];
+        for (int e = 0; e < 9; ++e) S.R[lane * 9 + e] = ((e % 4 == 0) ? 1.0f : 0.0f) + sn * K[e] + (1.0f - cs) * KK[e];
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     // pose_feature = (rot_mats[:,1:] - I).view(-1)
     const int NP = 9 * (NJ - 1);
-    if (lane < NP) coef[NB + lane] = s_R[9 + lane] - ((lane % 9) % 4 == 0 ? 1.0f : 0.0f);
-    if (lane >= NP && NB + lane < a.Kp) coef[NB + lane] = 0.0f;
-    if (lane == 0) {
-        // batch_rigid_transform: chain along parents, A_j = [Rg_j | tg_j - Rg_j J_j]
-        float Rg[MAXJ][9], tg[MAXJ][3];
-        for (int j = 0; j < NJ; ++j) {
-            const int par = s_par[j];
-            float rel[3];
-            for (int c = 0; c < 3; ++c) rel[c] = s_J[j * 3 + c] - (j > 0 ? s_J[par * 3 + c] : 0.0f);
-            if (j == 0) {
-                for (int e = 0; e < 9; ++e) Rg[0][e] = s_R[e];
-                for (int c = 0; c < 3; ++c) tg[0][c] = rel[c];
-            } else {
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c)
-                        Rg[j][r * 3 + c] = Rg[par][r * 3 + 0] * s_R[j * 9 + 0 * 3 + c] + Rg[par][r * 3 + 1] * s_R[j * 9 + 1 * 3 + c] +
-                                           Rg[par][r * 3 + 2] * s_R[j * 9 + 2 * 3 + c];
-                    tg[j][r] = Rg[par][r * 3 + 0] * rel[0] + Rg[par][r * 3 + 1] * rel[1] + Rg[par][r * 3 + 2] * rel[2] + tg[par][r];
-                }
-            }
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c) hp[HP_A + j * 12 + r * 4 + c] = Rg[j][r * 3 + c];
-                hp[HP_A + j * 12 + r * 4 + 3] =
-                    tg[j][r] - (Rg[j][r * 3 + 0] * s_J[j * 3 + 0] + Rg[j][r * 3 + 1] * s_J[j * 3 + 1] + Rg[j][r * 3 + 2] * s_J[j * 3 + 2]);
-                if (a.joints_out) a.joints_out[((int64_t)h * NJ + j) * 3 + r] = tg[j][r];
-            }
+    if (lane < NP) coef[(int64_t)(NB + lane) * cstride] = S.R[9 + lane] - ((lane % 9) % 4 == 0 ? 1.0f : 0.0f);
+    if (lane >= NP && NB + lane < a.Kp) coef[(int64_t)(NB + lane) * cstride] = 0.0f;
+    // batch_rigid_transform: chain along parents, A_j = [Rg_j | tg_j - Rg_j J_j].  Twelve lanes own one entry each (lanes 0-8: the
+    // 3x3 of Rg_j, lanes 9-11: tg_j), the chain state lives in LDS (a per-lane array indexed by the runtime `parents` would sit in
+    // scratch memory: ~100 dependent global round trips, the bulk of the old single-lane prologue's ~45 us)
+    for (int j = 0; j < NJ; ++j) {
+        const int par = S.par[j];
+        float rel[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rel[c] = S.J[j * 3 + c] - (j > 0 ? S.J[par * 3 + c] : 0.0f);
+        if (lane < 9) {
+            const int r = lane / 3, c = lane - r * 3;
+            S.Rg[j * 9 + lane] = (j == 0) ? S.R[lane]
+                                          : S.Rg[par * 9 + r * 3 + 0] * S.R[j * 9 + 0 * 3 + c] + S.Rg[par * 9 + r * 3 + 1] * S.R[j * 9 + 1 * 3 + c] +
+                                                S.Rg[par * 9 + r * 3 + 2] * S.R[j * 9 + 2 * 3 + c];
+        } else if (lane < 12) {
+            const int r = lane - 9;
+            S.tg[j * 3 + r] = (j == 0) ? rel[r]
+                                       : S.Rg[par * 9 + r * 3 + 0] * rel[0] + S.Rg[par * 9 + r * 3 + 1] * rel[1] + S.Rg[par * 9 + r * 3 + 2] * rel[2] + S.tg[par * 3 + r];
         }
-        // rot_mat_from_6dof (utils.py:120-128): F.normalize eps = 1e-12, columns (b1, b2, b3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int e = lane; e < 12 * NJ; e += 64) {
+        const int j = e / 12, q = e - j * 12, r = q >> 2, c = q & 3;
+        float v;
+        if (c < 3)
+            v = S.Rg[j * 9 + r * 3 + c];
+        else
+            v = S.tg[j * 3 + r] - (S.Rg[j * 9 + r * 3 + 0] * S.J[j * 3 + 0] + S.Rg[j * 9 + r * 3 + 1] * S.J[j * 3 + 1] + S.Rg[j * 9 + r * 3 + 2] * S.J[j * 3 + 2]);
+        hp[HP_A + e] = v;
+        if (emit && a.joints_out && c == 3) a.joints_out[((int64_t)h * NJ + j) * 3 + r] = S.tg[j * 3 + r];
+    }
+    if (lane == 1) {
+        // rot_mat_from_6dof (utils.py:120-128): F.normalize eps = 1e-12, columns (b1, b2, b3) -- on a second lane, next to the chain
         float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         float sc = 1.0f, t[3] = {0, 0, 0};
         if (p) {
-            const float* v = s_tail + 3;
+            const float* v = S.tail + 3;
             float b1[3], b3[3], b2[3];
             float n1 = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
             for (int c = 0; c < 3; ++c) b1[c] = v[c] / n1;
@@ -198,48 +209,61 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
                 R[r * 3 + 1] = b2[r];
                 R[r * 3 + 2] = b3[r];
             }
-            sc = fmaxf(s_tail[12], 1e-8f);  // torch.clamp(scale, 1e-8)
-            for (int c = 0; c < 3; ++c) t[c] = s_tail[9 + c];
+            sc = fmaxf(S.tail[12], 1e-8f);  // torch.clamp(scale, 1e-8)
+            for (int c = 0; c < 3; ++c) t[c] = S.tail[9 + c];
         }
         for (int e = 0; e < 9; ++e) {
             hp[HP_R + e] = R[e];
-            if (a.rot_out) a.rot_out[(int64_t)h * 9 + e] = R[e];
+            if (emit && a.rot_out) a.rot_out[(int64_t)h * 9 + e] = R[e];
         }
         hp[HP_S] = sc;
         for (int c = 0; c < 3; ++c) hp[HP_T + c] = t[c];
-        hp[HP_U + 0] = s_unpad[0];
-        hp[HP_U + 1] = s_unpad[1];
-        hp[HP_U + 2] = s_unpad[2];
-        if (a.rpy_out) {
+        hp[HP_U + 0] = S.unpad[0];
+        hp[HP_U + 1] = S.unpad[1];
+        hp[HP_U + 2] = S.unpad[2];
+        if (emit && a.rpy_out) {
             // calculate_rpy (utils.py:146-151): Rotation.from_matrix(R^T).as_euler("xyz", degrees) in closed form.
             // M = R^T = Rz(c) Ry(b) Rx(a) (extrinsic xyz): b = -asin(M20), a = atan2(M21, M22), c = atan2(M10, M00);
-            // at gimbal lock (|M20| = 1) scipy sets the third angle to 0 and folds it into the first.
-            const double m00 = R[0], m10 = R[1], m20 = R[2], m21 = R[5], m22 = R[8], m01 = R[3], m11 = R[4];
-            const double RAD = 57.29577951308232;
-            double ea, eb, ec;
-            const double cb = sqrt(m00 * m00 + m10 * m10);
-            eb = atan2(-m20, cb);
-            if (cb > 1e-7) {
-                ea = atan2(m21, m22);
-                ec = atan2(m10, m00);
+            // at gimbal lock (|M20| = 1) scipy sets the third angle to 0 and folds it into the first.  fp32 throughout: R itself
+            // is fp32, and atan2f stays within ~1e-5 degrees of the double-precision evaluation (which, being software fp64 atan2 on
+            // a single lane, took ~40 us per launch)
+            const float m00 = R[0], m10 = R[1], m20 = R[2], m21 = R[5], m22 = R[8], m01 = R[3], m11 = R[4];
+            const float RAD = 57.29577951308232f;
+            float ea, eb, ec;
+            const float cb = sqrtf(m00 * m00 + m10 * m10);
+            eb = atan2f(-m20, cb);
+            if (cb > 1e-6f) {
+                ea = atan2f(m21, m22);
+                ec = atan2f(m10, m00);
             } else {
-                ec = 0.0;
-                ea = (m20 < 0) ? atan2(m01, m11) : atan2(-m01, m11);
+                ec = 0.0f;
+                ea = (m20 < 0) ? atan2f(m01, m11) : atan2f(-m01, m11);
             }
-            double ang[3] = {ec * RAD, ea * RAD - 180.0, eb * RAD};  // roll = a[2], pitch = a[0] - 180, yaw = a[1]
+            float ang[3] = {ec * RAD, ea * RAD - 180.0f, eb * RAD};  // roll = a[2], pitch = a[0] - 180, yaw = a[1]
             for (int c = 0; c < 3; ++c) {
-                double g = ang[c];  // limit_angle (utils.py:131-143)
-                if (g < -180.0) {
-                    const int q = (int)(g / 180.0);                      // int() truncates, // floors (q <= -1 here)
+                float g = ang[c];  // limit_angle (utils.py:131-143)
+                if (g < -180.0f) {
+                    const int q = (int)(g / 180.0f);                     // int() truncates, // floors (q <= -1 here)
                     const int fl = (q >= 0) ? q / 2 : -((-q + 1) / 2);
-                    g += -2.0 * (double)fl * 180.0;
+                    g += -2.0f * (float)fl * 180.0f;
                 }
-                if (g > 180.0) g -= 2.0 * (double)((((int)(g / 180.0)) + 1) / 2) * 180.0;
-                a.rpy_out[(int64_t)h * 3 + c] = (float)g;
+                if (g > 180.0f) g -= 2.0f * (float)((((int)(g / 180.0f)) + 1) / 2) * 180.0f;
+                a.rpy_out[(int64_t)h * 3 + c] = g;
             }
         }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// stand-alone prologue (large batches, and the detector's capacity-sized launches): one wave per head
+__global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
+    __shared__ PrepScratch S;
+    __shared__ float s_hp[HP_SIZE];  // the head pack is assembled here and leaves as one coalesced store
+    const int h = blockIdx.x, lane = threadIdx.x;
+    if (a.n_dev && h >= *a.n_dev) return;
+    prep_head(a, h, lane, S, a.coef + (int64_t)h * a.Kp, 1, s_hp, true);
+    float* const hpg = a.headpack + (int64_t)h * HP_SIZE;
     for (int e = lane; e < HP_SIZE; e += 64) hpg[e] = s_hp[e];
 }
 
@@ -258,11 +282,16 @@ struct VertArgs {
     int do_unpad;
 };
 
-// BT = threads per block: 256 normally; 64 when the grid would otherwise be a handful of blocks (n <= ~50 heads), so that the
-// basis stream is pulled by 4x as many CUs.  The per-lane arithmetic is identical in every (HT, BT) variant.
-template <int HT, int BT>
-__global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a) {
-    constexpr int UNR = HT >= 8 ? 4 : 8;
+// BT = threads per block, VPL = vertices per lane (4: 16-byte basis loads; 1: dword loads, 4x the blocks -- the basis stream of a
+// handful of heads is pure latency, so it is spread over as many CUs as there are vertices / 64), HT = heads per block (every basis
+// value fetched feeds HT FMAs).  FUSED: the block computes the prologue of its own HT heads (prep_head, one wave per head) instead
+// of reading what flame_prep_kernel left in HBM: one launch, no dependent kernel boundary.  The per-vertex arithmetic (fmaf chain in
+// ascending k, skinning, rigid, un-pad) is identical in every variant, so results do not depend on the batch a head is decoded in.
+template <int HT, int BT, int VPL, bool FUSED>
+__global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a, PrepArgs pa) {
+#pragma clang fp contract(off)  // same reason as prep_head: identical roundings in every (HT, BT, VPL, FUSED) instantiation
+    constexpr int UNR = VPL == 1 ? 16 : (HT >= 8 ? 4 : 8);
+    constexpr int NWV = BT / 64;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* s_coef = fsm;                   // [Kp][HT]
     float* s_hp = fsm + (size_t)a.Kp * HT; // [HT][HP_SIZE]
@@ -272,47 +301,60 @@ __global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a) {
         a.n = min(a.n, *a.n_dev);
         if (h0 >= a.n) return;
     }
-    for (int e = tid; e < a.Kp * HT; e += BT) {
-        const int k = e / HT, hh = e - k * HT;
-        s_coef[e] = (h0 + hh < a.n) ? a.coef[(int64_t)(h0 + hh) * a.Kp + k] : 0.0f;
-    }
-    for (int e = tid; e < HT * HP_SIZE; e += BT) {
-        const int hh = e / HP_SIZE;
-        s_hp[e] = (h0 + hh < a.n) ? a.headpack[(int64_t)(h0 + hh) * HP_SIZE + (e - hh * HP_SIZE)] : 0.0f;
+    if constexpr (FUSED) {
+        PrepScratch* scr = (PrepScratch*)(s_hp + HT * HP_SIZE);  // one per wave
+        const int wv = tid >> 6, lane = tid & 63;
+        for (int hh = wv; hh < HT; hh += NWV) {
+            if (h0 + hh < a.n) {
+                prep_head(pa, h0 + hh, lane, scr[wv], s_coef + hh, HT, s_hp + hh * HP_SIZE, blockIdx.x == 0);
+            } else {
+                for (int k = lane; k < a.Kp; k += 64) s_coef[k * HT + hh] = 0.0f;
+                for (int e = lane; e < HP_SIZE; e += 64) s_hp[hh * HP_SIZE + e] = 0.0f;
+            }
+        }
+    } else {
+        for (int e = tid; e < a.Kp * HT; e += BT) {
+            const int k = e / HT, hh = e - k * HT;
+            s_coef[e] = (h0 + hh < a.n) ? a.coef[(int64_t)(h0 + hh) * a.Kp + k] : 0.0f;
+        }
+        for (int e = tid; e < HT * HP_SIZE; e += BT) {
+            const int hh = e / HP_SIZE;
+            s_hp[e] = (h0 + hh < a.n) ? a.headpack[(int64_t)(h0 + hh) * HP_SIZE + (e - hh * HP_SIZE)] : 0.0f;
+        }
     }
     __syncthreads();
-    const int v0 = (blockIdx.x * BT + tid) * 4;
+    const int v0 = (blockIdx.x * BT + tid) * VPL;
     if (v0 >= a.Vp) return;
     const int64_t plane = a.Vp;
-    f32x4_t acc[HT][3];
+    typedef float vecf __attribute__((ext_vector_type(VPL == 1 ? 1 : 4)));
+    float acc[HT][3][VPL];
     {
-        const f32x4_t tx = *(const f32x4_t*)(a.vt + 0 * plane + v0);
-        const f32x4_t ty = *(const f32x4_t*)(a.vt + 1 * plane + v0);
-        const f32x4_t tz = *(const f32x4_t*)(a.vt + 2 * plane + v0);
 #pragma unroll
-        for (int hh = 0; hh < HT; ++hh) {
-            acc[hh][0] = tx;
-            acc[hh][1] = ty;
-            acc[hh][2] = tz;
+        for (int c = 0; c < 3; ++c) {
+            const vecf tv = *(const vecf*)(a.vt + c * plane + v0);
+#pragma unroll
+            for (int hh = 0; hh < HT; ++hh)
+#pragma unroll
+                for (int e = 0; e < VPL; ++e) acc[hh][c][e] = ((const float*)&tv)[e];
         }
     }
     auto run = [&](int kb, int ke) {
         const float* bp = a.basis + (int64_t)kb * 3 * plane + v0;
-        // the basis stream is pure latency at small n (one block per 1024 vertices): keep UNR k-planes (3 x 16 B each) in flight
+        // the basis stream is pure latency at small n: keep UNR k-planes (3 loads each) in flight
 #pragma unroll UNR
         for (int k = kb; k < ke; ++k, bp += 3 * plane) {
-            const f32x4_t bx = *(const f32x4_t*)(bp);
-            const f32x4_t by = *(const f32x4_t*)(bp + plane);
-            const f32x4_t bz = *(const f32x4_t*)(bp + 2 * plane);
+            const vecf bx = *(const vecf*)(bp);
+            const vecf by = *(const vecf*)(bp + plane);
+            const vecf bz = *(const vecf*)(bp + 2 * plane);
             const float* ck = s_coef + k * HT;
 #pragma unroll
             for (int hh = 0; hh < HT; ++hh) {
                 const float c = ck[hh];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[hh][0][e] = fmaf(c, bx[e], acc[hh][0][e]);
-                    acc[hh][1][e] = fmaf(c, by[e], acc[hh][1][e]);
-                    acc[hh][2][e] = fmaf(c, bz[e], acc[hh][2][e]);
+                for (int e = 0; e < VPL; ++e) {
+                    acc[hh][0][e] = fmaf(c, ((const float*)&bx)[e], acc[hh][0][e]);
+                    acc[hh][1][e] = fmaf(c, ((const float*)&by)[e], acc[hh][1][e]);
+                    acc[hh][2][e] = fmaf(c, ((const float*)&bz)[e], acc[hh][2][e]);
                 }
             }
         }
@@ -320,18 +362,22 @@ __global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a) {
     run(a.r0_begin, a.r0_end);
     run(a.r1_begin, a.r1_end);
     run(a.r2_begin, a.r2_end);
-    // skinning weights for the 4 vertices
-    f32x4_t wj[MAXJ];
+    // skinning weights for this lane's vertices
+    float wj[MAXJ][VPL];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j)
-        if (j < a.NJ) wj[j] = *(const f32x4_t*)(a.wts + (int64_t)j * plane + v0);
+        if (j < a.NJ) {
+            const vecf wv = *(const vecf*)(a.wts + (int64_t)j * plane + v0);
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) wj[j][e] = ((const float*)&wv)[e];
+        }
 #pragma unroll
     for (int hh = 0; hh < HT; ++hh) {
         if (h0 + hh >= a.n) break;
         const float* hp = s_hp + hh * HP_SIZE;
-        float outv[12], outp[12];
+        float outv[3 * VPL], outp[3 * VPL];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < VPL; ++e) {
             float T[12];
 #pragma unroll
             for (int q = 0; q < 12; ++q) T[q] = 0.0f;
@@ -363,19 +409,19 @@ __global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a) {
             outp[e * 3 + 2] = qz;
         }
         const int64_t obase = ((int64_t)(h0 + hh) * a.V + v0) * 3;
-        const int nv = min(4, a.V - v0);
+        const int nv = min(VPL, a.V - v0);
         if (a.verts) {
-            if (nv == 4 && (obase & 3) == 0) {
+            if (VPL == 4 && nv == 4 && (obase & 3) == 0) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) *(f32x4_t*)(a.verts + obase + q * 4) = f32x4_t{outv[q * 4], outv[q * 4 + 1], outv[q * 4 + 2], outv[q * 4 + 3]};
+                for (int q = 0; q < 3; ++q) *(f32x4_t*)(a.verts + obase + q * 4) = f32x4_t{outv[(q * 4) % (3 * VPL)], outv[(q * 4 + 1) % (3 * VPL)], outv[(q * 4 + 2) % (3 * VPL)], outv[(q * 4 + 3) % (3 * VPL)]};
             } else {
                 for (int q = 0; q < nv * 3; ++q) a.verts[obase + q] = outv[q];
             }
         }
         if (a.proj) {
-            if (nv == 4 && (obase & 3) == 0) {
+            if (VPL == 4 && nv == 4 && (obase & 3) == 0) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) *(f32x4_t*)(a.proj + obase + q * 4) = f32x4_t{outp[q * 4], outp[q * 4 + 1], outp[q * 4 + 2], outp[q * 4 + 3]};
+                for (int q = 0; q < 3; ++q) *(f32x4_t*)(a.proj + obase + q * 4) = f32x4_t{outp[(q * 4) % (3 * VPL)], outp[(q * 4 + 1) % (3 * VPL)], outp[(q * 4 + 2) % (3 * VPL)], outp[(q * 4 + 3) % (3 * VPL)]};
             } else {
                 for (int q = 0; q < nv * 3; ++q) a.proj[obase + q] = outp[q];
             }
@@ -383,16 +429,12 @@ __global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a) {
     }
 }
 
-template <int HT>
-int launch_vertex(const VertArgs& va, hipStream_t st) {
-    const size_t lds = ((size_t)va.Kp * HT + (size_t)HT * HP_SIZE) * sizeof(float);
-    const int quads = va.Vp / 4;
+template <int HT, int BT, int VPL, bool FUSED>
+int launch_vertex_cfg(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
+    const size_t lds = ((size_t)va.Kp * HT + (size_t)HT * HP_SIZE) * sizeof(float) + (FUSED ? (BT / 64) * sizeof(PrepScratch) : 0);
+    const int lanes = (va.Vp + VPL - 1) / VPL;
     const int groups = (va.n + HT - 1) / HT;
-    if (((quads + 255) / 256) * groups < 32) {  // a handful of blocks (n <= ~24 heads): quarter-size blocks put 4x as many CUs on the basis stream
-        hipLaunchKernelGGL((flame_vertex_kernel<HT, 64>), dim3((quads + 63) / 64, groups), dim3(64), lds, st, va);
-    } else {
-        hipLaunchKernelGGL((flame_vertex_kernel<HT, 256>), dim3((quads + 255) / 256, groups), dim3(256), lds, st, va);
-    }
+    hipLaunchKernelGGL((flame_vertex_kernel<HT, BT, VPL, FUSED>), dim3((lanes + BT - 1) / BT, groups), dim3(BT), lds, st, va, pa);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -412,8 +454,11 @@ int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int e
         if (pa.unpad) pa.unpad += (int64_t)done * 3;
         if (pa.rot_out) pa.rot_out += (int64_t)done * 9;
         if (pa.joints_out) pa.joints_out += (int64_t)done * f->NJ * 3;
-        hipLaunchKernelGGL(flame_prep_kernel, dim3(m), dim3(64), 0, st, pa);
-        VGH_HIP(hipGetLastError());
+        const bool fused = !pa.n_dev && m <= 256;  // small direct batches: the vertex kernel computes its own heads' prologue (one launch)
+        if (!fused || (!verts && !proj)) {
+            hipLaunchKernelGGL(flame_prep_kernel, dim3(m), dim3(64), 0, st, pa);
+            VGH_HIP(hipGetLastError());
+        }
         if (!verts && !proj) continue;
         VertArgs va;
         va.basis = f->basis;
@@ -445,12 +490,20 @@ int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int e
         va.z_offset = detector_mode ? 0.05f : 0.0f;  // MESH_OFFSET_Z, flame.py:34,164
         va.do_unpad = pa.unpad != nullptr;
         int rc;
-        if (m <= 2 && !pa.n_dev)
-            rc = launch_vertex<1>(va, st);
-        else if (m <= 24)
-            rc = launch_vertex<4>(va, st);
-        else
-            rc = launch_vertex<8>(va, st);
+        if (fused) {
+            if (m <= 4)
+                rc = launch_vertex_cfg<1, 64, 1, true>(va, pa, st);   // 79 blocks per head: the whole chip pulls the basis of one head
+            else if (m <= 32)
+                rc = launch_vertex_cfg<4, 64, 1, true>(va, pa, st);   // 79 x ceil(m/4) blocks
+            else if (m <= 96)
+                rc = launch_vertex_cfg<4, 64, 4, true>(va, pa, st);   // 20 x ceil(m/4)
+            else
+                rc = launch_vertex_cfg<8, 256, 4, true>(va, pa, st);  // 5 x ceil(m/8)
+        } else if (m <= 24) {
+            rc = launch_vertex_cfg<4, 64, 4, false>(va, pa, st);
+        } else {
+            rc = launch_vertex_cfg<8, 256, 4, false>(va, pa, st);
+        }
         if (rc) return rc;
     }
     return VGH_OK;

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
+from head_detector_amd import _lib  # noqa: E402
 from head_detector_amd.flame import FLAMELayer  # noqa: E402
 from head_detector_amd.synthetic import synthetic_flame_model  # noqa: E402
 
@@ -16,6 +17,7 @@ from head_detector_amd.synthetic import synthetic_flame_model  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     fl = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=8192)
+    lib = _lib.load()
     rows = []
     for live, (sl, el) in (("M heads 64+32", (64, 32)), ("L heads 128+64", (128, 64)), ("all 300+100", (300, 100))):
         for n in (1, 8, 64, 96, 1024, 8192):
@@ -23,14 +25,21 @@ def main():
             p[:, sl:300] = 0
             p[:, 300 + el:400] = 0
             unpad = torch.tensor([[3.0, 4.0, 1.25]], device=dev).expand(n, 3).contiguous()
-            for _ in range(3):
-                fl.decode(p, unpad=unpad, shape_live=sl, expr_live=el, want_vertices=False)
+            # straight through the C ABI with preallocated outputs: the facade's torch.empty + ctypes marshalling (~20 us of host
+            # time per call) would otherwise be what the events see at small n
+            proj = torch.empty(n, fl.num_vertices, 3, device=dev)
+            rot = torch.empty(n, 3, 3, device=dev)
+            h = fl._need_handle()
+            st = torch.cuda.current_stream().cuda_stream
+            call = lambda: _lib.check(lib.vgh_flame_decode(h, p.data_ptr(), n, sl, el, unpad.data_ptr(), None, rot.data_ptr(), proj.data_ptr(), st))  # noqa: E731
+            for _ in range(5):
+                call()
             torch.cuda.synchronize()
-            it = 50 if n <= 1024 else 10
+            it = 200 if n <= 1024 else 20
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(it):
-                fl.decode(p, unpad=unpad, shape_live=sl, expr_live=el, want_vertices=False)
+                call()
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / it
