@@ -132,6 +132,7 @@ SYMBOLS = {
     "vgh_detector_join": (_I, [_P, _P]),
     "vgh_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_flame_lbs": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "vgh_flame_set_matrix_path": (_I, [_I]),
     "vgh_create": (_I, [C.POINTER(Config), C.POINTER(_P)]),
     "vgh_destroy": (None, [_P]),
     "vgh_ctx_last_error": (C.c_char_p, [_P]),

@@ -16,10 +16,13 @@
 //    broadcast from LDS), the skinning / rigid / un-pad epilogue runs in registers and results leave with
 //    16-byte stores.  Exact fp32 FMA chains in fixed k order.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
 #include "vgh_internal.h"
+
+typedef __attribute__((ext_vector_type(3))) float f32x3_t;
 
 namespace {
 
@@ -42,9 +45,12 @@ struct vgh_flame {
     float* J0;       // [3*NJ]
     float* JS;       // [3*NJ][NB]
     int32_t* parents;  // [NJ]
-    float* coef;     // scratch [max_heads][Kp]
+    float* coef;     // scratch [Kp][npad] (TRANSPOSED: heads contiguous; npad = max_heads rounded up to 128, rows beyond n are zero)
+    int npad;
     float* headpack; // scratch [max_heads][HP_SIZE]
 };
+
+static bool g_flame_mfma = true;  // vgh_flame_set_matrix_path: the two vertex kernels are bit-identical, tests switch between them
 
 namespace {
 
@@ -56,8 +62,9 @@ struct PrepArgs {
     const float* J0;
     const float* JS;
     const int32_t* parents;
-    float* coef;
+    float* coef;        // [Kp][npad]
     float* headpack;
+    int npad;
     float* rot_out;     // [n,9] or null
     float* joints_out;  // [n,NJ,3] or null
     int NB, NJ, Kp;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
     __shared__ float s_hp[HP_SIZE];  // the head pack is assembled here and leaves as one coalesced store
     const int h = blockIdx.x, lane = threadIdx.x;
     if (a.n_dev && h >= *a.n_dev) return;
-    prep_head(a, h, lane, S, a.coef + (int64_t)h * a.Kp, 1, s_hp, true);
+    prep_head(a, h, lane, S, a.coef + h, a.npad, s_hp, true);
     float* const hpg = a.headpack + (int64_t)h * HP_SIZE;
     for (int e = lane; e < HP_SIZE; e += 64) hpg[e] = s_hp[e];
 }
@@ -271,8 +278,9 @@ struct VertArgs {
     const float* basis;  // [K][3][Vp]
     const float* vt;     // [3][Vp]
     const float* wts;    // [NJ][Vp]
-    const float* coef;   // [n][Kp]
+    const float* coef;   // [Kp][npad]
     const float* headpack;
+    int npad;
     float* verts;  // [n][V][3] or null
     float* proj;   // [n][V][3] or null
     const int32_t* n_dev;  // live head count on the device (fused detector) or null
@@ -280,6 +288,7 @@ struct VertArgs {
     int r0_begin, r0_end, r1_begin, r1_end, r2_begin, r2_end;  // k ranges (shape live, expr live, pose)
     float z_offset;
     int do_unpad;
+    int ablate;  // -DVGH_EXPERIMENTS only: bit0 no operand loads, bit1 no epilogue
 };
 
 // BT = threads per block, VPL = vertices per lane (4: 16-byte basis loads; 1: dword loads, 4x the blocks -- the basis stream of a
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(BT) void flame_vertex_kernel(VertArgs a, PrepArgs p
     } else {
         for (int e = tid; e < a.Kp * HT; e += BT) {
             const int k = e / HT, hh = e - k * HT;
-            s_coef[e] = (h0 + hh < a.n) ? a.coef[(int64_t)(h0 + hh) * a.Kp + k] : 0.0f;
+            s_coef[e] = (h0 + hh < a.n) ? a.coef[(int64_t)k * a.npad + h0 + hh] : 0.0f;
         }
         for (int e = tid; e < HT * HP_SIZE; e += BT) {
             const int hh = e / HP_SIZE;
@@ -439,6 +448,172 @@ int launch_vertex_cfg(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
     return VGH_OK;
 }
 
+// ---- matrix-core vertex kernel ----------------------------------------------------------------------------------------------
+// The blend is a dense [heads x K] . [K x 3V] contraction (K = 436, or 228 / 132 live): on v_mfma_f32_32x32x2_f32 it runs at the
+// f32 vector rate with ONE VGPR per operand instead of a broadcast + FMA per element.  gfx950's f32 MFMA is an exact, k-ordered fmaf
+// chain (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per product), i.e. bit-for-bit what flame_vertex_kernel computes per
+// vertex, so the two kernels are interchangeable and the choice between them is a pure speed choice.
+//   tile roles : MFMA rows i = heads (A operand = coefficients, read from the transposed scratch coef[k][head]: 128-byte coalesced),
+//                MFMA cols j = 32 consecutive vertices of ONE coordinate plane (B operand = basis[k][c][v], coalesced);
+//                a wave owns 32 vertices x (x, y, z) x MT head tiles, so a lane ends up with x, y, z of its vertex for 16 heads per
+//                tile and runs the skinning / rigid / un-pad epilogue on them in registers;
+//   operands   : straight from L2 / Infinity Cache into VGPRs (the 26 MB basis is resident there), two bursts of UQ k-pairs in
+//                flight; no LDS traffic in the loop (LDS only holds the head packs for the epilogue).
+template <int MT>
+__global__ __launch_bounds__(256) void flame_mfma_kernel(VertArgs a) {
+#pragma clang fp contract(off)
+    constexpr int UQ = 8;  // k-pairs per burst (two bursts in flight: the basis comes from L2 / Infinity Cache)
+    constexpr int NH = MT * 32;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* s_hpT = fsm;  // [HP_SIZE][NH]: the head packs TRANSPOSED (field-major), so that 32 lanes reading one field of 32 heads hit 32 banks
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h0 = blockIdx.y * NH;
+    if (a.n_dev) a.n = min(a.n, *a.n_dev);
+    if (h0 >= a.n) return;
+    for (int e = tid; e < NH * HP_SIZE; e += 256) {
+        const int hh = e / HP_SIZE, fld = e - hh * HP_SIZE;
+        s_hpT[fld * NH + hh] = (h0 + hh < a.n) ? a.headpack[(int64_t)(h0 + hh) * HP_SIZE + fld] : 0.0f;
+    }
+    __syncthreads();
+    const int vbase = (blockIdx.x * 4 + wv) * 32;
+    if (vbase >= a.V) return;
+    const int j = lane & 31, half = lane >> 5;
+    const int v = vbase + j;  // < Vp (Vp is a multiple of 32)
+    const int64_t plane = a.Vp;
+    f32x16_t acc[MT][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float tv = a.vt[c * plane + v];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = tv;
+    }
+    // ---- blend: ascending k over the three live ranges (even lengths), pairs (k, k+1) per MFMA ----
+    const float* const bl = a.basis + v + (int64_t)half * 3 * plane;  // + k*3*plane + c*plane
+    const float* const al = a.coef + h0 + j + (int64_t)half * a.npad; // + k*npad + t*32
+    auto run = [&](int kb, int ke) {
+        const int np = (ke - kb) >> 1;
+        if (np <= 0) return;
+        float B0[UQ][3], A0[UQ][MT], B1[UQ][3], A1[UQ][MT];
+        auto fetch = [&](float (&B)[UQ][3], float (&A)[UQ][MT], int p0) {
+#pragma unroll
+            for (int u = 0; u < UQ; ++u) {
+                const int p = (p0 + u < np) ? p0 + u : np - 1;  // past the end: a valid, unused pair
+                const int64_t k = kb + 2 * p;
+                if (VGH_ABLATE(a, 1)) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) B[u][c] = (float)(lane + c);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) A[u][t] = (float)(lane - t);
+                    continue;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) B[u][c] = bl[(k * 3 + c) * plane];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) A[u][t] = al[k * a.npad + t * 32];
+            }
+        };
+        auto consume = [&](const float (&B)[UQ][3], const float (&A)[UQ][MT], int p0) {
+#pragma unroll
+            for (int u = 0; u < UQ; ++u) {
+                if (p0 + u < np) {  // wave-uniform
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][t], B[u][c], acc[t][c], 0, 0, 0);
+                }
+            }
+        };
+        fetch(B0, A0, 0);
+        for (int p = 0; p < np; p += 2 * UQ) {
+            fetch(B1, A1, p + UQ);
+            consume(B0, A0, p);
+            fetch(B0, A0, p + 2 * UQ);
+            consume(B1, A1, p + UQ);
+        }
+    };
+    run(a.r0_begin, a.r0_end);
+    run(a.r1_begin, a.r1_end);
+    run(a.r2_begin, a.r2_end);
+    // ---- skinning on the matrix cores too: T[h][q](v) = sum_j w_j(v) A_j(h)[q] is a K = NJ contraction whose result lands in the
+    //      SAME (head, vertex) -> (lane, register) map as the blend accumulators; chain order j ascending from 0, as the VALU kernel's
+    //      fmaf chain (the pad joint contributes fma(0, 0, T) = T).  One output row (4 entries of T) at a time: 4 accumulators. ----
+    if (VGH_ABLATE(a, 2)) {
+        if (a.proj && lane == 0) a.proj[((int64_t)h0 * a.V + v) * 3] = acc[0][0][0] + acc[MT - 1][2][15];
+        return;
+    }
+    const int njp = (a.NJ + 1) >> 1;
+    float wq[(MAXJ + 1) / 2];  // this lane's B operands: w_{2p + half}(v)
+#pragma unroll
+    for (int p = 0; p < (MAXJ + 1) / 2; ++p) {
+        const int jn = 2 * p + half;
+        wq[p] = (p < njp && jn < a.NJ) ? a.wts[(int64_t)jn * plane + v] : 0.0f;
+    }
+    const bool vok = v < a.V;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        float outv[3][16];
+#pragma unroll
+        for (int row = 0; row < 3; ++row) {
+            f32x16_t T[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[q][r] = 0.0f;
+#pragma unroll
+            for (int p = 0; p < (MAXJ + 1) / 2; ++p) {
+                if (p < njp) {  // wave-uniform
+                    const int jn = 2 * p + half;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float av = (jn < a.NJ) ? s_hpT[(HP_A + jn * 12 + row * 4 + q) * NH + t * 32 + j] : 0.0f;
+                        T[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wq[p], T[q], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float o = fmaf(T[0][r], acc[t][0][r], fmaf(T[1][r], acc[t][1][r], fmaf(T[2][r], acc[t][2][r], T[3][r])));
+                outv[row][r] = row == 2 ? o + a.z_offset : o;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int hh = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (!vok || h0 + hh >= a.n) continue;
+            const float vx = outv[0][r], vy = outv[1][r], vz = outv[2][r];
+            const int64_t obase = ((int64_t)(h0 + hh) * a.V + v) * 3;
+            if (a.verts) *(f32x3_t*)(a.verts + obase) = f32x3_t{vx, vy, vz};  // 12 bytes per lane, contiguous across the wave
+            if (a.proj) {
+                const float* hp = s_hpT + hh;  // field f of this head: hp[f * NH] (all lanes of a half-wave read the same word)
+                const float s = hp[HP_S * NH];
+                float qx = (hp[(HP_R + 0) * NH] * vx + hp[(HP_R + 1) * NH] * vy + hp[(HP_R + 2) * NH] * vz) * s + hp[(HP_T + 0) * NH];
+                float qy = (hp[(HP_R + 3) * NH] * vx + hp[(HP_R + 4) * NH] * vy + hp[(HP_R + 5) * NH] * vz) * s + hp[(HP_T + 1) * NH];
+                float qz = (hp[(HP_R + 6) * NH] * vx + hp[(HP_R + 7) * NH] * vy + hp[(HP_R + 8) * NH] * vz) * s + hp[(HP_T + 2) * NH];
+                if (a.do_unpad) {  // detector.py:67-69
+                    const float us = hp[(HP_U + 2) * NH];
+                    qx = (qx - hp[(HP_U + 0) * NH]) / us;
+                    qy = (qy - hp[(HP_U + 1) * NH]) / us;
+                    qz = qz / us;
+                }
+                *(f32x3_t*)(a.proj + obase) = f32x3_t{qx, qy, qz};
+            }
+        }
+    }
+}
+
+static bool f_mfma_enabled() { return g_flame_mfma; }
+
+template <int MT>
+int launch_mfma(const VertArgs& va, hipStream_t st) {
+    const size_t lds = (size_t)MT * 32 * HP_SIZE * sizeof(float);
+    const int vgroups = (va.V + 31) / 32, hgroups = (va.n + MT * 32 - 1) / (MT * 32);
+    hipLaunchKernelGGL((flame_mfma_kernel<MT>), dim3((vgroups + 3) / 4, hgroups), dim3(256), lds, st, va);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
 int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (pa_in.n_dev && n > f->max_heads) {
@@ -454,7 +629,14 @@ int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int e
         if (pa.unpad) pa.unpad += (int64_t)done * 3;
         if (pa.rot_out) pa.rot_out += (int64_t)done * 9;
         if (pa.joints_out) pa.joints_out += (int64_t)done * f->NJ * 3;
-        const bool fused = !pa.n_dev && m <= 256;  // small direct batches: the vertex kernel computes its own heads' prologue (one launch)
+        // matrix-core path from a handful of heads on (or the live count is only known on the device) and the
+        // live ranges have even length; tiny direct batches keep the fused VALU kernel (one launch, the whole chip on one head's basis)
+        const bool even = ((shape_live | expr_live | f->NB | f->K) & 1) == 0;
+        // (measured, profiles/r02_flame_sweep.json: the matrix-core kernel wins from a handful of heads up to a few thousand; at crowd scale the
+        //  VALU kernel's 8-heads-per-basis-load reuse is ahead again; with a device-side count the launch is capacity-sized and mostly
+        //  exits at once, so the tile count that matters is the live one)
+        const bool mfma = even && f_mfma_enabled() && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048));
+        const bool fused = !mfma && !pa.n_dev && m <= 256;  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
             hipLaunchKernelGGL(flame_prep_kernel, dim3(m), dim3(64), 0, st, pa);
             VGH_HIP(hipGetLastError());
@@ -465,6 +647,7 @@ int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int e
         va.vt = f->vt;
         va.wts = f->wts;
         va.coef = f->coef;
+        va.npad = f->npad;
         va.headpack = f->headpack;
         va.verts = verts ? verts + (int64_t)done * f->V * 3 : nullptr;
         va.proj = proj ? proj + (int64_t)done * f->V * 3 : nullptr;
@@ -489,8 +672,17 @@ int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int e
         va.r2_end = f->K;
         va.z_offset = detector_mode ? 0.05f : 0.0f;  // MESH_OFFSET_Z, flame.py:34,164
         va.do_unpad = pa.unpad != nullptr;
+        va.ablate = 0;
+#ifdef VGH_EXPERIMENTS
+        if (getenv("VGH_FLAME_ABLATE")) va.ablate = atoi(getenv("VGH_FLAME_ABLATE"));
+#endif
         int rc;
-        if (fused) {
+        if (mfma) {
+            if (pa.n_dev || m <= 512)
+                rc = launch_mfma<1>(va, st);  // one 32-head tile per wave: twice the waves, two resident per SIMD
+            else
+                rc = launch_mfma<2>(va, st);
+        } else if (fused) {
             if (m <= 4)
                 rc = launch_vertex_cfg<1, 64, 1, true>(va, pa, st);   // 79 blocks per head: the whole chip pulls the basis of one head
             else if (m <= 32)
@@ -526,7 +718,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
     memset(f, 0, sizeof(*f));
     f->device = device;
     f->V = V;
-    f->Vp = (V + 3) / 4 * 4;
+    f->Vp = (V + 31) / 32 * 32;  // whole 32-vertex MFMA column groups (and 16-byte lanes for the VALU kernel)
     f->NB = NB;
     f->NJ = NJ;
     f->NP = 9 * (NJ - 1);
@@ -574,7 +766,9 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
 #undef UP
     VGH_HIP(hipMalloc((void**)&f->parents, NJ * sizeof(int32_t)));
     VGH_HIP(hipMemcpy(f->parents, parents, NJ * sizeof(int32_t), hipMemcpyHostToDevice));
-    VGH_HIP(hipMalloc((void**)&f->coef, (size_t)f->max_heads * f->Kp * sizeof(float)));
+    f->npad = (f->max_heads + 127) / 128 * 128;
+    VGH_HIP(hipMalloc((void**)&f->coef, (size_t)f->npad * f->Kp * sizeof(float)));
+    VGH_HIP(hipMemset(f->coef, 0, (size_t)f->npad * f->Kp * sizeof(float)));
     VGH_HIP(hipMalloc((void**)&f->headpack, (size_t)f->max_heads * HP_SIZE * sizeof(float)));
     *out = f;
     return VGH_OK;
@@ -608,6 +802,7 @@ int vgh_flame_decode(vgh_flame* f, const float* params_dev, int n, int shape_liv
     pa.JS = f->JS;
     pa.parents = f->parents;
     pa.coef = f->coef;
+    pa.npad = f->npad;
     pa.headpack = f->headpack;
     pa.rot_out = rot_dev;
     pa.NB = f->NB;
@@ -633,6 +828,7 @@ int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32
     pa.JS = f->JS;
     pa.parents = f->parents;
     pa.coef = f->coef;
+    pa.npad = f->npad;
     pa.headpack = f->headpack;
     pa.rot_out = rot_dev;
     pa.rpy_out = rpy_dev;
@@ -643,6 +839,11 @@ int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32
     pa.NJ = f->NJ;
     pa.Kp = f->Kp;
     return run_decode(f, pa, capacity, shape_live, expr_live, true, verts_dev, proj_dev, stream);
+}
+
+int vgh_flame_set_matrix_path(int enable) {
+    g_flame_mfma = enable != 0;
+    return VGH_OK;
 }
 
 int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream) {
@@ -657,6 +858,7 @@ int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, i
     pa.JS = f->JS;
     pa.parents = f->parents;
     pa.coef = f->coef;
+    pa.npad = f->npad;
     pa.headpack = f->headpack;
     pa.joints_out = joints_dev;
     pa.NB = f->NB;

@@ -213,6 +213,10 @@ int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32
 /* General FLAMELayer.forward core = smplx lbs(betas, full_pose): betas_dev [n,NB], pose_dev [n,3*NJ]
  * axis-angle per joint -> verts_dev [n,V,3] (NO z offset, NO global rotation), joints_dev [n,NJ,3] or NULL. */
 int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream);
+/* The vertex stage has two interchangeable kernels: FP32 matrix cores (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain) and
+ * VALU FMAs; they produce bit-identical vertices and the library picks by batch size.  enable = 0 forces the VALU kernels
+ * (process-wide; parity tests and A/B measurements). */
+int vgh_flame_set_matrix_path(int enable);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused detector: HeadDetector._process + the device-side arithmetic of _parse_predictions

@@ -1117,6 +1117,33 @@ def test_c_only_create_and_detect(gpu_lib, flame_model, tmp_path):
     assert gpu_lib.vgh_create(C.byref(bad), C.byref(h)) != 0 and b"not a readable" in gpu_lib.vgh_last_error()
 
 
+@pytest.mark.parametrize("n,live", [(12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (257, (128, 64))])
+def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame_model, n, live):
+    """The FP32-MFMA vertex kernel (v_mfma_f32_32x32x2_f32 = an exact k-ordered fmaf chain) and the VALU kernel produce the SAME bits
+    for every vertex (unrotated and projected / un-padded), for partial head tiles, every live-coefficient split and through the
+    detector's device-side head count -- so which one runs is a pure speed choice -- and both stay within the f64-oracle bar."""
+    from head_detector_amd.flame import FLAMELayer
+    from oracle import flame_oracle as fo
+
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=512)
+    p = fo.synthetic_params(n, seed=n, live_shape=live[0], live_expr=live[1]).to(_dev())
+    unpad = torch.tensor([[3.0, 7.0, 1.3]], device=_dev()).expand(n, 3).contiguous()
+    outs = {}
+    try:
+        for on in (1, 0):
+            assert gpu_lib.vgh_flame_set_matrix_path(on) == 0
+            outs[on] = [t.clone() for t in fl.decode(p, unpad=unpad, shape_live=live[0], expr_live=live[1])]
+    finally:
+        gpu_lib.vgh_flame_set_matrix_path(1)
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a, b)
+    _, _, q = fo.reproject(fo.FlameConstants(flame_model, torch.float64), p.cpu().double())
+    q[:, :, 0] -= 3.0
+    q[:, :, 1] -= 7.0
+    q = q / 1.3
+    assert float((outs[1][2].cpu().double() - q).abs().max()) < 2e-6 * max(1000.0, float(q.abs().max()))
+
+
 def test_flame_decode_large_n_equals_chunks(gpu_lib, flame_model):
     """FLAME decode at crowd scale (n = 8192 heads, BASELINE config 5) equals the same heads decoded in chunks of 1000 (different
     HT tile variants and launch shapes must not change a single bit), and every vertex is finite."""
