@@ -135,7 +135,7 @@ def main():
     import torch.distributed as dist
 
     from head_detector_amd import _lib
-    from head_detector_amd.dist import gather_detections, init_from_env
+    from head_detector_amd.dist import DetectionGatherer, init_from_env
     from head_detector_amd.engine import VGHeadsEngine
     from head_detector_amd.flame import FLAMELayer
     from head_detector_amd.synthetic import synthetic_flame_model
@@ -184,7 +184,21 @@ def main():
         if args.tuning:
             eng.load_tuning(args.tuning)
 
+        # N>1: the detections of every rank go to rank 0 -- fixed-capacity slabs allocated once, two output slots, collectives queued
+        # on a communication stream behind the detector's side stream: the gather of batch s runs under the network of batch s+1 and
+        # nothing in the steady-state loop waits on the host (head_detector_amd/dist.py::DetectionGatherer)
+        slots = gat = None
+        if world > 1:
+            slots = [eng.new_output_slot(flame) for _ in range(2)]
+            gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * args.heads_per_image + 1), device=dev, dst=0)
+            ready = [torch.cuda.Event() for _ in range(2)]
+        nstep = [0]
+
         def step(i=None):
+            s = nstep[0] & 1
+            nstep[0] += 1
+            if gat is not None:
+                gat.wait_slot_free(s, eng.stream)  # the exchange that last read this output slot (two batches ago) is over
             if i is not None:
                 ev0[i].record(eng.stream)  # HIP events on the stream the kernels are launched on
             eng.forward_net(images, use_graph=args.graph)
@@ -194,11 +208,16 @@ def main():
             # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
             eng.candidates(B)
             k = i if i is not None else 0
-            det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1])
-            if world > 1:  # the gather consumes this batch's results: join first (serialises the select of this step only)
-                eng.join()
-                with torch.cuda.stream(eng.stream):
-                    gather_detections(det.boxes, det.scores, det.flame_params, det.counts, det.vertices_3d, dst=0)
+            det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1],
+                             slot=slots[s] if slots else None)
+            if gat is not None:
+                if overlap:
+                    eng.join_into(gat.stream)  # the communication stream (not the engine stream) waits for this batch's select
+                    ev = None
+                else:
+                    ev = ready[s]
+                    ev.record(eng.stream)
+                gat.submit(s, det.boxes, det.scores, det.flame_params, det.counts, det.n_heads, det.vertices_cap, ev)
 
         for _ in range(warmup):
             step()
@@ -209,6 +228,9 @@ def main():
         for i in range(steps):
             step(i)
         eng.join()
+        if gat is not None:
+            for s in range(2):
+                gat.result(s)  # the last two exchanges
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

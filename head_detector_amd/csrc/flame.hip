@@ -48,6 +48,10 @@ struct vgh_flame {
     float* coef;     // scratch [Kp][npad] (TRANSPOSED: heads contiguous; npad = max_heads rounded up to 128, rows beyond n are zero)
     int npad;
     float* headpack; // scratch [max_heads][HP_SIZE]
+    // the scratch is per handle: a decode on another stream than the previous one is ordered after it (event on the previous stream)
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev_scratch = nullptr;
+    bool used = false;
 };
 
 static bool g_flame_mfma = true;  // vgh_flame_set_matrix_path: the two vertex kernels are bit-identical, tests switch between them
@@ -616,6 +620,13 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
 
 int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    if (f->used && f->last_stream != st) {  // coef / headpack are still owned by the decode queued on the other stream
+        if (!f->ev_scratch) VGH_HIP(hipEventCreateWithFlags(&f->ev_scratch, hipEventDisableTiming));
+        if (hipEventRecord(f->ev_scratch, f->last_stream) == hipSuccess) VGH_HIP(hipStreamWaitEvent(st, f->ev_scratch, 0));
+        else (void)hipGetLastError();  // that stream is gone (destroyed by its owner): its work has drained
+    }
+    f->last_stream = st;
+    f->used = true;
     if (pa_in.n_dev && n > f->max_heads) {
         vgh_set_error("flame decode (indirect): capacity %d exceeds max_heads %d", n, f->max_heads);
         return VGH_ERR_INVALID;
@@ -784,6 +795,7 @@ void vgh_flame_destroy(vgh_flame* f) {
     hipFree(f->parents);
     hipFree(f->coef);
     hipFree(f->headpack);
+    if (f->ev_scratch) hipEventDestroy(f->ev_scratch);
     delete f;
 }
 

@@ -4,8 +4,11 @@ rank.  The reference has no multi-GPU inference at all (its only 
 all-reduce, yolo_head_loss.py:463-465); this is the MI355X-native addition north_star asks for.
 
 xGMI is a point-to-point full mesh, so the right shape is a direct gather (7 peers -> root on 7 independent links),
-not a ring: counts first (tiny all_gather), then fixed-capacity slabs with dist.gather (RCCL ncclSend/ncclRecv group),
-then -- only if requested -- the variable-length vertex payload padded to the global max head count."""
+not a ring.  Two implementations of the same exchange:
+  * ``gather_detections``  -- one-shot, synchronous convenience (sizes the vertex payload from the counts: one host sync);
+  * ``DetectionGatherer``  -- the throughput path: every buffer pre-allocated once, fixed-capacity messages only (no size ever
+    visits the host), collectives queued asynchronously on a communication stream, two slots so that the gather of batch s
+    runs underneath the network of batch s+1 ("must be overlapped with the next batch")."""
 from __future__ import annotations
 
 import os
@@ -47,6 +50,10 @@ class GatheredDetections:
     counts: torch.Tensor  # [B_total]
     vertices_3d: Optional[torch.Tensor] = None  # [n_total, V, 3], image-major
     head_image: Optional[torch.Tensor] = None  # [n_total] global image index
+    # DetectionGatherer.result only (capacity-shaped, nothing trimmed on the host):
+    n_heads_per_rank: Optional[torch.Tensor] = None  # [world] int32
+    vertex_slabs: Optional[torch.Tensor] = None  # [world, vertex_rows, V, 3]: rank r's first min(n_heads[r], vertex_rows) rows are live
+    images_per_rank: Optional[torch.Tensor] = None  # [world] int32: rows [r*B_local, r*B_local + images[r]) of the slabs are real images
 
 
 def gather_detections(boxes: torch.Tensor, scores: torch.Tensor, flame_params: torch.Tensor, counts: torch.Tensor, vertices_3d: Optional[torch.Tensor] = None,
@@ -84,3 +91,146 @@ def gather_detections(boxes: torch.Tensor, scores: torch.Tensor, flame_params: t
     cnt = torch.cat(all_counts, dim=0)
     hi = torch.repeat_interleave(torch.arange(cnt.numel(), device=cnt.device), cnt.long()) if verts_all is not None else None
     return GatheredDetections(full[..., :4], full[..., 4], full[..., 5:], cnt, verts_all, hi)
+
+
+class DetectionGatherer:
+    """Sync-free gather of per-rank detection slabs to ``dst``, double-buffered.
+
+    Per step and rank the message is ONE packed slab ``[B_local, keep, 418]`` (boxes 4 | score 1 | FLAME 413) + ``counts [B_local]``
+    (+ ``n_heads [1]``), and -- optionally -- the first ``vertex_rows`` rows of the image-major vertex list ``[vertex_rows, V, 3]``
+    (rows beyond the rank's head count are don't-care; ``n_heads`` > ``vertex_rows`` means the tail was cut and is visible to the
+    consumer).  All sizes are fixed at construction, so nothing here reads a device value on the host:
+
+        g = DetectionGatherer(B_local, keep, num_vertices, vertex_rows, device)
+        for s in ...:
+            slot = s & 1
+            g.wait_slot_free(slot, stream)            # the engine may overwrite the slot's producer buffers again
+            ... engine writes its outputs ...         # (any stream; record `ready` on it)
+            g.submit(slot, boxes, scores, flame, counts, n_heads, vertices, ready_event)   # returns at once
+        out = g.result(slot)                           # on dst: tensors valid once the current stream has waited (done inside)
+
+    ``submit`` packs on the communication stream (after ``ready_event``), then queues the collectives there; ``result`` makes the
+    caller's stream wait for them.  Ranks may own different numbers of images (uneven shards): pass ``B_local`` = the largest shard
+    and ``local_images`` = this rank's count; rows beyond it carry count 0."""
+
+    def __init__(self, B_local: int, keep: int, num_vertices: int = 0, vertex_rows: int = 0, device=None, dst: int = 0, group=None, slots: int = 2):
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.B, self.keep, self.V, self.vrows = B_local, keep, num_vertices, vertex_rows
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.cuda = self.device.type == "cuda"
+        f32 = dict(dtype=torch.float32, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        W = self.world if self.rank == dst else 0
+        self.slots = []
+        for _ in range(slots):
+            sl = dict(
+                send=torch.zeros(B_local, keep, 418, **f32), send_counts=torch.zeros(B_local + 2, **i32),  # [counts | n_heads | images owned]
+                send_verts=torch.zeros(vertex_rows, num_vertices, 3, **f32) if vertex_rows else None,
+                recv=torch.zeros(max(W, 1), B_local, keep, 418, **f32) if self.rank == dst else None,
+                recv_counts=torch.zeros(self.world, B_local + 2, **i32),  # all_gather target: every rank has it
+                recv_verts=torch.zeros(max(W, 1), vertex_rows, num_vertices, 3, **f32) if (self.rank == dst and vertex_rows) else None,
+                work=[], done=torch.cuda.Event() if self.cuda else None, busy=False, reader=None)
+            self.slots.append(sl)
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    # -------------------------------------------------------------------------------------------------------------------
+    def wait_slot_free(self, slot: int, stream=None):
+        """Order ``stream`` (default: current) after the slot's previous exchange: its producer buffers may be reused afterwards."""
+        sl = self.slots[slot]
+        if not sl["busy"]:
+            return
+        if self.cuda:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(sl["done"])
+        else:
+            for w in sl["work"]:
+                w.wait()
+            sl["work"] = []
+
+    def submit(self, slot: int, boxes: torch.Tensor, scores: torch.Tensor, flame_params: torch.Tensor, counts: torch.Tensor, n_heads: Optional[torch.Tensor] = None,
+               vertices: Optional[torch.Tensor] = None, ready_event=None, local_images: Optional[int] = None):
+        sl = self.slots[slot]
+        nb = boxes.shape[0] if local_images is None else local_images
+        ctx = torch.cuda.stream(self.stream) if self.cuda else _NullCtx()
+        if self.cuda and ready_event is not None:
+            self.stream.wait_event(ready_event)
+        if self.cuda and sl["reader"] is not None:  # whoever took result(slot) reads the receive buffers on that stream: let it finish
+            self.stream.wait_stream(sl["reader"])
+            sl["reader"] = None
+        with ctx:
+            # pack into the pre-allocated send buffers (device-side copies, no allocation)
+            sl["send"][:nb, :, 0:4].copy_(boxes[:nb], non_blocking=True)
+            sl["send"][:nb, :, 4].copy_(scores[:nb], non_blocking=True)
+            sl["send"][:nb, :, 5:].copy_(flame_params[:nb], non_blocking=True)
+            sl["send_counts"][:nb].copy_(counts[:nb], non_blocking=True)
+            if nb < self.B:
+                sl["send_counts"][nb : self.B].zero_()
+            if n_heads is not None:
+                sl["send_counts"][self.B : self.B + 1].copy_(n_heads.reshape(1), non_blocking=True)
+            else:
+                sl["send_counts"][self.B] = sl["send_counts"][: self.B].sum()
+            sl["send_counts"][self.B + 1] = nb
+            if self.vrows and vertices is not None:
+                r = min(self.vrows, vertices.shape[0])
+                sl["send_verts"][:r].copy_(vertices[:r], non_blocking=True)
+            work = []
+            if self.world > 1:
+                work.append(dist.all_gather(list(sl["recv_counts"].unbind(0)), sl["send_counts"], group=self.group, async_op=True))
+                gl = list(sl["recv"].unbind(0)) if self.rank == self.dst else None
+                work.append(dist.gather(sl["send"], gl, dst=self.dst, group=self.group, async_op=True))
+                if self.vrows:
+                    gv = list(sl["recv_verts"].unbind(0)) if self.rank == self.dst else None
+                    work.append(dist.gather(sl["send_verts"], gv, dst=self.dst, group=self.group, async_op=True))
+            else:
+                sl["recv_counts"][0].copy_(sl["send_counts"])
+                sl["recv"][0].copy_(sl["send"])
+                if self.vrows:
+                    sl["recv_verts"][0].copy_(sl["send_verts"])
+            if self.cuda:
+                for w in work:
+                    w.wait()  # NCCL: orders the communication stream after the collective, does not block the host
+                sl["done"].record(self.stream)
+                sl["work"] = []
+            else:
+                sl["work"] = work
+        sl["busy"] = True
+
+    def result(self, slot: int) -> Optional[GatheredDetections]:
+        """On ``dst``: the gathered batch of the slot (views of the receive buffers; the next submit of the slot is ordered after the
+        work the calling stream has queued by then, so read -- or copy -- them on the stream that called ``result``).
+        Per-head tensors stay capacity-shaped -- ``counts`` / ``n_heads_per_rank`` say which rows are live -- so no size is read on the
+        host here either; ``compact()`` does the host-side trimming when a caller wants the one-shot layout."""
+        sl = self.slots[slot]
+        self.wait_slot_free(slot)
+        if self.rank != self.dst:
+            return None
+        if self.cuda:
+            sl["reader"] = torch.cuda.current_stream(self.device)
+        full = sl["recv"].reshape(self.world * self.B, self.keep, 418)
+        out = GatheredDetections(full[..., :4], full[..., 4], full[..., 5:], sl["recv_counts"][:, : self.B].reshape(-1))
+        out.n_heads_per_rank = sl["recv_counts"][:, self.B]
+        out.images_per_rank = sl["recv_counts"][:, self.B + 1]
+        out.vertex_slabs = sl["recv_verts"]  # [world, vertex_rows, V, 3] or None
+        return out
+
+    def compact(self, out: GatheredDetections) -> GatheredDetections:
+        """Host-side trimming of ``result`` into the layout of ``gather_detections`` (reads the counts: one sync): the padding rows
+        of short shards are dropped, so row i is global image i of a ``shard_batch`` split; vertices are image-major."""
+        imgs = out.images_per_rank.tolist()
+        rows = torch.cat([torch.arange(r * self.B, r * self.B + imgs[r]) for r in range(self.world)]).to(out.counts.device)
+        cnt = out.counts[rows]
+        verts = hi = None
+        if out.vertex_slabs is not None:
+            nh = [min(int(n), self.vrows) for n in out.n_heads_per_rank.tolist()]
+            verts = torch.cat([out.vertex_slabs[r, : nh[r]] for r in range(self.world)], dim=0)
+            hi = torch.repeat_interleave(torch.arange(cnt.numel(), device=cnt.device), cnt.long())[: verts.shape[0]] if sum(nh) == int(cnt.sum()) else None
+        return GatheredDetections(out.boxes[rows], out.scores[rows], out.flame_params[rows], cnt, verts, hi)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -27,7 +27,12 @@ TUNING_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
 class Detections:
     """Fixed-capacity slabs on the GPU + per-head outputs (valid heads only, image-major order).  Nothing here forces a
     host synchronisation until ``num_heads`` / ``vertices_3d`` / ``head_image`` / ``head_pose`` are read: the per-head
-    tensors are capacity-sized on the device and the live count is a device scalar."""
+    tensors are capacity-sized on the device and the live count is a device scalar.
+
+    Lifetime: what ``VGHeadsEngine.detect`` / ``model`` return by default are FRESH tensors the caller owns (like the reference's
+    TorchScript module).  ``select``, ``detect(reuse_outputs=True)`` and ``model(copy=False)`` -- the benchmark's zero-allocation
+    variants -- return views of engine-owned buffers (or of the ``slot`` passed in): valid until the next call that writes the
+    same buffers, and in overlap mode only after ``join()``."""
 
     boxes: torch.Tensor  # [B, keep, 4] xyxy in network (padded-square) pixels
     scores: torch.Tensor  # [B, keep]
@@ -258,44 +263,69 @@ class VGHeadsEngine:
         if getattr(self, "_overlap", False):
             _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))
 
-    def model(self, images: torch.Tensor, use_graph: bool = False):
-        """Drop-in for ``self.model(image)`` (detector.py:58-59)."""
+    def model(self, images: torch.Tensor, use_graph: bool = False, copy: bool = True):
+        """Drop-in for ``self.model(image)`` (detector.py:58-59): fresh tensors; ``copy=False`` returns views of the engine's candidate
+        buffers instead (overwritten by the next forward)."""
         B = self.forward_candidates(images, use_graph)
         self._join_if_overlap()
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
-        return self.cand_boxes[:B], self.cand_scores[:B].unsqueeze(-1), self.cand_flame[:B]
+        out = self.cand_boxes[:B], self.cand_scores[:B].unsqueeze(-1), self.cand_flame[:B]
+        return tuple(t.clone() for t in out) if copy else out
 
-    def _detect_out(self, B: int, flame: Optional[FLAMELayer], unpad: Optional[torch.Tensor], n_heads_out: Optional[torch.Tensor] = None) -> Tuple["_lib.DetectOut", Detections]:
+    def new_output_slot(self, flame: Optional[FLAMELayer] = None, batch: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """A private set of result buffers for ``select(..., slot=...)``: with two of them the results of batch s stay intact (for a
+        consumer on another stream, e.g. dist.DetectionGatherer) while batch s+1 is being written."""
+        B, kk = batch or self.max_batch, self.keep_k
+        f32 = dict(dtype=torch.float32, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        slot = dict(boxes=torch.zeros(B, kk, 4, **f32), scores=torch.zeros(B, kk, **f32), flame=torch.zeros(B, kk, _lib.NUM_FLAME_PARAMS, **f32), counts=torch.zeros(B, **i32),
+                    n_heads=torch.zeros(1, **i32))
+        if flame is not None:
+            cap = min(B * self.keep_k, flame.max_heads)  # per-head rows beyond the live count are never written: no need to clear them
+            slot.update(cap=cap, head_image=torch.empty(cap, **i32), proj=torch.empty(cap, flame.num_vertices, 3, **f32), rpy=torch.empty(cap, 3, **f32))
+        return slot
+
+    def _detect_out(self, B: int, flame: Optional[FLAMELayer], unpad: Optional[torch.Tensor], n_heads_out: Optional[torch.Tensor] = None,
+                    slot: Optional[Dict[str, torch.Tensor]] = None) -> Tuple["_lib.DetectOut", Detections]:
         o = _lib.DetectOut()
-        o.boxes_dev, o.scores_dev, o.flame_dev, o.counts_dev = self.out_boxes.data_ptr(), self.out_scores.data_ptr(), self.out_flame.data_ptr(), self.counts.data_ptr()
-        det = Detections(self.out_boxes[:B], self.out_scores[:B], self.out_flame[:B], self.counts[:B])
+        ob, os_, of, oc = (slot["boxes"], slot["scores"], slot["flame"], slot["counts"]) if slot is not None else (self.out_boxes, self.out_scores, self.out_flame, self.counts)
+        o.boxes_dev, o.scores_dev, o.flame_dev, o.counts_dev = ob.data_ptr(), os_.data_ptr(), of.data_ptr(), oc.data_ptr()
+        det = Detections(ob[:B], os_[:B], of[:B], oc[:B])
         if flame is not None:
             handle = flame._need_handle()
             if self._flame_ref is not flame:
                 _lib.check(self.lib.vgh_detector_set_flame(self._det, handle))
                 self._flame_ref = flame
-            cap = min(self.max_batch * self.keep_k, flame.max_heads)
-            if self._head_out is None or self._head_out[0] != cap or self._head_out[2].shape[1] != flame.num_vertices:
-                self._head_out = (cap, torch.empty(cap, dtype=torch.int32, device=self.device), torch.empty(cap, flame.num_vertices, 3, dtype=torch.float32, device=self.device),
-                                  torch.empty(cap, 3, dtype=torch.float32, device=self.device))
-            cap, himg, proj, rpy = self._head_out
+            if slot is not None:
+                if "proj" not in slot or slot["proj"].shape[1] != flame.num_vertices:
+                    raise ValueError("output slot was created without (or for another) FLAME layer: new_output_slot(flame)")
+                cap, himg, proj, rpy = slot["cap"], slot["head_image"], slot["proj"], slot["rpy"]
+            else:
+                cap = min(self.max_batch * self.keep_k, flame.max_heads)
+                if self._head_out is None or self._head_out[0] != cap or self._head_out[2].shape[1] != flame.num_vertices:
+                    self._head_out = (cap, torch.empty(cap, dtype=torch.int32, device=self.device), torch.empty(cap, flame.num_vertices, 3, dtype=torch.float32, device=self.device),
+                                      torch.empty(cap, 3, dtype=torch.float32, device=self.device))
+                cap, himg, proj, rpy = self._head_out
             if unpad is not None:
                 if unpad.shape != (B, 3) or unpad.dtype != torch.float32 or not unpad.is_cuda or not unpad.is_contiguous():
                     raise ValueError("unpad must be a contiguous float32 GPU tensor [B,3] = (pad_x, pad_y, scale) per image")
                 o.unpad_dev = unpad.data_ptr()
-            nh = self.n_heads if n_heads_out is None else n_heads_out
+            nh = n_heads_out if n_heads_out is not None else (slot["n_heads"] if slot is not None else self.n_heads)
             o.n_heads_dev, o.head_image_dev, o.head_capacity = nh.data_ptr(), himg.data_ptr(), cap
             o.proj_dev, o.rpy_dev = proj.data_ptr(), rpy.data_ptr()
             det.n_heads, det.head_image_cap, det.vertices_cap, det.rpy_cap = nh, himg, proj, rpy
         return o, det
 
     def detect(self, images: torch.Tensor, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
-               unpad: Optional[torch.Tensor] = None, use_graph: bool = False) -> Detections:
+               unpad: Optional[torch.Tensor] = None, use_graph: bool = False, reuse_outputs: bool = False) -> Detections:
         """net -> top-k -> NMS (every image) -> optional FLAME decode + head pose of every surviving head: ONE asynchronous
         library call (vgh_detect); the data-dependent head count stays on the device (see ``Detections``).
-        ``unpad`` [B,3] = (pad_x, pad_y, scale) per image fuses detector.py:67-69."""
+        ``unpad`` [B,3] = (pad_x, pad_y, scale) per image fuses detector.py:67-69.  The result is written into fresh tensors the
+        caller owns; ``reuse_outputs=True`` writes into the engine's own output buffers (no allocation, see ``Detections``)."""
         B, fmt = self._check_images(images)
-        o, det = self._detect_out(B, flame, unpad)
+        with torch.cuda.stream(self.stream):  # allocate on the stream that writes them: the caching allocator's reuse stays ordered
+            slot = None if reuse_outputs else self.new_output_slot(flame, B)
+        o, det = self._detect_out(B, flame, unpad, None, slot)
         if use_graph and B <= self.arena_batch:
             self.forward_candidates(images, True)
             _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
@@ -308,13 +338,18 @@ class VGHeadsEngine:
         return det
 
     def select(self, B: int, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
-               unpad: Optional[torch.Tensor] = None, n_heads_out: Optional[torch.Tensor] = None) -> Detections:
+               unpad: Optional[torch.Tensor] = None, n_heads_out: Optional[torch.Tensor] = None, slot: Optional[Dict[str, torch.Tensor]] = None) -> Detections:
         """The post-candidate half of ``detect`` for the B images whose candidates are already in place
         (after ``forward_candidates`` / ``forward_net`` + ``candidates``).  In overlap mode it is queued on the detector's side
         stream: ``join()`` before reading the result.  ``n_heads_out`` [1] int32: where to write the head count."""
-        o, det = self._detect_out(B, flame, unpad, n_heads_out)
+        o, det = self._detect_out(B, flame, unpad, n_heads_out, slot)
         _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         return det
+
+    def join_into(self, stream: "torch.cuda.Stream"):
+        """Make ``stream`` (not the engine stream) wait for the last queued select: a consumer on its own stream -- e.g. the
+        communication stream of dist.DetectionGatherer -- picks the results up without stalling the next batch's network."""
+        _lib.check(self.lib.vgh_detector_join(self._det, stream.cuda_stream))
 
     # ---------------------------------------------------------------------------------------------------
     def profile_ops(self, images: torch.Tensor) -> List[dict]:

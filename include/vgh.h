@@ -183,6 +183,10 @@ int vgh_topk_nms(const float* boxes_dev, const float* scores_dev, const float* f
  * vgh_flame_create takes exactly the buffers FLAMELayer.__init__ registers (flame.py:75-95), host f32:
  *   v_template [V,3], shapedirs [V,3,NB], posedirs [(NJ-1)*9, 3V], J_regressor [NJ,V] dense,
  *   parents [NJ] (parents[0] = -1), lbs_weights [V,NJ].
+ * A handle owns one set of scratch buffers (per-head coefficients and packed transforms): decodes are asynchronous on the
+ * stream they are given, and a decode queued on a different stream than the previous one is ordered after it on the device
+ * (event wait, no host sync) -- calls from several streams are safe, they just do not overlap.  Not safe for concurrent
+ * calls from several host threads; use one handle per thread.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vgh_flame vgh_flame;
 int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template, const float* shapedirs, const float* posedirs,

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from head_detector_amd.dist import gather_detections, shard_batch
+from head_detector_amd.dist import DetectionGatherer, gather_detections, shard_batch
 
 
 def _free_port():
@@ -71,3 +71,90 @@ def test_single_process_passthrough_and_sharding():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         sizes = [b_ - a_ for a_, b_ in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the throughput path: pre-allocated slabs, asynchronous collectives, two slots (what bench.py's N>1 step drives)
+def _shard_outputs(step, rank, world, total, keep=5, V=7):
+    """What the engine would leave in its output slot for this rank's shard of global batch ``step``: a function of the GLOBAL image
+    index only, so the expected gathered batch does not depend on how it was sharded."""
+    lo, hi = shard_batch(total, rank, world)
+    g = [torch.Generator().manual_seed(1000 * step + i) for i in range(lo, hi)]
+    counts = torch.tensor([int(torch.randint(0, keep + 1, (1,), generator=gi)) for gi in g], dtype=torch.int32)
+    boxes = torch.stack([torch.rand(keep, 4, generator=gi) for gi in g])
+    scores = torch.stack([torch.rand(keep, generator=gi) for gi in g])
+    flame = torch.stack([torch.rand(keep, 413, generator=gi) for gi in g])
+    verts = torch.cat([torch.rand(int(c), V, 3, generator=gi) for c, gi in zip(counts, g)] + [torch.zeros(0, V, 3)])
+    return boxes, scores, flame, counts, verts
+
+
+def _gatherer_worker(rank, world, port, q, total, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keep, V = 5, 7
+    B_max = shard_batch(total, 0, world)[1]  # rank 0 owns the largest shard
+    g = DetectionGatherer(B_max, keep, V, vertex_rows=B_max * keep, device="cpu", dst=0)
+    got = []
+
+    def collect(slot):
+        out = g.result(slot)
+        if rank == 0:
+            c = g.compact(out)
+            got.append({k: getattr(c, k).clone().numpy() for k in ("boxes", "scores", "flame_params", "counts", "vertices_3d", "head_image")})
+        else:
+            assert out is None
+
+    for s in range(steps):  # the loop of bench.py's N>1 step: slot s&1 is reused every second batch, the previous batch is read late
+        slot = s & 1
+        g.wait_slot_free(slot)
+        b, sc, f, c, v = _shard_outputs(s, rank, world, total, keep, V)
+        nb = b.shape[0]
+        pad = lambda t: torch.cat([t, torch.full((B_max - nb, *t.shape[1:]), 7, dtype=t.dtype)])  # rows beyond the shard hold junk
+        g.submit(slot, pad(b), pad(sc), pad(f), pad(c), None, v, None, local_images=nb)
+        if s >= 1:
+            collect((s - 1) & 1)
+    collect((steps - 1) & 1)
+    if rank == 0:
+        q.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_gatherer(world, total, steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, port, q, total, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == steps
+    for s, out in enumerate(got):
+        exp = _shard_outputs(s, 0, 1, total)  # the unsharded batch
+        for k, e in zip(("boxes", "scores", "flame_params", "counts", "vertices_3d"), exp):
+            assert torch.equal(torch.from_numpy(out[k]), e), (s, k)
+        assert out["head_image"].tolist() == torch.repeat_interleave(torch.arange(total), exp[3].long()).tolist()
+
+
+def test_gatherer_double_buffered_world2_gloo():
+    _run_gatherer(world=2, total=6, steps=5)
+
+
+def test_gatherer_uneven_shards_10_images_4_ranks():
+    _run_gatherer(world=4, total=10, steps=3)
+
+
+def test_gatherer_single_process_and_vertex_cut():
+    keep, V, B = 5, 7, 3
+    g = DetectionGatherer(B, keep, V, vertex_rows=2, device="cpu")
+    b, sc, f, c, v = _shard_outputs(0, 0, 1, B, keep, V)
+    c[:] = torch.tensor([2, 0, 1])
+    v = torch.rand(3, V, 3)
+    g.submit(0, b, sc, f, c, None, v)
+    out = g.result(0)
+    assert int(out.n_heads_per_rank[0]) == 3 and out.vertex_slabs.shape == (1, 2, V, 3)  # the cut is visible: 3 heads, 2 rows sent
+    assert torch.equal(out.vertex_slabs[0], v[:2]) and torch.equal(out.boxes, b) and torch.equal(out.counts, c)
+    assert g.compact(out).head_image is None  # head list and vertex rows no longer line up

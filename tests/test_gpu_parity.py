@@ -931,6 +931,110 @@ def test_overlap_mode_is_race_free_and_identical(gpu_lib, flame_model):
     eng.close()
 
 
+def test_output_slots_and_gatherer_pipeline_without_host_syncs(gpu_lib, flame_model):
+    """The N>1 step of bench.py on one GPU (a one-rank gatherer copies instead of calling RCCL; everything else is the same code):
+    two engine output slots, select on the side stream, the communication stream joined to it (not the engine stream), the previous
+    batch read only after the next one has been queued.  Every batch must come out bit-identical to a stream-ordered detect()."""
+    from head_detector_amd.dist import DetectionGatherer
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    S, B, V = 256, 4, 5023
+    g = torch.Generator().manual_seed(29)
+    xs = [torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(_dev()) for _ in range(3)]
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=1024)
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=5)
+    conf = float(eng.model(xs[0])[1][:, 25, 0].max())
+
+    def snap(det):
+        n = det.num_heads
+        return [t.clone() for t in (det.boxes, det.scores, det.flame_params, det.counts)], det.vertices_cap[:n].clone(), n
+
+    refs = [snap(eng.detect(x, confidence_threshold=conf, flame=fl)) for x in xs]
+    assert all(r[2] > 0 for r in refs)
+    rows = max(r[2] for r in refs) + 3
+    for overlap in (True, False):
+        eng.set_overlap(overlap)
+        slots = [eng.new_output_slot(fl) for _ in range(2)]
+        gat = DetectionGatherer(B, eng.keep_k, fl.num_vertices, vertex_rows=rows, device=_dev())
+        ready = [torch.cuda.Event() for _ in range(2)]
+        seen = []
+
+        def collect(step):
+            out = gat.result(step & 1)
+            seen.append((step, [t.clone() for t in (out.boxes, out.scores, out.flame_params, out.counts)], out.vertex_slabs[0].clone(), int(out.n_heads_per_rank[0])))
+
+        for step in range(7):
+            s = step & 1
+            gat.wait_slot_free(s, eng.stream)
+            eng.forward_net(xs[step % 3])
+            eng.candidates(B)
+            det = eng.select(B, confidence_threshold=conf, flame=fl, slot=slots[s])
+            if overlap:
+                eng.join_into(gat.stream)
+                ev = None
+            else:
+                ev = ready[s]
+                ev.record(eng.stream)
+            gat.submit(s, det.boxes, det.scores, det.flame_params, det.counts, det.n_heads, det.vertices_cap, ev)
+            if step >= 1:
+                collect(step - 1)  # read late: batch `step` is already queued behind it
+        collect(6)
+        torch.cuda.synchronize()
+        assert len(seen) == 7
+        for step, slabs, verts, n in seen:
+            (rs, rv, rn) = refs[step % 3]
+            assert n == rn
+            for a, b in zip(rs, slabs):
+                assert torch.equal(a, b), (overlap, step)
+            assert torch.equal(verts[:n], rv), (overlap, step)
+    eng.set_overlap(False)
+    eng.close()
+
+
+def test_results_are_owned_by_the_caller_and_flame_scratch_is_stream_safe(gpu_lib, flame_model):
+    """detect()/model() hand out fresh tensors (the reference's TorchScript module does): a result held across the next call keeps
+    its contents.  And one FLAME handle driven from two streams back to back (its coefficient scratch is per handle) must give
+    each stream its own result."""
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    S, B = 256, 2
+    g = torch.Generator().manual_seed(31)
+    xa = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(_dev())
+    xb = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=1024)
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=5)
+    ma = eng.model(xa)
+    keep = [t.clone() for t in ma]
+    conf = float(ma[1][:, 25, 0].max())
+    da = eng.detect(xa, confidence_threshold=conf, flame=fl)
+    snap = [t.clone() for t in (da.boxes, da.scores, da.flame_params, da.counts, da.vertices_3d, da.head_pose)]
+    mb = eng.model(xb)
+    db = eng.detect(xb, confidence_threshold=conf, flame=fl)
+    assert not torch.equal(mb[0], ma[0]) and not torch.equal(db.boxes, da.boxes)
+    for a, b in zip(keep, ma):
+        assert torch.equal(a, b)
+    for a, b in zip(snap, (da.boxes, da.scores, da.flame_params, da.counts, da.vertices_3d, da.head_pose)):
+        assert torch.equal(a, b)
+    va = eng.detect(xa, confidence_threshold=conf, flame=fl, reuse_outputs=True)  # the aliasing variant says so
+    vb = eng.detect(xb, confidence_threshold=conf, flame=fl, reuse_outputs=True)
+    assert va.boxes.data_ptr() == vb.boxes.data_ptr() and torch.equal(va.boxes, db.boxes)
+    eng.close()
+
+    pa, pb = torch.randn(700, 413, device=_dev()) * 0.3, torch.randn(700, 413, device=_dev()) * 0.3
+    ref_a, ref_b = fl.decode(pa)[2].clone(), fl.decode(pb)[2].clone()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            oa = fl.decode(pa)[2]
+        with torch.cuda.stream(s2):
+            ob = fl.decode(pb)[2]
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
+
+
 def test_batch_split_lanes_are_invisible(gpu_lib, flame_model):
     """vgh_net_set_split: the batch as 2 / 3 / 4 independent sub-batches on the net's lane streams (uneven sizes included) must give
     bit-identical activations, candidates and detections to the single-stream run -- also combined with overlap mode."""
