@@ -190,7 +190,7 @@ def main():
         slots = gat = None
         if world > 1:
             slots = [eng.new_output_slot(flame) for _ in range(2)]
-            gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * args.heads_per_image + 1), device=dev, dst=0)
+            gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * args.heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream())
             ready = [torch.cuda.Event() for _ in range(2)]
         nstep = [0]
 

@@ -147,6 +147,10 @@ SYMBOLS = {
     "vgh_refined_head_bbox": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "vgh_letterbox": (_I, [_P, _I, _I, _I, _I64, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
     "vgh_stream_create": (_I, [_I, C.POINTER(_P)]),
+    "vgh_stream_acquire": (_I, [_I, C.POINTER(_P), _I, C.POINTER(_P)]),
+    "vgh_stream_release": (_I, [_I, _P]),
+    "vgh_streams_overlap": (_I, [_P, _P]),
+    "vgh_detector_streams": (_I, [_P, _P, C.POINTER(_P)]),
     "vgh_stream_destroy": (_I, [_P]),
     "vgh_stream_sync": (_I, [_P]),
     "vgh_event_create": (_I, [C.POINTER(_P)]),

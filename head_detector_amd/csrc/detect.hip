@@ -29,7 +29,7 @@ struct vgh_detector {
     // overlap mode: the select half (NMS .. FLAME decode: small, latency-bound kernels) runs on a detector-owned side stream,
     // concurrently with the network of the NEXT batch on the caller's stream
     bool overlap = false, side_pending = false;
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, side_main = nullptr;  // side: picked by ensure_side for work entering on side_main
     hipEvent_t ev_net = nullptr, ev_cand = nullptr, ev_side = nullptr;
 };
 
@@ -67,6 +67,22 @@ __global__ __launch_bounds__(1024) void head_list_kernel(const int32_t* __restri
     }
 }
 
+// The side stream has to run next to the network of the following batch: measured to overlap with the caller's stream and the
+// net's lane streams (streams.hip), picked on first use and again when the caller's stream changes.
+int ensure_side(vgh_detector* d, hipStream_t main) {
+    if (d->side && d->side_main == main) return VGH_OK;
+    hipStream_t avoid[4] = {main};
+    if (int rc = vgh_net_lane_streams(d->net, main, avoid + 1)) return rc;
+    if (d->side) {
+        VGH_HIP(hipStreamSynchronize(d->side));
+        vgh_stream_release_internal(d->device, d->side);
+        d->side = nullptr;
+    }
+    if (int rc = vgh_stream_acquire_internal(d->device, avoid, 4, &d->side)) return rc;
+    d->side_main = main;
+    return VGH_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -84,6 +100,7 @@ int vgh_detector_create(vgh_net* net, vgh_flame* flame, const vgh_detect_cfg* cf
     d->flame = flame;
     d->cfg = *cfg;
     d->S = vgh_net_image_size(net);
+    d->device = vgh_net_device(net);
     d->arena_batch = vgh_net_max_batch(net);
     int A = 0;
     for (int l = 0; l < cfg->n_levels; ++l) {
@@ -134,7 +151,7 @@ void vgh_detector_destroy(vgh_detector* d) {
     hipFree(d->head_image);
     if (d->side) {
         hipStreamSynchronize(d->side);
-        hipStreamDestroy(d->side);
+        vgh_stream_release_internal(d->device, d->side);
     }
     if (d->net) vgh_net_set_pred_guard(d->net, nullptr);
     if (d->ev_net) hipEventDestroy(d->ev_net);
@@ -172,6 +189,7 @@ int vgh_detector_decode_candidates(vgh_detector* d, int n, int at, void* stream)
     }
     void* st = stream;
     if (d->overlap) {  // predictions ready on `stream` -> side stream (ordered after everything queued there, incl. the last select)
+        if (int rc0 = ensure_side(d, (hipStream_t)stream)) return rc0;
         VGH_HIP(hipEventRecord(d->ev_net, (hipStream_t)stream));
         VGH_HIP(hipStreamWaitEvent(d->side, d->ev_net, 0));
         st = d->side;
@@ -246,6 +264,7 @@ int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, v
     VGH_REQUIRE(o->boxes_dev && o->scores_dev && o->flame_dev && o->counts_dev, "detector_select: boxes/scores/flame/counts outputs are mandatory");
     if (!d->overlap) return select_on(d, B, conf_thr, iou_thr, o, stream);
     // overlap mode: the candidates were produced on the side stream; the select simply follows them there
+    if (int rc0 = ensure_side(d, (hipStream_t)stream)) return rc0;
     const int rc = select_on(d, B, conf_thr, iou_thr, o, d->side);
     d->side_pending = true;
     return rc;
@@ -253,8 +272,7 @@ int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, v
 
 int vgh_detector_set_overlap(vgh_detector* d, int enable) {
     VGH_REQUIRE(d, "detector_set_overlap: null handle");
-    if (enable && !d->side) {
-        VGH_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+    if (enable && !d->ev_net) {  // the side stream itself is picked on first use (ensure_side: it has to overlap with the caller's stream)
         VGH_HIP(hipEventCreateWithFlags(&d->ev_net, hipEventDisableTiming));
         VGH_HIP(hipEventCreateWithFlags(&d->ev_cand, hipEventDisableTiming));
         VGH_HIP(hipEventCreateWithFlags(&d->ev_side, hipEventDisableTiming));
@@ -265,6 +283,19 @@ int vgh_detector_set_overlap(vgh_detector* d, int enable) {
         d->side_pending = false;
     }
     d->overlap = enable != 0;
+    return VGH_OK;
+}
+
+int vgh_detector_streams(vgh_detector* d, void* main_stream, void** out) {
+    VGH_REQUIRE(d && out, "detector_streams: null argument");
+    hipStream_t lanes[3];
+    if (int rc = vgh_net_lane_streams(d->net, (hipStream_t)main_stream, lanes)) return rc;
+    for (int i = 0; i < 3; ++i) out[i] = (void*)lanes[i];
+    out[3] = nullptr;
+    if (d->overlap) {
+        if (int rc = ensure_side(d, (hipStream_t)main_stream)) return rc;
+        out[3] = (void*)d->side;
+    }
     return VGH_OK;
 }
 

@@ -618,15 +618,21 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
     return VGH_OK;
 }
 
+int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, hipStream_t st);
+
 int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (f->used && f->last_stream != st) {  // coef / headpack are still owned by the decode queued on the other stream
-        if (!f->ev_scratch) VGH_HIP(hipEventCreateWithFlags(&f->ev_scratch, hipEventDisableTiming));
-        if (hipEventRecord(f->ev_scratch, f->last_stream) == hipSuccess) VGH_HIP(hipStreamWaitEvent(st, f->ev_scratch, 0));
-        else (void)hipGetLastError();  // that stream is gone (destroyed by its owner): its work has drained
-    }
+    if (f->used && f->last_stream != st) VGH_HIP(hipStreamWaitEvent(st, f->ev_scratch, 0));  // coef / headpack still belong to the decode queued there
+    const int rc = run_decode_on(f, pa_in, n, shape_live, expr_live, detector_mode, verts, proj, st);
+    // recorded after every decode (never on a remembered stream handle: its owner may have destroyed it by the next call)
+    if (!f->ev_scratch) VGH_HIP(hipEventCreateWithFlags(&f->ev_scratch, hipEventDisableTiming));
+    VGH_HIP(hipEventRecord(f->ev_scratch, st));
     f->last_stream = st;
     f->used = true;
+    return rc;
+}
+
+int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, hipStream_t st) {
     if (pa_in.n_dev && n > f->max_heads) {
         vgh_set_error("flame decode (indirect): capacity %d exceeds max_heads %d", n, f->max_heads);
         return VGH_ERR_INVALID;

@@ -37,7 +37,9 @@ struct vgh_net {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     static constexpr int kLanes = 4;  // lane 0 = the caller's stream
-    hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};  // picked by ensure_lanes for `lanes_main`
+    hipStream_t lanes_main = nullptr;
+    bool lanes_ready = false;
     hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     // optional guard (borrowed event): the first op that writes an fp32 prediction buffer waits for it, so a consumer of the
     // PREVIOUS forward's predictions may still be running on another stream while this forward's backbone / neck execute
@@ -131,6 +133,39 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
     return VGH_OK;
 }
 
+// Lane streams that are measured to overlap with the caller's stream and with each other (streams.hip: a fresh hipStreamCreate may
+// share a hardware queue with `main`, which serialises the lanes and costs ~40 % of the forward).  Picked on the first forward that
+// enters on `main`; a different caller stream re-picks.  Not callable while `main` is capturing (vgh_net_capture picks first).
+static int ensure_lanes(vgh_net* n, hipStream_t main) {
+    if (n->lanes_ready && n->lanes_main == main) return VGH_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        VGH_REQUIRE(n->lanes_ready, "net: the lane streams cannot be picked while the caller's stream is capturing; run vgh_net_capture (or one forward) first");
+        return VGH_OK;  // captured with the lanes picked for another caller stream: still correct, possibly not side by side
+    }
+    hipStream_t avoid[vgh_net::kLanes] = {main};
+    for (int l = 1; l < vgh_net::kLanes; ++l) {
+        if (n->side[l]) {
+            VGH_HIP(hipStreamSynchronize(n->side[l]));
+            vgh_stream_release_internal(n->device, n->side[l]);
+            n->side[l] = nullptr;
+        }
+    }
+    for (int l = 1; l < vgh_net::kLanes; ++l) {
+        if (int rc = vgh_stream_acquire_internal(n->device, avoid, l, &n->side[l])) return rc;
+        avoid[l] = n->side[l];
+    }
+    n->lanes_main = main;
+    n->lanes_ready = true;
+    return VGH_OK;
+}
+
+int vgh_net_lane_streams(vgh_net* n, hipStream_t main, hipStream_t* out) {
+    if (int rc = ensure_lanes(n, main)) return rc;
+    for (int l = 1; l < vgh_net::kLanes; ++l) out[l - 1] = n->side[l];
+    return VGH_OK;
+}
+
 // The batch as nsplit independent sub-batches, one per lane stream (lane 0 = the caller's stream); launches are interleaved
 // op by op so the lanes advance together.
 static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, int B, hipStream_t main) {
@@ -189,10 +224,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     VGH_HIP(hipMalloc((void**)&n->zeros, 256));
     VGH_HIP(hipMemset(n->zeros, 0, 256));
     VGH_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
-    for (int l = 1; l < vgh_net::kLanes; ++l) {
-        VGH_HIP(hipStreamCreateWithFlags(&n->side[l], hipStreamNonBlocking));
-        VGH_HIP(hipEventCreateWithFlags(&n->ev_join[l], hipEventDisableTiming));
-    }
+    for (int l = 1; l < vgh_net::kLanes; ++l) VGH_HIP(hipEventCreateWithFlags(&n->ev_join[l], hipEventDisableTiming));  // lane streams: ensure_lanes
     // ---- weights: pack on the host, one upload ----
     int64_t wbytes = 0;
     std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0);
@@ -256,7 +288,10 @@ void vgh_net_destroy(vgh_net* n) {
     if (n->graph_exec) hipGraphExecDestroy(n->graph_exec);
     if (n->graph) hipGraphDestroy(n->graph);
     for (int l = 1; l < vgh_net::kLanes; ++l) {
-        if (n->side[l]) hipStreamDestroy(n->side[l]);
+        if (n->side[l]) {
+            hipStreamSynchronize(n->side[l]);
+            vgh_stream_release_internal(n->device, n->side[l]);
+        }
         if (n->ev_join[l]) hipEventDestroy(n->ev_join[l]);
     }
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
@@ -273,6 +308,7 @@ int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
     // the first op of a lane after it makes that lane's stream wait for the event, and every used lane is joined back into
     // the main stream at the end (also valid under stream capture: the graph gets parallel branches).
     hipStream_t main = (hipStream_t)stream;
+    if (int rc = ensure_lanes(n, main)) return rc;
     if (n->nsplit > 1 && B > 1) return net_forward_split(n, image_dev, image_fmt, B, main);
     bool pending[vgh_net::kLanes] = {false, false, false, false}, used[vgh_net::kLanes] = {false, false, false, false};
     bool guard_pending = n->pred_guard != nullptr;
@@ -313,6 +349,7 @@ int vgh_net_profile(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
     VGH_REQUIRE(n && image_dev && op_ms, "net_profile: null argument");
     VGH_REQUIRE(B >= 0 && B <= n->max_batch, "net_profile: B=%d exceeds max_batch=%d", B, n->max_batch);
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = ensure_lanes(n, st)) return rc;
     const size_t m = n->ops.size();
     std::vector<hipEvent_t> ev(m + 1);
     for (auto& e : ev) VGH_HIP(hipEventCreate(&e));
@@ -357,6 +394,7 @@ int vgh_net_capture(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
         hipGraphDestroy(n->graph);
         n->graph = nullptr;
     }
+    if (int rc = ensure_lanes(n, st)) return rc;  // probing launches kernels: before the capture begins
     VGH_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = vgh_net_forward(n, image_dev, image_fmt, B, stream);
     hipError_t e = hipStreamEndCapture(st, &n->graph);
@@ -390,6 +428,7 @@ int vgh_net_set_pred_guard(vgh_net* n, void* event) {
 }
 
 int vgh_net_max_batch(vgh_net* n) { return n ? n->max_batch : 0; }
+int vgh_net_device(vgh_net* n) { return n ? n->device : 0; }
 int vgh_net_image_size(vgh_net* n) { return n ? n->image_size : 0; }
 
 int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {

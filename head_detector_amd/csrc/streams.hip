@@ -1,0 +1,110 @@
+// Streams that really run side by side.
+//
+// HIP multiplexes every stream of a process onto a handful of hardware queues (4 by default); which queue a new stream lands on
+// depends on what else the process created and destroyed before.  Two streams that share a queue execute their kernels one after the
+// other, whatever the events between them say.  Measured (tools/order_probe.py, profiles/r02_stream_queues.txt): the same two-lane
+// vgg_heads_m b32 forward takes 5.1 ms when its lanes sit on different queues and 7.1 ms when they share one -- the 2nd, 3rd, ...
+// engine of a process flipped between the two depending on the creation history, and GPU_MAX_HW_QUEUES only moved the pattern.
+//
+// So the library does not trust a fresh hipStreamCreate: vgh_stream_acquire hands out a stream that was MEASURED to overlap with
+// every stream in `avoid` (two 150 us spin kernels launched back to back on the pair: side by side they take ~150 us together, on one
+// queue ~300 us).  Candidates that fail stay parked (alive, so the runtime's queue assignment keeps moving on) and are offered to later
+// requests; released streams go back to the same per-device park instead of being destroyed.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <mutex>
+#include <vector>
+
+#include "vgh_internal.h"
+
+namespace {
+
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();  // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+constexpr long long kSpinTicks = 15000;  // 150 us
+constexpr int kMaxDev = 16, kMaxTries = 10;
+
+std::mutex g_mu;
+std::vector<hipStream_t> g_park[kMaxDev];
+
+// true when kernels queued on a and b at the same time overlap
+bool runs_concurrently(hipStream_t a, hipStream_t b) {
+    if (a == b) return false;
+    // untimed pass: pays the one-off launch set-up of a new stream and leaves both idle
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 100);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 100);
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, kSpinTicks);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, kSpinTicks);
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipGetLastError();
+    return us < 1.6 * (double)kSpinTicks / 100.0;
+}
+
+int overlap_score(hipStream_t c, const hipStream_t* avoid, int n_avoid) {
+    int score = 0;
+    for (int i = 0; i < n_avoid; ++i)
+        if (runs_concurrently(avoid[i], c)) score += 1 << (n_avoid - 1 - i);  // earlier entries of `avoid` weigh more
+    return score;
+}
+
+}  // namespace
+
+int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoid, hipStream_t* out) {
+    VGH_REQUIRE(out && device >= 0 && device < kMaxDev && n_avoid >= 0 && n_avoid <= 8, "stream_acquire: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    int cur = 0;
+    VGH_HIP(hipGetDevice(&cur));
+    if (cur != device) VGH_HIP(hipSetDevice(device));
+    const int perfect = (1 << n_avoid) - 1;
+    std::vector<hipStream_t>& park = g_park[device];
+    int best = -1, best_score = -1;
+    for (int i = 0; i < (int)park.size() && best_score < perfect; ++i) {
+        const int s = overlap_score(park[i], avoid, n_avoid);
+        if (s > best_score) best = i, best_score = s;
+    }
+    for (int t = 0; t < kMaxTries && best_score < perfect; ++t) {
+        hipStream_t c;
+        VGH_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        park.push_back(c);
+        const int s = overlap_score(c, avoid, n_avoid);
+        if (s > best_score) best = (int)park.size() - 1, best_score = s;
+    }
+    *out = park[best];
+    park.erase(park.begin() + best);
+    if (cur != device) VGH_HIP(hipSetDevice(cur));
+    return VGH_OK;
+}
+
+void vgh_stream_release_internal(int device, hipStream_t s) {
+    if (!s || device < 0 || device >= kMaxDev) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_park[device].push_back(s);
+}
+
+extern "C" {
+
+int vgh_stream_acquire(int device, void* const* avoid, int n_avoid, void** stream_out) {
+    VGH_REQUIRE(stream_out && (avoid || n_avoid == 0), "stream_acquire: null argument");
+    hipStream_t s = nullptr;
+    const int rc = vgh_stream_acquire_internal(device, (const hipStream_t*)avoid, n_avoid, &s);
+    *stream_out = (void*)s;
+    return rc;
+}
+
+int vgh_stream_release(int device, void* stream) {
+    vgh_stream_release_internal(device, (hipStream_t)stream);
+    return VGH_OK;
+}
+
+int vgh_streams_overlap(void* a, void* b) { return runs_concurrently((hipStream_t)a, (hipStream_t)b) ? 1 : 0; }
+
+}  // extern "C"

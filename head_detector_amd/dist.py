@@ -113,7 +113,7 @@ class DetectionGatherer:
     caller's stream wait for them.  Ranks may own different numbers of images (uneven shards): pass ``B_local`` = the largest shard
     and ``local_images`` = this rank's count; rows beyond it carry count 0."""
 
-    def __init__(self, B_local: int, keep: int, num_vertices: int = 0, vertex_rows: int = 0, device=None, dst: int = 0, group=None, slots: int = 2):
+    def __init__(self, B_local: int, keep: int, num_vertices: int = 0, vertex_rows: int = 0, device=None, dst: int = 0, group=None, slots: int = 2, stream=None):
         self.group, self.dst = group, dst
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -133,7 +133,8 @@ class DetectionGatherer:
                 recv_verts=torch.zeros(max(W, 1), vertex_rows, num_vertices, 3, **f32) if (self.rank == dst and vertex_rows) else None,
                 work=[], done=torch.cuda.Event() if self.cuda else None, busy=False, reader=None)
             self.slots.append(sl)
-        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        # `stream`: the communication stream; pass VGHeadsEngine.acquire_stream() so that it does not share a hardware queue with the engine
+        self.stream = (stream if stream is not None else torch.cuda.Stream(device=self.device)) if self.cuda else None
 
     # -------------------------------------------------------------------------------------------------------------------
     def wait_slot_free(self, slot: int, stream=None):

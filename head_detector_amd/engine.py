@@ -346,6 +346,19 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         return det
 
+    def acquire_stream(self) -> "torch.cuda.Stream":
+        """A stream measured to run side by side with the streams this engine works on (its own, the net lanes in use, the overlap-mode
+        side stream): HIP maps streams onto 4 hardware queues and two streams on one queue serialise (include/vgh.h,
+        vgh_stream_acquire).  For consumers that must not stall the pipeline, e.g. the communication stream of dist.DetectionGatherer."""
+        out = (C.c_void_p * 4)()
+        _lib.check(self.lib.vgh_detector_streams(self._det, self._sp(), out))
+        lanes, side = [out[i] for i in range(3)], out[3]
+        order = [self._sp()] + lanes[: max(self.nsplit - 1, 0)] + ([side] if side else []) + lanes[max(self.nsplit - 1, 0):]
+        avoid = (C.c_void_p * len(order))(*order)
+        got = C.c_void_p()
+        _lib.check(self.lib.vgh_stream_acquire(self.device.index or 0, avoid, len(order), C.byref(got)))
+        return torch.cuda.ExternalStream(got.value, device=self.device)
+
     def join_into(self, stream: "torch.cuda.Stream"):
         """Make ``stream`` (not the engine stream) wait for the last queued select: a consumer on its own stream -- e.g. the
         communication stream of dist.DetectionGatherer -- picks the results up without stalling the next batch's network."""

@@ -291,6 +291,7 @@ int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, fl
  * not read them). */
 int vgh_detector_set_overlap(vgh_detector* d, int enable);
 int vgh_detector_join(vgh_detector* d, void* stream);
+int vgh_detector_streams(vgh_detector* d, void* main_stream, void** out /*[4]*/);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-pipeline context from ONE pack file: replaces HeadDetector.__init__ (head_detector/detector.py:19-30: hub download,
@@ -364,6 +365,18 @@ int vgh_letterbox(const uint8_t* src_dev, int src_h, int src_w, int src_channels
  * HIP-event helpers so Python can time work on the stream the kernels actually run on.
  * ---------------------------------------------------------------------------------------------- */
 int vgh_stream_create(int device, void** stream_out);
+/* Streams that really run side by side.  HIP multiplexes a process's streams onto a few hardware queues (4 by default) and two
+ * streams on one queue execute serially; which queue a new stream gets depends on the process's creation history (measured:
+ * the same two-lane forward 5.1 ms vs 7.1 ms, profiles/r02_stream_queues.txt).  vgh_stream_acquire returns a stream MEASURED
+ * (150 us spin-kernel pairs) to overlap with every stream in avoid[0..n_avoid) -- earlier entries win when the queues do not
+ * suffice -- taking it from a per-device park of earlier candidates / released streams before creating new ones; it
+ * synchronises the streams in `avoid`.  The net's lane streams and the detector's side stream are picked this way on first use.
+ * vgh_stream_release parks a stream (never destroyed).  vgh_streams_overlap: the measurement itself (1 = side by side).
+ * vgh_detector_streams: the streams a detector uses for work entering on main_stream: out[0..2] net lanes, out[3] the
+ * overlap-mode side stream (NULL when overlap is off) -- e.g. to acquire a communication stream that avoids them. */
+int vgh_stream_acquire(int device, void* const* avoid, int n_avoid, void** stream_out);
+int vgh_stream_release(int device, void* stream);
+int vgh_streams_overlap(void* stream_a, void* stream_b);
 int vgh_stream_destroy(void* stream);
 int vgh_stream_sync(void* stream);
 int vgh_event_create(void** ev_out);

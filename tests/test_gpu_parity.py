@@ -1035,6 +1035,37 @@ def test_results_are_owned_by_the_caller_and_flame_scratch_is_stream_safe(gpu_li
         assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
 
 
+def test_lane_and_side_streams_are_measured_to_overlap(gpu_lib):
+    """HIP maps streams onto 4 hardware queues; two streams on one queue serialise (the same 2-lane forward: 5.1 vs 7.1 ms).  The
+    net's lane stream and the detector's side stream are picked by measurement, so they must overlap with the engine's stream (and
+    with each other) for the 1st, 2nd, 3rd ... engine of a process alike, whatever was created and destroyed before."""
+    import ctypes as C
+
+    from head_detector_amd.engine import VGHeadsEngine
+
+    lib = gpu_lib
+    junk = []
+    for round_ in range(4):
+        eng = VGHeadsEngine("vgg_heads_m", image_size=128, max_batch=4, seed=1)
+        eng.set_overlap(True)
+        eng.set_split(2)
+        x = torch.randint(0, 256, (4, 128, 128, 3), dtype=torch.uint8).to(_dev())
+        eng.forward_candidates(x)
+        eng.join()
+        torch.cuda.synchronize()
+        out = (C.c_void_p * 4)()
+        assert lib.vgh_detector_streams(eng._det, eng._sp(), out) == 0
+        main, lane1, side = eng._sp(), out[0], out[3]
+        assert lane1 and side
+        assert lib.vgh_streams_overlap(main, lane1) == 1, round_
+        assert lib.vgh_streams_overlap(main, side) == 1, round_
+        assert lib.vgh_streams_overlap(lane1, side) == 1, round_
+        comm = eng.acquire_stream()
+        assert lib.vgh_streams_overlap(main, comm.cuda_stream) == 1 and lib.vgh_streams_overlap(lane1, comm.cuda_stream) == 1
+        junk.append(torch.cuda.Stream())  # perturb the runtime's queue assignment between rounds
+        eng.close()
+
+
 def test_batch_split_lanes_are_invisible(gpu_lib, flame_model):
     """vgh_net_set_split: the batch as 2 / 3 / 4 independent sub-batches on the net's lane streams (uneven sizes included) must give
     bit-identical activations, candidates and detections to the single-stream run -- also combined with overlap mode."""
