@@ -18,7 +18,10 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <vector>
+
+#define AS3 __attribute__((address_space(3)))
 
 #include "vgh_internal.h"
 
@@ -43,18 +46,24 @@ struct vgh_flame {
     float* vt;       // [3][Vp]
     float* wts;      // [NJ][Vp]
     float* J0;       // [3*NJ]
-    float* JS;       // [3*NJ][NB]
+    float* JS;       // [NB][MAXJ*3] (coefficient-major, zero columns beyond 3*NJ: the prologue reads a row as six 16-byte loads)
     int32_t* parents;  // [NJ]
     float* coef;     // scratch [Kp][npad] (TRANSPOSED: heads contiguous; npad = max_heads rounded up to 128, rows beyond n are zero)
     int npad;
-    float* headpack; // scratch [max_heads][HP_SIZE]
+    float* headpack; // scratch [npad][HP_SIZE]
     // the scratch is per handle: a decode on another stream than the previous one is ordered after it (event on the previous stream)
     hipStream_t last_stream = nullptr;
     hipEvent_t ev_scratch = nullptr;
     bool used = false;
 };
 
-static bool g_flame_mfma = true;  // vgh_flame_set_matrix_path: the two vertex kernels are bit-identical, tests switch between them
+// vgh_flame_set_matrix_path: 0 VALU kernels only, 1 automatic (default), 2 always the register-fed matrix-core kernel, 3 / 4 always the
+// LDS-staged one (register allocation for 4 / 2 waves per SIMD).  All vertex kernels are bit-identical; tests and tools/flame_sweep.py switch between them.
+static int g_flame_mode = 1;
+#ifdef VGH_EXPERIMENTS
+static unsigned long long* g_prep_trace = nullptr;  // vgh_flame_set_trace
+#endif
+constexpr int kLdsMinHeads = 1024;
 
 namespace {
 
@@ -78,7 +87,16 @@ struct PrepArgs {
     const int32_t* head_image;
     const int32_t* n_dev;
     float* rpy_out;  // [n,3] (roll, pitch, yaw) degrees or null: calculate_rpy, utils.py:146-151
+    int n;           // heads of this launch (capacity when n_dev is set)
+    int live0_end, live1_begin, live1_end;  // betas outside [0, live0_end) u [live1_begin, live1_end) are exact zeros (skipped: fma(w, 0, s) = s)
+    unsigned long long* trace;  // -DVGH_EXPERIMENTS only: wall-clock (100 MHz) phase stamps of head 0's prologue
 };
+
+#ifdef VGH_EXPERIMENTS
+#define PMARK(a, h, lane, k) do { if ((a).trace && (h) == 0 && (lane) == 0) (a).trace[k] = wall_clock64(); } while (0)
+#else
+#define PMARK(a, h, lane, k) do { } while (0)
+#endif
 
 // Per-wave LDS scratch of the per-head prologue
 struct PrepScratch {
@@ -101,6 +119,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
 // must not be contracted differently from one to the next, or a head's vertices would depend on the batch it is decoded in
 #pragma clang fp contract(off)
     const int NB = a.NB, NJ = a.NJ;
+    PMARK(a, h, lane, 0);
     for (int e = lane; e < HP_SIZE; e += 64) hp[e] = 0.0f;
     const int64_t prow = a.head_row ? a.head_row[h] : h;
     const int64_t urow = a.head_image ? a.head_image[h] : h;
@@ -111,6 +130,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
         S.beta[l] = v;
         coef[(int64_t)l * cstride] = v;
     }
+    const float j0 = lane < NJ * 3 ? a.J0[lane] : 0.0f;
     if (p && lane < 13) S.tail[lane] = p[400 + lane];
     if (lane < NJ) S.par[lane] = a.parents[lane];
     if (lane < 3) S.unpad[lane] = a.unpad ? a.unpad[urow * 3 + lane] : (lane == 2 ? 1.0f : 0.0f);
@@ -125,28 +145,39 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    PMARK(a, h, lane, 1);
     // joints: J = J0 + JS beta.  All 3*NJ dot products advance together (independent loads in flight); per output a lane-strided
     // fmaf chain in ascending l, then the xor butterfly.
     {
+        // (a [3*NJ][NB] layout with a runtime bound per output made hipcc wait for every one of the ~105 loads in turn: 16 of the
+        //  prologue's 21 us.  Coefficient-major rows padded to MAXJ*3 columns: six independent 16-byte loads per coefficient, no branch.)
         float s[MAXJ * 3];
 #pragma unroll
         for (int o = 0; o < MAXJ * 3; ++o) s[o] = 0.0f;
+        // lane-strided over l as if every coefficient were visited (l = lane, lane + 64, ...): the skipped ones are zeros, so the chain
+        // per output is the same whatever the live ranges are
         for (int l = lane; l < NB; l += 64) {
+            if (!(l < a.live0_end || (l >= a.live1_begin && l < a.live1_end))) continue;
             const float bl = S.beta[l];
+            const f32x4_t* const row = (const f32x4_t*)(a.JS + (int64_t)l * (MAXJ * 3));
+            f32x4_t w[MAXJ * 3 / 4];
 #pragma unroll
-            for (int o = 0; o < MAXJ * 3; ++o)
-                if (o < NJ * 3) s[o] = fmaf(a.JS[(int64_t)o * NB + l], bl, s[o]);
+            for (int q = 0; q < MAXJ * 3 / 4; ++q) w[q] = row[q];
+#pragma unroll
+            for (int o = 0; o < MAXJ * 3; ++o) s[o] = fmaf(w[o >> 2][o & 3], bl, s[o]);
         }
+        // (J0[o] used to be loaded by lane 0 inside this loop: 15 dependent global round trips behind exec-masked branches, ~4.5 us)
+        float mine = 0.0f;
 #pragma unroll
         for (int o = 0; o < MAXJ * 3; ++o) {
-            if (o < NJ * 3) {
-                float v = s[o];
+            float v = s[o];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if (lane == 0) S.J[o] = a.J0[o] + v;
-            }
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            mine = lane == o ? v : mine;
         }
+        if (lane < NJ * 3) S.J[lane] = j0 + mine;
     }
+    PMARK(a, h, lane, 2);
     // smplx batch_rodrigues per joint
     if (lane < NJ) {
         const float rx0 = S.pose[lane * 3 + 0], ry0 = S.pose[lane * 3 + 1], rz0 = S.pose[lane * 3 + 2];
@@ -165,6 +196,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    PMARK(a, h, lane, 3);
     // pose_feature = (rot_mats[:,1:] - I).view(-1)
     const int NP = 9 * (NJ - 1);
     if (lane < NP) coef[(int64_t)(NB + lane) * cstride] = S.R[9 + lane] - ((lane % 9) % 4 == 0 ? 1.0f : 0.0f);
@@ -190,6 +222,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
+    PMARK(a, h, lane, 4);
     for (int e = lane; e < 12 * NJ; e += 64) {
         const int j = e / 12, q = e - j * 12, r = q >> 2, c = q & 3;
         float v;
@@ -200,6 +233,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
         hp[HP_A + e] = v;
         if (emit && a.joints_out && c == 3) a.joints_out[((int64_t)h * NJ + j) * 3 + r] = S.tg[j * 3 + r];
     }
+    PMARK(a, h, lane, 5);
     if (lane == 1) {
         // rot_mat_from_6dof (utils.py:120-128): F.normalize eps = 1e-12, columns (b1, b2, b3) -- on a second lane, next to the chain
         float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -265,6 +299,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    PMARK(a, h, lane, 6);
 }
 
 // stand-alone prologue (large batches, and the detector's capacity-sized launches): one wave per head
@@ -276,6 +311,31 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
     prep_head(a, h, lane, S, a.coef + h, a.npad, s_hp, true);
     float* const hpg = a.headpack + (int64_t)h * HP_SIZE;
     for (int e = lane; e < HP_SIZE; e += 64) hpg[e] = s_hp[e];
+}
+
+// HB heads per block, one wave each: the blend coefficients go to the TRANSPOSED scratch coef[k][head] (what the matrix-core kernels
+// read 128-byte coalesced), so a lone wave's column is 436 scattered 4-byte stores -- at n = 8192 the single-head kernel spent 112 us
+// mostly on that write amplification.  Here the HB columns meet in LDS and leave as HB*4-byte row segments.
+template <int HB>
+__global__ __launch_bounds__(HB * 64) void flame_prep_multi_kernel(PrepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    PrepScratch* const S = (PrepScratch*)psm;                                   // [HB]
+    float* const s_hp = psm + HB * (sizeof(PrepScratch) / sizeof(float));      // [HB][HP_SIZE]
+    float* const s_coef = s_hp + HB * HP_SIZE;                                  // [Kp][HB]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h0 = blockIdx.x * HB, h = h0 + wv;
+    const int n = a.n_dev ? min(a.n, *a.n_dev) : a.n;
+    if (h0 >= n) return;
+    if (h < n) {
+        prep_head(a, h, lane, S[wv], s_coef + wv, HB, s_hp + wv * HP_SIZE, true);
+    } else {
+        for (int k = lane; k < a.Kp; k += 64) s_coef[k * HB + wv] = 0.0f;
+        for (int e = lane; e < HP_SIZE; e += 64) s_hp[wv * HP_SIZE + e] = 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < a.Kp * HB; e += HB * 64) a.coef[(int64_t)(e / HB) * a.npad + h0 + (e % HB)] = s_coef[e];
+    float* const hpg = a.headpack + (int64_t)h0 * HP_SIZE;
+    for (int e = tid; e < HB * HP_SIZE; e += HB * 64) hpg[e] = s_hp[e];
 }
 
 struct VertArgs {
@@ -463,10 +523,97 @@ int launch_vertex_cfg(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
 //                tile and runs the skinning / rigid / un-pad epilogue on them in registers;
 //   operands   : straight from L2 / Infinity Cache into VGPRs (the 26 MB basis is resident there), two bursts of UQ k-pairs in
 //                flight; no LDS traffic in the loop (LDS only holds the head packs for the epilogue).
+// Shared tail of the matrix-core kernels: skinning transform on the MFMA pipe, rigid transform + un-pad, 12-byte stores.
+// acc[t][c]: blend result of heads h0 + hoff + t*32 + (MFMA row map) x vertex v, component c.  s_hpT: [HP_SIZE][NH] head packs of the
+// block's NH heads (field-major).
+template <int MT>
+__device__ __forceinline__ void mfma_epilogue(const VertArgs& a, f32x16_t (&acc)[MT][3], const float* s_hpT, const int NH, const int hoff, const int h0, const int v,
+                                              const int half, const int j, const int lane) {
+#pragma clang fp contract(off)
+    const int64_t plane = a.Vp;
+    // ---- skinning on the matrix cores too: T[h][q](v) = sum_j w_j(v) A_j(h)[q] is a K = NJ contraction whose result lands in the
+    //      SAME (head, vertex) -> (lane, register) map as the blend accumulators; chain order j ascending from 0, as the VALU kernel's
+    //      fmaf chain (the pad joint contributes fma(0, 0, T) = T).  One output row (4 entries of T) at a time: 4 accumulators. ----
+    if (VGH_ABLATE(a, 2)) {
+        if (a.proj && lane == 0) a.proj[((int64_t)(h0 + hoff) * a.V + v) * 3] = acc[0][0][0] + acc[MT - 1][2][15];
+        return;
+    }
+    // Branch-free over all MAXJ joint slots: the head packs hold exact zeros for joints >= NJ (prep_head clears them), so a pad joint
+    // contributes fma(0, w, T) = T like the VALU chain's pad; the weight plane index is clamped (its value is multiplied by 0).
+    // (per-lane conditional loads here made hipcc split the epilogue into ~200 exec-masked blocks and spill the accumulators)
+    float wq[(MAXJ + 1) / 2];  // this lane's B operands: w_{2p + half}(v)
+#pragma unroll
+    for (int p = 0; p < (MAXJ + 1) / 2; ++p) {
+        const int jn = 2 * p + half;
+        const float w = a.wts[(int64_t)min(jn, a.NJ - 1) * plane + v];
+        wq[p] = jn < a.NJ ? w : 0.0f;
+    }
+    const bool vok = v < a.V;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        float outv[3][16];
+#pragma unroll
+        for (int row = 0; row < 3; ++row) {
+            // o = fmaf(T0, x, fmaf(T1, y, fmaf(T2, z, T3))) built innermost first, two transform entries at a time (register pressure:
+            // four live 16-register accumulators next to the 96 blend accumulators spilled)
+            float o[16];
+#pragma unroll
+            for (int qp = 1; qp >= 0; --qp) {
+                f32x16_t T[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) T[q][r] = 0.0f;
+#pragma unroll
+                for (int p = 0; p < (MAXJ + 1) / 2; ++p) {
+                    const int jn = 2 * p + half;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float av = s_hpT[(HP_A + jn * 12 + row * 4 + qp * 2 + q) * NH + hoff + t * 32 + j];
+                        T[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wq[p], T[q], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (qp == 1) o[r] = fmaf(T[0][r], acc[t][2][r], T[1][r]);                         // fmaf(T2, z, T3)
+                    else o[r] = fmaf(T[0][r], acc[t][0][r], fmaf(T[1][r], acc[t][1][r], o[r]));  // fmaf(T0, x, fmaf(T1, y, .))
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the transform entries sequential: the scheduler otherwise starts all of them at once
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) outv[row][r] = row == 2 ? o[r] + a.z_offset : o[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int hh = hoff + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (!vok || h0 + hh >= a.n) continue;
+            const float vx = outv[0][r], vy = outv[1][r], vz = outv[2][r];
+            const int64_t obase = ((int64_t)(h0 + hh) * a.V + v) * 3;
+            if (a.verts) *(f32x3_t*)(a.verts + obase) = f32x3_t{vx, vy, vz};  // 12 bytes per lane, contiguous across the wave
+            if (a.proj) {
+                const float* hp = s_hpT + hh;  // field f of this head: hp[f * NH] (all lanes of a half-wave read the same word)
+                const float s = hp[HP_S * NH];
+                float qx = (hp[(HP_R + 0) * NH] * vx + hp[(HP_R + 1) * NH] * vy + hp[(HP_R + 2) * NH] * vz) * s + hp[(HP_T + 0) * NH];
+                float qy = (hp[(HP_R + 3) * NH] * vx + hp[(HP_R + 4) * NH] * vy + hp[(HP_R + 5) * NH] * vz) * s + hp[(HP_T + 1) * NH];
+                float qz = (hp[(HP_R + 6) * NH] * vx + hp[(HP_R + 7) * NH] * vy + hp[(HP_R + 8) * NH] * vz) * s + hp[(HP_T + 2) * NH];
+                if (a.do_unpad) {  // detector.py:67-69
+                    const float us = hp[(HP_U + 2) * NH];
+                    qx = (qx - hp[(HP_U + 0) * NH]) / us;
+                    qy = (qy - hp[(HP_U + 1) * NH]) / us;
+                    qz = qz / us;
+                }
+                *(f32x3_t*)(a.proj + obase) = f32x3_t{qx, qy, qz};
+            }
+            asm volatile("" ::: "memory");  // one head's 16 pack fields at a time: hoisting all 16 x 16 LDS reads costs 256 registers
+        }
+    }
+}
+
 template <int MT>
 __global__ __launch_bounds__(256) void flame_mfma_kernel(VertArgs a) {
 #pragma clang fp contract(off)
-    constexpr int UQ = 8;  // k-pairs per burst (two bursts in flight: the basis comes from L2 / Infinity Cache)
+    constexpr int UQ = MT == 1 ? 16 : 8;  // k-pairs per burst (two bursts in flight: the basis comes from L2 / Infinity Cache; at MT = 1 the
+                                           // accumulators leave room for twice the depth, and small batches are pure load latency)
     constexpr int NH = MT * 32;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* s_hpT = fsm;  // [HP_SIZE][NH]: the head packs TRANSPOSED (field-major), so that 32 lanes reading one field of 32 heads hit 32 banks
@@ -540,74 +687,201 @@ __global__ __launch_bounds__(256) void flame_mfma_kernel(VertArgs a) {
     run(a.r0_begin, a.r0_end);
     run(a.r1_begin, a.r1_end);
     run(a.r2_begin, a.r2_end);
-    // ---- skinning on the matrix cores too: T[h][q](v) = sum_j w_j(v) A_j(h)[q] is a K = NJ contraction whose result lands in the
-    //      SAME (head, vertex) -> (lane, register) map as the blend accumulators; chain order j ascending from 0, as the VALU kernel's
-    //      fmaf chain (the pad joint contributes fma(0, 0, T) = T).  One output row (4 entries of T) at a time: 4 accumulators. ----
-    if (VGH_ABLATE(a, 2)) {
-        if (a.proj && lane == 0) a.proj[((int64_t)h0 * a.V + v) * 3] = acc[0][0][0] + acc[MT - 1][2][15];
-        return;
-    }
-    const int njp = (a.NJ + 1) >> 1;
-    float wq[(MAXJ + 1) / 2];  // this lane's B operands: w_{2p + half}(v)
+    mfma_epilogue<MT>(a, acc, s_hpT, NH, 0, h0, v, half, j, lane);
+}
+
+// Tail of the LDS-staged matrix-core kernel: the skinning / rigid / un-pad arithmetic of flame_vertex_kernel, statement for statement
+// (same fmaf chains, same operation order => bit-identical), on the MFMA accumulator layout: register r of acc[t][c] is head
+// hoff + t*32 + (r&3) + 8*(r>>2) + 4*half, vertex v.  s_hp: [NH][HP_SIZE] head packs (head-major: a half-wave reads ONE head, so every
+// 16-byte LDS read is a broadcast).  One head at a time keeps this at ~40 live registers next to the 96 accumulators.
+template <int MT>
+__device__ __forceinline__ void valu_epilogue(const VertArgs& a, f32x16_t (&acc)[MT][3], const float* s_hp, const int hoff, const int h0, const int v, const int half) {
+#pragma clang fp contract(off)
+    const int64_t plane = a.Vp;
+    float wj[MAXJ];
 #pragma unroll
-    for (int p = 0; p < (MAXJ + 1) / 2; ++p) {
-        const int jn = 2 * p + half;
-        wq[p] = (p < njp && jn < a.NJ) ? a.wts[(int64_t)jn * plane + v] : 0.0f;
-    }
+    for (int j = 0; j < MAXJ; ++j) wj[j] = j < a.NJ ? a.wts[(int64_t)j * plane + v] : 0.0f;
     const bool vok = v < a.V;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        float outv[3][16];
-#pragma unroll
-        for (int row = 0; row < 3; ++row) {
-            f32x16_t T[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T[q][r] = 0.0f;
-#pragma unroll
-            for (int p = 0; p < (MAXJ + 1) / 2; ++p) {
-                if (p < njp) {  // wave-uniform
-                    const int jn = 2 * p + half;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float av = (jn < a.NJ) ? s_hpT[(HP_A + jn * 12 + row * 4 + q) * NH + t * 32 + j] : 0.0f;
-                        T[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wq[p], T[q], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float o = fmaf(T[0][r], acc[t][0][r], fmaf(T[1][r], acc[t][1][r], fmaf(T[2][r], acc[t][2][r], T[3][r])));
-                outv[row][r] = row == 2 ? o + a.z_offset : o;
-            }
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int hh = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (!vok || h0 + hh >= a.n) continue;
-            const float vx = outv[0][r], vy = outv[1][r], vz = outv[2][r];
-            const int64_t obase = ((int64_t)(h0 + hh) * a.V + v) * 3;
-            if (a.verts) *(f32x3_t*)(a.verts + obase) = f32x3_t{vx, vy, vz};  // 12 bytes per lane, contiguous across the wave
-            if (a.proj) {
-                const float* hp = s_hpT + hh;  // field f of this head: hp[f * NH] (all lanes of a half-wave read the same word)
-                const float s = hp[HP_S * NH];
-                float qx = (hp[(HP_R + 0) * NH] * vx + hp[(HP_R + 1) * NH] * vy + hp[(HP_R + 2) * NH] * vz) * s + hp[(HP_T + 0) * NH];
-                float qy = (hp[(HP_R + 3) * NH] * vx + hp[(HP_R + 4) * NH] * vy + hp[(HP_R + 5) * NH] * vz) * s + hp[(HP_T + 1) * NH];
-                float qz = (hp[(HP_R + 6) * NH] * vx + hp[(HP_R + 7) * NH] * vy + hp[(HP_R + 8) * NH] * vz) * s + hp[(HP_T + 2) * NH];
-                if (a.do_unpad) {  // detector.py:67-69
-                    const float us = hp[(HP_U + 2) * NH];
-                    qx = (qx - hp[(HP_U + 0) * NH]) / us;
-                    qy = (qy - hp[(HP_U + 1) * NH]) / us;
-                    qz = qz / us;
+            const int hh = hoff + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float* hp = s_hp + hh * HP_SIZE;
+            float T[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) T[q] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j)
+                if (j < a.NJ) {  // wave-uniform
+                    const f32x4_t A0 = *(const f32x4_t*)(hp + HP_A + j * 12), A1 = *(const f32x4_t*)(hp + HP_A + j * 12 + 4), A2 = *(const f32x4_t*)(hp + HP_A + j * 12 + 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        T[q] = fmaf(wj[j], A0[q], T[q]);
+                        T[4 + q] = fmaf(wj[j], A1[q], T[4 + q]);
+                        T[8 + q] = fmaf(wj[j], A2[q], T[8 + q]);
+                    }
                 }
-                *(f32x3_t*)(a.proj + obase) = f32x3_t{qx, qy, qz};
+            const float px = acc[t][0][r], py = acc[t][1][r], pz = acc[t][2][r];
+            const float vx = fmaf(T[0], px, fmaf(T[1], py, fmaf(T[2], pz, T[3])));
+            const float vy = fmaf(T[4], px, fmaf(T[5], py, fmaf(T[6], pz, T[7])));
+            const float vz = fmaf(T[8], px, fmaf(T[9], py, fmaf(T[10], pz, T[11]))) + a.z_offset;
+            if (vok && h0 + hh < a.n) {
+                const int64_t obase = ((int64_t)(h0 + hh) * a.V + v) * 3;
+                if (a.verts) *(f32x3_t*)(a.verts + obase) = f32x3_t{vx, vy, vz};  // 12 bytes per lane, contiguous across a half-wave
+                if (a.proj) {
+                    const f32x4_t R0 = *(const f32x4_t*)(hp + HP_R), R1 = *(const f32x4_t*)(hp + HP_R + 4), R2 = *(const f32x4_t*)(hp + HP_R + 8), R3 = *(const f32x4_t*)(hp + HP_R + 12);
+                    // R0 = R[0..3], R1 = R[4..7], R2 = {R[8], s, t0, t1}, R3 = {t2, u0, u1, u2}
+                    const float s = R2[1];
+                    float qx = (R0[0] * vx + R0[1] * vy + R0[2] * vz) * s + R2[2];
+                    float qy = (R0[3] * vx + R1[0] * vy + R1[1] * vz) * s + R2[3];
+                    float qz = (R1[2] * vx + R1[3] * vy + R2[0] * vz) * s + R3[0];
+                    if (a.do_unpad) {  // detector.py:67-69
+                        qx = (qx - R3[1]) / R3[3];
+                        qy = (qy - R3[2]) / R3[3];
+                        qz = qz / R3[3];
+                    }
+                    *(f32x3_t*)(a.proj + obase) = f32x3_t{qx, qy, qz};
+                }
             }
+            asm volatile("" ::: "memory");  // one head at a time
         }
     }
 }
 
-static bool f_mfma_enabled() { return g_flame_mfma; }
+// Crowd-scale variant of the matrix-core kernel: block = 128 heads x 128 vertices (8 waves = 2 head groups x 4 vertex groups, each
+// wave the same 64 heads x 32 vertices x 3 components as flame_mfma_kernel<2>), operands staged through LDS by LDS-DMA in slabs of
+// 8 k-pairs, double buffered.  Why: the register-fed kernel loads 5 operand dwords per lane per 6 MFMAs straight from L2 -- 13 B/clk/CU,
+// which is what pins it (and the VALU kernel) near 66 TFLOP/s at n = 8192; here a slab of 32 KB feeds 384 MFMAs (49 FLOP per byte
+// from L2, < 3.2 TB/s at the full fp32 matrix rate) and the MFMA operands are conflict-free ds_read_b32.  Same k-ordered chain per
+// output element, so results are bit-identical to the other FLAME kernels.
+constexpr int LB_H = 128, LB_V = 128, LB_KS = 16;                 // heads, vertices, k rows per slab
+constexpr int LB_A = LB_KS * LB_H, LB_B = LB_KS * 3 * LB_V;       // floats per slab: coefficients [k][128], basis [k][c][128]
+constexpr int LB_STAGE = LB_A + LB_B;                             // 8192 floats = 32 KiB
+
+template <int WPS>  // waves per SIMD the register allocation aims for: 4 = two resident blocks per CU (128 registers), 2 = one
+__global__ __launch_bounds__(512, WPS) void flame_mfma_lds_kernel(VertArgs a) {
+#pragma clang fp contract(off)
+    constexpr int MT = 2;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];  // 2 slabs during the blend loop, then the head packs [HP_SIZE][128]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int hw = wv >> 2, vw = wv & 3;
+    const int h0 = blockIdx.y * LB_H, v0 = blockIdx.x * LB_V;
+    if (a.n_dev) a.n = min(a.n, *a.n_dev);
+    if (h0 >= a.n) return;
+    const int j = lane & 31, half = lane >> 5;
+    const int v = v0 + vw * 32 + j;
+    const int64_t plane = a.Vp;
+    f32x16_t acc[MT][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float tv = (v < a.Vp) ? a.vt[c * plane + v] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = tv;
+    }
+    // virtual k-pair index q over the three live ranges -> first k of the pair
+    const int np0 = (a.r0_end - a.r0_begin) >> 1, np1 = (a.r1_end - a.r1_begin) >> 1, np2 = (a.r2_end - a.r2_begin) >> 1;
+    const int npt = np0 + np1 + np2;
+    const int nstage = (npt + LB_KS / 2 - 1) / (LB_KS / 2);
+    // this wave's 4 LDS-DMA pieces of a slab (1 KiB each = two 512-byte rows): waves 0-1 the coefficient rows, 2-7 the basis rows
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (unsigned)((int64_t)a.Kp * a.npad * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.basis, 0, (unsigned)((int64_t)a.r2_end * 3 * plane * 4), 0x00020000);  // r2_end = K: the basis has K rows
+    const int col = (lane & 31) * 4;  // first of this lane's 4 floats inside a 128-float row
+    // first k of every virtual pair (-1 past the end), once per block: keeps the per-slab address math to one LDS read + one multiply
+    int* const s_kq = (int*)(fsm + 2 * LB_STAGE);
+    for (int q = tid; q < nstage * (LB_KS / 2); q += 512)
+        s_kq[q] = q < np0 ? a.r0_begin + 2 * q : q < np0 + np1 ? a.r1_begin + 2 * (q - np0) : q < npt ? a.r2_begin + 2 * (q - np0 - np1) : -1;
+    __syncthreads();
+    // per-piece constants of this lane: k slot inside the slab and the k-independent part of the byte offset
+    int p_ks[4];
+    unsigned p_mul[4], p_add[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wv * 4 + i;
+        if (piece < 8) {  // coefficient rows 2*piece + half: [k][npad]
+            p_ks[i] = piece * 2 + half;
+            p_mul[i] = (unsigned)a.npad * 4u;
+            p_add[i] = (unsigned)(h0 + col) * 4u;
+        } else {          // basis rows rr = (piece-8)*2 + half -> (k slot, component): [k][c][Vp]
+            const int rr = (piece - 8) * 2 + half;
+            const int ks = rr / 3, c = rr - ks * 3;
+            p_ks[i] = ks;
+            p_mul[i] = (unsigned)plane * 12u;
+            p_add[i] = (unsigned)(c * plane + v0 + col) * 4u;
+        }
+    }
+    auto issue = [&](int st, int buf) {
+        float* const base = fsm + buf * LB_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wv * 4 + i;  // wave-uniform
+            const int k0 = s_kq[st * (LB_KS / 2) + (p_ks[i] >> 1)];
+            const unsigned off = k0 >= 0 ? (unsigned)(k0 + (p_ks[i] & 1)) * p_mul[i] + p_add[i] : 0xFFFFFFF0u;  // past the end: out of range -> zeros
+            if (piece < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(base + piece * 256), 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (AS3 void*)(base + LB_A + (piece - 8) * 256), 16, off, 0, 0, 0);
+        }
+    };
+    issue(0, 0);
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) {
+            issue(st + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const float* const sa = fsm + buf * LB_STAGE + half * LB_H + hw * 64 + j;            // + pair*2*LB_H + t*32
+        const float* const sb = fsm + buf * LB_STAGE + LB_A + half * 3 * LB_V + vw * 32 + j;  // + pair*6*LB_V + c*LB_V
+        const int pairs = min(LB_KS / 2, npt - st * (LB_KS / 2));
+        float A[2][MT], B[2][3];
+        auto rd = [&](int u, float (&Ao)[MT], float (&Bo)[3]) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) Ao[t] = sa[u * 2 * LB_H + t * 32];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Bo[c] = sb[u * 6 * LB_V + c * LB_V];
+        };
+        rd(0, A[0], B[0]);
+#pragma unroll
+        for (int u = 0; u < LB_KS / 2; ++u) {
+            if (u + 1 < LB_KS / 2) rd(u + 1, A[(u + 1) & 1], B[(u + 1) & 1]);  // next pair's operands under this pair's MFMAs
+            if (u < pairs) {  // wave-uniform
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u & 1][t], B[u & 1][c], acc[t][c], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // slab `buf` is rewritten by the loads issued at the top of the next iteration
+    }
+    // head packs of the block's 128 heads into the (now free) slab memory: a straight copy, [head][HP_SIZE]
+    float* const s_hp = fsm;
+    for (int e = tid * 4; e < LB_H * HP_SIZE; e += 512 * 4) {
+        const int hh = e / HP_SIZE;
+        *(f32x4_t*)(s_hp + e) = (h0 + hh < a.n) ? *(const f32x4_t*)(a.headpack + (int64_t)h0 * HP_SIZE + e) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    __syncthreads();
+    if (v >= a.Vp) return;
+    valu_epilogue<MT>(a, acc, s_hp, hw * 64, h0, v, half);
+}
+
+template <int WPS>
+int launch_mfma_lds(const VertArgs& va, hipStream_t st) {
+    static_assert(LB_H * HP_SIZE * 4 == 2 * LB_STAGE * 4, "the head packs reuse the two slabs");
+    const size_t lds = (size_t)2 * LB_STAGE * sizeof(float) + 1024;  // 64 KiB + the pair table (<= 256 entries): two blocks per CU
+    static std::atomic<int> attr_done[16];
+    int dev = 0;
+    VGH_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
+        VGH_HIP(hipFuncSetAttribute((const void*)flame_mfma_lds_kernel<WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[dev].store(1, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(flame_mfma_lds_kernel<WPS>, dim3((va.V + LB_V - 1) / LB_V, (va.n + LB_H - 1) / LB_H), dim3(512), lds, st, va);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
 
 template <int MT>
 int launch_mfma(const VertArgs& va, hipStream_t st) {
@@ -640,6 +914,13 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
     for (int done = 0; done < n; done += f->max_heads) {
         const int m = (n - done < f->max_heads) ? n - done : f->max_heads;
         PrepArgs pa = pa_in;
+        pa.n = m;
+        pa.live0_end = detector_mode ? shape_live : f->NB;
+        pa.live1_begin = detector_mode ? 300 : 0;
+        pa.live1_end = detector_mode ? 300 + expr_live : 0;
+#ifdef VGH_EXPERIMENTS
+        pa.trace = g_prep_trace;
+#endif
         if (pa.params) pa.params += (int64_t)done * VGH_NUM_FLAME_PARAMS;
         if (pa.betas) pa.betas += (int64_t)done * f->NB;
         if (pa.pose) pa.pose += (int64_t)done * f->NJ * 3;
@@ -652,10 +933,26 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         // (measured, profiles/r02_flame_sweep.json: the matrix-core kernel wins from a handful of heads up to a few thousand; at crowd scale the
         //  VALU kernel's 8-heads-per-basis-load reuse is ahead again; with a device-side count the launch is capacity-sized and mostly
         //  exits at once, so the tile count that matters is the live one)
-        const bool mfma = even && f_mfma_enabled() && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048));
+        const int mode = g_flame_mode;
+        const bool lds = even && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMinHeads));  // crowd scale: operands staged through LDS
+        const bool mfma = lds || (even && (mode == 2 || (mode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
         const bool fused = !mfma && !pa.n_dev && m <= 256;  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
-            hipLaunchKernelGGL(flame_prep_kernel, dim3(m), dim3(64), 0, st, pa);
+            constexpr int HB = 16;
+            if (m >= 512) {  // coalesced coefficient rows (measured: 16 waves per block cost 17 us vs 9.5 us at n = 96, but 92 vs 112 us at n = 8192); the
+                            // padded heads of the last block stay inside the scratch (npad is a multiple of 128)
+                const size_t lds = (size_t)HB * sizeof(PrepScratch) + (size_t)HB * HP_SIZE * 4 + (size_t)f->Kp * HB * 4;
+                static std::atomic<int> attr_done[16];
+                int dev = 0;
+                VGH_HIP(hipGetDevice(&dev));
+                if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
+                    VGH_HIP(hipFuncSetAttribute((const void*)flame_prep_multi_kernel<HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    attr_done[dev].store(1, std::memory_order_release);
+                }
+                hipLaunchKernelGGL(flame_prep_multi_kernel<HB>, dim3((m + HB - 1) / HB), dim3(HB * 64), lds, st, pa);
+            } else {
+                hipLaunchKernelGGL(flame_prep_kernel, dim3(m), dim3(64), 0, st, pa);
+            }
             VGH_HIP(hipGetLastError());
         }
         if (!verts && !proj) continue;
@@ -694,7 +991,9 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         if (getenv("VGH_FLAME_ABLATE")) va.ablate = atoi(getenv("VGH_FLAME_ABLATE"));
 #endif
         int rc;
-        if (mfma) {
+        if (lds) {
+            rc = mode == 4 ? launch_mfma_lds<2>(va, st) : launch_mfma_lds<4>(va, st);
+        } else if (mfma) {
             if (pa.n_dev || m <= 512)
                 rc = launch_mfma<1>(va, st);  // one 32-head tile per wave: twice the waves, two resident per SIMD
             else
@@ -754,7 +1053,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
     for (int v = 0; v < V; ++v)
         for (int j = 0; j < NJ; ++j) wts[(size_t)j * Vp + v] = lbs_weights[(size_t)v * NJ + j];
     // fold the joint regressor into the shape basis (fp64)
-    std::vector<float> J0((size_t)3 * NJ), JS((size_t)3 * NJ * NB);
+    std::vector<float> J0((size_t)3 * NJ), JS((size_t)NB * MAXJ * 3, 0.0f);
     {
         std::vector<double> accS((size_t)NB);
         for (int j = 0; j < NJ; ++j)
@@ -769,7 +1068,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
                     for (int l = 0; l < NB; ++l) accS[l] += w * (double)sd[l];
                 }
                 J0[(size_t)j * 3 + c] = (float)a0;
-                for (int l = 0; l < NB; ++l) JS[((size_t)j * 3 + c) * NB + l] = (float)accS[l];
+                for (int l = 0; l < NB; ++l) JS[(size_t)l * (MAXJ * 3) + j * 3 + c] = (float)accS[l];
             }
     }
 #define UP(dst, vec)                                                                              \
@@ -786,7 +1085,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
     f->npad = (f->max_heads + 127) / 128 * 128;
     VGH_HIP(hipMalloc((void**)&f->coef, (size_t)f->npad * f->Kp * sizeof(float)));
     VGH_HIP(hipMemset(f->coef, 0, (size_t)f->npad * f->Kp * sizeof(float)));
-    VGH_HIP(hipMalloc((void**)&f->headpack, (size_t)f->max_heads * HP_SIZE * sizeof(float)));
+    VGH_HIP(hipMalloc((void**)&f->headpack, (size_t)f->npad * HP_SIZE * sizeof(float)));  // npad rows: the multi-head prologue writes whole 16-head groups
     *out = f;
     return VGH_OK;
 }
@@ -859,8 +1158,16 @@ int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32
     return run_decode(f, pa, capacity, shape_live, expr_live, true, verts_dev, proj_dev, stream);
 }
 
-int vgh_flame_set_matrix_path(int enable) {
-    g_flame_mfma = enable != 0;
+#ifdef VGH_EXPERIMENTS
+int vgh_flame_set_trace(void* dev_buffer) {
+    g_prep_trace = (unsigned long long*)dev_buffer;
+    return VGH_OK;
+}
+#endif
+
+int vgh_flame_set_matrix_path(int mode) {
+    VGH_REQUIRE(mode >= 0 && mode <= 4, "flame_set_matrix_path: mode %d outside 0..4", mode);
+    g_flame_mode = mode;
     return VGH_OK;
 }
 

@@ -1252,26 +1252,28 @@ def test_c_only_create_and_detect(gpu_lib, flame_model, tmp_path):
     assert gpu_lib.vgh_create(C.byref(bad), C.byref(h)) != 0 and b"not a readable" in gpu_lib.vgh_last_error()
 
 
-@pytest.mark.parametrize("n,live", [(12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (257, (128, 64))])
+@pytest.mark.parametrize("n,live", [(12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (257, (128, 64)), (1300, (64, 32)), (1100, (300, 100))])
 def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame_model, n, live):
-    """The FP32-MFMA vertex kernel (v_mfma_f32_32x32x2_f32 = an exact k-ordered fmaf chain) and the VALU kernel produce the SAME bits
-    for every vertex (unrotated and projected / un-padded), for partial head tiles, every live-coefficient split and through the
-    detector's device-side head count -- so which one runs is a pure speed choice -- and both stay within the f64-oracle bar."""
+    """The FP32-MFMA vertex kernels (v_mfma_f32_32x32x2_f32 = an exact k-ordered fmaf chain; register-fed for small / medium batches,
+    LDS-staged 128 x 128 tiles at crowd scale) and the VALU kernel produce the SAME bits for every vertex (unrotated and projected /
+    un-padded), for partial head tiles, every live-coefficient split -- so which one runs is a pure speed choice -- and all stay
+    within the f64-oracle bar.  Modes of vgh_flame_set_matrix_path: 0 VALU, 1 automatic, 2 register-fed, 3 / 4 LDS-staged."""
     from head_detector_amd.flame import FLAMELayer
     from oracle import flame_oracle as fo
 
-    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=512)
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=max(512, n))
     p = fo.synthetic_params(n, seed=n, live_shape=live[0], live_expr=live[1]).to(_dev())
     unpad = torch.tensor([[3.0, 7.0, 1.3]], device=_dev()).expand(n, 3).contiguous()
     outs = {}
     try:
-        for on in (1, 0):
-            assert gpu_lib.vgh_flame_set_matrix_path(on) == 0
-            outs[on] = [t.clone() for t in fl.decode(p, unpad=unpad, shape_live=live[0], expr_live=live[1])]
+        for mode in (1, 0, 2, 3, 4):
+            assert gpu_lib.vgh_flame_set_matrix_path(mode) == 0
+            outs[mode] = [t.clone() for t in fl.decode(p, unpad=unpad, shape_live=live[0], expr_live=live[1])]
     finally:
         gpu_lib.vgh_flame_set_matrix_path(1)
-    for a, b in zip(outs[1], outs[0]):
-        assert torch.equal(a, b)
+    for mode in (1, 2, 3, 4):
+        for a, b in zip(outs[mode], outs[0]):
+            assert torch.equal(a, b), mode
     _, _, q = fo.reproject(fo.FlameConstants(flame_model, torch.float64), p.cpu().double())
     q[:, :, 0] -= 3.0
     q[:, :, 1] -= 7.0

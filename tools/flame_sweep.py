@@ -18,9 +18,12 @@ def main():
     dev = torch.device("cuda", 0)
     fl = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=8192)
     lib = _lib.load()
+    mode = int(os.environ.get("FLAME_MODE", "1"))  # vgh_flame_set_matrix_path: 0 VALU, 1 automatic, 2 register-fed MFMA, 3 / 4 LDS-staged MFMA
+    _lib.check(lib.vgh_flame_set_matrix_path(mode))
+    ns = tuple(int(x) for x in os.environ.get("FLAME_NS", "1,8,64,96,1024,8192").split(","))
     rows = []
     for live, (sl, el) in (("M heads 64+32", (64, 32)), ("L heads 128+64", (128, 64)), ("all 300+100", (300, 100))):
-        for n in (1, 8, 64, 96, 1024, 8192):
+        for n in ns:
             p = torch.randn(n, 413, device=dev)
             p[:, sl:300] = 0
             p[:, 300 + el:400] = 0
@@ -44,7 +47,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / it
             k = sl + el + 36
-            rows.append(dict(live=live, n=n, us_per_call=round(us, 2), us_per_head=round(us / n, 3), gflops=round(n * (2.0 * k * 15069 + 0.12e6 + 0.8e6) / us / 1e3, 1),
+            rows.append(dict(mode=mode, live=live, n=n, us_per_call=round(us, 2), us_per_head=round(us / n, 3), gflops=round(n * (2.0 * k * 15069 + 0.12e6 + 0.8e6) / us / 1e3, 1),
                              out_GBps=round(n * 60276 / us / 1e3, 1)))
             print(rows[-1])
     if len(sys.argv) > 1:
