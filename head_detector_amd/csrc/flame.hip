@@ -100,7 +100,6 @@ struct PrepArgs {
 
 // Per-wave LDS scratch of the per-head prologue
 struct PrepScratch {
-    float beta[1024];
     float J[MAXJ * 3];
     float R[MAXJ * 9];
     float pose[MAXJ * 3];
@@ -124,11 +123,26 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     const int64_t prow = a.head_row ? a.head_row[h] : h;
     const int64_t urow = a.head_image ? a.head_image[h] : h;
     const float* p = a.params ? a.params + prow * VGH_NUM_FLAME_PARAMS : nullptr;
-    // betas = [shape(300) | expression(100)]  (flame.py:132-140; FLAME_CONSTS widths make the padding empty)
+    // betas = [shape(300) | expression(100)]  (flame.py:132-140; FLAME_CONSTS widths make the padding empty) -> blend coefficients, and
+    // joints J = J0 + JS beta in the same pass: a lane owns the coefficients l = lane, lane + 64, ..., per output a lane-strided fmaf
+    // chain in ascending l (the xor butterfly follows).  Coefficients outside the live ranges are exact zeros: fma(w, 0, s) = s, so
+    // skipping them leaves every chain as it is.  Row l of JS is six independent 16-byte loads, no branch per output.
+    // (history: a [3*NJ][NB] layout with a runtime bound per output made hipcc wait for each of ~105 loads in turn -- 16 of the
+    //  prologue's 21 us; J0[o] loaded by lane 0 inside the butterfly was another 4.5 us of dependent round trips)
+    float s[MAXJ * 3];
+#pragma unroll
+    for (int o = 0; o < MAXJ * 3; ++o) s[o] = 0.0f;
+#pragma unroll 4
     for (int l = lane; l < NB; l += 64) {
         const float v = p ? p[l] : a.betas[(int64_t)h * NB + l];
-        S.beta[l] = v;
         coef[(int64_t)l * cstride] = v;
+        if (!(l < a.live0_end || (l >= a.live1_begin && l < a.live1_end))) continue;
+        const f32x4_t* const row = (const f32x4_t*)(a.JS + (int64_t)l * (MAXJ * 3));
+        f32x4_t w[MAXJ * 3 / 4];
+#pragma unroll
+        for (int q = 0; q < MAXJ * 3 / 4; ++q) w[q] = row[q];
+#pragma unroll
+        for (int o = 0; o < MAXJ * 3; ++o) s[o] = fmaf(w[o >> 2][o & 3], v, s[o]);
     }
     const float j0 = lane < NJ * 3 ? a.J0[lane] : 0.0f;
     if (p && lane < 13) S.tail[lane] = p[400 + lane];
@@ -146,27 +160,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     PMARK(a, h, lane, 1);
-    // joints: J = J0 + JS beta.  All 3*NJ dot products advance together (independent loads in flight); per output a lane-strided
-    // fmaf chain in ascending l, then the xor butterfly.
     {
-        // (a [3*NJ][NB] layout with a runtime bound per output made hipcc wait for every one of the ~105 loads in turn: 16 of the
-        //  prologue's 21 us.  Coefficient-major rows padded to MAXJ*3 columns: six independent 16-byte loads per coefficient, no branch.)
-        float s[MAXJ * 3];
-#pragma unroll
-        for (int o = 0; o < MAXJ * 3; ++o) s[o] = 0.0f;
-        // lane-strided over l as if every coefficient were visited (l = lane, lane + 64, ...): the skipped ones are zeros, so the chain
-        // per output is the same whatever the live ranges are
-        for (int l = lane; l < NB; l += 64) {
-            if (!(l < a.live0_end || (l >= a.live1_begin && l < a.live1_end))) continue;
-            const float bl = S.beta[l];
-            const f32x4_t* const row = (const f32x4_t*)(a.JS + (int64_t)l * (MAXJ * 3));
-            f32x4_t w[MAXJ * 3 / 4];
-#pragma unroll
-            for (int q = 0; q < MAXJ * 3 / 4; ++q) w[q] = row[q];
-#pragma unroll
-            for (int o = 0; o < MAXJ * 3; ++o) s[o] = fmaf(w[o >> 2][o & 3], bl, s[o]);
-        }
-        // (J0[o] used to be loaded by lane 0 inside this loop: 15 dependent global round trips behind exec-masked branches, ~4.5 us)
         float mine = 0.0f;
 #pragma unroll
         for (int o = 0; o < MAXJ * 3; ++o) {
