@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--split", type=int, default=2, help="independent sub-batches per forward on the net's lane streams (1 = off)")
     ap.add_argument("--no-overlap", action="store_true", help="run NMS..FLAME decode on the network stream instead of the detector's side stream")
     ap.add_argument("--graph", action="store_true", help="replay the network through a captured hipGraph")
+    ap.add_argument("--exchange", action="store_true", help="run the N>1 step (output slots + RCCL gather to rank 0 on the communication stream) even with one rank")
     ap.add_argument("--tuning", default=None, help="tile table to load instead of head_detector_amd/tuning/conv_cfg.json")
     args = ap.parse_args()
     leaked = sorted(k for k in os.environ if k.startswith("VGH_"))
@@ -140,7 +141,7 @@ def main():
     from head_detector_amd.flame import FLAMELayer
     from head_detector_amd.synthetic import synthetic_flame_model
 
-    rank, world, local = init_from_env()
+    rank, world, local = init_from_env(single_rank_group=args.exchange)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -188,9 +189,10 @@ def main():
         # on a communication stream behind the detector's side stream: the gather of batch s runs under the network of batch s+1 and
         # nothing in the steady-state loop waits on the host (head_detector_amd/dist.py::DetectionGatherer)
         slots = gat = None
-        if world > 1:
+        if world > 1 or args.exchange:
             slots = [eng.new_output_slot(flame) for _ in range(2)]
-            gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * args.heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream())
+            gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * args.heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream(),
+                                    always_collective=args.exchange)
             ready = [torch.cuda.Event() for _ in range(2)]
         nstep = [0]
 
@@ -221,7 +223,7 @@ def main():
 
         for _ in range(warmup):
             step()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -232,10 +234,10 @@ def main():
             for s in range(2):
                 gat.result(s)  # the last two exchanges
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([dt], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
@@ -274,7 +276,7 @@ def main():
                 traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
         config = {"workload": f"{args.variant} bf16 batch {B}/GPU @ {S}x{S}, u8 NHWC input resident in HBM, ~{main_run['heads_per_img']:.2f} heads/img decoded",
                   "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(main_run["flops_per_image"] / 1e9, 2),
-                  "graph": bool(args.graph), "overlap_post": overlap, "batch_split": nsplit, "flame_decode_us_per_head_n96": round(decode_us_per_head, 3),
+                  "graph": bool(args.graph), "exchange_to_rank0": bool(world > 1 or args.exchange), "overlap_post": overlap, "batch_split": nsplit, "flame_decode_us_per_head_n96": round(decode_us_per_head, 3),
                   "net_ms_per_step": round(main_run["net_ms"], 3)}
         if world == 1 and not args.no_secondary and (args.variant, B) != ("vgg_heads_m", 32):
             m = run_workload("vgg_heads_m", 32, max(50, args.steps // 2), args.warmup)
@@ -298,7 +300,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.variant, S, flame_model)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -19,12 +19,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world_size, local_rank) from torchrun's environment; initialises the default process group if needed."""
+def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's environment; initialises the default process group if needed
+    (``single_rank_group``: also for WORLD_SIZE = 1, so that the exchange path can be exercised on one GPU)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -113,8 +114,10 @@ class DetectionGatherer:
     caller's stream wait for them.  Ranks may own different numbers of images (uneven shards): pass ``B_local`` = the largest shard
     and ``local_images`` = this rank's count; rows beyond it carry count 0."""
 
-    def __init__(self, B_local: int, keep: int, num_vertices: int = 0, vertex_rows: int = 0, device=None, dst: int = 0, group=None, slots: int = 2, stream=None):
+    def __init__(self, B_local: int, keep: int, num_vertices: int = 0, vertex_rows: int = 0, device=None, dst: int = 0, group=None, slots: int = 2, stream=None, always_collective: bool = False):
         self.group, self.dst = group, dst
+        # always_collective: go through the process group even when it has a single rank (exercises the RCCL calls on a 1-GPU box)
+        self.collective = dist.is_initialized() and (dist.get_world_size(group) > 1 or always_collective)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.B, self.keep, self.V, self.vrows = B_local, keep, num_vertices, vertex_rows
@@ -176,7 +179,7 @@ class DetectionGatherer:
                 r = min(self.vrows, vertices.shape[0])
                 sl["send_verts"][:r].copy_(vertices[:r], non_blocking=True)
             work = []
-            if self.world > 1:
+            if self.collective:
                 work.append(dist.all_gather(list(sl["recv_counts"].unbind(0)), sl["send_counts"], group=self.group, async_op=True))
                 gl = list(sl["recv"].unbind(0)) if self.rank == self.dst else None
                 work.append(dist.gather(sl["send"], gl, dst=self.dst, group=self.group, async_op=True))

@@ -1066,6 +1066,52 @@ def test_lane_and_side_streams_are_measured_to_overlap(gpu_lib):
         eng.close()
 
 
+def test_gatherer_collectives_on_rccl_single_rank(gpu_lib):
+    """The exact torch.distributed calls of DetectionGatherer (async all_gather into views, gather, work.wait() on a communication
+    stream acquired from the library) on the real RCCL backend -- a one-rank group is all a 1-GPU box offers, but it goes through the
+    same ProcessGroupNCCL code as N ranks."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from head_detector_amd.dist import DetectionGatherer
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        B, keep, V = 4, 100, 5023
+        import ctypes as C
+
+        got = C.c_void_p()
+        main = torch.cuda.current_stream().cuda_stream
+        avoid = (C.c_void_p * 1)(main)
+        assert gpu_lib.vgh_stream_acquire(0, avoid, 1, C.byref(got)) == 0
+        comm = torch.cuda.ExternalStream(got.value, device=_dev())
+        g = DetectionGatherer(B, keep, V, vertex_rows=16, device=_dev(), stream=comm, always_collective=True)
+        assert g.collective
+        gen = torch.Generator().manual_seed(5)
+        for step in range(5):
+            slot = step & 1
+            g.wait_slot_free(slot)
+            boxes, scores, flame = torch.rand(B, keep, 4, generator=gen).to(_dev()), torch.rand(B, keep, generator=gen).to(_dev()), torch.rand(B, keep, 413, generator=gen).to(_dev())
+            counts = torch.randint(0, 4, (B,), generator=gen).int().to(_dev())
+            verts = torch.rand(16, V, 3, generator=gen).to(_dev())
+            ev = torch.cuda.Event()
+            ev.record()
+            g.submit(slot, boxes, scores, flame, counts, None, verts, ev)
+            out = g.result(slot)
+            assert torch.equal(out.boxes, boxes) and torch.equal(out.scores, scores) and torch.equal(out.flame_params, flame) and torch.equal(out.counts, counts)
+            assert int(out.n_heads_per_rank[0]) == int(counts.sum()) and torch.equal(out.vertex_slabs[0], verts)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_batch_split_lanes_are_invisible(gpu_lib, flame_model):
     """vgh_net_set_split: the batch as 2 / 3 / 4 independent sub-batches on the net's lane streams (uneven sizes included) must give
     bit-identical activations, candidates and detections to the single-stream run -- also combined with overlap mode."""
