@@ -136,7 +136,7 @@ def main():
     import torch.distributed as dist
 
     from head_detector_amd import _lib
-    from head_detector_amd.dist import DetectionGatherer, init_from_env
+    from head_detector_amd.dist import DetectionGatherer, init_from_env, steer_collective_stream
     from head_detector_amd.engine import VGHeadsEngine
     from head_detector_amd.flame import FLAMELayer
     from head_detector_amd.synthetic import synthetic_flame_model
@@ -151,6 +151,8 @@ def main():
     flame = FLAMELayer(model=flame_model, device=dev, max_heads=max(1024, max(args.batch, 32) * 100))
     nsplit = 1 if args.graph else max(1, min(4, args.split))
     overlap = not args.no_overlap and not args.graph
+
+    steered = [False]
 
     def run_workload(variant: str, B: int, steps: int, warmup: int, per_layer_path=None) -> dict:
         """The timed region of the contract for one (variant, batch): W warm-up steps, barrier + synchronize, K steps, synchronize +
@@ -194,6 +196,12 @@ def main():
             gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * args.heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream(),
                                     always_collective=args.exchange)
             ready = [torch.cuda.Event() for _ in range(2)]
+            if gat.collective and not steered[0]:
+                # RCCL launches its kernels on a stream of torch's pool; on the hardware queue of the engine stream or of a lane they would
+                # hold up the next batch's network (a queue is in-order).  Steer the pool before the first collective, then measure.
+                steered[0] = True
+                ok = steer_collective_stream(eng.streams_in_use())
+                print(f"[bench] rank {rank}: collective stream {'clear of' if ok else 'SHARES a hardware queue with'} the engine's streams", file=sys.stderr)
         nstep = [0]
 
         def step(i=None):

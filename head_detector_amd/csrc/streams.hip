@@ -107,4 +107,11 @@ int vgh_stream_release(int device, void* stream) {
 
 int vgh_streams_overlap(void* a, void* b) { return runs_concurrently((hipStream_t)a, (hipStream_t)b) ? 1 : 0; }
 
+int vgh_stream_spin(void* stream, int microseconds) {
+    VGH_REQUIRE(microseconds >= 0 && microseconds <= 100000, "stream_spin: 0..100000 us");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
 }  // extern "C"

@@ -36,6 +36,78 @@ def init_from_env(backend: Optional[str] = None, single_rank_group: bool = False
     return rank, world, local
 
 
+def collective_shares_queue_with(stream: "torch.cuda.Stream", group=None, spin_us: int = 400) -> bool:
+    """Does the process group's internal stream (RCCL runs its kernels on a stream of its own, taken from torch's pool) share a
+    hardware queue with ``stream``?  HIP maps streams onto 4 hardware queues and a queue is in-order: a collective that waits for its
+    input would then hold up every kernel queued behind it on ``stream``.  Measured, like vgh_streams_overlap: a tiny all_reduce issued
+    while ``stream`` spins for ``spin_us`` finishes at once (different queues) or only after the spin (same queue)."""
+    from . import _lib
+
+    import ctypes as C
+
+    lib = _lib.load()
+    dev = stream.device
+    # the observer must neither sit on the spinning stream's queue (its event would wait behind the spin) nor come from torch's pool
+    # (a draw here would shift the pool index the group's first collective is about to take)
+    got = C.c_void_p()
+    avoid = (C.c_void_p * 1)(stream.cuda_stream)
+    _lib.check(lib.vgh_stream_acquire(dev.index or 0, avoid, 1, C.byref(got)))
+    probe = torch.cuda.ExternalStream(got.value, device=dev)
+    t = torch.ones(1, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    worst = 0.0
+    for _ in range(2):  # the first pass also pays the communicator's lazy set-up
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(probe):
+            e0.record()
+            _lib.check(lib.vgh_stream_spin(stream.cuda_stream, spin_us))
+            w = dist.all_reduce(t, group=group, async_op=True)
+            w.wait()
+            e1.record()
+        torch.cuda.synchronize(dev)
+        worst = e0.elapsed_time(e1) * 1e3
+    lib.vgh_stream_release(dev.index or 0, got)
+    return worst > 0.6 * spin_us
+
+
+def steer_collective_stream(avoid: List["torch.cuda.Stream"], group=None, max_draws: int = 24) -> bool:
+    """Best effort, BEFORE the group's first collective on this device: torch hands RCCL the next stream of its round-robin pool, and
+    pool streams land on the hardware queues in creation order.  Draw pool streams until the one RCCL is about to get is measured to
+    overlap with every stream in ``avoid`` -- by finding a good one and skipping one full period of the queue count -- then verify
+    with ``collective_shares_queue_with``.  Returns True when the verification finds no shared queue."""
+    from . import _lib
+
+    lib = _lib.load()
+    dev = avoid[0].device
+    held = []  # keep the drawn streams alive: pool streams are never destroyed anyway
+
+    def good(s):
+        return all(lib.vgh_streams_overlap(a.cuda_stream, s.cuda_stream) == 1 for a in avoid)
+
+    period = None
+    first_good = None
+    for i in range(max_draws):
+        s = torch.cuda.Stream(device=dev)
+        held.append(s)
+        if first_good is None:
+            if good(s):
+                first_good = i
+            continue
+        # the period of the pool -> queue map: the next draw that does NOT overlap with the first good one sits on its queue
+        if lib.vgh_streams_overlap(held[first_good].cuda_stream, s.cuda_stream) == 0 and good(s):
+            period = i - first_good
+            break
+    if period:
+        for _ in range(period - 1):  # RCCL's draw is the one after these: first_good + 2 * period
+            held.append(torch.cuda.Stream(device=dev))
+    shared = [collective_shares_queue_with(a, group) for a in avoid]
+    if os.environ.get("HEAD_DETECTOR_AMD_DEBUG_STREAMS"):
+        import sys
+
+        print(f"[steer] first_good={first_good} period={period} draws={len(held)} shared_with={shared}", file=sys.stderr)
+    return not any(shared)
+
+
 def shard_batch(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous shard [start, stop) of a global batch; the first (total % world) ranks take one extra image."""
     base, rem = divmod(total, world)

@@ -346,6 +346,14 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         return det
 
+    def streams_in_use(self) -> List["torch.cuda.Stream"]:
+        """The streams this engine queues work on in its current mode: its own, the net lanes of the batch split, the overlap-mode side
+        stream (library-owned ones as ExternalStream views)."""
+        out = (C.c_void_p * 4)()
+        _lib.check(self.lib.vgh_detector_streams(self._det, self._sp(), out))
+        ptrs = [out[i] for i in range(max(self.nsplit - 1, 0))] + ([out[3]] if out[3] else [])
+        return [self.stream] + [torch.cuda.ExternalStream(p, device=self.device) for p in ptrs]
+
     def acquire_stream(self) -> "torch.cuda.Stream":
         """A stream measured to run side by side with the streams this engine works on (its own, the net lanes in use, the overlap-mode
         side stream): HIP maps streams onto 4 hardware queues and two streams on one queue serialise (include/vgh.h,

@@ -377,6 +377,9 @@ int vgh_stream_create(int device, void** stream_out);
 int vgh_stream_acquire(int device, void* const* avoid, int n_avoid, void** stream_out);
 int vgh_stream_release(int device, void* stream);
 int vgh_streams_overlap(void* stream_a, void* stream_b);
+/* One wave busy-waiting for `microseconds` on `stream`: the probe behind vgh_streams_overlap, exported so that a host can test
+ * streams it does not own (e.g. a communication library's internal stream) for a shared hardware queue. */
+int vgh_stream_spin(void* stream, int microseconds);
 int vgh_stream_destroy(void* stream);
 int vgh_stream_sync(void* stream);
 int vgh_event_create(void** ev_out);

@@ -1092,6 +1092,12 @@ def test_gatherer_collectives_on_rccl_single_rank(gpu_lib):
         avoid = (C.c_void_p * 1)(main)
         assert gpu_lib.vgh_stream_acquire(0, avoid, 1, C.byref(got)) == 0
         comm = torch.cuda.ExternalStream(got.value, device=_dev())
+        # RCCL's own stream comes from torch's pool: steer it off the compute stream's hardware queue before the first collective,
+        # then the measurement must agree with itself (a stream that shares the queue is seen as sharing it)
+        from head_detector_amd.dist import collective_shares_queue_with, steer_collective_stream
+
+        clear = steer_collective_stream([torch.cuda.current_stream()])
+        assert clear == (not collective_shares_queue_with(torch.cuda.current_stream()))
         g = DetectionGatherer(B, keep, V, vertex_rows=16, device=_dev(), stream=comm, always_collective=True)
         assert g.collective
         gen = torch.Generator().manual_seed(5)
