@@ -25,6 +25,16 @@ __global__ void spin_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 
+// many more workgroups than the chip holds at once (80 KiB of LDS each: two per CU), each spinning briefly: two such kernels on
+// streams whose workgroups the dispatcher can interleave finish together; when the second kernel's workgroups only start once the
+// first kernel's have all been dispatched, the first one finishes in half the time of the pair
+__global__ void spin_grid_kernel(long long ticks) {
+    extern __shared__ float pad_lds[];
+    if (threadIdx.x == 0) pad_lds[0] = 0.0f;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 constexpr long long kSpinTicks = 15000;  // 150 us
 constexpr int kMaxDev = 16, kMaxTries = 10;
 
@@ -106,6 +116,46 @@ int vgh_stream_release(int device, void* stream) {
 }
 
 int vgh_streams_overlap(void* a, void* b) { return runs_concurrently((hipStream_t)a, (hipStream_t)b) ? 1 : 0; }
+
+// first-kernel completion time / pair completion time for two multi-round kernels launched back to back on a and b:
+// ~1.0 = their workgroups interleave, ~0.5 = b's only start when a's are all dispatched.  *1000 (integer per-mille).
+int vgh_streams_interleave_permille(void* a, void* b) {
+    static bool attr = false;
+    const int lds = 80 * 1024;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)spin_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipStream_t sa = (hipStream_t)a, sb = (hipStream_t)b;
+    hipEvent_t e0, ea, eb;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return -1;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = cus * 2 * 4;  // 4 rounds of the resident capacity
+    int result = -1;
+    for (int pass = 0; pass < 2; ++pass) {  // first pass warms both streams up
+        (void)hipStreamSynchronize(sa);
+        (void)hipStreamSynchronize(sb);
+        (void)hipEventRecord(e0, sa);
+        hipLaunchKernelGGL(spin_grid_kernel, dim3(grid), dim3(64), lds, sa, 2000);  // 20 us per workgroup
+        (void)hipEventRecord(ea, sa);
+        hipLaunchKernelGGL(spin_grid_kernel, dim3(grid), dim3(64), lds, sb, 2000);
+        (void)hipEventRecord(eb, sb);
+        (void)hipStreamSynchronize(sa);
+        (void)hipStreamSynchronize(sb);
+        float ta = 0, tb = 0, tab = 0;
+        (void)hipEventElapsedTime(&ta, e0, ea);
+        (void)hipEventElapsedTime(&tab, ea, eb);
+        tb = ta + tab;
+        result = tb > 0 ? (int)(1000.0f * ta / tb) : -1;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    (void)hipGetLastError();
+    return result;
+}
 
 int vgh_stream_spin(void* stream, int microseconds) {
     VGH_REQUIRE(microseconds >= 0 && microseconds <= 100000, "stream_spin: 0..100000 us");
