@@ -760,7 +760,7 @@ __global__ __launch_bounds__(512, WPS) void flame_mfma_lds_kernel(VertArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];  // 2 slabs during the blend loop, then the head packs [HP_SIZE][128]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hw = wv >> 2, vw = wv & 3;
-    const int h0 = blockIdx.y * LB_H, v0 = blockIdx.x * LB_V;
+    const int h0 = blockIdx.x * LB_H, v0 = blockIdx.y * LB_V;  // heads fastest: co-resident blocks share the (3x larger) basis slabs
     if (a.n_dev) a.n = min(a.n, *a.n_dev);
     if (h0 >= a.n) return;
     const int j = lane & 31, half = lane >> 5;
@@ -872,7 +872,7 @@ int launch_mfma_lds(const VertArgs& va, hipStream_t st) {
         VGH_HIP(hipFuncSetAttribute((const void*)flame_mfma_lds_kernel<WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[dev].store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(flame_mfma_lds_kernel<WPS>, dim3((va.V + LB_V - 1) / LB_V, (va.n + LB_H - 1) / LB_H), dim3(512), lds, st, va);
+    hipLaunchKernelGGL(flame_mfma_lds_kernel<WPS>, dim3((va.n + LB_H - 1) / LB_H, (va.V + LB_V - 1) / LB_V), dim3(512), lds, st, va);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
