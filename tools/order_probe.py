@@ -26,17 +26,13 @@ def run(variant, B, iters=60, split=2, keep=False):
     return eng
 
 
-import os
 mode = sys.argv[1] if len(sys.argv) > 1 else "close"
-
-if mode == "split":
-    pass
-elif mode == "close":
-    for v, b in (("vgg_heads_m", 32), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_m", 32), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_l", 64)):
-        run(v, b)
-else:  # keep every engine alive: each new one gets memory that was never handed back
-    held = [run(v, b, keep=True) for v, b in (("vgg_heads_m", 32), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_l", 64))]
-if mode == "split":
+if mode == "split":  # lane count with every lane on its own hardware queue
     for v, b in (("vgg_heads_m", 32), ("vgg_heads_l", 64)):
         for sp in (1, 2, 3, 4):
             run(v, b, split=sp)
+elif mode == "close":  # every engine is closed before the next is created
+    for v, b in (("vgg_heads_m", 32), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_m", 32), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_l", 64)):
+        run(v, b)
+else:  # keep every engine alive: no stream is ever destroyed
+    held = [run(v, b, keep=True) for v, b in (("vgg_heads_m", 32), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_m", 32), ("vgg_heads_l", 64), ("vgg_heads_l", 64))]
