@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where does the bf16 mode's box error come from?  CPU emulation (tests/program_ref.py: the lowered program with torch ops, bf16 storage
+rounding switched per op) of VERDICT r01's proposed mixed mode -- fp32 for the last box-tower layers / the prediction convs / the whole
+heads -- against all-fp32, on the 100 highest-scoring anchors of six seeded images, random-init weights.  usage: bf16_attribution.py [variant]"""
+import sys, time
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
+import numpy as np, torch
+from head_detector_amd import arch
+import program_ref as pr
+from oracle.postproc_oracle import make_anchors, REG_MAX
+torch.set_num_threads(32)
+variant=sys.argv[1] if len(sys.argv)>1 else 'vgg_heads_l'
+sd=arch.random_state_dict(variant,1)
+P=arch.build_program(variant, sd, 640)
+w_all,b_all=P.arrays()
+def boxes_scores(outs):
+    red_l=[];cls_l=[];sizes=[]
+    for reg,cls,_ in outs:
+        b,_,h,w=reg.shape; hw=h*w; sizes.append((h,w))
+        r=torch.permute(reg.reshape([-1,4,REG_MAX+1,hw]),[0,2,3,1])
+        proj=torch.linspace(0,REG_MAX,REG_MAX+1).reshape([1,REG_MAX+1,1,1])
+        red_l.append(torch.softmax(r,dim=1).mul(proj).sum(1)); cls_l.append(cls.reshape([b,-1,hw]))
+    red=torch.cat(red_l,1); cl=torch.cat(cls_l,-1).permute(0,2,1)
+    ap,st=make_anchors(sizes,(8,16,32))
+    lt,rb=torch.split(red,2,-1)
+    return torch.cat([-lt+ap, rb+ap],-1)*st, cl.sigmoid()[...,0]
+def iou(a,b):
+    lt=torch.maximum(a[...,:2],b[...,:2]); rb=torch.minimum(a[...,2:],b[...,2:]); wh=(rb-lt).clamp(min=0); inter=wh[...,0]*wh[...,1]
+    return inter/((a[...,2]-a[...,0])*(a[...,3]-a[...,1])+(b[...,2]-b[...,0])*(b[...,3]-b[...,1])-inter)
+def run(x, policy):
+    bufs=pr.alloc(P,x.shape[0])
+    for op in P.ops: pr.run_op(P,op,bufs,x,policy(op),w_all,b_all)
+    return boxes_scores(pr.head_outputs(P,bufs))
+last_tower=lambda n: ('cls_convs|reg_convs' in n) or ('reg_pred|cls_pred' in n)
+policies={
+ 'bf16 everywhere': lambda op: True,
+ 'fp32 box tower (stem, cls|reg convs, preds), bf16 rest': lambda op: not (op['name'].startswith('heads.') and ('bbox_stem' in op['name'] or last_tower(op['name']))),
+ 'fp32 last box conv + pred only': lambda op: not (op['name'].startswith('heads.') and last_tower(op['name'])),
+ 'fp32 pred conv only (reads bf16 tower output)': lambda op: not (op['name'].startswith('heads.') and 'reg_pred|cls_pred' in op['name']),
+ 'fp32 heads, bf16 backbone+neck': lambda op: not op['name'].startswith('heads.'),
+ 'bf16 heads, fp32 backbone+neck': lambda op: op['name'].startswith('heads.'),
+}
+res={k:[] for k in policies}
+for seed in range(6):
+    x=torch.randint(0,256,(1,640,640,3),dtype=torch.uint8,generator=torch.Generator().manual_seed(seed))
+    bref,sref=run(x,lambda op:False)
+    top=torch.topk(sref[0],100).indices
+    for k,pol in policies.items():
+        b,s=run(x,pol)
+        i=iou(b[0,top],bref[0,top])
+        res[k].append((float(i.min()),float(i.median()),float((s[0,top]-sref[0,top]).abs().max())))
+for k,v in res.items():
+    a=np.array(v); print(f"{k:62s} IoU min over seeds {a[:,0].min():.5f} (per seed {np.round(a[:,0],4)}) median {np.median(a[:,1]):.6f} score err {a[:,2].max():.2e}")
