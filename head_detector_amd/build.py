@@ -31,7 +31,9 @@ def needs_build() -> bool:
 LIB_EXP = os.path.join(HERE, "libvgh_exp.so")  # -DVGH_EXPERIMENTS build (work-skipping switches, env-var knobs): tools/ only
 
 
-def build_lib(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+def build_lib(force: bool = False, verbose: bool = True, experiments: bool = False, variant_defines=None) -> str:
+    if variant_defines:  # A/B builds of the PRODUCT code with one compile-time knob changed (no experiment switches): libvgh_var.so
+        return _build(os.path.join(HERE, "libvgh_var.so"), [f"-D{d}" for d in variant_defines], "build_var", verbose)
     if experiments:
         return _build(LIB_EXP, ["-DVGH_EXPERIMENTS"], "build_exp", verbose)
     if not force and not needs_build():
@@ -76,4 +78,4 @@ def _build(LIB: str, extra, objdir: str, verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    build_lib(force="--force" in sys.argv, experiments="--experiments" in sys.argv)
+    build_lib(force="--force" in sys.argv, experiments="--experiments" in sys.argv, variant_defines=[a[2:] for a in sys.argv[1:] if a.startswith("-D")])

@@ -206,6 +206,9 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
     auto stage_compute = [&](const char* sbase) {
         constexpr int NSUB = 2 * KBS;
         bf16x8_t a0[TI], b0[TJ], a1[TI], b1[TJ];
+#ifdef VGH_SETPRIO_IGEMM
+        __builtin_amdgcn_s_setprio(VGH_SETPRIO_IGEMM);
+#endif
         load_frags(sbase, 0, a0, b0);
 #pragma unroll
         for (int sub = 0; sub < NSUB; sub += 2) {
@@ -218,6 +221,9 @@ __global__ __launch_bounds__((BP / WP) * (BC / WC) * 64, ((BP / WP) * (BC / WC) 
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef VGH_SETPRIO_IGEMM
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- main loop ------------------------------------------------------------------------------------
@@ -610,6 +616,9 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
             return;
         }
 #endif
+#ifdef VGH_SETPRIO
+        __builtin_amdgcn_s_setprio(VGH_SETPRIO);  // A/B knob (build.py -DVGH_SETPRIO=n): the wave inside its MFMA phase wins issue arbitration
+#endif
         load_frags(X, Wt, ky, 0, a0, b0);
 #pragma unroll
         for (int sub = 0; sub < 6; sub += 2) {
@@ -622,6 +631,9 @@ __global__ __launch_bounds__(NWP * NWC * 64, (patch_wps<TW, TH, BC, NWP, NWC>())
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef VGH_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- main loop over (channel block, kernel row) steps.  Weights of step s+1 (L2-resident, short latency) are issued at the
@@ -981,6 +993,9 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
         };
         auto compute = [&](const char* X, const char* Wt, int ky) {
             bf16x8_t a0[TI], b0[TJ], a1[TI], b1[TJ];
+#ifdef VGH_SETPRIO
+            __builtin_amdgcn_s_setprio(VGH_SETPRIO);
+#endif
             load_frags(X, Wt, ky, 0, a0, b0);
 #pragma unroll
             for (int sub = 0; sub < 6; sub += 2) {
@@ -993,6 +1008,9 @@ __global__ __launch_bounds__(NWP * NWC * 64, (Patch3<TW, TH, BC, NWP, NWC>::wps(
                 mma(a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef VGH_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
 
         // ---- operands of step 0 landed (they are older than the NS stores of the previous tile's epilogue); every wave has
