@@ -1356,6 +1356,13 @@ const CfgEntry g_cfgs[] = {
     QCFG(32, 8, 64, 4, 2),     // 91
     QCFG(32, 4, 128, 4, 2),    // 92
     QCFG(40, 8, 96, 5, 1),     // 93
+    PCFG(16, 8, 64, 4, 1),     // 94  128 px x 64: 48 KiB of LDS -> three blocks per CU (3 waves per SIMD), 1.5 KiB of fragments per MFMA
+    QCFG(16, 8, 64, 4, 1),     // 95
+    PCFG(16, 8, 128, 4, 2),    // 96  128 px x 128, 8 waves: 72 KiB -> two blocks = 4 waves per SIMD
+    QCFG(16, 8, 128, 4, 2),    // 97
+    PCFG(16, 8, 256, 4, 4),    // 98  128 px x 256, 16 waves
+    // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
+    //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
 constexpr int kNumCfgs = sizeof(g_cfgs) / sizeof(g_cfgs[0]);
 
