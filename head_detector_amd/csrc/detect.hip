@@ -69,16 +69,21 @@ __global__ __launch_bounds__(1024) void head_list_kernel(const int32_t* __restri
 
 // The side stream has to run next to the network of the following batch: measured to overlap with the caller's stream and the
 // net's lane streams (streams.hip), picked on first use and again when the caller's stream changes.
+// the side stream runs at the lowest stream priority: its small latency-bound kernels then fill in around the network's instead of
+// taking compute units from them (measured r02, L b64: 13.25 ms per step vs 13.42 without overlap and 13.6-13.7 with a normal-priority
+// side stream; M b32 5.32 vs 5.42)
+constexpr bool kSideLowPriority = true;
+
 int ensure_side(vgh_detector* d, hipStream_t main) {
     if (d->side && d->side_main == main) return VGH_OK;
     hipStream_t avoid[4] = {main};
     if (int rc = vgh_net_lane_streams(d->net, main, avoid + 1)) return rc;
     if (d->side) {
         VGH_HIP(hipStreamSynchronize(d->side));
-        vgh_stream_release_internal(d->device, d->side);
+        vgh_stream_release_internal(d->device, d->side, kSideLowPriority);
         d->side = nullptr;
     }
-    if (int rc = vgh_stream_acquire_internal(d->device, avoid, 4, &d->side)) return rc;
+    if (int rc = vgh_stream_acquire_internal(d->device, avoid, 4, &d->side, kSideLowPriority)) return rc;
     d->side_main = main;
     return VGH_OK;
 }
@@ -151,7 +156,7 @@ void vgh_detector_destroy(vgh_detector* d) {
     hipFree(d->head_image);
     if (d->side) {
         hipStreamSynchronize(d->side);
-        vgh_stream_release_internal(d->device, d->side);
+        vgh_stream_release_internal(d->device, d->side, kSideLowPriority);
     }
     if (d->net) vgh_net_set_pred_guard(d->net, nullptr);
     if (d->ev_net) hipEventDestroy(d->ev_net);

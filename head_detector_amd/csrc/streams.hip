@@ -39,7 +39,7 @@ constexpr long long kSpinTicks = 15000;  // 150 us
 constexpr int kMaxDev = 16, kMaxTries = 10;
 
 std::mutex g_mu;
-std::vector<hipStream_t> g_park[kMaxDev];
+std::vector<hipStream_t> g_park[2][kMaxDev];  // [normal | lowest priority]
 
 // true when kernels queued on a and b at the same time overlap
 bool runs_concurrently(hipStream_t a, hipStream_t b) {
@@ -73,14 +73,16 @@ int overlap_score(hipStream_t c, const hipStream_t* avoid, int n_avoid) {
 
 }  // namespace
 
-int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoid, hipStream_t* out) {
+int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoid, hipStream_t* out, bool low_priority) {
     VGH_REQUIRE(out && device >= 0 && device < kMaxDev && n_avoid >= 0 && n_avoid <= 8, "stream_acquire: bad argument");
     std::lock_guard<std::mutex> lk(g_mu);
     int cur = 0;
     VGH_HIP(hipGetDevice(&cur));
     if (cur != device) VGH_HIP(hipSetDevice(device));
     const int perfect = (1 << n_avoid) - 1;
-    std::vector<hipStream_t>& park = g_park[device];
+    std::vector<hipStream_t>& park = g_park[low_priority ? 1 : 0][device];
+    int least = 0, greatest = 0;
+    if (low_priority) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     int best = -1, best_score = -1;
     for (int i = 0; i < (int)park.size() && best_score < perfect; ++i) {
         const int s = overlap_score(park[i], avoid, n_avoid);
@@ -88,7 +90,10 @@ int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoi
     }
     for (int t = 0; t < kMaxTries && best_score < perfect; ++t) {
         hipStream_t c;
-        VGH_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        if (low_priority)
+            VGH_HIP(hipStreamCreateWithPriority(&c, hipStreamNonBlocking, least));
+        else
+            VGH_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
         park.push_back(c);
         const int s = overlap_score(c, avoid, n_avoid);
         if (s > best_score) best = (int)park.size() - 1, best_score = s;
@@ -99,10 +104,10 @@ int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoi
     return VGH_OK;
 }
 
-void vgh_stream_release_internal(int device, hipStream_t s) {
+void vgh_stream_release_internal(int device, hipStream_t s, bool low_priority) {
     if (!s || device < 0 || device >= kMaxDev) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    g_park[device].push_back(s);
+    g_park[low_priority ? 1 : 0][device].push_back(s);
 }
 
 extern "C" {
@@ -110,13 +115,13 @@ extern "C" {
 int vgh_stream_acquire(int device, void* const* avoid, int n_avoid, void** stream_out) {
     VGH_REQUIRE(stream_out && (avoid || n_avoid == 0), "stream_acquire: null argument");
     hipStream_t s = nullptr;
-    const int rc = vgh_stream_acquire_internal(device, (const hipStream_t*)avoid, n_avoid, &s);
+    const int rc = vgh_stream_acquire_internal(device, (const hipStream_t*)avoid, n_avoid, &s, false);
     *stream_out = (void*)s;
     return rc;
 }
 
 int vgh_stream_release(int device, void* stream) {
-    vgh_stream_release_internal(device, (hipStream_t)stream);
+    vgh_stream_release_internal(device, (hipStream_t)stream, false);
     return VGH_OK;
 }
 

@@ -113,8 +113,8 @@ int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, in
 
 // streams.hip: a stream MEASURED to run side by side with every stream in `avoid` (earlier entries matter more when the hardware
 // queues do not suffice for all of them); released streams are parked, never destroyed
-int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoid, hipStream_t* out);
-void vgh_stream_release_internal(int device, hipStream_t s);
+int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoid, hipStream_t* out, bool low_priority = false);
+void vgh_stream_release_internal(int device, hipStream_t s, bool low_priority = false);
 struct vgh_net;
 // net.hip: the net's lane streams for work entering on `main` (picked on first use, re-picked when `main` changes); out[3]
 int vgh_net_lane_streams(vgh_net* n, hipStream_t main, hipStream_t* out);
