@@ -928,7 +928,9 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         //  VALU kernel's 8-heads-per-basis-load reuse is ahead again; with a device-side count the launch is capacity-sized and mostly
         //  exits at once, so the tile count that matters is the live one)
         const int mode = g_flame_mode;
-        const bool lds = even && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMinHeads));  // crowd scale: operands staged through LDS
+        const int npairs = ((detector_mode ? shape_live + expr_live : f->NB) + f->NP + 1) / 2;
+        // crowd scale: operands staged through LDS (its k-pair table holds 256 entries: FLAME has 218; a model with more coefficients keeps the other kernels)
+        const bool lds = even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMinHeads));
         const bool mfma = lds || (even && (mode == 2 || (mode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
         const bool fused = !mfma && !pa.n_dev && m <= 256;  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
