@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("VGH_LIB_PATH") or os.path.join(HERE, "libvgh.so")
 VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
 VGH_IMG_F32_NCHW, VGH_IMG_U8_NHWC = 0, 1
+VGH_FMT_BF16, VGH_FMT_F32, VGH_FMT_BF16X2, VGH_FMT_F16X2 = 0, 1, 2, 3
 NUM_FLAME_PARAMS = 413
 
 
@@ -35,6 +36,7 @@ class OpDesc(C.Structure):
         ("b_off", C.c_int64),
         ("force_cfg", C.c_int32),
         ("lane", C.c_int32),
+        ("grp_cout", C.c_int32), ("grp_in_stride", C.c_int32),
     ]
 
 
@@ -50,6 +52,8 @@ class ConvCall(C.Structure):
         ("alpha", C.c_float),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32), ("shuffle", C.c_int32),
         ("force_cfg", C.c_int32),
+        ("grp_cout", C.c_int32), ("grp_in_stride", C.c_int32),
+        ("fmt", C.c_int32), ("out_scale", C.c_float),
     ]
 
 
@@ -105,6 +109,7 @@ SYMBOLS = {
     "vgh_net_image_size": (_I, [_P]),
     "vgh_conv2d": (_I, [C.POINTER(ConvCall), _P]),
     "vgh_pack_conv_weights": (_I, [_P, _I, _I, _I, _P]),
+    "vgh_pack_conv_weights_split": (_I, [_P, _I, _I, _I, _I, _P, C.POINTER(_F)]),
     "vgh_conv_num_cfgs": (_I, []),
     "vgh_conv_cfg_name": (C.c_char_p, [_I]),
     "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),

@@ -41,6 +41,10 @@ VARIANTS: Dict[str, dict] = {
         head=dict(bbox=(256, 256, 256), flame=256, blocks=2, shape_inter=128, expr_inter=64, shape_out=64, expr_out=32, tr_inter=16, width_mult=0.75),
     ),
 }
+# activation storage formats (VGH_FMT_* of include/vgh.h; the buffer field keeps its historical name is_f32) per precision mode
+FMT_BF16, FMT_F32, FMT_BF16X2, FMT_F16X2 = 0, 1, 2, 3
+PRECISION_FMT = {"bf16": FMT_BF16, "fp32": FMT_F32, "bf16x3": FMT_BF16X2, "fp16x3": FMT_F16X2}
+FMT_BYTES = {FMT_BF16: 2, FMT_F32: 4, FMT_BF16X2: 4, FMT_F16X2: 4}  # bytes per logical element
 TR_OUTS = (("rotation", 6), ("jaw", 3), ("translation", 3), ("scale", 1))  # order of the transform branches in the prediction buffer
 STRIDES = (8, 16, 32)
 
@@ -278,8 +282,10 @@ class Program:
         return wo, bo
 
     def conv(self, name: str, src: View, dst: View, W: np.ndarray, b: np.ndarray, k: int, stride: int = 1, act: int = 1, res: Optional[Tuple[View, float]] = None,
-             split: Optional[Tuple[int, int]] = None, shuffle: bool = False, cout_store: Optional[int] = None, flops_macs: Optional[float] = None):
-        """W: [rows, k, k, cin_view] (rows padded to 32 here); b: [rows]."""
+             split: Optional[Tuple[int, int]] = None, shuffle: bool = False, cout_store: Optional[int] = None, flops_macs: Optional[float] = None,
+             groups: Optional[Tuple[int, int]] = None):
+        """W: [rows, k, k, cin_view] (rows padded to 32 here); b: [rows].  groups = (grp_cout, grp_in_stride): rows [g*grp_cout, (g+1)*grp_cout)
+        read the cin_view channels starting at src.coff + g*grp_in_stride (sibling branches as one block-diagonal launch)."""
         rows, kk1, kk2, cin = W.shape
         assert kk1 == k and kk2 == k and cin == src.c and cin % 32 == 0, (name, W.shape, src)
         rp = _r32(rows)
@@ -296,9 +302,12 @@ class Program:
             cout_store=cout_store if cout_store is not None else rows, out_split=split[0] if split else rp, out_coff2=split[1] if split else 0,
             res_buf=res[0].buf if res else -1, res_coff=res[0].coff if res else 0, alpha=float(res[1]) if res else 0.0,
             ksize=k, stride=stride, act=act, shuffle=int(shuffle), w_off=wo, b_off=bo, force_cfg=-1,
+            grp_cout=groups[0] if groups else 0, grp_in_stride=groups[1] if groups else 0,
             macs=float(ho * wo_) * float(flops_macs if flops_macs is not None else rows * k * k * cin),
             gemm=(ho * wo_, rp, k * k * cin),
         ))
+        if groups:
+            assert rp % groups[0] == 0 and groups[0] % 32 == 0, (name, rp, groups)
 
     def arrays(self):
         return np.concatenate(self.weights), np.concatenate(self.biases)
@@ -330,8 +339,10 @@ def _stack(parts: List[Tuple[np.ndarray, np.ndarray]], pad_to: int = 1) -> Tuple
 
 
 def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640, precision: str = "bf16", head_lanes: bool = False) -> Program:
-    """precision: 'bf16' (throughput mode: bf16 activations/weights, fp32 accumulate) or 'fp32' (parity mode: no bf16 anywhere)."""
-    assert precision in ("bf16", "fp32")
+    """precision: 'bf16' (throughput mode: bf16 activations/weights, fp32 accumulate); 'fp16x3' (matrix-core parity mode: two fp16 planes
+    per value, three MFMAs per product, csrc/conv_split.hip); 'bf16x3' (the same with bf16 planes: 16 significand bits, kept for the
+    comparison); 'fp32' (VALU parity mode: no 16-bit format anywhere)."""
+    assert precision in PRECISION_FMT, precision
     v = VARIANTS[variant]
     F = fold_state_dict(variant, sd)
     P = Program(variant=variant, image_size=image_size)
@@ -490,28 +501,39 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
         width = Wf.shape[0]
         cur = P.buf(f"{p}.f0", r, r, width)
         P.conv(f"{p}.flame_*_pred.0", View(hs, 0, fl), View(cur, 0, width), Wf, bf, 3, cout_store=width, flops_macs=sum(inters) * 9 * fl)
+        assert offs[3] == offs[2] + trp and offs[5] == offs[2] + 3 * trp
         for bi in range(1, nb):
             nxt = P.buf(f"{p}.f{bi}", r, r, width)
-            for n_, inter, off in zip(names, inters, offs):
+            for n_, inter, off in zip(names[:2], inters[:2], offs[:2]):
                 W, b = F[f"{p}.flame_{n_}_pred.{bi}"]
                 ip = _r32(inter)
                 P.conv(f"{p}.flame_{n_}_pred.{bi}", View(cur, off, ip), View(nxt, off, ip), _ohwi(W, ip), b, 3, cout_store=ip, flops_macs=inter * 9 * inter)
+            # the four transform branches (rotation / jaw / translation / scale: 3x3, tr -> tr each) are ONE grouped launch: cout group g
+            # reads its own trp-channel window of the previous layer (four launches of a [M,32,288] GEMM could not fill the chip)
+            parts = [(_ohwi(F[f"{p}.flame_{n_}_pred.{bi}"][0], trp), F[f"{p}.flame_{n_}_pred.{bi}"][1]) for n_, _ in TR_OUTS]
+            Wg, bg, _ = _stack(parts, pad_to=trp)
+            P.conv(f"{p}.flame_transform_pred.{bi}", View(cur, offs[2], trp), View(nxt, offs[2], 4 * trp), Wg, bg, 3, cout_store=4 * trp, flops_macs=4 * tr * 9 * tr,
+                   groups=(trp, trp))
             cur = nxt
-        # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | shape | expr | rot6 | jaw3 | trans3 | scale1]
+        # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | .. | shape | expr | rot6 | jaw3 | trans3 | scale1]: one block-diagonal
+        # GEMM over the whole last-layer buffer [shape inter | expr inter | 4 x tr] (three launches at 5-250 TFLOP/s before); the zero blocks
+        # add exact zeros, so every output is bit-identical to its own 1x1 conv
+        n_out = Sc + Ec + 13
+        Wd = np.zeros((n_out, 1, 1, width), dtype=np.float64)
+        bd = np.zeros(n_out, dtype=np.float64)
         W, b = F[f"{p}.flame_shape_pred.{nb}"]
-        P.conv(f"{p}.flame_shape_pred.{nb}", View(cur, offs[0], _r32(inters[0])), View(pred, FO, Sc), _ohwi(W, _r32(inters[0])), b, 1, act=0)
+        Wd[:Sc, 0, 0, offs[0] : offs[0] + inters[0]] = W[:, :, 0, 0]
+        bd[:Sc] = b
         W, b = F[f"{p}.flame_expression_pred.{nb}"]
-        P.conv(f"{p}.flame_expression_pred.{nb}", View(cur, offs[1], _r32(inters[1])), View(pred, FO + Sc, Ec), _ohwi(W, _r32(inters[1])), b, 1, act=0)
-        Wd = np.zeros((13, 1, 1, 4 * trp), dtype=np.float64)
-        bd = np.zeros(13, dtype=np.float64)
-        row = 0
+        Wd[Sc : Sc + Ec, 0, 0, offs[1] : offs[1] + inters[1]] = W[:, :, 0, 0]
+        bd[Sc : Sc + Ec] = b
+        row = Sc + Ec
         for j, (n_, o_) in enumerate(TR_OUTS):
             W, b = F[f"{p}.flame_{n_}_pred.{nb}"]
-            Wd[row : row + o_, 0, 0, j * trp : j * trp + tr] = W[:, :, 0, 0]
+            Wd[row : row + o_, 0, 0, offs[2] + j * trp : offs[2] + j * trp + tr] = W[:, :, 0, 0]
             bd[row : row + o_] = b
             row += o_
-        assert offs[3] == offs[2] + trp and offs[5] == offs[2] + 3 * trp
-        P.conv(f"{p}.flame_transform_pred.{nb}", View(cur, offs[2], 4 * trp), View(pred, FO + Sc + Ec, 13), Wd, bd, 1, act=0, flops_macs=13 * tr)
+        P.conv(f"{p}.flame_*_pred.{nb}", View(cur, 0, width), View(pred, FO, n_out), Wd, bd, 1, act=0, flops_macs=Sc * inters[0] + Ec * inters[1] + 13 * tr)
         P.levels.append(dict(buf=pred, h=r, w=r, pitch=pred_pitch, stride=stride))
         P.shape_c, P.expr_c = Sc, Ec
         if head_lanes:
@@ -519,8 +541,10 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
                 op["lane"] = lv
 
     P.flops = 2.0 * sum(o["macs"] for o in P.ops)
-    if precision == "fp32":
+    fmt = PRECISION_FMT[precision]
+    if fmt != FMT_BF16:
         for bf in P.bufs:
-            bf["is_f32"] = 1
+            if bf["is_f32"] == FMT_BF16:  # the fp32 prediction buffers stay fp32 in every mode
+                bf["is_f32"] = fmt
     P.precision = precision
     return P

@@ -6,6 +6,7 @@
 // Replaces HeadDetector.__init__ (head_detector/detector.py:19-30: hub download + torch.jit.load + FLAMELayer()) and, through
 // vgh_ctx_detect, HeadDetector._process + the device arithmetic of _parse_predictions for a whole batch (detector.py:54-90).
 #include <stdarg.h>
+#include <sys/stat.h>
 
 #include <string>
 #include <vector>
@@ -64,12 +65,27 @@ int vgh_create(const vgh_config* cfg, vgh_ctx** out) {
     std::vector<float> w, b, v_template, shapedirs, posedirs, jreg, lbsw;
     std::vector<int32_t> parents;
     bool ok = read_exact(f, &h, sizeof(h)) && memcmp(h.magic, "VGHPACK", 8) == 0;
-    if (ok && h.version != 1) {
+    if (ok && h.version != 2) {
         fclose(f);
-        VGH_REQUIRE(false, "vgh_create: %s is pack version %u, this library reads version 1", cfg->pack_path, h.version);
+        VGH_REQUIRE(false, "vgh_create: %s is pack version %u, this library reads version 2", cfg->pack_path, h.version);
     }
     ok = ok && h.n_bufs > 0 && h.n_ops > 0 && h.n_levels > 0 && h.n_levels <= VGH_MAX_LEVELS && h.n_weights > 0 && h.n_biases > 0 && h.header_bytes >= sizeof(h) &&
          fseek(f, h.header_bytes, SEEK_SET) == 0;
+    if (ok) {
+        // the header's counts size every allocation below: bound them by what the file can actually hold before trusting them
+        // (a corrupt pack must fail with an error code, not with std::bad_alloc thrown across the C ABI)
+        struct stat st;
+        ok = fstat(fileno(f), &st) == 0;
+        const int64_t fsz = ok ? (int64_t)st.st_size : 0;
+        ok = ok && h.n_bufs < (1 << 20) && h.n_ops < (1 << 20) && h.n_weights < fsz / 4 + 1 && h.n_biases < fsz / 4 + 1 && h.V >= 0 && h.NB >= 0 && h.NJ >= 0 &&
+             h.V < (1 << 24) && h.NB < (1 << 16) && h.NJ < (1 << 12);
+        if (ok) {
+            int64_t need = (int64_t)h.header_bytes + (int64_t)h.n_bufs * sizeof(vgh_buf_desc) + (int64_t)h.n_ops * (sizeof(vgh_op_desc) + 32) + (int64_t)h.n_levels * sizeof(Level) +
+                           4 * (h.n_weights + h.n_biases);
+            if (h.has_flame) need += 4 * ((int64_t)h.V * 3 + (int64_t)h.V * 3 * h.NB + (int64_t)(h.NJ > 0 ? h.NJ - 1 : 0) * 27 * h.V + 2 * (int64_t)h.NJ * h.V + h.NJ);
+            ok = need <= fsz;
+        }
+    }
     if (ok) {
         bufs.resize(h.n_bufs);
         ops.resize(h.n_ops);
@@ -103,7 +119,7 @@ int vgh_create(const vgh_config* cfg, vgh_ctx** out) {
     // activation arena: every tensor below 2 GiB (32-bit loader offsets) -> larger batches run in arena-sized chunks
     int64_t per_image = 1;
     for (const vgh_buf_desc& bd : bufs) {
-        const int64_t by = (int64_t)bd.h * bd.w * bd.pitch * (bd.is_f32 ? 4 : 2);
+        const int64_t by = (int64_t)bd.h * bd.w * bd.pitch * vgh_fmt_bytes(bd.is_f32);
         if (by > per_image) per_image = by;
     }
     int arena = (int)(((1ll << 31) - 1) / per_image);

@@ -22,6 +22,7 @@ struct NetOp {
     uint16_t* wpack = nullptr;  // device (conv)
     float* wf32 = nullptr;      // device (stem [27][48])
     float* bias = nullptr;      // device
+    float out_scale = 1.0f;     // split parity modes: accumulator scale of the op (vgh_pack_conv_weights_split_host)
 };
 
 struct vgh_net {
@@ -50,7 +51,7 @@ struct vgh_net {
     int nsplit = 1;
 };
 
-static inline int64_t buf_image_bytes(const vgh_buf_desc& b) { return (int64_t)b.h * b.w * b.pitch * (b.is_f32 ? 4 : 2); }
+static inline int64_t buf_image_bytes(const vgh_buf_desc& b) { return (int64_t)b.h * b.w * b.pitch * vgh_fmt_bytes(b.is_f32); }
 
 static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -60,7 +61,15 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     const vgh_buf_desc& ob = n->bufs[d.out_buf];
     memset(a, 0, sizeof(*a));
     a->in = (const uint16_t*)((const char*)n->buf_ptr[d.in_buf] + at * buf_image_bytes(ib));
-    a->in_pitch = ib.pitch;
+    // split parity modes: a pixel is [hi plane | lo plane]; the kernels address it with the physical pitch and the plane stride
+    const int ipl = vgh_fmt_planes(ib.is_f32), opl = vgh_fmt_planes(ob.is_f32);
+    a->split = ipl > 1 ? ib.is_f32 : 0;
+    a->in_plane = ib.pitch;
+    a->out_plane = ob.pitch;
+    a->out_scale = op.out_scale;
+    a->grp_cout = d.grp_cout;
+    a->grp_in_stride = d.grp_in_stride;
+    a->in_pitch = (int64_t)ib.pitch * ipl;
     a->in_coff = d.in_coff;
     a->cin = d.cin;
     a->B = B;
@@ -74,15 +83,18 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->wpack = op.wpack;
     a->bias = op.bias;
     a->out = (char*)n->buf_ptr[d.out_buf] + at * buf_image_bytes(ob);
-    a->out_pitch = ob.pitch;
+    a->out_pitch = (int64_t)ob.pitch * opl;
     a->out_coff = d.out_coff;
     a->out_coff2 = d.out_coff2;
     a->out_split = d.out_split;
     a->cout_pad = d.cout_pad;
     a->cout_store = d.cout_store;
-    a->out_f32 = ob.is_f32;
+    a->out_f32 = ob.is_f32 == VGH_FMT_F32;
     a->res = d.res_buf >= 0 ? (const uint16_t*)((const char*)n->buf_ptr[d.res_buf] + at * buf_image_bytes(n->bufs[d.res_buf])) : nullptr;
-    a->res_pitch = d.res_buf >= 0 ? n->bufs[d.res_buf].pitch : 0;
+    a->res_pitch = d.res_buf >= 0 ? (int64_t)n->bufs[d.res_buf].pitch * vgh_fmt_planes(n->bufs[d.res_buf].is_f32) : 0;
+    a->res_plane = d.res_buf >= 0 ? n->bufs[d.res_buf].pitch : 0;
+    VGH_REQUIRE(a->out_f32 || ob.is_f32 == ib.is_f32, "net: op writes buffer %d in another 16-bit format than it reads", d.out_buf);
+    VGH_REQUIRE(d.res_buf < 0 || n->bufs[d.res_buf].is_f32 == ib.is_f32, "net: residual buffer %d has another format than the input", d.res_buf);
     a->res_coff = d.res_coff;
     a->alpha = d.alpha;
     a->act = d.act;
@@ -94,7 +106,7 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->nkb = d.ksize * d.ksize * a->cblocks;
     const int eh = d.shuffle ? 2 * a->Ho : a->Ho, ew = d.shuffle ? 2 * a->Wo : a->Wo;
     VGH_REQUIRE(ob.h == eh && ob.w == ew, "net: op output buffer %d is %dx%d, conv produces %dx%d", d.out_buf, ob.h, ob.w, eh, ew);
-    VGH_REQUIRE(d.in_coff + d.cin <= ib.pitch, "net: conv reads past the input pitch (buf %d)", d.in_buf);
+    VGH_REQUIRE(d.in_coff + d.cin + (d.grp_cout ? (d.cout_pad / d.grp_cout - 1) * d.grp_in_stride : 0) <= ib.pitch, "net: conv reads past the input pitch (buf %d)", d.in_buf);
     return VGH_OK;
 }
 
@@ -106,24 +118,26 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
     switch (d.kind) {
         case VGH_OP_STEM: {
             const vgh_buf_desc& ob = n->bufs[d.out_buf];
-            if (ob.is_f32)  // fp32 parity mode
+            if (ob.is_f32 == VGH_FMT_F32)  // fp32 parity mode
                 return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)bp(d.out_buf), ob.pitch, d.out_coff, st);
-            return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)bp(d.out_buf), ob.pitch, d.out_coff, st);
+            return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)bp(d.out_buf), (int64_t)ob.pitch * vgh_fmt_planes(ob.is_f32), d.out_coff,
+                                   ob.is_f32, ob.pitch, st);
         }
         case VGH_OP_CONV: {
             ConvArgs a;
             if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
             a.grid_share = share;
-            if (n->bufs[d.in_buf].is_f32) {  // fp32 parity mode: dense fp32 weights, FMA kernel
-                VGH_REQUIRE(a.out_f32 && (d.res_buf < 0 || n->bufs[d.res_buf].is_f32), "net: fp32 conv needs fp32 output / residual buffers");
+            if (n->bufs[d.in_buf].is_f32 == VGH_FMT_F32) {  // fp32 parity mode: dense fp32 weights, FMA kernel
+                VGH_REQUIRE(a.out_f32 && (d.res_buf < 0 || n->bufs[d.res_buf].is_f32 == VGH_FMT_F32), "net: fp32 conv needs fp32 output / residual buffers");
+                VGH_REQUIRE(!d.grp_cout, "net: the fp32 FMA kernel has no grouped mode");
                 return vgh_launch_conv_f32(a, op.wf32, st);
             }
             return vgh_launch_conv(a, d.force_cfg, st);
         }
         case VGH_OP_SPP_POOL: {
             const vgh_buf_desc& ib = n->bufs[d.in_buf];
-            if (ib.is_f32) return vgh_launch_spp_pool_f32((float*)bp(d.in_buf), ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
-            return vgh_launch_spp_pool((uint16_t*)bp(d.in_buf), ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
+            if (ib.is_f32 == VGH_FMT_F32) return vgh_launch_spp_pool_f32((float*)bp(d.in_buf), ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
+            return vgh_launch_spp_pool((uint16_t*)bp(d.in_buf), (int64_t)ib.pitch * vgh_fmt_planes(ib.is_f32), d.in_coff, d.cin, B, ib.h, ib.w, ib.is_f32, ib.pitch, st);
         }
         case VGH_OP_FORK:
             return VGH_OK;  // handled by the executor
@@ -178,7 +192,7 @@ static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, i
     bool guard_pending = n->pred_guard != nullptr;
     for (const NetOp& op : n->ops) {
         if (op.d.kind == VGH_OP_FORK) continue;  // head lanes are not combined with the batch split
-        if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32) {
+        if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32 == VGH_FMT_F32) {
             VGH_HIP(hipStreamWaitEvent(main, n->pred_guard, 0));
             for (int l = 1; l < L; ++l) VGH_HIP(hipStreamWaitEvent(n->side[l], n->pred_guard, 0));
             guard_pending = false;
@@ -212,7 +226,8 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     int64_t off = 0;
     std::vector<int64_t> offs(n_bufs);
     for (int i = 0; i < n_bufs; ++i) {
-        const int64_t bytes = (int64_t)max_batch * bufs[i].h * bufs[i].w * bufs[i].pitch * (bufs[i].is_f32 ? 4 : 2);
+        VGH_REQUIRE(bufs[i].is_f32 >= VGH_FMT_BF16 && bufs[i].is_f32 <= VGH_FMT_F16X2, "net_create: buffer %d has unknown format %d", i, bufs[i].is_f32);
+        const int64_t bytes = (int64_t)max_batch * bufs[i].h * bufs[i].w * bufs[i].pitch * vgh_fmt_bytes(bufs[i].is_f32);
         offs[i] = off;
         n->buf_bytes.push_back(bytes);
         off += align_up(bytes + 256, 256);  // +256: slack so 16-byte gathers at the very end stay in-bounds
@@ -236,7 +251,8 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             const int64_t we = (int64_t)d.cout_pad * d.ksize * d.ksize * d.cin;
             VGH_REQUIRE(d.w_off >= 0 && d.w_off + we <= n_weights && d.b_off >= 0 && d.b_off + d.cout_pad <= n_biases, "net_create: op %d weight range", i);
             woff[i] = wbytes;
-            wbytes += align_up(we * (bufs[d.in_buf].is_f32 ? 4 : 2), 256);
+            const int wf = bufs[d.in_buf].is_f32;  // weight image: bf16 (2 B), dense fp32 (4 B) or the three 16-bit segments of the split modes (6 B)
+            wbytes += align_up(we * (wf == VGH_FMT_BF16 ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
             boff[i] = wbytes;
             wbytes += align_up((int64_t)d.cout_pad * 4, 256);
         } else if (d.kind == VGH_OP_STEM) {
@@ -248,13 +264,17 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
         }
     }
     std::vector<char> host(wbytes > 0 ? wbytes : 1, 0);
+    std::vector<float> oscale(n_ops, 1.0f);
     for (int i = 0; i < n_ops; ++i) {
         const vgh_op_desc& d = ops[i];
         if (d.kind == VGH_OP_CONV) {
-            if (bufs[d.in_buf].is_f32)
+            const int wf = bufs[d.in_buf].is_f32;
+            if (wf == VGH_FMT_F32)
                 memcpy(host.data() + woff[i], weights_host + d.w_off, (size_t)d.cout_pad * d.ksize * d.ksize * d.cin * 4);
-            else
+            else if (wf == VGH_FMT_BF16)
                 vgh_pack_conv_weights_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint16_t*)(host.data() + woff[i]));
+            else
+                vgh_pack_conv_weights_split_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, wf, (uint16_t*)(host.data() + woff[i]), &oscale[i]);
             memcpy(host.data() + boff[i], biases_host + d.b_off, (size_t)d.cout_pad * 4);
         } else if (d.kind == VGH_OP_STEM) {
             // host gives [48][3(ky)][3(kx)][3(ci)] -> device [27][48]
@@ -269,6 +289,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     for (int i = 0; i < n_ops; ++i) {
         NetOp op;
         op.d = ops[i];
+        op.out_scale = oscale[i];
         if (ops[i].kind == VGH_OP_CONV) {
             op.wpack = (uint16_t*)(n->wblob + woff[i]);
             op.wf32 = (float*)(n->wblob + woff[i]);  // same storage: bf16 image (throughput mode) or dense fp32 (parity mode)
@@ -313,7 +334,7 @@ int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
     bool pending[vgh_net::kLanes] = {false, false, false, false}, used[vgh_net::kLanes] = {false, false, false, false};
     bool guard_pending = n->pred_guard != nullptr;
     for (const NetOp& op : n->ops) {
-        if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32) {
+        if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32 == VGH_FMT_F32) {
             // every stream that may run a prediction conv waits (main; the lanes inherit it through the fork / their own wait)
             VGH_HIP(hipStreamWaitEvent(main, n->pred_guard, 0));
             for (int l = 1; l < vgh_net::kLanes; ++l)
@@ -451,8 +472,17 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream) {
     }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
+    const int planes = vgh_fmt_planes(c->fmt);
+    VGH_REQUIRE(c->fmt == VGH_FMT_BF16 || c->fmt == VGH_FMT_BF16X2 || c->fmt == VGH_FMT_F16X2, "conv2d: fmt %d", c->fmt);
+    a.split = planes > 1 ? c->fmt : 0;
+    a.in_plane = (int)c->in_pitch;
+    a.out_plane = (int)c->out_pitch;
+    a.res_plane = (int)c->res_pitch;
+    a.out_scale = c->out_scale;
+    a.grp_cout = c->grp_cout;
+    a.grp_in_stride = c->grp_in_stride;
     a.in = (const uint16_t*)c->in_dev;
-    a.in_pitch = c->in_pitch;
+    a.in_pitch = c->in_pitch * planes;
     a.in_coff = c->in_coff;
     a.cin = c->cin;
     a.B = c->B;
@@ -466,7 +496,7 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream) {
     a.wpack = (const uint16_t*)c->wpack_dev;
     a.bias = c->bias_dev;
     a.out = c->out_dev;
-    a.out_pitch = c->out_pitch;
+    a.out_pitch = c->out_f32 ? c->out_pitch : c->out_pitch * planes;
     a.out_coff = c->out_coff;
     a.out_coff2 = c->out_coff2;
     a.out_split = c->out_split;
@@ -474,7 +504,7 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream) {
     a.cout_store = c->cout_store;
     a.out_f32 = c->out_f32;
     a.res = (const uint16_t*)c->res_dev;
-    a.res_pitch = c->res_pitch;
+    a.res_pitch = c->res_pitch * planes;
     a.res_coff = c->res_coff;
     a.alpha = c->alpha;
     a.act = c->act;

@@ -8,6 +8,7 @@
 // SPP pool replaces the three nn.MaxPool2d(k, 1, k//2), k = 5, 9, 13 of SG's SPP (arch yaml :41-45) using the
 // exact cascade pool13 = pool5(pool5(pool5(x))), and writes the results next to x (concat-by-offset).
 #include "vgh_internal.h"
+#include "split_fmt.h"
 
 namespace {
 
@@ -15,10 +16,12 @@ constexpr int ST = 16;            // 16x16 output pixels per block
 constexpr int SIN = 2 * ST + 1;   // 33x33 input patch
 constexpr int STEM_CO = 48, STEM_CP = 64;
 
-template <int FMT, int STAGE>
+// SP != 0 (split parity modes, STAGE = 0 only): the exact fp32 result leaves as a hi and a lo 16-bit plane (split_fmt.h)
+template <int FMT, int STAGE, int SP = 0>
 __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ image, int H, int W, const float* __restrict__ wgt /*[27][48]*/,
                                                    const float* __restrict__ bias /*[48]*/, uint16_t* __restrict__ out, int64_t out_pitch,
-                                                   int out_coff) {
+                                                   int out_coff, int plane, float lo_scale) {
+    static_assert(SP == 0 || STAGE == 0, "the split modes store directly");
     // the 32 KiB output staging [pixel][chunk ^ (pixel & 7)] aliases the input patch (dead once every lane holds its 27 taps)
     __shared__ __attribute__((aligned(16))) char smem_raw[STAGE ? 256 * 8 * 16 : 3 * SIN * (SIN + 1) * 4];
     float (*patch)[SIN][SIN + 1] = (float (*)[SIN][SIN + 1]) smem_raw;
@@ -112,6 +115,21 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ i
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] = __builtin_elementwise_fma(xk, *(const f32x2_t*)(wgt + k * STEM_CO + cg * 16 + 2 * c), acc[c]);
         }
+        if constexpr (SP != 0) {
+            float r0[8], r1[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                r0[2 * c] = fmaxf(acc[c][0] + bias[cg * 16 + 2 * c], 0.0f);
+                r0[2 * c + 1] = fmaxf(acc[c][1] + bias[cg * 16 + 2 * c + 1], 0.0f);
+                r1[2 * c] = fmaxf(acc[4 + c][0] + bias[cg * 16 + 8 + 2 * c], 0.0f);
+                r1[2 * c + 1] = fmaxf(acc[4 + c][1] + bias[cg * 16 + 8 + 2 * c + 1], 0.0f);
+            }
+            if (ok) {
+                split_store<SP, 8>(r0, lo_scale, op + cg * 16, plane);
+                split_store<SP, 8>(r1, lo_scale, op + cg * 16 + 8, plane);
+            }
+            continue;
+        }
         bf16x8_t o0, o1;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -135,6 +153,10 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ i
         if (ok) {
             *(bf16x8_t*)(op + 48) = z;  // channels 48..63: exact zeros (K padding of the next conv)
             *(bf16x8_t*)(op + 56) = z;
+            if (SP != 0) {  // zero bits are zero in bf16 and fp16 alike
+                *(bf16x8_t*)(op + plane + 48) = z;
+                *(bf16x8_t*)(op + plane + 56) = z;
+            }
         }
         return;
     }
@@ -204,35 +226,119 @@ __global__ __launch_bounds__(256) void spp_pool_kernel(uint16_t* __restrict__ bu
     }
 }
 
+// Split parity modes: the same separable cascade on the JOINED fp32 values (hi + lo / L); the maximum is one of the inputs, so
+// re-splitting it reproduces that input's two planes bit for bit.  LDS [H*W][CG] fp32 x 2.
+template <int SP>
+__global__ __launch_bounds__(256) void spp_pool_split_kernel(uint16_t* __restrict__ buf, int64_t pitch, int plane, int coff, int C, int H, int W, int CG, float lo_scale,
+                                                             float lo_inv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int HW = H * W;
+    float* X = (float*)smem;
+    float* T = X + (size_t)HW * CG;
+    const int b = blockIdx.y, cg0 = blockIdx.x * CG;
+    uint16_t* base = buf + (int64_t)b * HW * pitch + coff + cg0;
+    const int cv = CG / 4, n = HW * cv;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int p = e / cv, v = e - p * cv;
+        float f[4];
+        join_load<SP, 4>(base + (int64_t)p * pitch + v * 4, plane, lo_inv, f);
+        *(f32x4_t*)(X + (size_t)p * CG + v * 4) = f32x4_t{f[0], f[1], f[2], f[3]};
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const int p = e / cv, v = e - p * cv;
+            const int y = p / W, x = p - y * W;
+            f32x4_t m = *(const f32x4_t*)(X + (size_t)p * CG + v * 4);
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if (dx != 0 && (unsigned)xx < (unsigned)W) {
+                    const f32x4_t o = *(const f32x4_t*)(X + (size_t)(y * W + xx) * CG + v * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[k] = m[k] >= o[k] ? m[k] : o[k];
+                }
+            }
+            *(f32x4_t*)(T + (size_t)p * CG + v * 4) = m;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const int p = e / cv, v = e - p * cv;
+            const int y = p / W, x = p - y * W;
+            f32x4_t m = *(const f32x4_t*)(T + (size_t)p * CG + v * 4);
+#pragma unroll
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if (dy != 0 && (unsigned)yy < (unsigned)H) {
+                    const f32x4_t o = *(const f32x4_t*)(T + (size_t)(yy * W + x) * CG + v * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[k] = m[k] >= o[k] ? m[k] : o[k];
+                }
+            }
+            *(f32x4_t*)(X + (size_t)p * CG + v * 4) = m;
+            const float mv[4] = {m[0], m[1], m[2], m[3]};
+            split_store<SP, 4>(mv, lo_scale, base + (int64_t)p * pitch + (int64_t)(pass + 1) * C + v * 4, plane);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w, const float* bias, uint16_t* out, int64_t out_pitch,
-                    int out_coff, hipStream_t stream) {
+                    int out_coff, int fmt, int plane, hipStream_t stream) {
     VGH_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: image size must be even");
-    VGH_REQUIRE(out_pitch % 8 == 0 && out_coff % 8 == 0, "stem: output alignment");
+    VGH_REQUIRE(out_pitch % 8 == 0 && out_coff % 8 == 0 && plane % 8 == 0, "stem: output alignment");
+    VGH_REQUIRE(image_fmt == VGH_IMG_F32_NCHW || image_fmt == VGH_IMG_U8_NHWC, "stem: unknown image format %d", image_fmt);
     if (B == 0) return VGH_OK;
     dim3 grid((W / 2 + ST - 1) / ST, (H / 2 + ST - 1) / ST, B);
-    static const int stage = getenv("VGH_STEM_STAGE") ? atoi(getenv("VGH_STEM_STAGE")) : 1;  // A/B switch: 0 = direct per-lane stores
-    if (image_fmt == VGH_IMG_F32_NCHW) {
-        if (stage)
-            hipLaunchKernelGGL((stem_kernel<VGH_IMG_F32_NCHW, 1>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
-        else
-            hipLaunchKernelGGL((stem_kernel<VGH_IMG_F32_NCHW, 0>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
-    } else if (image_fmt == VGH_IMG_U8_NHWC) {
-        if (stage)
-            hipLaunchKernelGGL((stem_kernel<VGH_IMG_U8_NHWC, 1>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
-        else
-            hipLaunchKernelGGL((stem_kernel<VGH_IMG_U8_NHWC, 0>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff);
+    const bool u8 = image_fmt == VGH_IMG_U8_NHWC;
+#define VGH_STEM_LAUNCH(FMT, STAGE, SP, LO) \
+    hipLaunchKernelGGL((stem_kernel<FMT, STAGE, SP>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff, plane, LO)
+    if (fmt == VGH_FMT_F16X2) {
+        if (u8) VGH_STEM_LAUNCH(VGH_IMG_U8_NHWC, 0, VGH_FMT_F16X2, 2048.0f);
+        else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, VGH_FMT_F16X2, 2048.0f);
+    } else if (fmt == VGH_FMT_BF16X2) {
+        if (u8) VGH_STEM_LAUNCH(VGH_IMG_U8_NHWC, 0, VGH_FMT_BF16X2, 1.0f);
+        else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, VGH_FMT_BF16X2, 1.0f);
+    } else {
+        VGH_REQUIRE(fmt == VGH_FMT_BF16, "stem: output format %d", fmt);
+#ifdef VGH_EXPERIMENTS
+        static const int stage = getenv("VGH_STEM_STAGE") ? atoi(getenv("VGH_STEM_STAGE")) : 1;  // A/B switch: 0 = direct per-lane stores
+        if (!stage) {
+            if (u8) VGH_STEM_LAUNCH(VGH_IMG_U8_NHWC, 0, 0, 1.0f);
+            else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, 0, 1.0f);
+        } else
+#endif
+        {
+            if (u8) VGH_STEM_LAUNCH(VGH_IMG_U8_NHWC, 1, 0, 1.0f);
+            else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 1, 0, 1.0f);
+        }
     }
-    else
-        VGH_REQUIRE(false, "stem: unknown image format %d", image_fmt);
+#undef VGH_STEM_LAUNCH
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
 
-int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, int H, int W, hipStream_t stream) {
+int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, int H, int W, int fmt, int plane, hipStream_t stream) {
     VGH_REQUIRE(C % 8 == 0 && pitch % 8 == 0 && coff % 8 == 0, "spp: channel alignment");
     if (B == 0) return VGH_OK;
+    if (fmt == VGH_FMT_BF16X2 || fmt == VGH_FMT_F16X2) {
+        int CG = 16;
+        while (CG > 4 && ((size_t)2 * H * W * CG * 4 > 64 * 1024 || C % CG != 0)) CG /= 2;
+        VGH_REQUIRE(C % CG == 0 && (size_t)2 * H * W * CG * 4 <= 160 * 1024, "spp: feature map %dx%d too large for the LDS tile", H, W);
+        const size_t lds = (size_t)2 * H * W * CG * 4;
+        if (fmt == VGH_FMT_F16X2) {
+            if (lds > 64 * 1024) VGH_HIP(hipFuncSetAttribute((const void*)spp_pool_split_kernel<VGH_FMT_F16X2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(spp_pool_split_kernel<VGH_FMT_F16X2>, dim3(C / CG, B), dim3(256), lds, stream, buf, pitch, plane, coff, C, H, W, CG, 2048.0f, 1.0f / 2048.0f);
+        } else {
+            if (lds > 64 * 1024) VGH_HIP(hipFuncSetAttribute((const void*)spp_pool_split_kernel<VGH_FMT_BF16X2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(spp_pool_split_kernel<VGH_FMT_BF16X2>, dim3(C / CG, B), dim3(256), lds, stream, buf, pitch, plane, coff, C, H, W, CG, 1.0f, 1.0f);
+        }
+        VGH_HIP(hipGetLastError());
+        return VGH_OK;
+    }
+    VGH_REQUIRE(fmt == VGH_FMT_BF16, "spp: format %d", fmt);
     int CG = 16;  // 16 channels per block: B * C/16 blocks (768 for the M net at B = 32) of 25 KiB LDS at 20x20
     while (CG > 8 && ((size_t)2 * H * W * CG * 2 > 64 * 1024 || C % CG != 0)) CG /= 2;
     VGH_REQUIRE(C % CG == 0 && (size_t)2 * H * W * CG * 2 <= 160 * 1024, "spp: feature map %dx%d too large for the LDS tile", H, W);

@@ -60,6 +60,17 @@ struct ConvArgs {
     int fast_epi;   // 1: LDS-transposed 16-byte epilogue (bf16 out, 8-channel aligned offsets)
     int stagger;    // persistent patch kernels: odd resident-slot blocks start this many ~0.5 us sleeps late (de-phases co-resident blocks)
     int grid_share; // persistent patch kernels: take 1/grid_share of the CU slots (the executor's other lane streams own the rest)
+    // ---- grouped convolution (block-diagonal launch of sibling branches): cout tile c0 belongs to group c0 / grp_cout and reads its
+    //      input channels at in_coff + group * grp_in_stride; every row of wpack holds that group's cin = a.cin channels ----
+    int grp_cout, grp_in_stride;  // 0: dense
+    // ---- split-precision parity modes (conv_split.hip): activations are two 16-bit planes per pixel [hi C | lo C] and the K loop runs
+    //      three segments x_hi*w_lo, x_lo*w_hi (corrections), then -- after one multiply of the accumulators by acc_scale -- x_hi*w_hi ----
+    int split;        // VGH_FMT_BF16 (0): plain; VGH_FMT_BF16X2 / VGH_FMT_F16X2: hi|lo planes
+    int in_plane, out_plane, res_plane;  // elements from a pixel's hi plane to its lo plane (the buffer's logical pitch)
+    int seg_kb;       // k-blocks per segment = ksize^2 * cblocks (nkb = 3 * seg_kb)
+    float acc_scale;  // 1/2048 (fp16: lo planes are stored scaled by 2^11) or 1 (bf16)
+    float lo_scale;   // lo = (v - hi) * lo_scale
+    float out_scale;  // undoes the per-op power-of-two weight prescale (fp16), applied to the accumulator before the bias
     int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
     unsigned long long* trace;  // -DVGH_EXPERIMENTS builds only: per-(block, tile) phase timestamps (s_memtime), or nullptr
 };
@@ -82,6 +93,13 @@ struct ConvArgs {
 #endif
 
 int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);
+int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);  // conv_split.hip: a.split = VGH_FMT_BF16X2 / VGH_FMT_F16X2
+// dense [cout_pad][ks][ks][cin] f32 -> the three-segment 16-bit image [w_lo | w_hi | w_hi] (each segment laid out like
+// vgh_pack_conv_weights_host); fmt = VGH_FMT_BF16X2 / VGH_FMT_F16X2.  Returns through *out_scale the factor the kernel multiplies the
+// accumulators by (fp16: 2^-s with 2^s the power-of-two prescale that brings max|w| to ~2^9; bf16: 1).
+void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, int cin, int fmt, uint16_t* dst, float* out_scale);
+static inline int vgh_fmt_bytes(int fmt) { return fmt == 0 ? 2 : 4; }  // bytes per logical element of an activation buffer
+static inline int vgh_fmt_planes(int fmt) { return fmt >= 2 ? 2 : 1; }
 int vgh_conv_pick_cfg(const ConvArgs& a);
 // host-side weight packing: dense [cout_pad][ks][ks][cin] f32 -> wpack bf16 image
 void vgh_pack_conv_weights_host(const float* w, int cout_pad, int ksize, int cin, uint16_t* dst);
@@ -103,13 +121,14 @@ static inline uint16_t vgh_f32_to_bf16_host(float f) {
 }
 
 // ---- other launchers --------------------------------------------------------------------
+// fmt / plane: VGH_FMT_BF16 (plane unused) or a split format: then out_pitch is the physical pitch and `plane` the elements from hi to lo
 int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w /*[64][27] dev*/,
-                    const float* bias /*[64] dev*/, uint16_t* out, int64_t out_pitch, int out_coff, hipStream_t stream);
+                    const float* bias /*[64] dev*/, uint16_t* out, int64_t out_pitch, int out_coff, int fmt, int plane, hipStream_t stream);
 int vgh_launch_conv_f32(const ConvArgs& a, const float* wdense, hipStream_t stream);
 int vgh_launch_stem_f32(const void* image, int image_fmt, int B, int H, int W, const float* w, const float* bias, float* out, int64_t out_pitch, int out_coff,
                         hipStream_t stream);
 int vgh_launch_spp_pool_f32(float* buf, int64_t pitch, int coff, int C, int B, int H, int W, hipStream_t stream);
-int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, int H, int W, hipStream_t stream);
+int vgh_launch_spp_pool(uint16_t* buf, int64_t pitch, int coff, int C, int B, int H, int W, int fmt, int plane, hipStream_t stream);
 
 // streams.hip: a stream MEASURED to run side by side with every stream in `avoid` (earlier entries matter more when the hardware
 // queues do not suffice for all of them); released streams are parked, never destroyed

@@ -96,7 +96,7 @@ class VGHeadsEngine:
         P = self.program
         # the conv loader addresses an input tensor with 32-bit byte offsets: keep every arena tensor below 2 GiB by running
         # large batches through the network in chunks (post-network stages always see the whole batch)
-        per_image = max(bf["h"] * bf["w"] * bf["pitch"] * (4 if bf["is_f32"] else 2) for bf in P.bufs)
+        per_image = max(bf["h"] * bf["w"] * bf["pitch"] * arch.FMT_BYTES[bf["is_f32"]] for bf in P.bufs)
         self.arena_batch = max(1, min(max_batch, ((1 << 31) - 1) // per_image, arena_batch or max_batch))
         w, b = P.arrays()
         bufs = (_lib.BufDesc * len(P.bufs))(*[_lib.BufDesc(bf["h"], bf["w"], bf["pitch"], bf["is_f32"]) for bf in P.bufs])
@@ -176,15 +176,20 @@ class VGHeadsEngine:
         return arr
 
     def buffer(self, name_or_id, B: int) -> torch.Tensor:
-        """Copy of an activation buffer as a torch tensor [B,h,w,pitch] (tests / debugging)."""
+        """Copy of an activation buffer as a torch tensor [B,h,w,pitch] (tests / debugging): bf16 / fp32 as stored; the two-plane split
+        formats joined to fp32 (hi + lo, fp16 planes: hi + lo / 2048 -- exact in fp32)."""
         P = self.program
         bid = name_or_id if isinstance(name_or_id, int) else next(i for i, bf in enumerate(P.bufs) if bf["name"] == name_or_id)
         bf = P.bufs[bid]
+        fmt = bf["is_f32"]
         n = B * bf["h"] * bf["w"] * bf["pitch"]
         self.stream.synchronize()
-
-        t = _alias(self.lib.vgh_net_buffer(self._net, bid), (n,), "<f4" if bf["is_f32"] else "<i2", self.device)
-        if not bf["is_f32"]:
+        if fmt in (arch.FMT_BF16X2, arch.FMT_F16X2):
+            t = _alias(self.lib.vgh_net_buffer(self._net, bid), (2 * n,), "<i2", self.device).clone().view(B, bf["h"], bf["w"], 2, bf["pitch"])
+            t = t.view(torch.bfloat16 if fmt == arch.FMT_BF16X2 else torch.float16).float()
+            return t[..., 0, :] + t[..., 1, :] * (1.0 if fmt == arch.FMT_BF16X2 else 1.0 / 2048.0)
+        t = _alias(self.lib.vgh_net_buffer(self._net, bid), (n,), "<f4" if fmt == arch.FMT_F32 else "<i2", self.device)
+        if fmt == arch.FMT_BF16:
             t = t.view(torch.bfloat16)
         return t.clone().view(B, bf["h"], bf["w"], bf["pitch"])
 

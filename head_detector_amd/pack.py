@@ -9,7 +9,7 @@ seeded synthetic weights of the exact architecture (what the benchmarks use: the
 `--batch/--split` select the tile-table bucket (head_detector_amd/tuning/conv_cfg.json) the per-op choices are resolved for.
 Pure host code: packing needs neither a GPU nor libvgh.so.
 
-Layout (little-endian):  header (128 B: magic "VGHPACK\\0", version 1, header_bytes, variant[32], image_size, precision,
+Layout (little-endian):  header (128 B: magic "VGHPACK\\0", version 2, header_bytes, variant[32], image_size, precision,
 n_bufs, n_ops, n_levels, shape_c, expr_c, has_flame, tune_batch, reserved, flops_per_image f64, n_weights i64, n_biases i64,
 V, NB, NJ, F) | vgh_buf_desc[n_bufs] | vgh_op_desc[n_ops] | char tile_name[n_ops][32] | level[n_levels]{buf,h,w,pitch,stride} |
 f32 weights | f32 biases | FLAME: v_template[V,3] shapedirs[V,3,NB] posedirs[(NJ-1)*9,3V] J_regressor[NJ,V] parents[NJ] i32
@@ -30,7 +30,7 @@ import numpy as np
 from . import _lib, arch
 
 MAGIC = b"VGHPACK\0"
-VERSION = 1
+VERSION = 2  # 2: vgh_op_desc grew grp_cout / grp_in_stride; precision = VGH_FMT_* of the activation buffers
 HEADER_BYTES = 128
 _HDR = "<8sII32s8i2idqq4i"
 assert struct.calcsize(_HDR) == HEADER_BYTES
@@ -68,7 +68,7 @@ def write_pack(path: str, program: "arch.Program", flame_model: Optional[Dict[st
     if flame_model is not None:
         fl = _flame_arrays(flame_model)
         V, NB, NJ, F = fl[0].shape[0], fl[1].shape[2], fl[3].shape[0], fl[6].shape[0]
-    hdr = struct.pack(_HDR, MAGIC, VERSION, HEADER_BYTES, P.variant.encode()[:31], P.image_size, 0 if P.precision == "bf16" else 1, len(P.bufs), len(P.ops), len(P.levels),
+    hdr = struct.pack(_HDR, MAGIC, VERSION, HEADER_BYTES, P.variant.encode()[:31], P.image_size, arch.PRECISION_FMT[P.precision], len(P.bufs), len(P.ops), len(P.levels),
                       P.shape_c, P.expr_c, int(fl is not None), tune_batch, 0, float(P.flops), int(w.size), int(b.size), V, NB, NJ, F)
     with open(path, "wb") as f:
         f.write(hdr)
@@ -146,7 +146,7 @@ def main(argv=None):
     ap.add_argument("--image-size", type=int, default=640)
     ap.add_argument("--batch", type=int, default=64, help="batch the per-op tile choices are resolved for")
     ap.add_argument("--split", type=int, default=1, help="lane count the tile choices are resolved for")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=sorted(arch.PRECISION_FMT))
     args = ap.parse_args(argv)
     P = arch.build_program(args.variant, _weights_arg(args.weights, args.variant), args.image_size, args.precision)
     names = tile_names_for(P, args.batch, args.split) if args.precision == "bf16" else {}

@@ -48,10 +48,16 @@ const char* vgh_last_error(void);
 #define VGH_OP_FORK 3     /* fork point: ops with lane > 0 issued after it run on side HIP streams that wait for */
                           /* everything enqueued on the main stream BEFORE this point; all lanes join at the end */
 
+/* activation storage formats (vgh_buf_desc.is_f32 -- the field keeps its historical name) */
+#define VGH_FMT_BF16 0   /* throughput mode: bf16 NHWC */
+#define VGH_FMT_F32 1    /* fp32 NHWC: head prediction outputs in every mode; every buffer in the fp32 (VALU) parity mode */
+#define VGH_FMT_BF16X2 2 /* split parity mode: per pixel [hi C | lo C] bf16, value = hi + lo (16 significand bits) */
+#define VGH_FMT_F16X2 3  /* split parity mode: per pixel [hi C | lo C] fp16, value = hi + lo / 2048 (22 significand bits) */
+
 typedef struct vgh_buf_desc {
     int32_t h, w;   /* spatial size per image */
-    int32_t pitch;  /* channels per pixel (concat width); bf16: multiple of 8, f32: any */
-    int32_t is_f32; /* 0: bf16 activations, 1: fp32 (head prediction outputs) */
+    int32_t pitch;  /* LOGICAL channels per pixel (concat width); 16-bit formats: multiple of 8; the two-plane formats occupy 2*pitch */
+    int32_t is_f32; /* VGH_FMT_* */
 } vgh_buf_desc;
 
 typedef struct vgh_op_desc {
@@ -68,6 +74,8 @@ typedef struct vgh_op_desc {
     int64_t b_off;                       /* offset (floats) of [cout_pad] in `biases`                  */
     int32_t force_cfg;                   /* -1: heuristic tile choice; else kernel config index        */
     int32_t lane;                        /* 0: main stream; 1..3: side stream (independent branch, see VGH_OP_FORK) */
+    int32_t grp_cout, grp_in_stride;     /* grouped conv (sibling branches in one launch): output channels [g*grp_cout, (g+1)*grp_cout) read  */
+                                         /*   the `cin` input channels starting at in_coff + g*grp_in_stride; 0: dense                      */
 } vgh_op_desc;
 
 typedef struct vgh_net vgh_net;
@@ -115,8 +123,15 @@ typedef struct vgh_conv_call {
     float alpha;
     int32_t ksize, stride, act, shuffle;
     int32_t force_cfg;
+    int32_t grp_cout, grp_in_stride;     /* grouped conv, see vgh_op_desc (0: dense) */
+    int32_t fmt;                         /* VGH_FMT_BF16 (0) or a split format: then in/out/res pitches are the LOGICAL pitches, the lo planes   */
+                                         /*   sit `pitch` elements behind the hi planes, wpack_dev comes from vgh_pack_conv_weights_split        */
+    float out_scale;                     /*   and out_scale is what that call returned                                                           */
 } vgh_conv_call;
 int vgh_conv2d(const vgh_conv_call* c, void* stream);
+/* Split-precision weight image (parity modes): dense [cout_pad][k][k][cin] f32 -> 3*cout_pad*k*k*cin u16 ([w_lo | w_hi | w_hi] segments);
+ * *out_scale receives the accumulator scale of the op (see vgh_conv_call.out_scale). */
+int vgh_pack_conv_weights_split(const float* w_host, int cout_pad, int ksize, int cin, int fmt, uint16_t* wpack_host, float* out_scale);
 /* dense [cout_pad][k][k][cin] f32 (host) -> kernel-private bf16 image (host, cout_pad*k*k*cin u16) */
 int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin, uint16_t* wpack_host);
 int vgh_conv_num_cfgs(void);

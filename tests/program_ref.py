@@ -43,8 +43,17 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None):
     k, cin, rp = op["ksize"], op["cin"], op["cout_pad"]
     W = torch.from_numpy(w_all[op["w_off"] : op["w_off"] + rp * k * k * cin].reshape(rp, k, k, cin)).permute(0, 3, 1, 2).contiguous()
     b = torch.from_numpy(b_all[op["b_off"] : op["b_off"] + rp])
-    x = bufs[op["in_buf"]][..., op["in_coff"] : op["in_coff"] + cin].permute(0, 3, 1, 2)
-    y = F.conv2d(rb(x, bf16), rb(W, bf16), None, stride=op["stride"], padding=k // 2) + b[None, :, None, None]
+    gc = op.get("grp_cout", 0)
+    if gc:  # grouped conv: cout group g reads its own cin-channel window
+        ys = []
+        for g in range(rp // gc):
+            c0 = op["in_coff"] + g * op["grp_in_stride"]
+            xg = bufs[op["in_buf"]][..., c0 : c0 + cin].permute(0, 3, 1, 2)
+            ys.append(F.conv2d(rb(xg, bf16), rb(W[g * gc : (g + 1) * gc], bf16), None, stride=op["stride"], padding=k // 2))
+        y = torch.cat(ys, 1) + b[None, :, None, None]
+    else:
+        x = bufs[op["in_buf"]][..., op["in_coff"] : op["in_coff"] + cin].permute(0, 3, 1, 2)
+        y = F.conv2d(rb(x, bf16), rb(W, bf16), None, stride=op["stride"], padding=k // 2) + b[None, :, None, None]
     if op["act"] == 1:
         y = torch.relu(y)
     elif op["act"] == 2:
