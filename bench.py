@@ -3,26 +3,36 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...          (no torchrun environment: spawns the N ranks itself through torch.distributed.run)
 
 One step = one pass of the whole hot path over one batch that is already resident in HBM:
-    network (stem + 120/150 fused convs) -> box/score decode -> per-image top-k(1000) -> candidate gather + FLAME
+    network (stem + ~125 fused convs) -> box/score decode -> per-image top-k(1000) -> candidate gather + FLAME
     fix-up -> NMS (every image) -> compaction -> FLAME decode of every surviving head -> (N>1) RCCL gather to rank 0.
 Workload at N=1 = BASELINE.json configs[2]: VGGHeads_L, bf16, batch 64 @ 640x640 with FLAME decode per detection (per GPU; weak
-scaling: configs[3] = 8 x this).  configs[1] (VGGHeads_M, batch 32) is measured too and reported on stderr (and inside `config`).
+scaling: configs[3] = 8 x this).  Measured in the same run and reported inside `config` (and on stderr):
+    configs[1]  VGGHeads_M, batch 32 @ 640                              -> config.secondary_vgg_heads_m_b32
+    configs[4]  VGGHeads_L @ 1280x1280 crowd (>= 32 heads / image)      -> config.secondary_vgg_heads_l_b16_1280_crowd
+    the matrix-core PARITY mode (fp16x3: outputs within north_star's IoU >= 0.999 / 1e-4 of the fp32 reference) and the fp32 VALU mode
+                                                                        -> config.parity_mode
 Weights / FLAME constants are seeded synthetic tensors of the exact architecture (no network for the real assets).
 The random-weight network's scores are arbitrary, so the NMS confidence threshold is calibrated ONCE (untimed) so that
 about 3 heads per image survive; nothing is skipped inside the timed region.
 
 The JSON line also carries
-  roofline     : the conv implicit-GEMM kernel family against the dense bf16 MFMA peak, measured live with HIP events on
-                 the engine's stream around the network part of every timed step;
-  cpu_baseline : the oracle (torch-CPU fp32 restatement of the reference pipeline) on a bounded sample, rank 0 / N=1 only;
-  config.bf16_vs_fp32 : deviation of the timed bf16 mode from the engine's fp32 parity mode on seeded inputs (untimed).
+  roofline     : the conv kernel family against the dense bf16 MFMA peak, measured live with HIP events on the engine's stream around
+                 the network part of every timed step; `traffic` = HBM bytes per forward from PMC passes (FETCH_SIZE / WRITE_SIZE,
+                 separate rocprofv3 runs of tools/traffic_run.py launched by this script when rocprofv3 is on the box, else the
+                 committed profiles/ figure) next to the algorithmic bytes of the op program;
+  cpu_baseline : the oracle (torch-CPU fp32 restatement of the reference pipeline) on a bounded sample, rank 0 / N=1 only; its
+                 outputs on one 640x640 image are also what config.parity_mode.vs_oracle compares the parity modes with.
 The run refuses to start with any VGH_* environment variable set (experiment knobs must not leak into a measurement).
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+NORTH_STAR_IMG_PER_S_PER_GPU = 1250.0  # BASELINE.json north_star: >= 10k images/sec on 8 GPUs
 
 
 def _cpu_model() -> str:
@@ -55,7 +66,8 @@ def _timed(fn, iters: int):
 def cpu_baseline(variant: str, image_size: int, flame_model):
     """Oracle (kind "port": the torch-CPU fp32 restatement of the reference pipeline, oracle/) timed on the host cores, on a bounded
     sample: end to end at batch 1 / 8 / 32 (best reported as `value`), FLAME decode alone at n = 1 / 100, top-k + NMS
-    alone on 1000 candidates; median and min of the iterations."""
+    alone on 1000 candidates; median and min of the iterations.  Also returns the oracle's dense outputs for ONE seeded image
+    (the checker role: config.parity_mode.vs_oracle)."""
     import torch
 
     from head_detector_amd import arch
@@ -104,9 +116,133 @@ def cpu_baseline(variant: str, image_size: int, flame_model):
 
     topk_nms()
     med, mn = _timed(topk_nms, 10)
-    return {"value": best, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+    line = {"value": best, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": _cpu_model(),
             "sample": f"{n_img} images ({variant} fp32 unfused torch-CPU net + top-k + NMS + FLAME decode at batch 1/8/32; median of the iterations, best batch reported) in {time.time() - t_start:.1f}s",
             "end_to_end": e2e, "flame_decode_alone": dec, "topk_nms_alone_1000cand": {"ms_median": round(med * 1e3, 3), "ms_min": round(mn * 1e3, 3)}}
+    # checker role: the oracle's dense decode of one seeded image (same weights as every engine below)
+    x1 = torch.rand(1, 3, image_size, image_size, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        ob, os_, of = net.dense(x1)
+    return line, dict(x=x1, boxes=ob, scores=os_, flame=of)
+
+
+def _iou(a, b):
+    import torch
+
+    lt, rb = torch.maximum(a[..., :2], b[..., :2]), torch.minimum(a[..., 2:], b[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / ((a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter)
+
+
+def deviation_from_oracle(variant: str, precision: str, ref: dict, dev) -> dict:
+    """One engine mode on the oracle's image: dense boxes / scores and the 413-vectors of the mode's own top-100 candidates, looked up
+    BY ANCHOR in the oracle's dense output (relative to |ref| + 1; the exp()-amplified scale channel on its logit)."""
+    import torch
+
+    from head_detector_amd.engine import VGHeadsEngine
+
+    S = ref["x"].shape[-1]
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=1, seed=1, precision=precision)
+    try:
+        _, _, flame = eng.model(ref["x"].to(dev))
+        torch.cuda.synchronize()
+        db, ds = eng.boxes_all[:1].cpu(), eng.scores_all[:1].cpu()
+        idx = eng.idx[0, :100].cpu().long()
+        of_at = ref["flame"][0, idx]
+        rel = (flame[0, :100].cpu() - of_at).abs() / (of_at.abs() + 1.0)
+        return {"dense_iou_min": round(float(_iou(db, ref["boxes"]).min()), 6), "top100_iou_min": round(float(_iou(db[0, idx], ref["boxes"][0, idx]).min()), 6),
+                "dense_score_max_abs_err": float((ds - ref["scores"][..., 0]).abs().max()), "top100_param_max_rel_err": float(rel[:, :412].max()),
+                "top100_log_scale_max_abs_err": float((torch.log(flame[0, :100, 412].cpu()) - torch.log(of_at[:, 412])).abs().max())}
+    finally:
+        eng.close()
+
+
+def make_step(eng, flame, images, unpad, conf, B, slots, gat, overlap, use_graph, n_heads_all, ev0=None, ev1=None, ready=None):
+    """One step of the benchmark loop as a closure (also driven by tests/test_dist_cpu.py with a stand-in engine on gloo, so that the
+    N>1 control flow -- two output slots, the gatherer's slot hand-shake, the join -- runs on every CPU test pass)."""
+    nstep = [0]
+
+    def step(i=None):
+        s = nstep[0] & 1
+        nstep[0] += 1
+        if gat is not None:
+            gat.wait_slot_free(s, eng.stream)  # the exchange that last read this output slot (two batches ago) is over
+        if i is not None and ev0 is not None:
+            ev0[i].record(eng.stream)  # HIP events on the stream the kernels are launched on
+        eng.forward_net(images, use_graph=use_graph)
+        if i is not None and ev1 is not None:
+            ev1[i].record(eng.stream)
+        # post-network stages: decode/top-k/gather, then ONE library call for NMS + compaction + head list + FLAME decode of every
+        # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
+        eng.candidates(B)
+        k = i if i is not None else 0
+        det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1],
+                         slot=slots[s] if slots else None)
+        if gat is not None:
+            if overlap:
+                eng.join_into(gat.stream)  # the communication stream (not the engine stream) waits for this batch's select
+                ev = None
+            else:
+                ev = ready[s]
+                ev.record(eng.stream)
+            gat.submit(s, det.boxes, det.scores, det.flame_params, det.counts, det.n_heads, det.vertices_cap, ev)
+        return det
+
+    return step
+
+
+def live_traffic(variant: str, batch: int, split: int, forwards: int = 6):
+    """HBM bytes of one forward, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass; kernel-trace
+    only) around `tools/traffic_run.py --forwards N` -- network forwards only, so counter sum / N is bytes per forward.  Counter
+    conventions per MI355X_MICROARCH.md (HBM section): KiB units, FETCH_SIZE doubled on gfx950, WRITE_SIZE as is.  Returns None when
+    rocprofv3 is missing or a pass fails (the caller then falls back to the committed profile)."""
+    import csv
+    import glob
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    out = {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    with tempfile.TemporaryDirectory(prefix="vgh_pmc_") as td:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--output-format", "csv", "--pmc", ctr, "-d", td, "-o", ctr, "--", sys.executable, os.path.join(ROOT, "tools", "traffic_run.py"),
+                   "--variant", variant, "--batch", str(batch), "--forwards", str(forwards), "--split", str(split)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            files = sorted(glob.glob(os.path.join(td, "**", f"{ctr}_counter_collection.csv"), recursive=True))
+            if r.returncode != 0 or not files:
+                return None
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"]
+                if row["Counter_Name"] == ctr and ("conv_igemm" in k or "patch_kernel" in k or "patch3_kernel" in k or "stem_kernel" in k or "spp_pool" in k):
+                    tot += float(row["Counter_Value"])
+                    n += 1
+            if n == 0:
+                return None
+            out[ctr] = (tot, n)
+    rd = out["FETCH_SIZE"][0] * 1024 * 2 / forwards
+    wr = out["WRITE_SIZE"][0] * 1024 / forwards
+    return dict(read_bytes_per_forward=rd, write_bytes_per_forward=wr, launches_per_forward=out["FETCH_SIZE"][1] / forwards, forwards=forwards,
+                source=f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) around tools/traffic_run.py --forwards {forwards} --split {split}")
+
+
+def _respawn_under_torchrun(n: int):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`
+    (one rank per GPU over RCCL) instead of silently measuring one rank."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher environment: running {' '.join(cmd)}", file=sys.stderr)
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
@@ -119,8 +255,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=640)
     ap.add_argument("--heads-per-image", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-accuracy", action="store_true", help="skip the (untimed) bf16-vs-fp32 deviation report")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the (separately timed) VGGHeads_M batch-32 line on stderr")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the (untimed) deviation reports of the bf16 / parity modes")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the separately timed secondary workloads (M b32, L @1280 crowd, parity modes)")
     ap.add_argument("--per-layer", default=None, help="write a per-op timing table (json) to this path")
     ap.add_argument("--split", type=int, default=2, help="independent sub-batches per forward on the net's lane streams (1 = off)")
     ap.add_argument("--overlap", action="store_true", help="force the post-stage overlap on (default: on for batch >= 8)")
@@ -128,43 +264,50 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the network through a captured hipGraph")
     ap.add_argument("--exchange", action="store_true", help="run the N>1 step (output slots + RCCL gather to rank 0 on the communication stream) even with one rank")
     ap.add_argument("--tuning", default=None, help="tile table to load instead of head_detector_amd/tuning/conv_cfg.json")
+    ap.add_argument("--precision", default="bf16", help="activation format of the main workload (bf16 = the headline; fp16x3 / fp32 are the parity modes)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"], help="roofline.traffic: PMC passes run by this script (live), the committed profile (file)")
+    ap.add_argument("--ramp-steps", type=int, default=30, help="untimed steps before the W warm-up steps (clock ramp of a cold box; 0 = off)")
     args = ap.parse_args()
     leaked = sorted(k for k in os.environ if k.startswith("VGH_"))
     if leaked:
         sys.exit(f"bench.py: refusing to measure with experiment switches in the environment: {leaked}")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        _respawn_under_torchrun(args.gpus)
 
     import torch
     import torch.distributed as dist
 
-    from head_detector_amd import _lib
+    from head_detector_amd import _lib, arch
     from head_detector_amd.dist import DetectionGatherer, init_from_env, steer_collective_stream
     from head_detector_amd.engine import VGHeadsEngine
     from head_detector_amd.flame import FLAMELayer
     from head_detector_amd.synthetic import synthetic_flame_model
 
     rank, world, local = init_from_env(single_rank_group=args.exchange)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; launch with --nproc-per-node {args.gpus} (or without a launcher: the script spawns the ranks itself)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
     S = args.image_size
     flame_model = synthetic_flame_model(seed=3)
-    flame = FLAMELayer(model=flame_model, device=dev, max_heads=max(1024, max(args.batch, 32) * 100))
+    flame = FLAMELayer(model=flame_model, device=dev, max_heads=max(4096, max(args.batch, 32) * 100))
     nsplit = 1 if args.graph else max(1, min(4, args.split))
-    # post stages of batch s under the network of batch s+1: pays from batch 8 up (measured r02: 2.89 vs 2.95 ms at B=8, 13.25 vs 13.42 at B=64), costs
-    # at B=1 (2.2 vs 1.9 ms: the network itself is a chain of small latency-bound kernels there)
-    overlap = (args.overlap or (args.batch >= 8 and not args.no_overlap)) and not args.graph
 
     steered = [False]
 
-    def run_workload(variant: str, B: int, steps: int, warmup: int, per_layer_path=None) -> dict:
+    def run_workload(variant: str, B: int, steps: int, warmup: int, per_layer_path=None, image_size: int = S, heads_per_image: float = args.heads_per_image,
+                     precision: str = "bf16") -> dict:
         """The timed region of the contract for one (variant, batch): W warm-up steps, barrier + synchronize, K steps, synchronize +
         barrier, max over ranks.  HIP events on the engine's stream bracket the network part of every timed step."""
-        eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=1)
+        # post stages of batch s under the network of batch s+1: pays from batch 8 up (measured r02: 2.89 vs 2.95 ms at B=8, 13.25 vs 13.42 at B=64), costs
+        # at B=1 (2.2 vs 1.9 ms: the network itself is a chain of small latency-bound kernels there)
+        overlap = (args.overlap or (B >= 8 and not args.no_overlap)) and not args.graph
+        eng = VGHeadsEngine(variant, image_size=image_size, max_batch=B, seed=1, precision=precision)
         if args.tuning:
             eng.load_tuning(args.tuning)
         # synthetic images, seed 0 (+rank): u8 NHWC resident in HBM (what the letterbox stage hands over, detector.py:48-51)
-        images = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(rank)).to(dev)
+        images = torch.randint(0, 256, (B, image_size, image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(rank)).to(dev)
         unpad = torch.tensor([[0.0, 0.0, 1.0]], device=dev).expand(B, 3).contiguous()
         # calibrate the confidence threshold once (untimed): ~heads_per_image survivors per image
         _, scores, _ = eng.model(images)
@@ -175,11 +318,11 @@ def main():
             mid = 0.5 * (lo + hi)
             mean_heads = float(eng.detect(images, confidence_threshold=mid).counts.float().mean())
             conf = mid
-            if mean_heads > args.heads_per_image:
+            if mean_heads > heads_per_image:
                 lo = mid
             else:
                 hi = mid
-            if abs(mean_heads - args.heads_per_image) < 0.25:
+            if abs(mean_heads - heads_per_image) < max(0.25, 0.05 * heads_per_image):
                 break
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
@@ -193,10 +336,10 @@ def main():
         # N>1: the detections of every rank go to rank 0 -- fixed-capacity slabs allocated once, two output slots, collectives queued
         # on a communication stream behind the detector's side stream: the gather of batch s runs under the network of batch s+1 and
         # nothing in the steady-state loop waits on the host (head_detector_amd/dist.py::DetectionGatherer)
-        slots = gat = None
+        slots = gat = ready = None
         if world > 1 or args.exchange:
             slots = [eng.new_output_slot(flame) for _ in range(2)]
-            gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * args.heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream(),
+            gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream(),
                                     always_collective=args.exchange)
             ready = [torch.cuda.Event() for _ in range(2)]
             if gat.collective and not steered[0]:
@@ -205,33 +348,10 @@ def main():
                 steered[0] = True
                 ok = steer_collective_stream(eng.streams_in_use())
                 print(f"[bench] rank {rank}: collective stream {'clear of' if ok else 'SHARES a hardware queue with'} the engine's streams", file=sys.stderr)
-        nstep = [0]
+        step = make_step(eng, flame, images, unpad, conf, B, slots, gat, overlap, args.graph, n_heads_all, ev0, ev1, ready)
 
-        def step(i=None):
-            s = nstep[0] & 1
-            nstep[0] += 1
-            if gat is not None:
-                gat.wait_slot_free(s, eng.stream)  # the exchange that last read this output slot (two batches ago) is over
-            if i is not None:
-                ev0[i].record(eng.stream)  # HIP events on the stream the kernels are launched on
-            eng.forward_net(images, use_graph=args.graph)
-            if i is not None:
-                ev1[i].record(eng.stream)
-            # post-network stages: decode/top-k/gather, then ONE library call for NMS + compaction + head list + FLAME decode of every
-            # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
-            eng.candidates(B)
-            k = i if i is not None else 0
-            det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1],
-                             slot=slots[s] if slots else None)
-            if gat is not None:
-                if overlap:
-                    eng.join_into(gat.stream)  # the communication stream (not the engine stream) waits for this batch's select
-                    ev = None
-                else:
-                    ev = ready[s]
-                    ev.record(eng.stream)
-                gat.submit(s, det.boxes, det.scores, det.flame_params, det.counts, det.n_heads, det.vertices_cap, ev)
-
+        for _ in range(args.ramp_steps):  # untimed: a cold box needs a few hundred ms of load before its clocks settle
+            step()
         for _ in range(warmup):
             step()
         if dist.is_initialized():
@@ -258,12 +378,19 @@ def main():
             eng.join()
             eng.set_split(1)  # per-op events make sense on one stream only: the table is the single-stream view of every op
             json.dump(eng.profile_ops(images), open(per_layer_path, "w"), indent=0)
-        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, heads_per_img=heads / max(steps * B, 1),
-                   value=B * world * steps / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12)
+        alg = arch.program_algorithmic_bytes(eng.program, B)
+        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, heads_per_img=heads / max(steps * B, 1), overlap=overlap,
+                   value=B * world * steps / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,
+                   alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch)
         eng.close()
         return out
 
-    main_run = run_workload(args.variant, args.batch, args.steps, args.warmup, args.per_layer)
+    def brief(m: dict) -> dict:
+        return {"images_per_sec": round(m["value"], 2), "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "net_ms_per_step": round(m["net_ms"], 3),
+                "conv_tflops": round(m["conv_tflops"], 2), "roofline_frac": round(m["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "steps": m["steps"],
+                "heads_per_image_decoded": round(m["heads_per_img"], 2)}
+
+    main_run = run_workload(args.variant, args.batch, args.steps, args.warmup, args.per_layer, precision=args.precision)
     B = args.batch
 
     # FLAME decode alone (second headline metric): us per head at n = 96
@@ -280,36 +407,68 @@ def main():
     decode_us_per_head = e0.elapsed_time(e1) * 1e3 / (20 * 96)
 
     if rank == 0:
-        traffic = None  # HBM bytes per conv launch from the committed PMC pass (profiles/), only for the exact workload it was taken on
-        for rnd in ("r02", "r01"):
-            tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{args.variant[-1]}{B}.json")
-            if traffic is None and os.path.exists(tpath) and S == 640:
-                traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
-        config = {"workload": f"{args.variant} bf16 batch {B}/GPU @ {S}x{S}, u8 NHWC input resident in HBM, ~{main_run['heads_per_img']:.2f} heads/img decoded",
+        config = {"workload": f"{args.variant} {args.precision} batch {B}/GPU @ {S}x{S}, u8 NHWC input resident in HBM, ~{main_run['heads_per_img']:.2f} heads/img decoded",
                   "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(main_run["flops_per_image"] / 1e9, 2),
-                  "graph": bool(args.graph), "exchange_to_rank0": bool(world > 1 or args.exchange), "overlap_post": overlap, "batch_split": nsplit, "flame_decode_us_per_head_n96": round(decode_us_per_head, 3),
-                  "net_ms_per_step": round(main_run["net_ms"], 3)}
-        if world == 1 and not args.no_secondary and (args.variant, B) != ("vgg_heads_m", 32):
-            m = run_workload("vgg_heads_m", 32, max(50, args.steps // 2), args.warmup)
-            config["secondary_vgg_heads_m_b32"] = {"images_per_sec": round(m["value"], 2), "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "net_ms_per_step": round(m["net_ms"], 3),
-                                                   "conv_tflops": round(m["conv_tflops"], 2), "roofline_frac": round(m["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "steps": m["steps"]}
-            print(f"[bench] BASELINE configs[1] vgg_heads_m bf16 batch 32 @ {S}: {m['value']:.1f} img/s, {m['dt'] / m['steps'] * 1e3:.3f} ms/step, "
-                  f"net {m['net_ms']:.3f} ms = {m['conv_tflops']:.1f} TFLOP/s ({m['conv_tflops'] / MFMA_BF16_DENSE_PEAK_TFLOPS:.3f} of the bf16 MFMA peak)", file=sys.stderr)
-        if world == 1 and not args.no_accuracy:
-            from head_detector_amd.accuracy import bf16_vs_fp32
-
-            config["bf16_vs_fp32"] = [bf16_vs_fp32("vgg_heads_m", S, 2, flame, split=nsplit), bf16_vs_fp32("vgg_heads_l", S, 1, flame, split=1)]
+                  "graph": bool(args.graph), "exchange_to_rank0": bool(world > 1 or args.exchange), "overlap_post": main_run["overlap"], "batch_split": nsplit,
+                  "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(main_run["net_ms"], 3), "ramp_steps": args.ramp_steps}
+        sec_steps = max(50, args.steps // 2)
+        if world == 1 and not args.no_secondary:
+            if (args.variant, B) != ("vgg_heads_m", 32):
+                m = run_workload("vgg_heads_m", 32, sec_steps, args.warmup)
+                config["secondary_vgg_heads_m_b32"] = brief(m)
+                print(f"[bench] BASELINE configs[1] vgg_heads_m bf16 batch 32 @ {S}: {m['value']:.1f} img/s, {m['dt'] / m['steps'] * 1e3:.3f} ms/step, "
+                      f"net {m['net_ms']:.3f} ms = {m['conv_tflops']:.1f} TFLOP/s ({m['conv_tflops'] / MFMA_BF16_DENSE_PEAK_TFLOPS:.3f} of the bf16 MFMA peak)", file=sys.stderr)
+            # BASELINE configs[4]: 1280 x 1280 crowd images (>= 32 heads per image survive NMS and are decoded), 33 600 anchors per image
+            m = run_workload("vgg_heads_l", 16, max(20, sec_steps // 4), max(3, args.warmup // 2), image_size=1280, heads_per_image=40.0)
+            config["secondary_vgg_heads_l_b16_1280_crowd"] = dict(brief(m), gflop_per_image=round(m["flops_per_image"] / 1e9, 2), anchors_per_image=33600)
+            print(f"[bench] BASELINE configs[4] vgg_heads_l bf16 batch 16 @ 1280 crowd: {m['value']:.1f} img/s, {m['heads_per_img']:.1f} heads/img decoded, "
+                  f"net {m['net_ms']:.3f} ms = {m['conv_tflops']:.1f} TFLOP/s", file=sys.stderr)
+            # the parity modes, timed by the same loop: fp16x3 on the matrix cores (csrc/conv_split.hip) and the fp32 VALU kernel
+            pm = run_workload(args.variant, 32, max(20, sec_steps // 4), max(3, args.warmup // 2), precision="fp16x3")
+            pv = run_workload(args.variant, 8, 10, 2, precision="fp32")
+            config["parity_mode"] = {
+                "dtype": "fp16x3: two fp16 planes per value, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (outputs within IoU >= 0.999 / 1e-4 of the fp32 oracle: "
+                         "tests/test_gpu_split.py::test_fp16x3_matrix_core_mode_meets_north_star_tolerances)",
+                "workload": f"{args.variant} fp16x3 batch 32 @ {S}", **brief(pm), "effective_conv_tflops": round(pm["conv_tflops"], 2),
+                "mfma_tflops_issued": round(3 * pm["conv_tflops"], 2), "north_star_target_images_per_sec_per_gpu": NORTH_STAR_IMG_PER_S_PER_GPU,
+                "meets_throughput_target": bool(pm["value"] >= NORTH_STAR_IMG_PER_S_PER_GPU),
+                "fp32_valu_mode": {"workload": f"{args.variant} fp32 (v_fma_f32, csrc/conv_f32.hip) batch 8 @ {S}", **brief(pv)}}
+            print(f"[bench] parity mode fp16x3 {args.variant} batch 32 @ {S}: {pm['value']:.1f} img/s (target {NORTH_STAR_IMG_PER_S_PER_GPU:.0f}/GPU), net {pm['net_ms']:.3f} ms; "
+                  f"fp32 VALU mode batch 8: {pv['value']:.1f} img/s", file=sys.stderr)
+        # roofline.traffic: HBM bytes of one forward of the main workload
+        traffic = None
+        if args.traffic in ("auto", "live") and world == 1 and S == 640 and args.precision == "bf16":
+            traffic = live_traffic(args.variant, B, nsplit)
+        if traffic is None and args.traffic in ("auto", "file") and S == 640:
+            for name in (f"r03_traffic_{args.variant[-1]}{B}_x{nsplit}.json",):
+                tpath = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tpath):
+                    t = json.load(open(tpath))
+                    traffic = dict(read_bytes_per_forward=t["read_bytes_per_forward"], write_bytes_per_forward=t["write_bytes_per_forward"], launches_per_forward=t["launches_per_forward"],
+                                   source=f"committed PMC pass profiles/{name} (not this run)")
+        roof = {"bound": "mfma", "achieved": round(main_run["conv_tflops"], 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(main_run["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "algorithmic_bytes_per_forward": round(main_run["alg_bytes"]),
+                "kernel": "conv_igemm_kernel<*> + conv3x3_patch_kernel<*> + conv3x3_patch3_kernel<*> + stem / pool (all launches of one forward = one pass of the op program over the batch: "
+                          "algorithmic 2*MACs / HIP-event time of the network part; traffic = PMC HBM bytes of one forward)"}
+        if traffic is not None:
+            tb = traffic["read_bytes_per_forward"] + traffic["write_bytes_per_forward"]
+            roof.update({"traffic": round(tb), "traffic_read_bytes": round(traffic["read_bytes_per_forward"]), "traffic_write_bytes": round(traffic["write_bytes_per_forward"]),
+                         "traffic_over_algorithmic": round(tb / main_run["alg_bytes"], 3), "traffic_launches_per_forward": round(traffic["launches_per_forward"], 1),
+                         "traffic_hbm_tbps_at_net_time": round(tb / (main_run["net_ms"] * 1e-3) / 1e12, 3), "traffic_source": traffic["source"]})
         line = {
             "metric": "images/sec at 640x640 (VGGHeads forward path: net -> top-k/NMS -> FLAME decode)",
             "value": round(main_run["value"], 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(main_run["dt"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic", "config": config,
-            "roofline": {"bound": "mfma", "achieved": round(main_run["conv_tflops"], 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(main_run["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "conv_igemm_kernel<*> + conv3x3_patch_kernel<*> + conv3x3_patch3_kernel<*> (all launches of one forward: algorithmic 2*MACs / HIP-event time of the network part; traffic = PMC HBM bytes per launch, mean over the conv + stem launches of a single-lane forward)"},
+            "dtype": args.precision, "data": "synthetic", "config": config, "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.variant, S, flame_model)
+            line["cpu_baseline"], ref = cpu_baseline(args.variant, S, flame_model)
+            if not args.no_accuracy and S == 640:
+                # checker role of the oracle: every precision mode on the oracle's image (parity_mode.vs_oracle is what north_star's bar reads)
+                dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16")}
+                config.setdefault("parity_mode", {})["vs_oracle"] = dev_tab["fp16x3"]
+                config["modes_vs_oracle_one_image"] = dev_tab
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

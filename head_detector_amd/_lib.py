@@ -112,6 +112,7 @@ SYMBOLS = {
     "vgh_pack_conv_weights_split": (_I, [_P, _I, _I, _I, _I, _P, C.POINTER(_F)]),
     "vgh_conv_num_cfgs": (_I, []),
     "vgh_conv_cfg_name": (C.c_char_p, [_I]),
+    "vgh_conv_cfg_cout_tile": (_I, [_I]),
     "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "vgh_conv_set_max_blocks_per_xcd": (_I, [_I]),
     "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),

@@ -212,7 +212,17 @@ def fold_state_dict(variant: str, sd: Dict[str, np.ndarray]) -> Dict[str, Tuple[
 
     for sp in layer_specs(variant):
         n = sp.name
-        if sp.kind == "qarep":
+        if sp.kind == "qarep" and f"{n}.branch_3x3.conv.weight" not in sd and f"{n}.rbr_reparam.weight" in sd:
+            # an archive exported after super_gradients' QARepVGGBlock fusion.  `rbr_reparam` then holds the fused
+            # 3x3 conv -- branches + alpha (+ identity) folded -- and, after FULL fusion, post_bn too (post_bn is an Identity: no keys);
+            # after PARTIAL fusion post_bn is still a BatchNorm and is folded here.
+            K = need(f"{n}.rbr_reparam.weight", (sp.cout, sp.cin, 3, 3))
+            bias = need(f"{n}.rbr_reparam.bias", (sp.cout,))
+            if f"{n}.post_bn.running_var" in sd:
+                sp_, tp = _bn_affine(sd, f"{n}.post_bn")
+                K, bias = K * sp_[:, None, None, None], bias * sp_ + tp
+            out[n] = (K, bias)
+        elif sp.kind == "qarep":
             w3 = need(f"{n}.branch_3x3.conv.weight", (sp.cout, sp.cin, 3, 3))
             s3, t3 = _bn_affine(sd, f"{n}.branch_3x3.bn")
             w1 = need(f"{n}.branch_1x1.weight", (sp.cout, sp.cin, 1, 1))
@@ -548,3 +558,40 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
                 bf["is_f32"] = fmt
     P.precision = precision
     return P
+
+
+def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]:
+    """HBM bytes one op moves when every tensor is read / written exactly once (SURVEY.md 8(d) "algorithmic bytes"): the input view, the
+    residual view and the packed weights read, the stored channels written.  What `roofline.traffic` (PMC FETCH_SIZE / WRITE_SIZE) is
+    compared with: 3x3 halos and multi-consumer tensors that miss L2 / MALL show up as measured > algorithmic."""
+    kind = op["kind"]
+    if kind == 3:
+        return dict(read=0.0, write=0.0)
+    if kind == 0:  # stem: u8 image in, 64-channel (48 live + 16 zero) activation out
+        ob = P.bufs[op["out_buf"]]
+        return dict(read=float(batch * P.image_size * P.image_size * 3), write=float(batch * ob["h"] * ob["w"] * 64 * FMT_BYTES[ob["is_f32"]]))
+    ib = P.bufs[op["in_buf"]]
+    eb_in = FMT_BYTES[ib["is_f32"]]
+    if kind == 2:  # SPP pools: C channels in, 3 x C out
+        px = batch * ib["h"] * ib["w"]
+        return dict(read=float(px * op["cin"] * eb_in), write=float(3 * px * op["cin"] * eb_in))
+    ob = P.bufs[op["out_buf"]]
+    eb_out = FMT_BYTES[ob["is_f32"]]
+    groups = op["cout_pad"] // op["grp_cout"] if op.get("grp_cout") else 1
+    rd = batch * ib["h"] * ib["w"] * op["cin"] * groups * eb_in
+    out_px = batch * ob["h"] * ob["w"]
+    store = op["cout_store"] if not op["shuffle"] else op["cout_pad"] // 4
+    wr = out_px * store * eb_out
+    if op["res_buf"] >= 0:
+        rd += out_px * store * FMT_BYTES[P.bufs[op["res_buf"]]["is_f32"]]
+    rd += op["cout_pad"] * op["ksize"] ** 2 * op["cin"] * (2 if ib["is_f32"] == FMT_BF16 else 4 if ib["is_f32"] == FMT_F32 else 6)
+    return dict(read=float(rd), write=float(wr))
+
+
+def program_algorithmic_bytes(P: "Program", batch: int) -> Dict[str, float]:
+    tot = dict(read=0.0, write=0.0)
+    for op in P.ops:
+        b = op_algorithmic_bytes(P, op, batch)
+        tot["read"] += b["read"]
+        tot["write"] += b["write"]
+    return tot

@@ -247,6 +247,7 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     return 1;
 }
 const char* vgh_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].name : "?"; }
+int vgh_conv_cfg_cout_tile(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].BC : 0; }
 // as vgh_conv_cfg_ok, for a concrete launch: a grouped conv additionally needs cout tiles that do not straddle groups
 static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) return 0;
@@ -346,7 +347,8 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     vgh_fastdiv_magic((unsigned)(a.Ho * a.Wo), &const_cast<ConvArgs&>(a).div_howo_m, &const_cast<ConvArgs&>(a).div_howo_s);
     vgh_fastdiv_magic((unsigned)a.Wo, &const_cast<ConvArgs&>(a).div_wo_m, &const_cast<ConvArgs&>(a).div_wo_s);
     const bool al8 = a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_split % 8 == 0 && a.cout_store % 8 == 0 && a.out_pitch % 8 == 0 &&
-                     (!a.res || (a.res_coff % 8 == 0 && a.res_pitch % 8 == 0)) && (!a.shuffle || a.shuffle_c % 8 == 0);
+                     (!a.res || (a.res_coff % 8 == 0 && a.res_pitch % 8 == 0)) && (!a.shuffle || a.shuffle_c % 8 == 0) &&
+                     (!a.split || (a.out_plane % 8 == 0 && (!a.res || a.res_plane % 8 == 0)));
     // fp32 outputs (prediction buffers) take the transposed epilogue too when every pixel row starts 16-byte aligned
     const bool al4f = a.out_f32 && a.out_coff % 4 == 0 && a.out_pitch % 4 == 0 && a.out_split >= a.cout_store && !a.res && !a.shuffle;
     const_cast<ConvArgs&>(a).fast_epi = (((!a.out_f32 && al8) || al4f) && !(ablate & 4)) ? 1 : 0;

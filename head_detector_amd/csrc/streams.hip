@@ -37,6 +37,19 @@ __global__ void spin_grid_kernel(long long ticks) {
 
 constexpr long long kSpinTicks = 15000;  // 150 us
 constexpr int kMaxDev = 16, kMaxTries = 10;
+// Upper bound on the streams one (device, priority) park ever holds.  With H hardware queues at most H - n_avoid candidates can be
+// "perfect"; when none is (e.g. main + 3 lanes already occupy the 4 default queues) every further hipStreamCreate lands on one of the
+// same H queues, so a full park already contains a member of every queue class and creating more only leaks streams and lengthens the
+// probe of the next acquire.
+constexpr int kMaxPark = 16;
+
+struct DeviceGuard {  // restores the caller's current device on every exit path
+    int prev = -1;
+    bool switched = false;
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 std::mutex g_mu;
 std::vector<hipStream_t> g_park[2][kMaxDev];  // [normal | lowest priority]
@@ -76,9 +89,12 @@ int overlap_score(hipStream_t c, const hipStream_t* avoid, int n_avoid) {
 int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoid, hipStream_t* out, bool low_priority) {
     VGH_REQUIRE(out && device >= 0 && device < kMaxDev && n_avoid >= 0 && n_avoid <= 8, "stream_acquire: bad argument");
     std::lock_guard<std::mutex> lk(g_mu);
-    int cur = 0;
-    VGH_HIP(hipGetDevice(&cur));
-    if (cur != device) VGH_HIP(hipSetDevice(device));
+    DeviceGuard guard;
+    VGH_HIP(hipGetDevice(&guard.prev));
+    if (guard.prev != device) {
+        VGH_HIP(hipSetDevice(device));
+        guard.switched = true;
+    }
     const int perfect = (1 << n_avoid) - 1;
     std::vector<hipStream_t>& park = g_park[low_priority ? 1 : 0][device];
     int least = 0, greatest = 0;
@@ -88,7 +104,7 @@ int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoi
         const int s = overlap_score(park[i], avoid, n_avoid);
         if (s > best_score) best = i, best_score = s;
     }
-    for (int t = 0; t < kMaxTries && best_score < perfect; ++t) {
+    for (int t = 0; t < kMaxTries && best_score < perfect && (int)park.size() < kMaxPark; ++t) {
         hipStream_t c;
         if (low_priority)
             VGH_HIP(hipStreamCreateWithPriority(&c, hipStreamNonBlocking, least));
@@ -98,9 +114,9 @@ int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoi
         const int s = overlap_score(c, avoid, n_avoid);
         if (s > best_score) best = (int)park.size() - 1, best_score = s;
     }
+    VGH_REQUIRE(best >= 0, "stream_acquire: no candidate stream");
     *out = park[best];
     park.erase(park.begin() + best);
-    if (cur != device) VGH_HIP(hipSetDevice(cur));
     return VGH_OK;
 }
 

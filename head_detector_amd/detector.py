@@ -65,21 +65,35 @@ def weight_manifest_diff(variant: str, sd: Dict[str, np.ndarray]) -> Dict[str, l
     from . import arch
 
     want = {k: v.shape for k, v in arch.random_state_dict(variant, 0).items()}
-    ignore = re.compile(r"(num_batches_tracked|rbr_reparam\.|anchor_points|stride_tensor|proj_conv|max_batch)")
+    # u4: a RepVGG block exported AFTER fusion carries `<block>.rbr_reparam.{weight,bias}` (+ post_bn.* when only partially fused) instead
+    # of its branch tensors -- arch.fold_state_dict reads either form, so the branch keys of such a block are not "missing"
+    for spec in arch.layer_specs(variant):
+        if spec.kind == "qarep" and f"{spec.name}.rbr_reparam.weight" in sd and f"{spec.name}.branch_3x3.conv.weight" not in sd:
+            for k in [k for k in want if k.startswith(spec.name + ".")]:
+                if not (k.startswith(spec.name + ".post_bn.") and k in sd):
+                    del want[k]
+            want[f"{spec.name}.rbr_reparam.weight"] = (spec.cout, spec.cin, 3, 3)
+            want[f"{spec.name}.rbr_reparam.bias"] = (spec.cout,)
+    ignore = re.compile(r"(num_batches_tracked|anchor_points|stride_tensor|proj_conv|max_batch)")
     have = {k: tuple(np.asarray(v).shape) for k, v in sd.items() if not ignore.search(k)}
-    return {"missing": sorted(k for k in want if k not in have), "unexpected": sorted(k for k in have if k not in want),
+    # an UNFUSED block may still carry an unused rbr_reparam conv (SG keeps the attribute around): not an error
+    unexpected = sorted(k for k in have if k not in want and not (".rbr_reparam." in k and k.rsplit(".rbr_reparam.", 1)[0] + ".branch_3x3.conv.weight" in have))
+    return {"missing": sorted(k for k in want if k not in have), "unexpected": unexpected,
             "shape": sorted(f"{k}: expected {tuple(want[k])}, got {have[k]}" for k in want if k in have and tuple(want[k]) != have[k])}
 
 
 class HeadDetector:
     def __init__(self, model: str = "vgg_heads_l", image_size: int = 640, *, weights: Optional[str] = None, flame_path: Optional[str] = None,
                  flame_model: Optional[Dict[str, Any]] = None, seed: int = 1, max_batch: int = 1,
-                 assets_dir: Optional[str] = None, mesh_assets=None):
+                 assets_dir: Optional[str] = None, mesh_assets=None, precision: str = "bf16"):
+        """``precision``: "bf16" (throughput mode, the default) or "fp16x3" -- the matrix-core parity mode whose outputs match the reference's
+        fp32 CPU network to IoU >= 0.999 / 1e-4 (csrc/conv_split.hip; ~1/3 of the bf16 throughput); "fp32" = the VALU parity mode."""
         if not torch.cuda.is_available():
             raise _lib.VghError("HeadDetector: no GPU visible. This package is the MI355X HIP path only; it does not fall back to the CPU.")
         self._image_size = image_size
         self._device = torch.device("cuda", torch.cuda.current_device())
         self._max_batch = max_batch
+        self._precision = precision
         self._flame = FLAMELayer(flame_path=flame_path, model=flame_model, device=self._device, max_heads=max(1024, 100 * max_batch))
         self.model = self._read_model(model, weights, seed)
         # mesh assets of the reference (head_detector/assets) for PredictionResult.get_pncc(); user-supplied, optional
@@ -109,7 +123,7 @@ class HeadDetector:
             diff = weight_manifest_diff(model, sd)
             if any(diff.values()):
                 raise ValueError(f"{weights} does not match the {model} architecture this engine lowers:\n" + "\n".join(f"  {k}: {v[:12]}{' ...' if len(v) > 12 else ''}" for k, v in diff.items() if v))
-        return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=self._max_batch, seed=seed)
+        return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=self._max_batch, seed=seed, precision=self._precision)
 
     # ---- host-side image handling (detector.py:32-56) ----------------------------------------------------
     def _convert_image(self, image) -> np.ndarray:

@@ -328,18 +328,27 @@ class VGHeadsEngine:
         ``unpad`` [B,3] = (pad_x, pad_y, scale) per image fuses detector.py:67-69.  The result is written into fresh tensors the
         caller owns; ``reuse_outputs=True`` writes into the engine's own output buffers (no allocation, see ``Detections``)."""
         B, fmt = self._check_images(images)
-        with torch.cuda.stream(self.stream):  # allocate on the stream that writes them: the caching allocator's reuse stays ordered
+        cur = torch.cuda.current_stream(self.device)
+        # The result tensors are allocated (and zero-filled) on the engine stream, whose pool the caching allocator returns them to when the
+        # caller drops them.  Two orderings make that safe: the engine stream first waits for the caller's stream (a block freed by the caller
+        # may still be read by kernels the caller queued earlier), and the tensors are recorded on the caller's stream before they are handed
+        # out (the allocator then keeps a dropped block until the caller's reads of it have finished).
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
             slot = None if reuse_outputs else self.new_output_slot(flame, B)
         o, det = self._detect_out(B, flame, unpad, None, slot)
         if use_graph and B <= self.arena_batch:
             self.forward_candidates(images, True)
             _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         else:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
             _lib.check(self.lib.vgh_detect(self._det, images.data_ptr(), fmt, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         if getattr(self, "_overlap", False):
             _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))  # detect() keeps stream-ordered semantics
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        cur.wait_stream(self.stream)
+        if slot is not None:
+            for t in slot.values():
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
         return det
 
     def select(self, B: int, confidence_threshold: float = 0.5, iou_threshold: float = 0.5, flame: Optional[FLAMELayer] = None,
@@ -387,7 +396,9 @@ class VGHeadsEngine:
         out = []
         for op, t in zip(self.program.ops, ms):
             fl = 2.0 * op["macs"] * B
-            out.append(dict(name=op["name"], kind=op["kind"], ms=float(t), gflop=fl / 1e9, tflops=(fl / (t * 1e-3) / 1e12) if t > 0 else 0.0, gemm=op["gemm"]))
+            by = arch.op_algorithmic_bytes(self.program, op, B)
+            out.append(dict(name=op["name"], kind=op["kind"], ms=float(t), gflop=fl / 1e9, tflops=(fl / (t * 1e-3) / 1e12) if t > 0 else 0.0, gemm=op["gemm"],
+                            read_mb=by["read"] / 1e6, write_mb=by["write"] / 1e6, gbps=((by["read"] + by["write"]) / (t * 1e-3) / 1e9) if t > 0 else 0.0))
         return out
 
     def set_cfg(self, op_index: int, cfg: int):
@@ -422,4 +433,5 @@ def tuning_key(op: dict, batch: int, nsplit: int = 1) -> str:
     m, n, k = op["gemm"]
     bucket = 1 if batch <= 2 else (8 if batch <= 16 else 32)
     lanes = f"x{nsplit}" if nsplit > 1 else ""  # tile choices measured with the batch split over `nsplit` lane streams
-    return f"b{bucket}{lanes}_m{m}_n{n}_k{k}_ks{op['ksize']}_s{op['stride']}"
+    grp = f"_g{op['grp_cout']}" if op.get("grp_cout") else ""
+    return f"b{bucket}{lanes}_m{m}_n{n}_k{k}_ks{op['ksize']}_s{op['stride']}{grp}"

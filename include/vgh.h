@@ -136,6 +136,7 @@ int vgh_pack_conv_weights_split(const float* w_host, int cout_pad, int ksize, in
 int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin, uint16_t* wpack_host);
 int vgh_conv_num_cfgs(void);
 const char* vgh_conv_cfg_name(int cfg);
+int vgh_conv_cfg_cout_tile(int cfg); /* output channels per tile: a grouped conv (vgh_op_desc.grp_cout) needs grp_cout % tile == 0 */
 /* 1 if tile configuration `cfg` can run a conv of this kind (tuning tools). */
 int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle);
 /* Cap on the persistent 3x3 kernels' grid: at most `blocks` workgroups per XCD (0 = as many as stay resident, the default).
@@ -232,10 +233,11 @@ int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32
 /* General FLAMELayer.forward core = smplx lbs(betas, full_pose): betas_dev [n,NB], pose_dev [n,3*NJ]
  * axis-angle per joint -> verts_dev [n,V,3] (NO z offset, NO global rotation), joints_dev [n,NJ,3] or NULL. */
 int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream);
-/* The vertex stage has two interchangeable kernels: FP32 matrix cores (v_mfma_f32_32x32x2_f32: an exact k-ordered fmaf chain) and
- * VALU FMAs; they produce bit-identical vertices and the library picks by batch size.  enable = 0 forces the VALU kernels
- * (process-wide; parity tests and A/B measurements). */
-int vgh_flame_set_matrix_path(int enable);
+/* The vertex stage has interchangeable kernels that produce bit-identical vertices (each output is the same fp32 fmaf chain in ascending
+ * k): VALU FMAs, FP32 matrix cores fed from registers (v_mfma_f32_32x32x2_f32), and LDS-staged matrix-core tiles.  mode (process-wide,
+ * atomic; for parity tests and A/B measurements): 0 VALU only, 1 automatic by batch size (default), 2 register-fed matrix cores,
+ * 3 / 4 the LDS-staged tiles (128- / 64-head blocks) where their tables fit, else automatic. */
+int vgh_flame_set_matrix_path(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused detector: HeadDetector._process + the device-side arithmetic of _parse_predictions

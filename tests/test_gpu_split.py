@@ -1,0 +1,384 @@
+"""GPU (-m gpu): the matrix-core parity path (csrc/conv_split.hip).  north_star: "Outputs match the reference PyTorch CPU path on the
+same images (bbox IoU >= 0.999, FLAME params / vertices within 1e-4 fp32)" -- asserted here at 640 x 640 against the UNFUSED fp32
+oracle (oracle/net_oracle.py, the restatement of the network behind head_detector/detector.py:58-59) for the fp16x3 mode, whose
+convolutions run on v_mfma_f32_32x32x16_f16; the bf16x3 mode and the fp32 VALU mode are measured by the same routine so that
+DESIGN.md's comparison table comes from one code path."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import program_ref as pr
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+FMT_BF16X2, FMT_F16X2 = 2, 3
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _sp():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _split_planes(x: torch.Tensor, fmt: int) -> torch.Tensor:
+    """[..., C] float -> [..., 2, C] int16 bit patterns: hi | lo planes exactly as csrc/split_fmt.h writes them."""
+    if fmt == FMT_F16X2:
+        v = x.clamp(-65504.0, 65504.0)
+        hi = torch.where(v.abs() < 6.103515625e-05, torch.zeros_like(v), v).half()
+        lo = ((v - hi.float()) * 2048.0).half()
+    else:
+        hi = x.to(torch.bfloat16)
+        lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=-2).view(torch.int16)
+
+
+def _join_planes(t: torch.Tensor, fmt: int) -> torch.Tensor:
+    """[..., 2, C] int16 -> [..., C] float."""
+    f = t.view(torch.float16 if fmt == FMT_F16X2 else torch.bfloat16).float()
+    return f[..., 0, :] + f[..., 1, :] * (1.0 / 2048.0 if fmt == FMT_F16X2 else 1.0)
+
+
+def _run_conv_split(lib, fmt, x, W, b, k, stride, act=1, res=None, alpha=0.0, split=None, out_f32=False, shuffle=False, cfg=-1, cout_store=None, in_coff=0,
+                    in_pitch=None, out_coff=8, groups=None):
+    """x [B,H,W,Cin_total] float; W [rows,k,k,Cin] float.  Returns (engine output joined to float, float64 torch reference, store, out_coff)."""
+    from head_detector_amd import _lib
+
+    B, H, Wd, Ct = x.shape
+    rows, Cin = W.shape[0], W.shape[3]
+    rp = (rows + 31) // 32 * 32
+    Wp = torch.zeros(rp, k, k, Cin)
+    Wp[:rows] = W
+    bp = torch.zeros(rp)
+    bp[:rows] = b
+    pack = np.zeros(3 * Wp.numel(), dtype=np.uint16)
+    w_np = np.ascontiguousarray(Wp.numpy())
+    osc = C.c_float(0.0)
+    _lib.check(lib.vgh_pack_conv_weights_split(_lib.ptr(w_np), rp, k, Cin, fmt, _lib.ptr(pack), C.byref(osc)))
+    d_pack = torch.from_numpy(pack.view(np.int16)).to(_dev())
+    d_bias = bp.to(_dev())
+    in_pitch = in_pitch or (Ct + in_coff)
+    xin = torch.zeros(B, H, Wd, in_pitch)
+    xin[..., in_coff : in_coff + Ct] = x
+    d_x = _split_planes(xin, fmt).to(_dev()).contiguous()
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (Wd + 2 * (k // 2) - k) // stride + 1
+    store = cout_store if cout_store is not None else rows
+    oc = rp // 4 if shuffle else rp
+    oh, ow = (2 * Ho, 2 * Wo) if shuffle else (Ho, Wo)
+    out_pitch = oc + 16
+    if out_f32:
+        d_out = torch.full((B, oh, ow, out_pitch), -768.0, dtype=torch.float32, device=_dev())
+    else:
+        d_out = _split_planes(torch.full((B, oh, ow, out_pitch), -768.0), fmt).to(_dev()).contiguous()
+    d_res = _split_planes(res, fmt).to(_dev()).contiguous() if res is not None else None
+    call = _lib.ConvCall(
+        in_dev=d_x.data_ptr(), in_pitch=in_pitch, in_coff=in_coff, cin=Cin, B=B, H=H, W=Wd, wpack_dev=d_pack.data_ptr(), bias_dev=d_bias.data_ptr(),
+        out_dev=d_out.data_ptr(), out_pitch=out_pitch, out_coff=out_coff if not split else split[1], cout_pad=rp, cout_store=store,
+        out_split=rp if not split else split[0], out_coff2=0 if not split else split[2], out_f32=int(out_f32),
+        res_dev=d_res.data_ptr() if d_res is not None else None, res_pitch=res.shape[-1] if res is not None else 0, res_coff=0, alpha=alpha,
+        ksize=k, stride=stride, act=act, shuffle=int(shuffle), force_cfg=cfg, grp_cout=groups[0] if groups else 0, grp_in_stride=groups[1] if groups else 0,
+        fmt=fmt, out_scale=osc.value,
+    )
+    _lib.check(lib.vgh_conv2d(C.byref(call), _sp()))
+    torch.cuda.synchronize()
+    out = d_out.cpu() if out_f32 else _join_planes(d_out.cpu(), fmt)
+    # reference: float64 conv on what the planes actually hold (the split of the inputs is the storage format, not the kernel)
+    xr = _join_planes(_split_planes(x, fmt), fmt).double().permute(0, 3, 1, 2)
+    wr = Wp.double().permute(0, 3, 1, 2)
+    if groups:
+        gc, gs = groups
+        y = torch.cat([F.conv2d(xr[:, g * gs : g * gs + Cin], wr[g * gc : (g + 1) * gc], None, stride=stride, padding=k // 2) for g in range(rp // gc)], 1)
+    else:
+        y = F.conv2d(xr[:, :Cin], wr, None, stride=stride, padding=k // 2)
+    y = y + bp.double()[None, :, None, None]
+    if act == 1:
+        y = torch.relu(y)
+    y = y.permute(0, 2, 3, 1)
+    if shuffle:
+        Cc = rp // 4
+        z = torch.zeros(B, oh, ow, Cc, dtype=torch.float64)
+        for d in range(4):
+            z[:, d // 2 :: 2, d % 2 :: 2] = y[..., d * Cc : (d + 1) * Cc]
+        y = z
+    if res is not None:
+        y = y + alpha * _join_planes(_split_planes(res, fmt), fmt).double()[..., : y.shape[-1]]
+    return out, y, store, out_coff
+
+
+# absolute + relative tolerance of ONE conv with O(1) inputs / outputs: fp16x3 carries 22-bit operands and drops 2^-22 terms (fp32 accumulation
+# over K <= 2304 dominates); bf16x3 carries 16-bit operands
+TOL = {FMT_F16X2: (2e-5, 1e-5), FMT_BF16X2: (1.5e-3, 3e-4)}
+
+SPLIT_CONV_CASES = [
+    # (B, H, W, Cin, Cout, k, stride)
+    (1, 16, 16, 32, 32, 1, 1),
+    (2, 32, 32, 64, 64, 3, 1),      # patch tile 16x16x64
+    (1, 32, 48, 96, 96, 3, 1),      # patch tile 16x16x96
+    (2, 40, 40, 64, 128, 3, 2),     # stride 2: implicit GEMM
+    (1, 32, 32, 128, 256, 3, 1),    # patch tile 16x16x128, two cout tiles
+    (3, 20, 20, 192, 192, 1, 1),
+    (1, 33, 17, 64, 96, 3, 2),      # odd sizes, ragged tiles
+    (1, 8, 8, 768, 384, 1, 1),      # long K
+    (1, 5, 5, 32, 13, 1, 1),        # tiny cout
+    (2, 40, 40, 64, 128, 3, 1),     # 40-wide map: row-strip patch tile
+    (1, 21, 37, 32, 64, 3, 1),      # ragged: implicit GEMM
+    (2, 16, 16, 256, 32, 3, 1),     # patch tile 16x16x32, 8 channel blocks per segment
+]
+
+
+@pytest.mark.parametrize("fmt", [FMT_F16X2, FMT_BF16X2])
+@pytest.mark.parametrize("case", SPLIT_CONV_CASES)
+def test_split_conv_vs_float64(gpu_lib, case, fmt):
+    """Every split tile family (implicit GEMM 64/128/256-pixel tiles, 16x16 / 8x40 halo-patch tiles) against a float64 convolution:
+    bf16 / fp32 epilogue, untouched guard channels, small and large magnitudes (fp16 range handling: weight prescale, flushed hi)."""
+    B, H, Wd, Cin, Cout, k, s = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + fmt)
+    K = k * k * Cin
+    for mag_x, mag_w in ((1.0, 1.0), (40.0, 1e-3), (4e-3, 30.0)):
+        x = torch.randn(B, H, Wd, Cin, generator=g) * mag_x
+        W = torch.randn(Cout, k, k, Cin, generator=g) * (mag_w / K ** 0.5)
+        b = torch.randn(Cout, generator=g) * 0.1 * mag_x * mag_w
+        for out_f32 in (False, True):
+            if (out_f32 and Cout > 128) or (not out_f32 and Cout % 4):  # 16-bit outputs are written in groups of 4 channels
+                continue
+            out, ref, store, oc = _run_conv_split(gpu_lib, fmt, x, W, b, k, s, act=1 if not out_f32 else 0, out_f32=out_f32)
+            atol, rtol = TOL[fmt]
+            scale = mag_x * mag_w
+            err = (out[..., oc : oc + store].double() - ref[..., :store]).abs()
+            # fp16 planes: an activation below fp16's smallest normal (2^-14) lives in the lo plane alone, i.e. with an ABSOLUTE error <= 2^-26
+            tol = atol * scale + rtol * ref[..., :store].abs() + (5e-8 * mag_w if fmt == FMT_F16X2 else 0.0)
+            assert bool((err <= tol).all()), (case, fmt, mag_x, mag_w, out_f32, float((err / tol).max()), float(err.max()))
+            assert bool((out[..., :oc] == -768.0).all()) and bool((out[..., oc + store :] == -768.0).all()), "guard channels overwritten"
+
+
+@pytest.mark.parametrize("fmt", [FMT_F16X2, FMT_BF16X2])
+def test_split_conv_epilogues(gpu_lib, fmt):
+    """Residual (+ alpha * res after the activation, two-plane residual), two-segment store, ConvTranspose pixel-shuffle store, grouped conv,
+    forced tiles of both kernel families."""
+    g = torch.Generator().manual_seed(7 + fmt)
+    atol, rtol = TOL[fmt]
+
+    def check(out, ref, store, oc, what):
+        err = (out[..., oc : oc + store].double() - ref[..., :store]).abs()
+        tol = atol + rtol * ref[..., :store].abs()
+        assert bool((err <= tol).all()), (what, fmt, float((err / tol).max()))
+
+    # residual on the patch kernel (3x3 s1) and on the implicit-GEMM kernel (1x1)
+    for k, H in ((3, 32), (1, 24)):
+        x = torch.randn(2, H, H, 64, generator=g)
+        W = torch.randn(64, k, k, 64, generator=g) / (k * k * 64) ** 0.5
+        b = torch.randn(64, generator=g) * 0.1
+        res = torch.randn(2, H, H, 64, generator=g)
+        out, ref, store, oc = _run_conv_split(gpu_lib, fmt, x, W, b, k, 1, res=res, alpha=0.37)
+        check(out, ref, store, oc, f"residual k{k}")
+    # two-segment store: channels >= 32 go to a second offset
+    x = torch.randn(1, 16, 16, 64, generator=g)
+    W = torch.randn(64, 1, 1, 64, generator=g) / 8
+    b = torch.randn(64, generator=g) * 0.1
+    out, ref, _, _ = _run_conv_split(gpu_lib, fmt, x, W, b, 1, 1, split=(32, 0, 48))
+    check(out[..., 0:32], ref[..., :32], 32, 0, "split seg 1")
+    check(out[..., 48:80], ref[..., 32:64], 32, 0, "split seg 2")
+    # ConvTranspose 2x2 s2 as 4 pointwise GEMMs + pixel shuffle
+    x = torch.randn(1, 8, 8, 64, generator=g)
+    W = torch.randn(128, 1, 1, 64, generator=g) / 8
+    b = torch.randn(128, generator=g) * 0.1
+    out, ref, store, oc = _run_conv_split(gpu_lib, fmt, x, W, b, 1, 1, act=0, shuffle=True, cout_store=32)
+    check(out, ref, 32, oc, "shuffle")
+    # grouped 3x3: four 32 -> 32 branches reading their own 32-channel windows (the FLAME transform branches), at an input offset
+    x = torch.randn(2, 16, 16, 128, generator=g)
+    W = torch.randn(128, 3, 3, 32, generator=g) / 17
+    b = torch.randn(128, generator=g) * 0.1
+    out, ref, store, oc = _run_conv_split(gpu_lib, fmt, x, W, b, 3, 1, groups=(32, 32), in_coff=64)
+    check(out, ref, store, oc, "grouped")
+    # every split tile that can run a 128 -> 128 3x3 conv on a 32-wide map
+    x = torch.randn(1, 32, 32, 128, generator=g)
+    W = torch.randn(128, 3, 3, 128, generator=g) / 34
+    b = torch.randn(128, generator=g) * 0.1
+    for cfg in (0, 2, 3, 4, 6, 7, 8, 10, 11, 15):
+        out, ref, store, oc = _run_conv_split(gpu_lib, fmt, x, W, b, 3, 1, cfg=cfg)
+        check(out, ref, store, oc, f"cfg {cfg}")
+
+
+def test_grouped_conv_bf16_throughput_kernels(gpu_lib):
+    """The grouped launch in the bf16 throughput kernels (implicit GEMM, patch v2, patch v3 'q' tiles) against per-group convolutions."""
+    from test_gpu_parity import _assert_close
+    from head_detector_amd import _lib
+
+    g = torch.Generator().manual_seed(3)
+    B, H, Wd = 3, 32, 32
+    x = torch.randn(B, H, Wd, 128, generator=g).to(torch.bfloat16).float()
+    W = (torch.randn(128, 3, 3, 32, generator=g) / 17).to(torch.bfloat16).float()
+    b = torch.randn(128, generator=g) * 0.1
+    pack = np.zeros(W.numel(), dtype=np.uint16)
+    _lib.check(gpu_lib.vgh_pack_conv_weights(_lib.ptr(np.ascontiguousarray(W.numpy())), 128, 3, 32, _lib.ptr(pack)))
+    d_pack, d_bias = torch.from_numpy(pack.view(np.int16)).to(_dev()), b.to(_dev())
+    in_pitch, in_coff = 192, 64
+    xin = torch.zeros(B, H, Wd, in_pitch)
+    xin[..., in_coff:] = x
+    d_x = xin.to(torch.bfloat16).to(_dev())
+    ref = torch.cat([F.conv2d(x[..., 32 * q : 32 * q + 32].permute(0, 3, 1, 2), W[32 * q : 32 * q + 32].permute(0, 3, 1, 2), b[32 * q : 32 * q + 32], padding=1) for q in range(4)], 1)
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    ran = 0
+    for cfg in [-1] + [i for i, n in enumerate(names) if n in ("128x32_w32x32_k1", "64x32_w32x32_k1", "256x32_w64x32_k1", "p16x16x32_n4x1", "q16x16x32_n4x1", "128x32_w32x32_k1_r4")]:
+        d_out = torch.full((B, H, Wd, 144), -768.0, dtype=torch.bfloat16, device=_dev())
+        call = _lib.ConvCall(in_dev=d_x.data_ptr(), in_pitch=in_pitch, in_coff=in_coff, cin=32, B=B, H=H, W=Wd, wpack_dev=d_pack.data_ptr(), bias_dev=d_bias.data_ptr(),
+                             out_dev=d_out.data_ptr(), out_pitch=144, out_coff=8, cout_pad=128, cout_store=128, out_split=128, out_coff2=0, out_f32=0, res_dev=None, res_pitch=0,
+                             res_coff=0, alpha=0.0, ksize=3, stride=1, act=1, shuffle=0, force_cfg=cfg, grp_cout=32, grp_in_stride=32, fmt=0, out_scale=1.0)
+        _lib.check(gpu_lib.vgh_conv2d(C.byref(call), _sp()))
+        torch.cuda.synchronize()
+        _assert_close(d_out.float().cpu()[..., 8:136], ref, False, f"grouped cfg {cfg}")
+        ran += 1
+    assert ran >= 5
+    # a tile wider than a group is refused when forced
+    call.force_cfg = names.index("128x128_w64x64_k1")
+    assert gpu_lib.vgh_conv2d(C.byref(call), _sp()) != 0 and b"cannot run this conv" in gpu_lib.vgh_last_error()
+
+
+# ======================================================================================================
+# whole network against the UNFUSED fp32 oracle
+# ======================================================================================================
+def _box_iou(a, b):
+    x1, y1 = torch.maximum(a[..., 0], b[..., 0]), torch.maximum(a[..., 1], b[..., 1])
+    x2, y2 = torch.minimum(a[..., 2], b[..., 2]), torch.minimum(a[..., 3], b[..., 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    ua = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter
+    return inter / ua
+
+
+def network_vs_oracle(variant, okey, precision, S, B, flame_model, per_op_tol=None, weight_seed=21, image_seed=5, heads_per_image=8.0):
+    """Runs the engine in `precision` on seeded images and measures it against the unfused fp32 oracle (torch CPU) on the same images:
+    dense boxes / scores, the top-k candidates (matched by anchor: anchors whose scores differ by less than round-off may swap places), and
+    the detections the ORACLE keeps after NMS (~heads_per_image per image): IoU, parameter error, FLAME vertex error in metric space.
+    per_op_tol: additionally check every op against the torch executor on the engine's own inputs (relative to |ref| + 1)."""
+    from head_detector_amd import arch
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+    from oracle import flame_oracle as fo
+    from oracle import net_oracle
+    from oracle import postproc_oracle as po
+
+    sd = arch.random_state_dict(variant, weight_seed)
+    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, precision=precision)
+    P = eng.program
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(image_seed))
+    boxes, scores, flame = eng.model(x.to(_dev()))
+    out = {"variant": variant, "precision": precision, "image_size": S, "batch": B}
+    if per_op_tol is not None:
+        got = [eng.buffer(i, B).cpu() for i in range(len(P.bufs))]
+        w_all, b_all = P.arrays()
+        worst = 0.0
+        for op in P.ops:
+            if op["kind"] == 3:
+                continue
+            ob = op["out_buf"] if op["kind"] != 2 else op["in_buf"]
+            exp = list(got)
+            exp[ob] = got[ob].clone()
+            pr.run_op(P, op, exp, x, False, w_all, b_all)
+            err = float(((got[ob] - exp[ob]).abs() / (exp[ob].abs() + 1.0)).max())
+            assert err < per_op_tol, (op["name"], err)
+            worst = max(worst, err)
+        out["per_op_max_rel_err"] = worst
+        del got
+    oracle = net_oracle.YoloHeadsOracle(okey)
+    oracle.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    with torch.no_grad():
+        ob_, os_, of_ = oracle.dense(x)
+    A = ob_.shape[1]
+    dense_b, dense_s = eng.boxes_all[:B].cpu(), eng.scores_all[:B].cpu()
+    out["dense_iou_min"] = float(_box_iou(dense_b, ob_).min())
+    out["dense_score_max_abs_err"] = float((dense_s - os_[..., 0]).abs().max())
+    k = min(1000, A)
+    idx = eng.idx[:B, :k].cpu().long()
+    of_at = torch.stack([of_[b, idx[b]] for b in range(B)])
+    ob_at = torch.stack([ob_[b, idx[b]] for b in range(B)])
+    rel = (flame[:, :k].cpu() - of_at).abs() / (of_at.abs() + 1.0)
+    out["cand_param_max_rel_err"] = float(rel[..., :412].max())
+    out["cand_log_scale_max_abs_err"] = float((torch.log(flame[:, :k, 412].cpu()) - torch.log(of_at[..., 412])).abs().max())
+    out["cand_iou_min"] = float(_box_iou(boxes[:, :k].cpu(), ob_at).min())
+    osort = torch.stack([torch.sort(os_[b, :, 0], descending=True, stable=True).indices[:k] for b in range(B)])
+    out["topk_order_swaps_frac"] = float((idx != osort).float().mean())
+    # detections the oracle keeps (head_detector/utils.py:159-194 semantics on its own candidates), looked up BY ANCHOR in the engine's outputs
+    with torch.no_grad():
+        rb_, rs_, rf_ = oracle(x, k=k)
+    lo, hi = float(rs_.min()), float(rs_.max())
+    conf = hi
+    for _ in range(40):
+        conf = 0.5 * (lo + hi)
+        n = np.mean([r[0].shape[0] for r in po.postprocess_batched(rb_, rs_, rf_, conf, 0.5)])
+        if abs(n - heads_per_image) < 0.5:
+            break
+        lo, hi = (conf, hi) if n > heads_per_image else (lo, conf)
+    kept = po.postprocess_batched(rb_, rs_, rf_, conf, 0.5)
+    ious, dpar, dlog, rows_e, rows_o = [], [], [], [], []
+    for b in range(B):
+        where = {int(a): i for i, a in enumerate(idx[b].tolist())}
+        for kb, kf in zip(kept[b][0], kept[b][2]):
+            a = int((ob_[b] - kb).abs().sum(-1).argmin())  # the anchor of this oracle detection
+            assert float((ob_[b, a] - kb).abs().max()) == 0.0
+            ious.append(float(_box_iou(dense_b[b, a], ob_[b, a])))
+            assert a in where, "an oracle detection is missing from the engine's top-k"
+            re_, ro_ = flame[b, where[a]].cpu(), kf
+            dpar.append(float(((re_[:412] - ro_[:412]).abs() / (ro_[:412].abs() + 1.0)).max()))
+            dlog.append(float((torch.log(re_[412]) - torch.log(ro_[412])).abs()))
+            rows_e.append(re_)
+            rows_o.append(ro_)
+    out.update({"kept": len(ious), "kept_iou_min": min(ious), "kept_param_max_rel_err": max(dpar), "kept_log_scale_max_abs_err": max(dlog)})
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=max(64, len(rows_e)))
+    ve = fl.decode(torch.stack(rows_e).to(_dev()), shape_live=P.shape_c, expr_live=P.expr_c, want_projected=False)[0]
+    vo = fo.reproject(fo.FlameConstants(flame_model, torch.float64), torch.stack(rows_o).double())[0]  # unrotated vertices (flame.py:191, zero_rot=True)
+    d = (ve.cpu().double() - vo).norm(dim=-1)  # FLAME metric space (|v| ~ 0.2 m), unrotated vertices
+    out.update({"vertex_l2_metric_max": float(d.max()), "vertex_l2_metric_mean": float(d.mean())})
+    eng.close()
+    rec = os.path.join(ROOT, "gpurun_out", "parity_modes.jsonl")
+    os.makedirs(os.path.dirname(rec), exist_ok=True)
+    with open(rec, "a") as f:
+        f.write(json.dumps(out) + "\n")
+    print(f"[parity] {out}")
+    return out
+
+
+def _assert_north_star(r):
+    """BASELINE.json north_star: bbox IoU >= 0.999, FLAME params / vertices within 1e-4 (relative to |ref| + 1 for the 413-vector whose
+    channels span 1e-3 .. 640; absolute metres for the vertices; the exp()-amplified scale channel is judged on its logit)."""
+    assert r["dense_iou_min"] >= 0.999 and r["cand_iou_min"] >= 0.999 and r["kept_iou_min"] >= 0.999, r
+    assert r["dense_score_max_abs_err"] < 1e-5, r
+    assert r["cand_param_max_rel_err"] < 1e-4 and r["kept_param_max_rel_err"] < 1e-4, r
+    assert r["cand_log_scale_max_abs_err"] < 2e-3 and r["kept_log_scale_max_abs_err"] < 1e-3, r
+    assert r["vertex_l2_metric_max"] < 1e-4, r
+    assert r["kept"] >= 4
+
+
+@pytest.mark.parametrize("variant,okey,S,B", [("vgg_heads_m", "m", 160, 2), ("vgg_heads_l", "l", 160, 2), ("vgg_heads_m", "m", 640, 2), ("vgg_heads_l", "l", 640, 1)],
+                         ids=["m160", "l160", "m640", "l640"])
+def test_fp16x3_matrix_core_mode_meets_north_star_tolerances(gpu_lib, flame_model, variant, okey, S, B):
+    """The MFMA parity mode at BASELINE.json's bar against the unfused fp32 oracle -- at the benchmark's 640 x 640 geometry, every op
+    also against the fp32 torch executor on the engine's own inputs."""
+    r = network_vs_oracle(variant, okey, "fp16x3", S, B, flame_model, per_op_tol=2e-5)
+    _assert_north_star(r)
+
+
+@pytest.mark.parametrize("variant,okey,B", [("vgg_heads_m", "m", 2), ("vgg_heads_l", "l", 1)], ids=["m640", "l640"])
+def test_fp32_valu_mode_meets_north_star_tolerances_at_640(gpu_lib, flame_model, variant, okey, B):
+    """The fp32 FMA mode (csrc/conv_f32.hip) at 640 x 640 against the oracle (r02 checked it at 160 x 160 only)."""
+    r = network_vs_oracle(variant, okey, "fp32", 640, B, flame_model, per_op_tol=2e-5)
+    _assert_north_star(r)
+
+
+@pytest.mark.parametrize("variant,okey,B", [("vgg_heads_m", "m", 2), ("vgg_heads_l", "l", 1)], ids=["m640", "l640"])
+def test_bf16x3_and_bf16_deviation_from_the_oracle_at_640(gpu_lib, flame_model, variant, okey, B):
+    """The two modes that do NOT meet the bar, measured by the same routine against the same oracle (DESIGN.md's table): bf16x3 (16-bit
+    operands: three orders better than bf16, one short of 1e-4) and the bf16 throughput mode bench.py times.  Their levels are pinned so
+    that a regression cannot hide."""
+    r3 = network_vs_oracle(variant, okey, "bf16x3", 640, B, flame_model, per_op_tol=2e-3)
+    assert r3["dense_iou_min"] >= 0.99 and r3["kept_iou_min"] >= 0.999 and r3["kept_param_max_rel_err"] < 5e-3 and r3["vertex_l2_metric_max"] < 2e-3, r3
+    r1 = network_vs_oracle(variant, okey, "bf16", 640, B, flame_model)
+    assert r1["kept_iou_min"] >= 0.85 and r1["kept_param_max_rel_err"] < 0.5 and r1["vertex_l2_metric_max"] < 3e-2, r1
+    assert r3["kept_param_max_rel_err"] < r1["kept_param_max_rel_err"]

@@ -340,3 +340,34 @@ def test_pack_file_round_trip(tmp_path):
     # CLI
     pack.main(["vgg_heads_m", "seed:7", "none", str(tmp_path / "cli.vghpack"), "--image-size", "128", "--batch", "32"])
     assert pack.read_header(str(tmp_path / "cli.vghpack"))["has_flame"] == 0
+
+
+def test_fused_archive_keys_fold_to_the_same_network():
+    """an archive exported after QARepVGG fusion (`rbr_reparam` instead of the branch tensors; post_bn kept when only
+    partially fused) passes the manifest check and folds to the same conv + bias as the unfused keys."""
+    from head_detector_amd.detector import weight_manifest_diff
+
+    variant = "vgg_heads_m"
+    sd = arch.random_state_dict(variant, 9)
+    F = arch.fold_state_dict(variant, sd)
+    qarep = [sp for sp in arch.layer_specs(variant) if sp.kind == "qarep"]
+    full = {k: v for k, v in sd.items() if not any(k.startswith(sp.name + ".") for sp in qarep)}
+    part = dict(full)
+    for sp in qarep:
+        W, b = F[sp.name]
+        full[f"{sp.name}.rbr_reparam.weight"], full[f"{sp.name}.rbr_reparam.bias"] = W.astype(np.float32), b.astype(np.float32)
+        s_, t_ = arch._bn_affine(sd, f"{sp.name}.post_bn")
+        part[f"{sp.name}.rbr_reparam.weight"], part[f"{sp.name}.rbr_reparam.bias"] = (W / s_[:, None, None, None]).astype(np.float32), ((b - t_) / s_).astype(np.float32)
+        for k in sd:
+            if k.startswith(sp.name + ".post_bn."):
+                part[k] = sd[k]
+    for what, d, tol in (("full", full, 0.0), ("partial", part, 1e-5)):
+        diff = weight_manifest_diff(variant, d)
+        assert not any(diff.values()), (what, {k: v[:3] for k, v in diff.items()})
+        G = arch.fold_state_dict(variant, d)
+        for sp in qarep:
+            W, b = F[sp.name]
+            assert np.abs(G[sp.name][0] - W.astype(np.float32)).max() <= tol * (np.abs(W).max() + 1e-30) + 1e-12 and np.abs(G[sp.name][1] - b.astype(np.float32)).max() <= tol * (np.abs(b).max() + 1) + 1e-12, (what, sp.name)
+    broken = dict(full)
+    del broken[f"{qarep[3].name}.rbr_reparam.bias"]
+    assert weight_manifest_diff(variant, broken)["missing"] == [f"{qarep[3].name}.rbr_reparam.bias"]

@@ -20,7 +20,7 @@ def main():
     lib = _lib.load()
     mode = int(os.environ.get("FLAME_MODE", "1"))  # vgh_flame_set_matrix_path: 0 VALU, 1 automatic, 2 register-fed MFMA, 3 / 4 LDS-staged MFMA
     _lib.check(lib.vgh_flame_set_matrix_path(mode))
-    ns = tuple(int(x) for x in os.environ.get("FLAME_NS", "1,8,64,96,1024,8192").split(","))
+    ns = tuple(int(x) for x in os.environ.get("FLAME_NS", "1,8,64,96,256,512,1024,8192").split(","))
     rows = []
     for live, (sl, el) in (("M heads 64+32", (64, 32)), ("L heads 128+64", (128, 64)), ("all 300+100", (300, 100))):
         for n in ns:

@@ -1,0 +1,56 @@
+#!/bin/bash
+# One parametrised GPU-box script (replaces the per-experiment gpu_*.sh pile):
+#     tools/gpu_run.sh <out-subdir> <step> [<step> ...]        e.g.  gpurun -- 'tools/gpu_run.sh r3a tests bench prof pmc'
+# steps:  tests      pytest -m gpu (PYTEST_ARGS to narrow)           smoke      __graft_entry__.smoke()
+#         bench      default bench line + per-layer table             prof       rocprofv3 --kernel-trace --stats of the bench command
+#         pmc        HBM traffic + MFMA-busy PMC passes around tools/traffic_run.py, one and two lanes (separate --pmc passes, kernel-trace only)
+#         tune       retune the L b64 / M b32 tile tables             tune1280   retune the L b16 @1280 bucket
+#         flame      FLAME decode sweep (tools/flame_sweep.py)        pmcflame   MFMA-busy of the FLAME kernels at n = 8192
+#         probe      whole-net time of both benchmark buckets (two lanes)
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd $ROOT
+O=$ROOT/gpurun_out/$1; shift
+mkdir -p $O
+export TMPDIR=/tmp PYTHONPATH=$ROOT
+TAG=${TAG:-r03}
+FW=${FORWARDS:-8}
+for step in "$@"; do
+  echo "=== $step"
+  case $step in
+    tests)
+      timeout ${TEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS:-} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+      tail -${TAILN:-25} $O/pytest_gpu.log ;;
+    smoke)
+      timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log ;;
+    bench)
+      timeout 1200 python bench.py --per-layer $O/per_layer_l64.json ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -5 $O/bench.err; cut -c1-900 $O/bench.json ;;
+    prof)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $TAG -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-accuracy --no-secondary --traffic off > $O/prof.log 2>&1)
+      f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_bench_l64_kernel_stats.csv && head -14 "$f" | cut -c1-220
+      tail -1 $O/prof.log | cut -c1-300 ;;
+    pmc)
+      for L in 1 2; do
+        for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
+          t=$(echo $c | cut -d' ' -f1)
+          (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $O/pmc_x$L -o $t -- python $ROOT/tools/traffic_run.py --forwards $FW --split $L > $O/pmc_x${L}_$t.log 2>&1)
+        done
+        python tools/pmc_summary.py $O/pmc_x$L vgg_heads_l 64 $FW $L $O $TAG
+      done ;;
+    tune)
+      timeout 1500 python tools/tune_conv.py --variant vgg_heads_l --batch 64 --report $O/${TAG}_tune_l64.json > $O/tune.log 2>&1
+      timeout 1500 python tools/tune_conv.py --variant vgg_heads_m --batch 32 --report $O/${TAG}_tune_m32.json >> $O/tune.log 2>&1
+      tail -3 $O/tune.log; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
+    tune1280)
+      timeout 1500 python tools/tune_conv.py --variant vgg_heads_l --batch 16 --image-size 1280 --report $O/${TAG}_tune_l16_1280.json > $O/tune1280.log 2>&1
+      tail -2 $O/tune1280.log; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
+    flame)
+      timeout 900 python tools/flame_sweep.py $O/${TAG}_flame_sweep.json > $O/flame.log 2>&1; grep -v amdgpu $O/flame.log | tail -${TAILN:-30} ;;
+    pmcflame)
+      (cd /tmp && FLAME_NS=8192 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmcf -o f -- python $ROOT/tools/flame_sweep.py > $O/pmcflame.log 2>&1)
+      python tools/pmc_flame_summary.py $O/pmcf $O/${TAG}_pmc_flame.txt ;;
+    probe)
+      python tools/net_probe.py vgg_heads_l 64 2>&1 | grep -v amdgpu; python tools/net_probe.py vgg_heads_m 32 2>&1 | grep -v amdgpu ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

@@ -1,28 +1,35 @@
-"""Summarise the PMC passes of tools/gpu_r2_l.sh: HBM traffic per conv launch (profiles/r02_traffic_*.json) and whole-network MFMA
-busy fraction (profiles/r02_pmc_net_*.txt).  Counter conventions per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE
-are in KiB; on gfx950 FETCH_SIZE counts half of a wide read stream (doubled here); SQ_* / GRBM_* are summed over the 8 XCDs."""
+"""Summarise PMC passes taken around `tools/traffic_run.py --forwards N --split L` (tools/gpu_run.sh pmc): HBM traffic PER FORWARD and
+whole-network MFMA busy.  Counter conventions per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE counts half of a wide read stream (doubled here, its HBM section); WRITE_SIZE is taken as is (uncalibrated); SQ_* / GRBM_* are
+summed over the 8 XCDs.  Every dispatch of the run belongs to one of the N forwards (the engine's stream probes are spin kernels, listed
+under "other"), so sum / N is the per-forward figure -- no calibration forwards to subtract.
+
+    python tools/pmc_summary.py PMC_DIR VARIANT BATCH FORWARDS SPLIT OUT_DIR [TAG]
+"""
 import collections
 import csv
 import glob
 import json
+import os
 import sys
 
-pmc_dir, variant, batch, out_dir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+pmc_dir, variant, batch, forwards, split, out_dir = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+tag = sys.argv[7] if len(sys.argv) > 7 else "r03"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def is_conv(k):
-    return "conv_igemm" in k or "patch_kernel" in k or "patch3_kernel" in k
+def is_net(k):
+    return "conv_igemm" in k or "patch_kernel" in k or "patch3_kernel" in k or "stem_kernel" in k or "spp_pool" in k
 
 
-def load(tag):
-    f = glob.glob(f"{pmc_dir}/{tag}_counter_collection.csv")
+def load(name):
+    f = sorted(glob.glob(f"{pmc_dir}/**/{name}_counter_collection.csv", recursive=True))
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.defaultdict(collections.Counter)
     if not f:
         return per, n
     for r in csv.DictReader(open(f[0])):
-        k = r["Kernel_Name"]
-        key = "conv" if is_conv(k) else "stem" if "stem_kernel" in k else "other"
+        key = "net" if is_net(r["Kernel_Name"]) else "other"
         per[r["Counter_Name"]][key] += float(r["Counter_Value"])
         n[r["Counter_Name"]][key] += 1
     return per, n
@@ -30,27 +37,36 @@ def load(tag):
 
 fs, fn = load("FETCH_SIZE")
 ws, wn = load("WRITE_SIZE")
+suffix = f"{variant[-1]}{batch}_x{split}"
 if fs and ws:
-    launches = fn["FETCH_SIZE"]["conv"] + fn["FETCH_SIZE"]["stem"]
-    rd = (fs["FETCH_SIZE"]["conv"] + fs["FETCH_SIZE"]["stem"]) * 1024 * 2
-    wr = (ws["WRITE_SIZE"]["conv"] + ws["WRITE_SIZE"]["stem"]) * 1024
-    d = dict(workload=f"{variant} bf16 batch {batch} @ 640x640, two batch-split lanes", conv_and_stem_launches_in_run=launches,
-             read_bytes_per_launch=rd / launches, write_bytes_per_launch=wr / launches, traffic_bytes_per_launch=(rd + wr) / launches,
-             method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes around `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-                    "--no-accuracy --no-secondary`; counters in KiB summed over every conv + stem dispatch of the run (threshold calibration forwards included: same "
-                    "kernels, same shapes) / number of those dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE as is")
-    json.dump(d, open(f"{out_dir}/r02_traffic_{variant[-1]}{batch}.json", "w"), indent=1)
+    from head_detector_amd import arch
+
+    P = arch.build_program(variant, arch.random_state_dict(variant, 1), 640)
+    alg = arch.program_algorithmic_bytes(P, batch)
+    launches = fn["FETCH_SIZE"]["net"] / forwards
+    rd = fs["FETCH_SIZE"]["net"] * 1024 * 2 / forwards
+    wr = ws["WRITE_SIZE"]["net"] * 1024 / forwards
+    d = dict(workload=f"{variant} bf16 batch {batch} @ 640x640, {split} batch-split lane(s)", forwards_in_run=forwards, launches_per_forward=launches,
+             read_bytes_per_forward=rd, write_bytes_per_forward=wr, traffic_bytes_per_forward=rd + wr, traffic_bytes_per_launch=(rd + wr) / launches,
+             algorithmic_read_bytes_per_forward=alg["read"], algorithmic_write_bytes_per_forward=alg["write"], algorithmic_bytes_per_forward=alg["read"] + alg["write"],
+             traffic_over_algorithmic=(rd + wr) / (alg["read"] + alg["write"]),
+             method=f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes around `python tools/traffic_run.py --forwards {forwards} --split {split}` "
+                    "(network forwards only: no calibration, no post-network stages); counters in KiB summed over every stem / conv / pool dispatch / forwards; "
+                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE as is; algorithmic = every op's input view, residual and weights read once + its stored "
+                    "channels written once (head_detector_amd/arch.py::op_algorithmic_bytes)")
+    json.dump(d, open(f"{out_dir}/{tag}_traffic_{suffix}.json", "w"), indent=1)
     print(json.dumps(d, indent=1))
 ms, mn = load("SQ_VALU_MFMA_BUSY_CYCLES")
 qs, qn = load("SQ_WAVE_CYCLES")
 if ms:
-    with open(f"{out_dir}/r02_pmc_net_{variant[-1]}{batch}.txt", "w") as f:
-        for key in ("conv", "stem"):
-            busy, act = ms["SQ_VALU_MFMA_BUSY_CYCLES"][key], ms["GRBM_GUI_ACTIVE"][key]
-            line = (f"{key}: {mn['GRBM_GUI_ACTIVE'][key]} dispatches, GRBM_GUI_ACTIVE {act:.4g} (sum over 8 XCDs), SQ_VALU_MFMA_BUSY_CYCLES {busy:.4g} -> "
-                    f"MFMA busy = busy / (active / 8 * 1024 SIMDs) = {100 * busy / max(act / 8 * 1024, 1):.1f} %")
-            if qs:
-                line += f"; wave cycles waiting on an instruction / wave cycles {qs['SQ_WAIT_INST_ANY'][key] / max(qs['SQ_WAVE_CYCLES'][key], 1):.2f}"
-            print(line)
-            f.write(line + "\n")
-        f.write(f"# whole-network view: every conv dispatch of `python bench.py --steps 2 --warmup 1 ...` ({variant} batch {batch}), separate --pmc passes, kernel-trace only\n")
+    with open(f"{out_dir}/{tag}_pmc_net_{suffix}.txt", "w") as f:
+        busy, act = ms["SQ_VALU_MFMA_BUSY_CYCLES"]["net"], ms["GRBM_GUI_ACTIVE"]["net"]
+        line = (f"net: {mn['GRBM_GUI_ACTIVE']['net']} dispatches in {forwards} forwards, GRBM_GUI_ACTIVE {act:.4g} (sum over 8 XCDs), SQ_VALU_MFMA_BUSY_CYCLES {busy:.4g} -> "
+                f"MFMA busy per dispatch cycle = busy / (active / 8 * 1024 SIMDs) = {100 * busy / max(act / 8 * 1024, 1):.1f} %; MFMA-busy cycles per forward {busy / forwards:.4g}")
+        if qs:
+            line += f"; wave cycles waiting on an instruction / wave cycles {qs['SQ_WAIT_INST_ANY']['net'] / max(qs['SQ_WAVE_CYCLES']['net'], 1):.2f}"
+        print(line)
+        f.write(line + "\n")
+        f.write(f"# every stem / conv / pool dispatch of `python tools/traffic_run.py --forwards {forwards} --split {split}` ({variant} batch {batch}), separate --pmc passes, kernel-trace only.\n"
+                "# with 2 lanes the kernels of the two half-batches overlap in time, so the per-dispatch denominator counts wall time twice: divide MFMA-busy cycles per forward by\n"
+                "# 1024 SIMDs x the forward's wall time x the shader clock for the wall-clock figure (DESIGN.md 5).\n")

@@ -40,7 +40,9 @@ def main():
             al = all(op[k] % 8 == 0 for k in ("out_coff", "out_coff2", "out_split", "cout_store", "res_coff")) and ob["pitch"] % 8 == 0
             return int((not ob["is_f32"]) and al)
 
-        ok = [i for i in conv_idx if eng.lib.vgh_conv_cfg_ok(c, ops[i]["ksize"], ops[i]["stride"], ops[i]["cout_pad"], fast(ops[i]), ops[i]["shuffle"])]
+        bc = eng.lib.vgh_conv_cfg_cout_tile(c)
+        ok = [i for i in conv_idx if eng.lib.vgh_conv_cfg_ok(c, ops[i]["ksize"], ops[i]["stride"], ops[i]["cout_pad"], fast(ops[i]), ops[i]["shuffle"])
+              and (not ops[i].get("grp_cout") or ops[i]["grp_cout"] % bc == 0)]
         if not ok:
             continue
         for i in conv_idx:
