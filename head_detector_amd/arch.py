@@ -521,9 +521,13 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
             # the four transform branches (rotation / jaw / translation / scale: 3x3, tr -> tr each) are ONE grouped launch: cout group g
             # reads its own trp-channel window of the previous layer (four launches of a [M,32,288] GEMM could not fill the chip)
             parts = [(_ohwi(F[f"{p}.flame_{n_}_pred.{bi}"][0], trp), F[f"{p}.flame_{n_}_pred.{bi}"][1]) for n_, _ in TR_OUTS]
-            Wg, bg, _ = _stack(parts, pad_to=trp)
-            P.conv(f"{p}.flame_transform_pred.{bi}", View(cur, offs[2], trp), View(nxt, offs[2], 4 * trp), Wg, bg, 3, cout_store=4 * trp, flops_macs=4 * tr * 9 * tr,
-                   groups=(trp, trp))
+            if precision == "fp32":  # the fp32 VALU kernel (csrc/conv_f32.hip) has no grouped mode: one launch per branch
+                for j, ((n_, _), (Wj, bj)) in enumerate(zip(TR_OUTS, parts)):
+                    P.conv(f"{p}.flame_{n_}_pred.{bi}", View(cur, offs[2] + j * trp, trp), View(nxt, offs[2] + j * trp, trp), Wj, bj, 3, cout_store=trp, flops_macs=tr * 9 * tr)
+            else:
+                Wg, bg, _ = _stack(parts, pad_to=trp)
+                P.conv(f"{p}.flame_transform_pred.{bi}", View(cur, offs[2], trp), View(nxt, offs[2], 4 * trp), Wg, bg, 3, cout_store=4 * trp, flops_macs=4 * tr * 9 * tr,
+                       groups=(trp, trp))
             cur = nxt
         # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | .. | shape | expr | rot6 | jaw3 | trans3 | scale1]: one block-diagonal
         # GEMM over the whole last-layer buffer [shape inter | expr inter | 4 x tr] (three launches at 5-250 TFLOP/s before); the zero blocks

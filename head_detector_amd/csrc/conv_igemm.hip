@@ -320,7 +320,7 @@ int vgh_conv_pick_cfg(const ConvArgs& a) {
     return best >= 0 ? best : pick_size_only(a);
 }
 
-int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
+int vgh_conv_prepare(ConvArgs& a) {
     VGH_REQUIRE(a.cin % 32 == 0 && a.cin > 0, "conv: cin=%d must be a positive multiple of 32", a.cin);
     VGH_REQUIRE(a.cout_pad % 32 == 0 && a.cout_pad > 0, "conv: cout_pad=%d must be a multiple of 32", a.cout_pad);
     VGH_REQUIRE(a.ksize == 1 || a.ksize == 3, "conv: ksize=%d unsupported", a.ksize);
@@ -331,33 +331,42 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     VGH_REQUIRE((int64_t)a.B * a.H * a.W * a.in_pitch * 2 < (1ll << 31), "conv: input tensor must stay below 2 GiB (32-bit buffer offsets); run the batch in chunks");
     VGH_REQUIRE(!a.shuffle || (a.shuffle_c % 4 == 0 && a.cout_pad >= 4 * a.shuffle_c && a.ksize == 1 && a.stride == 1), "conv: bad shuffle");
     VGH_REQUIRE(a.grp_cout == 0 || (a.grp_cout % 32 == 0 && a.cout_pad % a.grp_cout == 0 && a.grp_in_stride % 8 == 0), "conv: bad group geometry (grp_cout=%d)", a.grp_cout);
-    if (a.P == 0) return VGH_OK;
     VGH_REQUIRE((int64_t)a.B * a.Ho * a.Wo < (1ll << 30), "conv: too many output pixels for one launch");
 #ifdef VGH_EXPERIMENTS
     static const int ablate = getenv("VGH_CONV_ABLATE") ? atoi(getenv("VGH_CONV_ABLATE")) : 0;
     static const int stagger_env = getenv("VGH_STAGGER") ? atoi(getenv("VGH_STAGGER")) : -1;
     static const int share_env = getenv("VGH_GRID_SHARE") ? atoi(getenv("VGH_GRID_SHARE")) : -1;
-    const_cast<ConvArgs&>(a).trace = g_trace;
-    if (stagger_env >= 0) const_cast<ConvArgs&>(a).stagger = stagger_env;
-    if (share_env >= 1) const_cast<ConvArgs&>(a).grid_share = share_env;
+    a.trace = g_trace;
+    if (stagger_env >= 0) a.stagger = stagger_env;
+    if (share_env >= 1) a.grid_share = share_env;
 #else
     constexpr int ablate = 0;
 #endif
-    const_cast<ConvArgs&>(a).ablate = ablate;
-    vgh_fastdiv_magic((unsigned)(a.Ho * a.Wo), &const_cast<ConvArgs&>(a).div_howo_m, &const_cast<ConvArgs&>(a).div_howo_s);
-    vgh_fastdiv_magic((unsigned)a.Wo, &const_cast<ConvArgs&>(a).div_wo_m, &const_cast<ConvArgs&>(a).div_wo_s);
+    a.ablate = ablate;
+    vgh_fastdiv_magic((unsigned)(a.Ho * a.Wo > 0 ? a.Ho * a.Wo : 1), &a.div_howo_m, &a.div_howo_s);
+    vgh_fastdiv_magic((unsigned)(a.Wo > 0 ? a.Wo : 1), &a.div_wo_m, &a.div_wo_s);
     const bool al8 = a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_split % 8 == 0 && a.cout_store % 8 == 0 && a.out_pitch % 8 == 0 &&
                      (!a.res || (a.res_coff % 8 == 0 && a.res_pitch % 8 == 0)) && (!a.shuffle || a.shuffle_c % 8 == 0) &&
                      (!a.split || (a.out_plane % 8 == 0 && (!a.res || a.res_plane % 8 == 0)));
     // fp32 outputs (prediction buffers) take the transposed epilogue too when every pixel row starts 16-byte aligned
     const bool al4f = a.out_f32 && a.out_coff % 4 == 0 && a.out_pitch % 4 == 0 && a.out_split >= a.cout_store && !a.res && !a.shuffle;
-    const_cast<ConvArgs&>(a).fast_epi = (((!a.out_f32 && al8) || al4f) && !(ablate & 4)) ? 1 : 0;
+    a.fast_epi = (((!a.out_f32 && al8) || al4f) && !(ablate & 4)) ? 1 : 0;
+    return VGH_OK;
+}
+
+int vgh_conv_pick_auto(const ConvArgs& a) { return a.split ? vgh_conv_split_pick(a) : vgh_conv_pick_cfg(a); }
+
+int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
+    ConvArgs a = a0;
+    if (int rc = vgh_conv_prepare(a)) return rc;
+    if (a.P == 0) return VGH_OK;
     if (a.split) return vgh_launch_conv_split(a, force_cfg, stream);  // parity modes: own tile set (conv_split.hip)
     int cfg = force_cfg >= 0 ? force_cfg : vgh_conv_pick_cfg(a);
     VGH_REQUIRE(cfg < kNumCfgs, "conv: cfg %d out of range", cfg);
     if (!cfg_ok_for(cfg, a)) {
-        VGH_REQUIRE(force_cfg < 0, "conv: cfg %s cannot run this conv (cout_pad=%d k=%d s=%d grp=%d)", g_cfgs[cfg].name, a.cout_pad, a.ksize, a.stride, a.grp_cout);
-        cfg = a.grp_cout ? pick_size_only(a) : 4;
+        VGH_REQUIRE(force_cfg < 0 || a.fallback_cfg1 > 0, "conv: cfg %s cannot run this conv (cout_pad=%d k=%d s=%d grp=%d)", g_cfgs[cfg].name, a.cout_pad, a.ksize, a.stride, a.grp_cout);
+        cfg = force_cfg >= 0 ? a.fallback_cfg1 - 1 : (a.grp_cout ? pick_size_only(a) : 4);
+        VGH_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "conv: fallback cfg %d out of range", cfg);
         VGH_REQUIRE(cfg_ok_for(cfg, a), "conv: no tile for this conv (cout_pad=%d k=%d s=%d grp=%d)", a.cout_pad, a.ksize, a.stride, a.grp_cout);
     }
     if (g_cfgs[cfg].patch == 2 && !(a.cout_store == a.cout_pad && (a.out_split >= a.cout_pad || a.out_split % g_cfgs[cfg].BC == 0))) {

@@ -192,6 +192,8 @@ void pack_image16(const uint16_t* w16, int cout_pad, int ksize, int cin, uint16_
 
 }  // namespace
 
+int vgh_conv_split_pick(const ConvArgs& a) { return pick_split_cfg(a); }
+
 void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, int cin, int fmt, uint16_t* dst, float* out_scale) {
     const size_t n = (size_t)cout_pad * ksize * ksize * cin;
     std::vector<uint16_t> hi(n), lo(n);
@@ -237,7 +239,7 @@ int vgh_launch_conv_split(const ConvArgs& a0, int force_cfg, hipStream_t stream)
     VGH_REQUIRE(a.out_scale > 0.0f, "conv_split: out_scale must come from vgh_pack_conv_weights_split");
     VGH_REQUIRE(a.in_plane % 8 == 0 && (a.out_f32 || a.out_plane % 4 == 0) && (!a.res || a.res_plane % 4 == 0), "conv_split: plane strides must keep the vector alignment");
     VGH_REQUIRE((int64_t)a.B * a.H * a.W * a.in_pitch * 2 < (1ll << 31), "conv_split: input tensor (both planes) must stay below 2 GiB; run the batch in chunks");
-    int cfg = (force_cfg >= 0 && scfg_ok(force_cfg, a)) ? force_cfg : pick_split_cfg(a);
+    int cfg = (force_cfg >= 0 && scfg_ok(force_cfg, a)) ? force_cfg : (a.fallback_cfg1 > 0 && scfg_ok(a.fallback_cfg1 - 1, a)) ? a.fallback_cfg1 - 1 : pick_split_cfg(a);
     VGH_REQUIRE(scfg_ok(cfg, a), "conv_split: no tile for cout_pad=%d k=%d s=%d grp=%d", a.cout_pad, a.ksize, a.stride, a.grp_cout);
     const SplitCfg& e = g_scfgs[cfg];
     const int ntc = a.cout_pad / e.BC;

@@ -23,6 +23,9 @@ struct NetOp {
     float* wf32 = nullptr;      // device (stem [27][48])
     float* bias = nullptr;      // device
     float out_scale = 1.0f;     // split parity modes: accumulator scale of the op (vgh_pack_conv_weights_split_host)
+    // automatic tile of the op, resolved ONCE for the arena batch: every forward -- any batch size, any chunk, any lane -- then runs the op
+    // on the same tile, so its fp32 summation order (hence every output bit) does not depend on how many images ride along
+    mutable int auto_cfg = -1;
 };
 
 struct vgh_net {
@@ -127,6 +130,16 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
             ConvArgs a;
             if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
             a.grid_share = share;
+            if (n->bufs[d.in_buf].is_f32 != VGH_FMT_F32) {
+                if (op.auto_cfg < 0) {
+                    ConvArgs ref;
+                    if (int rc = net_conv_args(n, op, n->max_batch, 0, &ref)) return rc;
+                    if (int rc = vgh_conv_prepare(ref)) return rc;
+                    op.auto_cfg = vgh_conv_pick_auto(ref);
+                }
+                a.fallback_cfg1 = op.auto_cfg + 1;
+                return vgh_launch_conv(a, d.force_cfg >= 0 ? d.force_cfg : op.auto_cfg, st);
+            }
             if (n->bufs[d.in_buf].is_f32 == VGH_FMT_F32) {  // fp32 parity mode: dense fp32 weights, FMA kernel
                 VGH_REQUIRE(a.out_f32 && (d.res_buf < 0 || n->bufs[d.res_buf].is_f32 == VGH_FMT_F32), "net: fp32 conv needs fp32 output / residual buffers");
                 VGH_REQUIRE(!d.grp_cout, "net: the fp32 FMA kernel has no grouped mode");

@@ -71,6 +71,7 @@ struct ConvArgs {
     float acc_scale;  // 1/2048 (fp16: lo planes are stored scaled by 2^11) or 1 (bf16)
     float lo_scale;   // lo = (v - hi) * lo_scale
     float out_scale;  // undoes the per-op power-of-two weight prescale (fp16), applied to the accumulator before the bias
+    int fallback_cfg1;  // 0: a forced tile that cannot run this conv is an error; k + 1: it falls back to tile k (network executor: a table may be stale)
     int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
     unsigned long long* trace;  // -DVGH_EXPERIMENTS builds only: per-(block, tile) phase timestamps (s_memtime), or nullptr
 };
@@ -101,6 +102,11 @@ void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, i
 static inline int vgh_fmt_bytes(int fmt) { return fmt == 0 ? 2 : 4; }  // bytes per logical element of an activation buffer
 static inline int vgh_fmt_planes(int fmt) { return fmt >= 2 ? 2 : 1; }
 int vgh_conv_pick_cfg(const ConvArgs& a);
+// validates `a` and fills its derived fields (fast-division constants, fast_epi); vgh_launch_conv calls it itself
+int vgh_conv_prepare(ConvArgs& a);
+// automatic tile of a PREPARED descriptor: index into the bf16 table (a.split == 0) or into conv_split.hip's table
+int vgh_conv_pick_auto(const ConvArgs& a);
+int vgh_conv_split_pick(const ConvArgs& a);
 // host-side weight packing: dense [cout_pad][ks][ks][cin] f32 -> wpack bf16 image
 void vgh_pack_conv_weights_host(const float* w, int cout_pad, int ksize, int cin, uint16_t* dst);
 static inline size_t vgh_wpack_elems(int cout_pad, int ksize, int cin) { return (size_t)cout_pad * ksize * ksize * cin; }
