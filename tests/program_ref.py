@@ -17,8 +17,10 @@ def alloc(P, B: int):
     return [torch.zeros(B, bf["h"], bf["w"], bf["pitch"], dtype=torch.float32) for bf in P.bufs]
 
 
-def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None):
-    """Executes one op in place on `bufs` (list of [B,h,w,pitch] float tensors)."""
+def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None, f64: bool = False):
+    """Executes one op in place on `bufs` (list of [B,h,w,pitch] float tensors).  f64: the arithmetic of the op in float64 (inputs and
+    stored result stay float32) -- the reference for the parity modes, whose own error is then not mixed with torch's fp32 summation order."""
+    up = (lambda t: t.double()) if f64 else (lambda t: t)
     if w_all is None:
         w_all, b_all = P.arrays()
     kind = op["kind"]
@@ -28,7 +30,7 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None):
         W = torch.from_numpy(w_all[op["w_off"] : op["w_off"] + 48 * 27].reshape(48, 3, 3, 3)).permute(0, 3, 1, 2).contiguous()
         b = torch.from_numpy(b_all[op["b_off"] : op["b_off"] + 48])
         x = image if image.dtype == torch.float32 else image.permute(0, 3, 1, 2).float() / 255.0
-        y = torch.relu(F.conv2d(x, W, b, stride=2, padding=1)).permute(0, 2, 3, 1)
+        y = torch.relu(F.conv2d(up(x), up(W), up(b), stride=2, padding=1)).permute(0, 2, 3, 1).float()
         out = bufs[op["out_buf"]]
         out[..., op["out_coff"] : op["out_coff"] + 48] = rb(y, bf16)
         out[..., op["out_coff"] + 48 : op["out_coff"] + 64] = 0
@@ -49,11 +51,11 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None):
         for g in range(rp // gc):
             c0 = op["in_coff"] + g * op["grp_in_stride"]
             xg = bufs[op["in_buf"]][..., c0 : c0 + cin].permute(0, 3, 1, 2)
-            ys.append(F.conv2d(rb(xg, bf16), rb(W[g * gc : (g + 1) * gc], bf16), None, stride=op["stride"], padding=k // 2))
-        y = torch.cat(ys, 1) + b[None, :, None, None]
+            ys.append(F.conv2d(up(rb(xg, bf16)), up(rb(W[g * gc : (g + 1) * gc], bf16)), None, stride=op["stride"], padding=k // 2))
+        y = torch.cat(ys, 1) + up(b)[None, :, None, None]
     else:
         x = bufs[op["in_buf"]][..., op["in_coff"] : op["in_coff"] + cin].permute(0, 3, 1, 2)
-        y = F.conv2d(rb(x, bf16), rb(W, bf16), None, stride=op["stride"], padding=k // 2) + b[None, :, None, None]
+        y = F.conv2d(up(rb(x, bf16)), up(rb(W, bf16)), None, stride=op["stride"], padding=k // 2) + up(b)[None, :, None, None]
     if op["act"] == 1:
         y = torch.relu(y)
     elif op["act"] == 2:
@@ -64,7 +66,7 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None):
     if op["shuffle"]:
         C = rp // 4
         B_, h, w, _ = y.shape
-        z = torch.zeros(B_, 2 * h, 2 * w, C)
+        z = torch.zeros(B_, 2 * h, 2 * w, C, dtype=y.dtype)
         for d in range(4):
             z[:, d // 2 :: 2, d % 2 :: 2, :] = y[..., d * C : (d + 1) * C]
         y = z
@@ -72,9 +74,10 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None):
         n = min(y.shape[-1], op["cout_store"])
         r = bufs[op["res_buf"]][..., op["res_coff"] : op["res_coff"] + n]
         y = y.clone()
-        y[..., :n] = y[..., :n] + np.float32(op["alpha"]) * r
+        y[..., :n] = y[..., :n] + (float(np.float32(op["alpha"])) * up(r) if f64 else np.float32(op["alpha"]) * r)
     store = op["cout_store"] if not op["shuffle"] else rp // 4
     split = min(op["out_split"], store)
+    y = y.float()
     y = y if is_f32 else rb(y, bf16)
     out[..., op["out_coff"] : op["out_coff"] + split] = y[..., :split]
     if store > split:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parametrised GPU-box script (replaces the per-experiment gpu_*.sh pile):
 #     tools/gpu_run.sh <out-subdir> <step> [<step> ...]        e.g.  gpurun -- 'tools/gpu_run.sh r3a tests bench prof pmc'
-# steps:  tests      pytest -m gpu (PYTEST_ARGS to narrow)           smoke      __graft_entry__.smoke()
+# steps:  tests      pytest -m gpu (PYTEST_K='expr' to narrow)             smoke      __graft_entry__.smoke()
 #         bench      default bench line + per-layer table             prof       rocprofv3 --kernel-trace --stats of the bench command
 #         pmc        HBM traffic + MFMA-busy PMC passes around tools/traffic_run.py, one and two lanes (separate --pmc passes, kernel-trace only)
 #         tune       retune the L b64 / M b32 tile tables             tune1280   retune the L b16 @1280 bucket
@@ -19,7 +19,11 @@ for step in "$@"; do
   echo "=== $step"
   case $step in
     tests)
-      timeout ${TEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS:-} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+      if [ -n "${PYTEST_K:-}" ]; then
+        timeout ${TEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS:-} -k "$PYTEST_K" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+      else
+        timeout ${TEST_TIMEOUT:-2400} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS:-} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+      fi
       tail -${TAILN:-25} $O/pytest_gpu.log ;;
     smoke)
       timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log ;;
