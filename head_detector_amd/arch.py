@@ -529,25 +529,22 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
                 P.conv(f"{p}.flame_transform_pred.{bi}", View(cur, offs[2], trp), View(nxt, offs[2], 4 * trp), Wg, bg, 3, cout_store=4 * trp, flops_macs=4 * tr * 9 * tr,
                        groups=(trp, trp))
             cur = nxt
-        # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | .. | shape | expr | rot6 | jaw3 | trans3 | scale1]: one block-diagonal
-        # GEMM over the whole last-layer buffer [shape inter | expr inter | 4 x tr] (three launches at 5-250 TFLOP/s before); the zero blocks
-        # add exact zeros, so every output is bit-identical to its own 1x1 conv
-        n_out = Sc + Ec + 13
-        Wd = np.zeros((n_out, 1, 1, width), dtype=np.float64)
-        bd = np.zeros(n_out, dtype=np.float64)
+        # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | .. | shape | expr | rot6 | jaw3 | trans3 | scale1].  (r03 measured ONE
+        # block-diagonal GEMM over the whole last-layer buffer instead of these three: 324 + 86 + 27 us vs 238 + 67 + 36 us at L b64 -- the zero
+        # blocks cost more MFMA time than the two saved launches return; kept as three launches.)
         W, b = F[f"{p}.flame_shape_pred.{nb}"]
-        Wd[:Sc, 0, 0, offs[0] : offs[0] + inters[0]] = W[:, :, 0, 0]
-        bd[:Sc] = b
+        P.conv(f"{p}.flame_shape_pred.{nb}", View(cur, offs[0], _r32(inters[0])), View(pred, FO, Sc), _ohwi(W, _r32(inters[0])), b, 1, act=0)
         W, b = F[f"{p}.flame_expression_pred.{nb}"]
-        Wd[Sc : Sc + Ec, 0, 0, offs[1] : offs[1] + inters[1]] = W[:, :, 0, 0]
-        bd[Sc : Sc + Ec] = b
-        row = Sc + Ec
+        P.conv(f"{p}.flame_expression_pred.{nb}", View(cur, offs[1], _r32(inters[1])), View(pred, FO + Sc, Ec), _ohwi(W, _r32(inters[1])), b, 1, act=0)
+        Wd = np.zeros((13, 1, 1, 4 * trp), dtype=np.float64)
+        bd = np.zeros(13, dtype=np.float64)
+        row = 0
         for j, (n_, o_) in enumerate(TR_OUTS):
             W, b = F[f"{p}.flame_{n_}_pred.{nb}"]
-            Wd[row : row + o_, 0, 0, offs[2] + j * trp : offs[2] + j * trp + tr] = W[:, :, 0, 0]
+            Wd[row : row + o_, 0, 0, j * trp : j * trp + tr] = W[:, :, 0, 0]
             bd[row : row + o_] = b
             row += o_
-        P.conv(f"{p}.flame_*_pred.{nb}", View(cur, 0, width), View(pred, FO, n_out), Wd, bd, 1, act=0, flops_macs=Sc * inters[0] + Ec * inters[1] + 13 * tr)
+        P.conv(f"{p}.flame_transform_pred.{nb}", View(cur, offs[2], 4 * trp), View(pred, FO + Sc + Ec, 13), Wd, bd, 1, act=0, flops_macs=13 * tr)
         P.levels.append(dict(buf=pred, h=r, w=r, pitch=pred_pitch, stride=stride))
         P.shape_c, P.expr_c = Sc, Ec
         if head_lanes:

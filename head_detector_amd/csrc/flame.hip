@@ -48,7 +48,9 @@ struct vgh_flame {
     float* J0;       // [3*NJ]
     float* JS;       // [NB][MAXJ*3] (coefficient-major, zero columns beyond 3*NJ: the prologue reads a row as six 16-byte loads)
     int32_t* parents;  // [NJ]
-    float* coef;     // scratch [Kp][npad] (TRANSPOSED: heads contiguous; npad = max_heads rounded up to 128, rows beyond n are zero)
+    float* coef;     // scratch [Kp][npad] (TRANSPOSED: heads contiguous; npad = max_heads rounded up to 128; columns beyond the heads of the last
+                     // decode hold zeros from creation or stale coefficients of an earlier, larger decode: harmless, MFMA rows are independent and
+                     // the stores are masked by the head count)
     int npad;
     float* headpack; // scratch [npad][HP_SIZE]
     // the scratch is per handle: a decode on another stream than the previous one is ordered after it (event on the previous stream)
@@ -58,12 +60,13 @@ struct vgh_flame {
 };
 
 // vgh_flame_set_matrix_path: 0 VALU kernels only, 1 automatic (default), 2 always the register-fed matrix-core kernel, 3 / 4 always the
-// LDS-staged one (register allocation for 4 / 2 waves per SIMD).  All vertex kernels are bit-identical; tests and tools/flame_sweep.py switch between them.
-static int g_flame_mode = 1;
+// LDS-staged one (3: 128-head blocks, 4: 64-head blocks).  All vertex kernels are bit-identical; tests and tools/flame_sweep.py switch between them.
+static std::atomic<int> g_flame_mode{1};
 #ifdef VGH_EXPERIMENTS
 static unsigned long long* g_prep_trace = nullptr;  // vgh_flame_set_trace
 #endif
-constexpr int kLdsMinHeads = 1024;
+constexpr int kLdsMinHeads = 1024;  // from here on: LDS-staged tiles with 128-head blocks
+constexpr int kLdsMidHeads = 192;   // ... 64-head blocks (r02: the register-fed kernel ran n = 256 .. 1024 at 0.22 - 0.35 of the fp32 roof)
 
 namespace {
 
@@ -749,18 +752,25 @@ __device__ __forceinline__ void valu_epilogue(const VertArgs& a, f32x16_t (&acc)
 // which is what pins it (and the VALU kernel) near 66 TFLOP/s at n = 8192; here a slab of 32 KB feeds 384 MFMAs (49 FLOP per byte
 // from L2, < 3.2 TB/s at the full fp32 matrix rate) and the MFMA operands are conflict-free ds_read_b32.  Same k-ordered chain per
 // output element, so results are bit-identical to the other FLAME kernels.
-constexpr int LB_H = 128, LB_V = 128, LB_KS = 16;                 // heads, vertices, k rows per slab
-constexpr int LB_A = LB_KS * LB_H, LB_B = LB_KS * 3 * LB_V;       // floats per slab: coefficients [k][128], basis [k][c][128]
-constexpr int LB_STAGE = LB_A + LB_B;                             // 8192 floats = 32 KiB
+constexpr int LB_V = 128, LB_KS = 16;      // vertices per block, k rows per slab
+constexpr int LB_B = LB_KS * 3 * LB_V;      // floats of a basis slab [k][c][128]
 
-template <int WPS>  // waves per SIMD the register allocation aims for: 4 = two resident blocks per CU (128 registers), 2 = one
-__global__ __launch_bounds__(512, WPS) void flame_mfma_lds_kernel(VertArgs a) {
+// LBH = heads per block: 128 (8 waves = 2 head groups x 4 vertex groups; crowd scale) or 64 (4 waves: twice the blocks for the same batch --
+// a few hundred heads then still give every CU work -- at the price of the basis slab feeding half as many MFMAs)
+template <int WPS, int LBH>  // WPS: waves per SIMD the register allocation aims for
+__global__ __launch_bounds__((LBH / 64) * 256, WPS) void flame_mfma_lds_kernel(VertArgs a) {
 #pragma clang fp contract(off)
     constexpr int MT = 2;
-    extern __shared__ __attribute__((aligned(16))) float fsm[];  // 2 slabs during the blend loop, then the head packs [HP_SIZE][128]
+    constexpr int NT = (LBH / 64) * 256, NWV = NT / 64;        // threads, waves
+    constexpr int LB_A = LB_KS * LBH, LB_STAGE = LB_A + LB_B;  // floats per slab: coefficients [k][LBH] + basis
+    constexpr int NPA = LB_A / 256, NPT = NPA + LB_B / 256;    // 1 KiB LDS-DMA pieces per slab: coefficient pieces, all pieces
+    constexpr int PPW = NPT / NWV;                             // pieces per wave (4 / 7)
+    constexpr int RPP = 256 / LBH, LPR = 64 / RPP;             // coefficient rows per piece (2 / 4), lanes per row
+    static_assert(NPT % NWV == 0 && LBH * HP_SIZE <= 2 * LB_STAGE, "slab pieces must split evenly; the head packs reuse the two slabs");
+    extern __shared__ __attribute__((aligned(16))) float fsm[];  // 2 slabs during the blend loop, then the head packs [LBH][HP_SIZE]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hw = wv >> 2, vw = wv & 3;
-    const int h0 = blockIdx.x * LB_H, v0 = blockIdx.y * LB_V;  // heads fastest: co-resident blocks share the (3x larger) basis slabs
+    const int h0 = blockIdx.x * LBH, v0 = blockIdx.y * LB_V;  // heads fastest: co-resident blocks share the (3x larger) basis slabs
     if (a.n_dev) a.n = min(a.n, *a.n_dev);
     if (h0 >= a.n) return;
     const int j = lane & 31, half = lane >> 5;
@@ -779,42 +789,41 @@ __global__ __launch_bounds__(512, WPS) void flame_mfma_lds_kernel(VertArgs a) {
     const int np0 = (a.r0_end - a.r0_begin) >> 1, np1 = (a.r1_end - a.r1_begin) >> 1, np2 = (a.r2_end - a.r2_begin) >> 1;
     const int npt = np0 + np1 + np2;
     const int nstage = (npt + LB_KS / 2 - 1) / (LB_KS / 2);
-    // this wave's 4 LDS-DMA pieces of a slab (1 KiB each = two 512-byte rows): waves 0-1 the coefficient rows, 2-7 the basis rows
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (unsigned)((int64_t)a.Kp * a.npad * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.basis, 0, (unsigned)((int64_t)a.r2_end * 3 * plane * 4), 0x00020000);  // r2_end = K: the basis has K rows
-    const int col = (lane & 31) * 4;  // first of this lane's 4 floats inside a 128-float row
     // first k of every virtual pair (-1 past the end), once per block: keeps the per-slab address math to one LDS read + one multiply
     int* const s_kq = (int*)(fsm + 2 * LB_STAGE);
-    for (int q = tid; q < nstage * (LB_KS / 2); q += 512)
+    for (int q = tid; q < nstage * (LB_KS / 2); q += NT)
         s_kq[q] = q < np0 ? a.r0_begin + 2 * q : q < np0 + np1 ? a.r1_begin + 2 * (q - np0) : q < npt ? a.r2_begin + 2 * (q - np0 - np1) : -1;
     __syncthreads();
-    // per-piece constants of this lane: k slot inside the slab and the k-independent part of the byte offset
-    int p_ks[4];
-    unsigned p_mul[4], p_add[4];
+    // per-piece constants of this lane: k slot inside the slab and the k-independent part of the byte offset.  A coefficient piece is RPP rows of
+    // LBH floats ([k][npad] in memory), a basis piece two 128-float rows rr -> (k slot, component) of [k][c][Vp]
+    int p_ks[PPW];
+    unsigned p_mul[PPW], p_add[PPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wv * 4 + i;
-        if (piece < 8) {  // coefficient rows 2*piece + half: [k][npad]
-            p_ks[i] = piece * 2 + half;
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wv * PPW + i;
+        if (piece < NPA) {
+            p_ks[i] = piece * RPP + lane / LPR;
             p_mul[i] = (unsigned)a.npad * 4u;
-            p_add[i] = (unsigned)(h0 + col) * 4u;
-        } else {          // basis rows rr = (piece-8)*2 + half -> (k slot, component): [k][c][Vp]
-            const int rr = (piece - 8) * 2 + half;
+            p_add[i] = (unsigned)(h0 + (lane % LPR) * 4) * 4u;
+        } else {
+            const int rr = (piece - NPA) * 2 + half;
             const int ks = rr / 3, c = rr - ks * 3;
             p_ks[i] = ks;
             p_mul[i] = (unsigned)plane * 12u;
-            p_add[i] = (unsigned)(c * plane + v0 + col) * 4u;
+            p_add[i] = (unsigned)(c * plane + v0 + (lane & 31) * 4) * 4u;
         }
     }
     auto issue = [&](int st, int buf) {
         float* const base = fsm + buf * LB_STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wv * 4 + i;  // wave-uniform
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wv * PPW + i;  // wave-uniform
             const int k0 = s_kq[st * (LB_KS / 2) + (p_ks[i] >> 1)];
             const unsigned off = k0 >= 0 ? (unsigned)(k0 + (p_ks[i] & 1)) * p_mul[i] + p_add[i] : 0xFFFFFFF0u;  // past the end: out of range -> zeros
-            if (piece < 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(base + piece * 256), 16, off, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (AS3 void*)(base + LB_A + (piece - 8) * 256), 16, off, 0, 0, 0);
+            if (piece < NPA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(base + piece * 256), 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (AS3 void*)(base + LB_A + (piece - NPA) * 256), 16, off, 0, 0, 0);
         }
     };
     issue(0, 0);
@@ -822,18 +831,18 @@ __global__ __launch_bounds__(512, WPS) void flame_mfma_lds_kernel(VertArgs a) {
         const int buf = st & 1;
         if (st + 1 < nstage) {
             issue(st + 1, buf ^ 1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        const float* const sa = fsm + buf * LB_STAGE + half * LB_H + hw * 64 + j;            // + pair*2*LB_H + t*32
+        const float* const sa = fsm + buf * LB_STAGE + half * LBH + hw * 64 + j;              // + pair*2*LBH + t*32
         const float* const sb = fsm + buf * LB_STAGE + LB_A + half * 3 * LB_V + vw * 32 + j;  // + pair*6*LB_V + c*LB_V
         const int pairs = min(LB_KS / 2, npt - st * (LB_KS / 2));
         float A[2][MT], B[2][3];
         auto rd = [&](int u, float (&Ao)[MT], float (&Bo)[3]) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) Ao[t] = sa[u * 2 * LB_H + t * 32];
+            for (int t = 0; t < MT; ++t) Ao[t] = sa[u * 2 * LBH + t * 32];
 #pragma unroll
             for (int c = 0; c < 3; ++c) Bo[c] = sb[u * 6 * LB_V + c * LB_V];
         };
@@ -850,9 +859,9 @@ __global__ __launch_bounds__(512, WPS) void flame_mfma_lds_kernel(VertArgs a) {
         }
         __syncthreads();  // slab `buf` is rewritten by the loads issued at the top of the next iteration
     }
-    // head packs of the block's 128 heads into the (now free) slab memory: a straight copy, [head][HP_SIZE]
+    // head packs of the block's heads into the (now free) slab memory: a straight copy, [head][HP_SIZE]
     float* const s_hp = fsm;
-    for (int e = tid * 4; e < LB_H * HP_SIZE; e += 512 * 4) {
+    for (int e = tid * 4; e < LBH * HP_SIZE; e += NT * 4) {
         const int hh = e / HP_SIZE;
         *(f32x4_t*)(s_hp + e) = (h0 + hh < a.n) ? *(const f32x4_t*)(a.headpack + (int64_t)h0 * HP_SIZE + e) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
     }
@@ -861,18 +870,17 @@ __global__ __launch_bounds__(512, WPS) void flame_mfma_lds_kernel(VertArgs a) {
     valu_epilogue<MT>(a, acc, s_hp, hw * 64, h0, v, half);
 }
 
-template <int WPS>
+template <int WPS, int LBH>
 int launch_mfma_lds(const VertArgs& va, hipStream_t st) {
-    static_assert(LB_H * HP_SIZE * 4 == 2 * LB_STAGE * 4, "the head packs reuse the two slabs");
-    const size_t lds = (size_t)2 * LB_STAGE * sizeof(float) + 1024;  // 64 KiB + the pair table (<= 256 entries): two blocks per CU
+    const size_t lds = (size_t)2 * (LB_KS * LBH + LB_B) * sizeof(float) + 1024;  // two slabs + the pair table (<= 256 entries): two blocks per CU
     static std::atomic<int> attr_done[16];
     int dev = 0;
     VGH_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)flame_mfma_lds_kernel<WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        VGH_HIP(hipFuncSetAttribute((const void*)flame_mfma_lds_kernel<WPS, LBH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[dev].store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(flame_mfma_lds_kernel<WPS>, dim3((va.n + LB_H - 1) / LB_H, (va.V + LB_V - 1) / LB_V), dim3(512), lds, st, va);
+    hipLaunchKernelGGL((flame_mfma_lds_kernel<WPS, LBH>), dim3((va.n + LBH - 1) / LBH, (va.V + LB_V - 1) / LB_V), dim3((LBH / 64) * 256), lds, st, va);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -927,10 +935,10 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         // (measured, profiles/r02_flame_sweep.json: the matrix-core kernel wins from a handful of heads up to a few thousand; at crowd scale the
         //  VALU kernel's 8-heads-per-basis-load reuse is ahead again; with a device-side count the launch is capacity-sized and mostly
         //  exits at once, so the tile count that matters is the live one)
-        const int mode = g_flame_mode;
+        const int mode = g_flame_mode.load(std::memory_order_relaxed);
         const int npairs = ((detector_mode ? shape_live + expr_live : f->NB) + f->NP + 1) / 2;
         // crowd scale: operands staged through LDS (its k-pair table holds 256 entries: FLAME has 218; a model with more coefficients keeps the other kernels)
-        const bool lds = even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMinHeads));
+        const bool lds = even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMidHeads));
         const bool mfma = lds || (even && (mode == 2 || (mode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
         const bool fused = !mfma && !pa.n_dev && m <= 256;  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
@@ -988,7 +996,8 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
 #endif
         int rc;
         if (lds) {
-            rc = mode == 4 ? launch_mfma_lds<2>(va, st) : launch_mfma_lds<4>(va, st);
+            // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
+            rc = (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);
         } else if (mfma) {
             if (pa.n_dev || m <= 512)
                 rc = launch_mfma<1>(va, st);  // one 32-head tile per wave: twice the waves, two resident per SIMD
@@ -1163,7 +1172,7 @@ int vgh_flame_set_trace(void* dev_buffer) {
 
 int vgh_flame_set_matrix_path(int mode) {
     VGH_REQUIRE(mode >= 0 && mode <= 4, "flame_set_matrix_path: mode %d outside 0..4", mode);
-    g_flame_mode = mode;
+    g_flame_mode.store(mode, std::memory_order_relaxed);
     return VGH_OK;
 }
 
