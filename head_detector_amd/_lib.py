@@ -113,6 +113,9 @@ SYMBOLS = {
     "vgh_conv_num_cfgs": (_I, []),
     "vgh_conv_cfg_name": (C.c_char_p, [_I]),
     "vgh_conv_cfg_cout_tile": (_I, [_I]),
+    "vgh_conv_split_num_cfgs": (_I, []),
+    "vgh_conv_split_cfg_name": (C.c_char_p, [_I]),
+    "vgh_conv_split_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "vgh_conv_set_max_blocks_per_xcd": (_I, [_I]),
     "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),

@@ -38,33 +38,33 @@ constexpr int igemm_lds(int BP, int BC, int WP, int WC, int KBS, int NST) {
 
 struct SplitCfg {
     const char* name;
-    int BP, BC, lds, patch, TW, TH;
+    int BP, BC, lds, patch, TW, TH, KBS;
     void (*launch)(const ConvArgs&, int sp, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t);
 };
 
-template <int BP, int BC, int WP, int WC, int SP>
+template <int BP, int BC, int WP, int WC, int KBS, int NST, int SP>
 void launch_igemm_sp(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
     static std::atomic<int> attr_done[kMaxDev];
     if (lds > 64 * 1024) {
         const int dev = cur_dev();
         if (!attr_done[dev].load(std::memory_order_acquire)) {
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, 1, 0, 2, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, 1, 1, 2, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done[dev].store(1, std::memory_order_release);
         }
     }
     const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64);
     if (a.fast_epi)
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, 1, 1, 2, SP>), grid, block, lds, st, a, ntc, total, chunk);
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, SP>), grid, block, lds, st, a, ntc, total, chunk);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, 1, 0, 2, SP>), grid, block, lds, st, a, ntc, total, chunk);
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST, SP>), grid, block, lds, st, a, ntc, total, chunk);
 }
-template <int BP, int BC, int WP, int WC>
+template <int BP, int BC, int WP, int WC, int KBS, int NST>
 void launch_igemm(const ConvArgs& a, int sp, int ntc, int, int, int total, int chunk, int lds, hipStream_t st) {
     if (sp == VGH_FMT_F16X2)
-        launch_igemm_sp<BP, BC, WP, WC, VGH_FMT_F16X2>(a, ntc, total, chunk, lds, st);
+        launch_igemm_sp<BP, BC, WP, WC, KBS, NST, VGH_FMT_F16X2>(a, ntc, total, chunk, lds, st);
     else
-        launch_igemm_sp<BP, BC, WP, WC, VGH_FMT_BF16X2>(a, ntc, total, chunk, lds, st);
+        launch_igemm_sp<BP, BC, WP, WC, KBS, NST, VGH_FMT_BF16X2>(a, ntc, total, chunk, lds, st);
 }
 
 template <int TW, int TH, int BC, int NWP, int NWC, int SP>
@@ -90,10 +90,13 @@ void launch_patch(const ConvArgs& a, int sp, int ntc, int ntx, int nty, int tota
 }
 
 #define SCFG(BP, BC, WP, WC) \
-    { "s" #BP "x" #BC "_w" #WP "x" #WC, BP, BC, igemm_lds(BP, BC, WP, WC, 1, 2), 0, 0, 0, launch_igemm<BP, BC, WP, WC> }
+    { "s" #BP "x" #BC "_w" #WP "x" #WC, BP, BC, igemm_lds(BP, BC, WP, WC, 1, 2), 0, 0, 0, 1, launch_igemm<BP, BC, WP, WC, 1, 2> }
+#define SCFGR(BP, BC, WP, WC, KBS, NST) \
+    { "s" #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, igemm_lds(BP, BC, WP, WC, KBS, NST), 0, 0, 0, KBS, launch_igemm<BP, BC, WP, WC, KBS, NST> }
 #define SPCFG(TW, TH, BC, NWP, NWC) \
-    { "sp" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, patch_lds<TW, TH, BC, NWP, NWC>(), 1, TW, TH, launch_patch<TW, TH, BC, NWP, NWC> }
+    { "sp" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, patch_lds<TW, TH, BC, NWP, NWC>(), 1, TW, TH, 1, launch_patch<TW, TH, BC, NWP, NWC> }
 
+// indices 0..15 are what pick_split_cfg returns; the rest are tuner candidates (tools/tune_conv.py --precision fp16x3)
 const SplitCfg g_scfgs[] = {
     SCFG(128, 128, 64, 64),    // 0
     SCFG(128, 96, 32, 96),     // 1
@@ -111,6 +114,21 @@ const SplitCfg g_scfgs[] = {
     SPCFG(40, 8, 96, 5, 1),    // 13
     SPCFG(40, 8, 64, 5, 1),    // 14
     SCFG(256, 128, 64, 64),    // 15  8 waves
+    SCFGR(256, 128, 64, 64, 1, 3),  // 16  the bf16 table's favourite on 40 / 20-wide maps
+    SCFGR(128, 128, 64, 64, 1, 3),  // 17
+    SCFGR(128, 128, 64, 64, 2, 2),  // 18
+    SCFGR(128, 64, 32, 64, 2, 2),   // 19
+    SCFGR(256, 64, 64, 64, 1, 2),   // 20
+    SCFGR(256, 256, 64, 64, 1, 3),  // 21  16 waves
+    SCFGR(128, 128, 32, 64, 1, 3),  // 22  8 waves
+    SPCFG(32, 8, 128, 4, 2),   // 23
+    SPCFG(32, 8, 64, 4, 1),    // 24
+    SPCFG(32, 8, 96, 4, 1),    // 25
+    SPCFG(20, 8, 128, 5, 2),   // 26  20-wide maps
+    SPCFG(32, 16, 128, 4, 2),  // 27  512 px x 128
+    SPCFG(16, 16, 256, 4, 4),  // 28
+    SPCFG(16, 8, 64, 4, 1),    // 29  128 px x 64: three blocks per CU
+    SPCFG(16, 8, 128, 4, 2),   // 30
 };
 constexpr int kNumSplitCfgs = sizeof(g_scfgs) / sizeof(g_scfgs[0]);
 
@@ -120,6 +138,9 @@ bool scfg_ok(int cfg, const ConvArgs& a) {
     if (a.cout_pad % e.BC) return false;
     if (a.grp_cout && a.grp_cout % e.BC) return false;
     if (e.patch && !(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle)) return false;
+    // the accumulators are rescaled between two steps of the K loop: the boundary (2 x the k-blocks of a segment) must fall on a step.  The
+    // ABI-level query has no channel count (cblocks = 0): there only KBS <= 2 is promised, which every segment length satisfies
+    if (e.KBS > 2 && (a.cblocks == 0 || (2 * a.ksize * a.ksize * a.cblocks) % e.KBS)) return false;
     return true;
 }
 
@@ -193,6 +214,20 @@ void pack_image16(const uint16_t* w16, int cout_pad, int ksize, int cin, uint16_
 }  // namespace
 
 int vgh_conv_split_pick(const ConvArgs& a) { return pick_split_cfg(a); }
+
+extern "C" int vgh_conv_split_num_cfgs(void) { return kNumSplitCfgs; }
+extern "C" const char* vgh_conv_split_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumSplitCfgs) ? g_scfgs[cfg].name : "?"; }
+extern "C" int vgh_conv_split_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle, int grp_cout) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ksize = ksize;
+    a.stride = stride;
+    a.cout_pad = cout_pad;
+    a.fast_epi = fast_epilogue;
+    a.shuffle = shuffle;
+    a.grp_cout = grp_cout;
+    return scfg_ok(cfg, a) ? 1 : 0;
+}
 
 void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, int cin, int fmt, uint16_t* dst, float* out_scale) {
     const size_t n = (size_t)cout_pad * ksize * ksize * cin;

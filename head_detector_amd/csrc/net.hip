@@ -467,7 +467,8 @@ int vgh_net_image_size(vgh_net* n) { return n ? n->image_size : 0; }
 
 int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {
     VGH_REQUIRE(n && op_index >= 0 && op_index < (int)n->ops.size(), "net_set_cfg: bad op index");
-    VGH_REQUIRE(cfg >= -1 && cfg < vgh_conv_num_cfgs(), "net_set_cfg: bad cfg");
+    const bool split_net = vgh_fmt_planes(n->bufs[n->ops[op_index].d.kind == VGH_OP_CONV ? n->ops[op_index].d.in_buf : 0].is_f32) > 1;
+    VGH_REQUIRE(cfg >= -1 && cfg < (split_net ? vgh_conv_split_num_cfgs() : vgh_conv_num_cfgs()), "net_set_cfg: bad cfg");
     n->ops[op_index].d.force_cfg = cfg;
     return VGH_OK;
 }

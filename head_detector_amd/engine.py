@@ -141,7 +141,7 @@ class VGHeadsEngine:
         self._head_out = None  # (capacity, head_image, proj, rpy) allocated on first FLAME use
         self._levels = None
         self._graph_key = None
-        self._use_tuning = bool(use_tuning and precision == "bf16")
+        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp16x3", "bf16x3"))  # the split modes have their own keys (precision prefix) and tile set
         self.nsplit = 1
         if self._use_tuning:
             self.load_tuning()
@@ -406,7 +406,21 @@ class VGHeadsEngine:
         self._graph_key = None
 
     def cfg_names(self) -> List[str]:
+        """Tile names ``set_cfg`` indexes: the bf16 table, or the split-precision table for the fp16x3 / bf16x3 modes."""
+        if self.precision in ("fp16x3", "bf16x3"):
+            return [self.lib.vgh_conv_split_cfg_name(i).decode() for i in range(self.lib.vgh_conv_split_num_cfgs())]
         return [self.lib.vgh_conv_cfg_name(i).decode() for i in range(self.lib.vgh_conv_num_cfgs())]
+
+    def cfg_ok(self, cfg: int, op: dict) -> bool:
+        """Can tile ``cfg`` of this engine's table run ``op`` (tuning tools)?"""
+        ob = self.program.bufs[op["out_buf"]]
+        al = all(op[k] % 8 == 0 for k in ("out_coff", "out_coff2", "out_split", "cout_store", "res_coff")) and ob["pitch"] % 8 == 0
+        fast = int(ob["is_f32"] != arch.FMT_F32 and al)
+        if self.precision in ("fp16x3", "bf16x3"):
+            return bool(self.lib.vgh_conv_split_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"], op.get("grp_cout", 0)))
+        if not self.lib.vgh_conv_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"]):
+            return False
+        return not op.get("grp_cout") or op["grp_cout"] % self.lib.vgh_conv_cfg_cout_tile(cfg) == 0
 
     def load_tuning(self, path: Optional[str] = None) -> int:
         """Apply a measured per-layer tile table: {gemm-shape key: cfg name}. Missing file -> heuristic choice."""
@@ -421,8 +435,9 @@ class VGHeadsEngine:
         for i, op in enumerate(self.program.ops):
             if op["kind"] != 1:
                 continue
-            key = tuning_key(op, self.max_batch, getattr(self, "nsplit", 1))
-            name = table.get(key, table.get(tuning_key(op, self.max_batch)))
+            pre = "" if self.precision == "bf16" else self.precision + ":"
+            key = pre + tuning_key(op, self.max_batch, getattr(self, "nsplit", 1))
+            name = table.get(key, table.get(pre + tuning_key(op, self.max_batch)))
             if name in names:
                 self.set_cfg(i, names[name])
                 applied += 1

@@ -139,6 +139,11 @@ const char* vgh_conv_cfg_name(int cfg);
 int vgh_conv_cfg_cout_tile(int cfg); /* output channels per tile: a grouped conv (vgh_op_desc.grp_cout) needs grp_cout % tile == 0 */
 /* 1 if tile configuration `cfg` can run a conv of this kind (tuning tools). */
 int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle);
+/* The tile set of the split-precision parity modes (csrc/conv_split.hip) is a table of its own: vgh_net_set_cfg indexes it for a net whose
+ * activation buffers are VGH_FMT_BF16X2 / VGH_FMT_F16X2. */
+int vgh_conv_split_num_cfgs(void);
+const char* vgh_conv_split_cfg_name(int cfg);
+int vgh_conv_split_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle, int grp_cout);
 /* Cap on the persistent 3x3 kernels' grid: at most `blocks` workgroups per XCD (0 = as many as stay resident, the default).
  * Process-wide.  Leaves CUs to other work; the parity tests use it to drive many tiles through one workgroup. */
 int vgh_conv_set_max_blocks_per_xcd(int blocks);

@@ -5,6 +5,7 @@
 #         bench      default bench line + per-layer table             prof       rocprofv3 --kernel-trace --stats of the bench command
 #         pmc        HBM traffic + MFMA-busy PMC passes around tools/traffic_run.py, one and two lanes (separate --pmc passes, kernel-trace only)
 #         tune       retune the L b64 / M b32 tile tables             tune1280   retune the L b16 @1280 bucket
+#         tunesplit  tile table of the fp16x3 parity mode (L b32)
 #         flame      FLAME decode sweep (tools/flame_sweep.py)        pmcflame   MFMA-busy of the FLAME kernels at n = 8192
 #         probe      whole-net time of both benchmark buckets (two lanes)
 set -u
@@ -45,6 +46,9 @@ for step in "$@"; do
       timeout 1500 python tools/tune_conv.py --variant vgg_heads_l --batch 64 --report $O/${TAG}_tune_l64.json > $O/tune.log 2>&1
       timeout 1500 python tools/tune_conv.py --variant vgg_heads_m --batch 32 --report $O/${TAG}_tune_m32.json >> $O/tune.log 2>&1
       tail -3 $O/tune.log; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
+    tunesplit)
+      timeout 1500 python tools/tune_conv.py --variant vgg_heads_l --batch 32 --precision fp16x3 --report $O/${TAG}_tune_fp16x3_l32.json > $O/tunesplit.log 2>&1
+      tail -2 $O/tunesplit.log; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     tune1280)
       timeout 1500 python tools/tune_conv.py --variant vgg_heads_l --batch 16 --image-size 1280 --report $O/${TAG}_tune_l16_1280.json > $O/tune1280.log 2>&1
       tail -2 $O/tune1280.log; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;

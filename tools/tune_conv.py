@@ -24,8 +24,9 @@ def main():
     ap.add_argument("--split", type=int, default=1, help="measure with the batch split over this many lane streams (vgh_net_set_split)")
     ap.add_argument("--out", default=os.path.join(TUNING_DIR, "conv_cfg.json"))
     ap.add_argument("--report", default=None)
+    ap.add_argument("--precision", default="bf16", help="bf16 (throughput tiles) or fp16x3 / bf16x3 (the split-precision tile set; keys get a precision prefix)")
     args = ap.parse_args()
-    eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, use_tuning=False)
+    eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, use_tuning=False, precision=args.precision)
     if args.split > 1:
         eng.set_split(args.split)
     names = eng.cfg_names()
@@ -35,14 +36,7 @@ def main():
     best = {}
     times = {i: {} for i in conv_idx}
     for c, name in enumerate(names):
-        def fast(op):
-            ob = eng.program.bufs[op["out_buf"]]
-            al = all(op[k] % 8 == 0 for k in ("out_coff", "out_coff2", "out_split", "cout_store", "res_coff")) and ob["pitch"] % 8 == 0
-            return int((not ob["is_f32"]) and al)
-
-        bc = eng.lib.vgh_conv_cfg_cout_tile(c)
-        ok = [i for i in conv_idx if eng.lib.vgh_conv_cfg_ok(c, ops[i]["ksize"], ops[i]["stride"], ops[i]["cout_pad"], fast(ops[i]), ops[i]["shuffle"])
-              and (not ops[i].get("grp_cout") or ops[i]["grp_cout"] % bc == 0)]
+        ok = [i for i in conv_idx if eng.cfg_ok(c, ops[i])]
         if not ok:
             continue
         for i in conv_idx:
@@ -52,7 +46,7 @@ def main():
             times[i][name] = min(r[i]["ms"] for r in runs)
     table, report = {}, []
     for i in conv_idx:
-        key = tuning_key(ops[i], args.batch, args.split)
+        key = ("" if args.precision == "bf16" else args.precision + ":") + tuning_key(ops[i], args.batch, args.split)
         w = min(times[i], key=times[i].get)
         if key not in best or times[i][w] < best[key][1]:
             best[key] = (w, times[i][w])
