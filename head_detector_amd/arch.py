@@ -589,10 +589,18 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     return dict(read=float(rd), write=float(wr))
 
 
-def program_algorithmic_bytes(P: "Program", batch: int) -> Dict[str, float]:
+def program_algorithmic_bytes(P: "Program", batch: int, fused_stem: Optional[bool] = None) -> Dict[str, float]:
+    """fused_stem (default: the bf16 program, whose executor runs stem + stage-1 downsample as one kernel): the stem tensor is neither written nor read."""
+    if fused_stem is None:
+        fused_stem = P.precision == "bf16"
     tot = dict(read=0.0, write=0.0)
-    for op in P.ops:
+    for i, op in enumerate(P.ops):
         b = op_algorithmic_bytes(P, op, batch)
+        if fused_stem and op["kind"] == 0:
+            b["write"] = 0.0
+        if fused_stem and i > 0 and P.ops[i - 1]["kind"] == 0 and op["kind"] == 1 and op["in_buf"] == P.ops[i - 1]["out_buf"]:
+            ib = P.bufs[op["in_buf"]]
+            b["read"] -= batch * ib["h"] * ib["w"] * op["cin"] * FMT_BYTES[ib["is_f32"]]
         tot["read"] += b["read"]
         tot["write"] += b["write"]
     return tot

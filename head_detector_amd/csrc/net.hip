@@ -26,6 +26,7 @@ struct NetOp {
     // automatic tile of the op, resolved ONCE for the arena batch: every forward -- any batch size, any chunk, any lane -- then runs the op
     // on the same tile, so its fp32 summation order (hence every output bit) does not depend on how many images ride along
     mutable int auto_cfg = -1;
+    uint16_t* wds = nullptr;    // stage-1 downsample only: its weights in the fused stem + downsample kernel's layout (stem_ds.hip)
 };
 
 struct vgh_net {
@@ -52,6 +53,10 @@ struct vgh_net {
     // (dispatch, tile prologue, first-load latency, epilogue store burst, tail) of one sub-batch hides under the main loops of
     // the others (measured on the M net at B = 32: 5.75 ms -> 5.35 ms with 4 lanes)
     int nsplit = 1;
+    // stem + stage-1 downsample as ONE kernel (stem_ds.hip: the 48-channel stem activation stays in LDS): index of the stem op when the pair
+    // qualifies (bf16 mode, the architecture's 3x3 / stride-2 / 64 -> 96 conv as the stem tensor's only reader), else -1; results are bit-identical
+    int stem_pair = -1;
+    int fuse_stem = 1;
 };
 
 static inline int64_t buf_image_bytes(const vgh_buf_desc& b) { return (int64_t)b.h * b.w * b.pitch * vgh_fmt_bytes(b.is_f32); }
@@ -118,8 +123,15 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
     const vgh_op_desc& d = op.d;
     const void* image = (const char*)image0 + (int64_t)at * n->image_size * n->image_size * 3 * (fmt == VGH_IMG_F32_NCHW ? 4 : 1);
     auto bp = [&](int id) { return (char*)n->buf_ptr[id] + at * buf_image_bytes(n->bufs[id]); };
+    const int op_index = (int)(&op - n->ops.data());
+    const bool fused = n->fuse_stem && n->stem_pair >= 0;
     switch (d.kind) {
         case VGH_OP_STEM: {
+            if (fused && op_index == n->stem_pair) {
+                const NetOp& ds = n->ops[op_index + 1];
+                const vgh_buf_desc& db = n->bufs[ds.d.out_buf];
+                return vgh_launch_stem_ds(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, ds.wds, ds.bias, (uint16_t*)bp(ds.d.out_buf), db.pitch, ds.d.out_coff, st);
+            }
             const vgh_buf_desc& ob = n->bufs[d.out_buf];
             if (ob.is_f32 == VGH_FMT_F32)  // fp32 parity mode
                 return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)bp(d.out_buf), ob.pitch, d.out_coff, st);
@@ -127,6 +139,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
                                    ob.is_f32, ob.pitch, st);
         }
         case VGH_OP_CONV: {
+            if (fused && op_index == n->stem_pair + 1) return VGH_OK;  // ran inside the stem's launch
             ConvArgs a;
             if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
             a.grid_share = share;
@@ -276,8 +289,26 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             wbytes += align_up(64 * 4, 256);
         }
     }
+    // stem + stage-1 downsample pair (see vgh_net::stem_pair)
+    int64_t wds_off = -1;
+    for (int i = 0; i + 1 < n_ops; ++i) {
+        const vgh_op_desc &a = ops[i], &d = ops[i + 1];
+        if (a.kind != VGH_OP_STEM || d.kind != VGH_OP_CONV) continue;
+        bool ok = d.in_buf == a.out_buf && d.in_coff == a.out_coff && d.ksize == 3 && d.stride == 2 && d.cin == 64 && d.cout_pad == 96 && d.cout_store == 96 && d.res_buf < 0 && !d.shuffle &&
+                  d.out_split >= 96 && d.act == VGH_ACT_RELU && d.grp_cout == 0 && bufs[a.out_buf].is_f32 == VGH_FMT_BF16 && bufs[d.out_buf].is_f32 == VGH_FMT_BF16 && d.out_coff % 8 == 0 &&
+                  bufs[d.out_buf].pitch % 8 == 0;
+        for (int j = 0; ok && j < n_ops; ++j)  // nobody else may read (or write) the stem tensor
+            if (j != i && j != i + 1 && (ops[j].kind == VGH_OP_CONV || ops[j].kind == VGH_OP_SPP_POOL) && (ops[j].in_buf == a.out_buf || ops[j].out_buf == a.out_buf || ops[j].res_buf == a.out_buf)) ok = false;
+        if (ok) {
+            n->stem_pair = i;
+            wds_off = wbytes;
+            wbytes += align_up((int64_t)9 * 3 * 96 * 16 * 2, 256);
+        }
+        break;
+    }
     std::vector<char> host(wbytes > 0 ? wbytes : 1, 0);
     std::vector<float> oscale(n_ops, 1.0f);
+    if (n->stem_pair >= 0) vgh_pack_stem_ds_weights_host(weights_host + ops[n->stem_pair + 1].w_off, (uint16_t*)(host.data() + wds_off));
     for (int i = 0; i < n_ops; ++i) {
         const vgh_op_desc& d = ops[i];
         if (d.kind == VGH_OP_CONV) {
@@ -311,6 +342,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             op.wf32 = (float*)(n->wblob + woff[i]);
             op.bias = (float*)(n->wblob + boff[i]);
         }
+        if (n->stem_pair >= 0 && i == n->stem_pair + 1) op.wds = (uint16_t*)(n->wblob + wds_off);
         n->ops.push_back(op);
     }
     *out = n;
@@ -452,6 +484,12 @@ int vgh_net_set_split(vgh_net* n, int nsplit) {
     VGH_REQUIRE(n, "net_set_split: null handle");
     VGH_REQUIRE(nsplit >= 1 && nsplit <= vgh_net::kLanes, "net_set_split: 1..%d lanes", vgh_net::kLanes);
     n->nsplit = nsplit;
+    return VGH_OK;
+}
+
+int vgh_net_set_fuse_stem(vgh_net* n, int enable) {
+    VGH_REQUIRE(n, "net_set_fuse_stem: null handle");
+    n->fuse_stem = enable ? 1 : 0;
     return VGH_OK;
 }
 

@@ -236,6 +236,12 @@ class VGHeadsEngine:
         if self._use_tuning:
             self.load_tuning()  # the table may hold tile choices measured in this split mode
 
+    def set_fuse_stem(self, enable: bool = True):
+        """vgh_net_set_fuse_stem: stem + stage-1 downsample as one kernel (default) or as the two launches (the stem buffer is then written:
+        per-op inspection; results are bit-identical)."""
+        _lib.check(self.lib.vgh_net_set_fuse_stem(self._net, int(bool(enable))))
+        self._graph_key = None
+
     def set_overlap(self, enable: bool = True):
         """Throughput mode (vgh_detector_set_overlap): ``select`` / the select half of ``detect`` run on a detector-owned side
         stream underneath the next batch's network.  Call ``join()`` before reading a batch's outputs."""

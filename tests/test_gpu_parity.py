@@ -505,6 +505,7 @@ def test_network_every_op(gpu_lib, variant, S, B):
     from head_detector_amd.engine import VGHeadsEngine
 
     eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=7, use_tuning=False)
+    eng.set_fuse_stem(False)  # every op's own buffer is inspected here (the fused stem + downsample kernel never writes the stem tensor; its own test follows)
     P = eng.program
     x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(2))
     eng.forward_net(x.to(_dev()))
@@ -527,6 +528,28 @@ def test_network_every_op(gpu_lib, variant, S, B):
     eng.close()
 
 
+@pytest.mark.parametrize("variant,S,B,fmt", [("vgg_heads_m", 256, 3, "u8"), ("vgg_heads_l", 160, 2, "f32"), ("vgg_heads_m", 672, 1, "u8"), ("vgg_heads_l", 640, 2, "u8")])
+def test_fused_stem_downsample_is_bit_identical(gpu_lib, variant, S, B, fmt):
+    """csrc/stem_ds.hip (stem 3 -> 48 s2 + stage-1 downsample 48 -> 96 s2 in one kernel, the stem activation staying in LDS) against the two launches it
+    replaces: the downsample output -- hence everything after it -- must be the same bits (same fp32 FMA chain in the stem, same k order in the MFMA
+    accumulation), for u8 and f32 images, image borders on every side and a map width that is not a multiple of the 16-pixel tile (672 -> 168)."""
+    from head_detector_amd.engine import VGHeadsEngine
+
+    g = torch.Generator().manual_seed(S + B)
+    x = (torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g) if fmt == "u8" else torch.rand(B, 3, S, S, generator=g)).to(_dev())
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=3, use_tuning=False)
+    outs = {}
+    for fuse in (True, False):
+        eng.set_fuse_stem(fuse)
+        eng.forward_net(x)
+        outs[fuse] = (eng.buffer("backbone.stage1.ds", B), [t.clone() for t in eng.model(x)])
+    assert float(outs[True][0].float().abs().max()) > 0
+    assert torch.equal(outs[True][0], outs[False][0]), "stage-1 downsample output differs"
+    for a, b in zip(outs[True][1], outs[False][1]):
+        assert torch.equal(a, b)
+    eng.close()
+
+
 def test_u8_nhwc_input_equals_f32_nchw(gpu_lib):
     """The fused /255 (detector.py:51) must reproduce the float path exactly."""
     from head_detector_amd.engine import VGHeadsEngine
@@ -535,11 +558,13 @@ def test_u8_nhwc_input_equals_f32_nchw(gpu_lib):
     eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=1, seed=3, use_tuning=False)
     u8 = torch.randint(0, 256, (1, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
     f = (u8.permute(0, 3, 1, 2).float() / 255.0).contiguous()
-    eng.forward_net(u8.to(_dev()))
-    a = eng.buffer("stem", 1).float().cpu()
-    eng.forward_net(f.to(_dev()))
-    b = eng.buffer("stem", 1).float().cpu()
-    assert torch.equal(a, b)
+    for fuse, name in ((False, "stem"), (True, "backbone.stage1.ds")):  # the stem kernel's own output; the fused stem + downsample kernel's output
+        eng.set_fuse_stem(fuse)
+        eng.forward_net(u8.to(_dev()))
+        a = eng.buffer(name, 1).float().cpu()
+        eng.forward_net(f.to(_dev()))
+        b = eng.buffer(name, 1).float().cpu()
+        assert float(a.abs().max()) > 0 and torch.equal(a, b), name
     eng.close()
 
 
