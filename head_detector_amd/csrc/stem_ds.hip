@@ -39,7 +39,7 @@ struct StemDsArgs {
 };
 
 template <int FMT>
-__global__ __launch_bounds__(FD_THREADS, 4) void stem_ds_kernel(const StemDsArgs a) {
+__global__ __launch_bounds__(FD_THREADS, 4) void stem_ds_kernel(const StemDsArgs a, const float* __restrict__ wstem /*[27][48]*/, const float* __restrict__ bstem /*[48]*/) {
     __shared__ __attribute__((aligned(16))) float img[3][FD_IH][FD_IW + 1];  // 15.5 KB; reused as the epilogue's transpose strips
     __shared__ __attribute__((aligned(16))) char X[FD_NS * FD_XP];           // 33.3 KB
     __shared__ float lut[256];
@@ -104,10 +104,11 @@ __global__ __launch_bounds__(FD_THREADS, 4) void stem_ds_kernel(const StemDsArgs
     }
     __syncthreads();
     // ---- stem: one pixel per lane, 48 channels in three groups of 16 (wave-uniform weights: scalar loads), exactly the arithmetic of stem_kernel ----
-    if (tid < FD_NS) {
-        const int sy = tid / FD_SW, sx = tid - sy * FD_SW;
+    {   // every lane computes (lanes beyond the 297 pixels redo the last one and do not store)
+        const int sp = tid < FD_NS ? tid : FD_NS - 1;
+        const int sy = sp / FD_SW, sx = sp - sy * FD_SW;
         const int gy = 2 * oy0 - 1 + sy, gx = 2 * ox0 - 1 + sx;  // position in the stem map
-        const bool inside = (unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws;  // outside: the downsample conv's zero padding
+        const float keep = ((unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws) ? 1.0f : 0.0f;
         float x[27];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(FD_THREADS, 4) void stem_ds_kernel(const StemDsArgs
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) x[(ky * 3 + kx) * 3 + ci] = img[ci][2 * sy + ky][2 * sx + kx];
-        char* const xp = X + tid * FD_XP;
+        char* const xp = X + sp * FD_XP;
+        const bool live = tid < FD_NS;
 #pragma unroll
         for (int cg = 0; cg < FD_CO / 16; ++cg) {
             f32x2_t acc[8];
@@ -125,18 +127,22 @@ __global__ __launch_bounds__(FD_THREADS, 4) void stem_ds_kernel(const StemDsArgs
             for (int k = 0; k < 27; ++k) {
                 const f32x2_t xk = {x[k], x[k]};
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = __builtin_elementwise_fma(xk, *(const f32x2_t*)(a.wstem + k * FD_CO + cg * 16 + 2 * c), acc[c]);
+                for (int c = 0; c < 8; ++c) acc[c] = __builtin_elementwise_fma(xk, *(const f32x2_t*)(wstem + k * FD_CO + cg * 16 + 2 * c), acc[c]);
             }
+            // pixels outside the stem map are the downsample conv's zero padding: a multiply by 0 / 1, NOT a select -- with `inside ? f(acc) : 0` hipcc
+            // turned the select into a branch and sank seven of the eight FMA chains into it, away from their weight loads (1100 spilled SGPRs, 3.3 ms)
             bf16x8_t o0, o1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                o0[2 * c] = (__bf16)(inside ? fmaxf(acc[c][0] + a.bstem[cg * 16 + 2 * c], 0.0f) : 0.0f);
-                o0[2 * c + 1] = (__bf16)(inside ? fmaxf(acc[c][1] + a.bstem[cg * 16 + 2 * c + 1], 0.0f) : 0.0f);
-                o1[2 * c] = (__bf16)(inside ? fmaxf(acc[4 + c][0] + a.bstem[cg * 16 + 8 + 2 * c], 0.0f) : 0.0f);
-                o1[2 * c + 1] = (__bf16)(inside ? fmaxf(acc[4 + c][1] + a.bstem[cg * 16 + 8 + 2 * c + 1], 0.0f) : 0.0f);
+                o0[2 * c] = (__bf16)(fmaxf(acc[c][0] + bstem[cg * 16 + 2 * c], 0.0f) * keep);
+                o0[2 * c + 1] = (__bf16)(fmaxf(acc[c][1] + bstem[cg * 16 + 2 * c + 1], 0.0f) * keep);
+                o1[2 * c] = (__bf16)(fmaxf(acc[4 + c][0] + bstem[cg * 16 + 8 + 2 * c], 0.0f) * keep);
+                o1[2 * c + 1] = (__bf16)(fmaxf(acc[4 + c][1] + bstem[cg * 16 + 8 + 2 * c + 1], 0.0f) * keep);
             }
-            *(bf16x8_t*)(xp + cg * 32) = o0;
-            *(bf16x8_t*)(xp + cg * 32 + 16) = o1;
+            if (live) {
+                *(bf16x8_t*)(xp + cg * 32) = o0;
+                *(bf16x8_t*)(xp + cg * 32 + 16) = o1;
+            }
         }
     }
     __syncthreads();
@@ -226,9 +232,9 @@ int vgh_launch_stem_ds(const void* image, int image_fmt, int B, int H, int W, co
     StemDsArgs a{image, wstem, bstem, wds, bds, out, out_pitch, out_coff, H, W};
     const dim3 grid((W / 4 + FD_TW - 1) / FD_TW, (H / 4 + FD_TH - 1) / FD_TH, B);
     if (image_fmt == VGH_IMG_U8_NHWC)
-        hipLaunchKernelGGL(stem_ds_kernel<VGH_IMG_U8_NHWC>, grid, dim3(FD_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(stem_ds_kernel<VGH_IMG_U8_NHWC>, grid, dim3(FD_THREADS), 0, stream, a, wstem, bstem);
     else
-        hipLaunchKernelGGL(stem_ds_kernel<VGH_IMG_F32_NCHW>, grid, dim3(FD_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(stem_ds_kernel<VGH_IMG_F32_NCHW>, grid, dim3(FD_THREADS), 0, stream, a, wstem, bstem);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
