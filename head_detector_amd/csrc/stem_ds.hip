@@ -104,44 +104,58 @@ __global__ __launch_bounds__(FD_THREADS, 4) void stem_ds_kernel(const StemDsArgs
     }
     __syncthreads();
     // ---- stem: one pixel per lane, 48 channels in three groups of 16 (wave-uniform weights: scalar loads), exactly the arithmetic of stem_kernel ----
-    {   // every lane computes (lanes beyond the 297 pixels redo the last one and do not store)
-        const int sp = tid < FD_NS ? tid : FD_NS - 1;
-        const int sy = sp / FD_SW, sx = sp - sy * FD_SW;
-        const int gy = 2 * oy0 - 1 + sy, gx = 2 * ox0 - 1 + sx;  // position in the stem map
-        const float keep = ((unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws) ? 1.0f : 0.0f;
-        float x[27];
+    // ---- stem on the FP32 matrix cores: D[cout][pixel] += W[k][cout] * x[pixel][k], v_mfma_f32_32x32x2_f32 = an exact fmaf chain in ascending k (two
+    //      k per instruction, in order; verified bit for bit in the FLAME kernels), so every stem value is the same fp32 number as stem_kernel's VALU
+    //      chain -- at the full 64 FLOP/clk/SIMD of the matrix pipe instead of the ~50 % of it the scalar-operand v_pk_fma stream reaches (r03 A/B:
+    //      the VALU version of this kernel ran 703 us against 307 + 369 us for the two launches).  K = 27 (+1 zero) = 14 steps, couts 48 (+16 zero rows)
+    //      = two 32-row groups, the block's 297 (+23 idle) pixels = ten 32-column groups, two per wave.
+    {
+        const int r32 = lane & 31, h = lane >> 5;
+        float A[14][2];  // this lane's A operands for every (k pair, cout group): W[2kp + h][32 r + r32], zero beyond k = 26 / cout 47
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int kp = 0; kp < 14; ++kp)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci) x[(ky * 3 + kx) * 3 + ci] = img[ci][2 * sy + ky][2 * sx + kx];
-        char* const xp = X + sp * FD_XP;
-        const bool live = tid < FD_NS;
-#pragma unroll
-        for (int cg = 0; cg < FD_CO / 16; ++cg) {
-            f32x2_t acc[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = f32x2_t{0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 27; ++k) {
-                const f32x2_t xk = {x[k], x[k]};
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = __builtin_elementwise_fma(xk, *(const f32x2_t*)(wstem + k * FD_CO + cg * 16 + 2 * c), acc[c]);
+            for (int r = 0; r < 2; ++r) {
+                const int k = 2 * kp + h, co = 32 * r + r32;
+                A[kp][r] = (k < 27 && co < FD_CO) ? wstem[k * FD_CO + co] : 0.0f;
             }
-            // pixels outside the stem map are the downsample conv's zero padding: a multiply by 0 / 1, NOT a select -- with `inside ? f(acc) : 0` hipcc
-            // turned the select into a branch and sank seven of the eight FMA chains into it, away from their weight loads (1100 spilled SGPRs, 3.3 ms)
-            bf16x8_t o0, o1;
+        f32x4_t bq[6];  // bias of this lane's output channels: group 0 rows 8q + 4h .. +3 (q < 4), group 1 rows 32 + 8q + 4h (q < 2)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                o0[2 * c] = (__bf16)(fmaxf(acc[c][0] + bstem[cg * 16 + 2 * c], 0.0f) * keep);
-                o0[2 * c + 1] = (__bf16)(fmaxf(acc[c][1] + bstem[cg * 16 + 2 * c + 1], 0.0f) * keep);
-                o1[2 * c] = (__bf16)(fmaxf(acc[4 + c][0] + bstem[cg * 16 + 8 + 2 * c], 0.0f) * keep);
-                o1[2 * c + 1] = (__bf16)(fmaxf(acc[4 + c][1] + bstem[cg * 16 + 8 + 2 * c + 1], 0.0f) * keep);
+        for (int q = 0; q < 6; ++q) bq[q] = *(const f32x4_t*)(bstem + 8 * q + 4 * h);
+        const float* const imgf = &img[0][0][0];
+        constexpr int IP = FD_IW + 1, IC = FD_IH * IP;  // row pitch, channel pitch of the image patch
+#pragma unroll 1
+        for (int gi = 0; gi < 2; ++gi) {
+            const int p = (w * 2 + gi) * 32 + r32;
+            const int sp = p < FD_NS ? p : FD_NS - 1;
+            const int sy = sp / FD_SW, sx = sp - sy * FD_SW;
+            const int gy = 2 * oy0 - 1 + sy, gx = 2 * ox0 - 1 + sx;  // position in the stem map
+            // pixels outside the stem map are the downsample conv's zero padding: a multiply by 0 / 1 (a select would let hipcc sink work into a branch)
+            const float keep = ((unsigned)gy < (unsigned)Hs && (unsigned)gx < (unsigned)Ws) ? 1.0f : 0.0f;
+            const int base = (2 * sy) * IP + 2 * sx;
+            f32x16_t acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+            for (int kp = 0; kp < 14; ++kp) {
+                // k = (ky*3 + kx)*3 + ci: even k for lanes 0..31, odd k for lanes 32..63 (k = 27 is the zero pad)
+                constexpr auto off = [](int k) { return (k % 3) * IC + (k / 9) * IP + (k / 3) % 3; };
+                const float xe = imgf[base + off(2 * kp)];
+                const float xo = (2 * kp + 1 < 27) ? imgf[base + off(2 * kp + 1 < 27 ? 2 * kp + 1 : 0)] : 0.0f;
+                const float bx = h ? xo : xe;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[kp][0], bx, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[kp][1], bx, acc1, 0, 0, 0);
             }
-            if (live) {
-                *(bf16x8_t*)(xp + cg * 32) = o0;
-                *(bf16x8_t*)(xp + cg * 32 + 16) = o1;
+            if (p < FD_NS) {
+                char* const xp = X + p * FD_XP;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int c0 = 8 * q + 4 * h;  // first of this lane's 4 consecutive channels
+                    bf16x4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(fmaxf((q < 4 ? acc0[q * 4 + e] : acc1[(q - 4) * 4 + e]) + bq[q][e], 0.0f) * keep);
+                    *(bf16x4_t*)(xp + c0 * 2) = o;
+                }
             }
         }
     }
