@@ -590,9 +590,8 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
 
 
 def program_algorithmic_bytes(P: "Program", batch: int, fused_stem: Optional[bool] = None) -> Dict[str, float]:
-    """fused_stem (default: the bf16 program, whose executor runs stem + stage-1 downsample as one kernel): the stem tensor is neither written nor read."""
-    if fused_stem is None:
-        fused_stem = P.precision == "bf16"
+    """fused_stem (the executor's opt-in vgh_net_set_fuse_stem): the stem tensor is neither written nor read."""
+    fused_stem = bool(fused_stem)
     tot = dict(read=0.0, write=0.0)
     for i, op in enumerate(P.ops):
         b = op_algorithmic_bytes(P, op, batch)

@@ -237,8 +237,8 @@ class VGHeadsEngine:
             self.load_tuning()  # the table may hold tile choices measured in this split mode
 
     def set_fuse_stem(self, enable: bool = True):
-        """vgh_net_set_fuse_stem: stem + stage-1 downsample as one kernel (default) or as the two launches (the stem buffer is then written:
-        per-op inspection; results are bit-identical)."""
+        """vgh_net_set_fuse_stem: stem + stage-1 downsample as one kernel (opt-in: less HBM traffic, same time; the stem buffer is then not written)
+        or as the two launches (default).  Results are bit-identical."""
         _lib.check(self.lib.vgh_net_set_fuse_stem(self._net, int(bool(enable))))
         self._graph_key = None
 

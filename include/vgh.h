@@ -99,9 +99,9 @@ int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
  * latency, epilogue store burst, tail -- of one sub-batch hides under the main loops of the others.  Results are identical
  * (images are independent; every op keeps its tile configuration). */
 int vgh_net_set_split(vgh_net* net, int nsplit);
-/* The stem (3 -> 48, stride 2) and the first backbone downsample (48 -> 96, stride 2) run as ONE kernel when the program has that pair in bf16
- * (default on; the 48-channel stem activation then never goes to HBM and its arena buffer is not written).  Results are bit-identical either way;
- * 0 restores the two launches (per-op inspection of the stem buffer, A/B timing). */
+/* Opt-in: the stem (3 -> 48, stride 2) and the first backbone downsample (48 -> 96, stride 2) as ONE kernel (csrc/stem_ds.hip) when the program has that
+ * pair in bf16: the 48-channel stem activation then never goes to HBM and its arena buffer is not written.  Results are bit-identical either way.
+ * Default off: measured (r03) it removes 1.5 GB of traffic per 64-image forward but is no faster than the two launches (latency-bound small tiles). */
 int vgh_net_set_fuse_stem(vgh_net* net, int enable);
 /* Borrowed HIP event (or NULL): the first op of the next forwards that writes a prediction buffer waits for it on its stream.
  * Lets a consumer of the previous forward's predictions run on another stream underneath this forward's backbone / neck. */

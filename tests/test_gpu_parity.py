@@ -505,7 +505,6 @@ def test_network_every_op(gpu_lib, variant, S, B):
     from head_detector_amd.engine import VGHeadsEngine
 
     eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=7, use_tuning=False)
-    eng.set_fuse_stem(False)  # every op's own buffer is inspected here (the fused stem + downsample kernel never writes the stem tensor; its own test follows)
     P = eng.program
     x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(2))
     eng.forward_net(x.to(_dev()))

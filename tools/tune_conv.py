@@ -27,7 +27,6 @@ def main():
     ap.add_argument("--precision", default="bf16", help="bf16 (throughput tiles) or fp16x3 / bf16x3 (the split-precision tile set; keys get a precision prefix)")
     args = ap.parse_args()
     eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, use_tuning=False, precision=args.precision)
-    eng.set_fuse_stem(False)  # the stage-1 downsample must run as its own launch to be timed
     if args.split > 1:
         eng.set_split(args.split)
     names = eng.cfg_names()
