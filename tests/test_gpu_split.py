@@ -386,3 +386,31 @@ def test_bf16x3_and_bf16_deviation_from_the_oracle_at_640(gpu_lib, flame_model, 
     r1 = network_vs_oracle(variant, okey, "bf16", 640, B, flame_model)
     assert r1["kept_iou_min"] >= 0.85 and r1["kept_param_max_rel_err"] < 0.5 and r1["vertex_l2_metric_max"] < 3e-2, r1
     assert r3["kept_param_max_rel_err"] < r1["kept_param_max_rel_err"]
+
+
+def test_head_detector_facade_in_the_parity_mode(gpu_lib, flame_model):
+    """The drop-in facade (head_detector/detector.py:97-102 contract) with precision="fp16x3": same heads as the fp32 VALU mode on the same image --
+    identical integer bboxes, scores within 1e-5, vertices within 2e-3 px (the letterbox, NMS and FLAME stages are shared; only the conv kernels differ)."""
+    import warnings
+
+    from head_detector_amd import HeadDetector
+
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    res = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for prec in ("fp32", "fp16x3"):
+            det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, precision=prec)
+            if prec == "fp32":
+                # a threshold that keeps a handful of heads on this image (random weights: arbitrary scores)
+                out = det(img, confidence_threshold=0.0)
+                sc = sorted((h.score for h in out.heads), reverse=True)
+                conf = float(sc[min(5, len(sc) - 1)]) - 1e-4
+            res[prec] = det(img, confidence_threshold=conf)
+    a, b = res["fp32"].heads, res["fp16x3"].heads
+    assert len(a) == len(b) >= 3
+    for ha, hb in zip(a, b):
+        assert (ha.bbox.x, ha.bbox.y, ha.bbox.w, ha.bbox.h) == (hb.bbox.x, hb.bbox.y, hb.bbox.w, hb.bbox.h)
+        assert abs(ha.score - hb.score) < 1e-5
+        assert float(np.abs(np.asarray(ha.vertices_3d) - np.asarray(hb.vertices_3d)).max()) < 2e-3
