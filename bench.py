@@ -233,6 +233,64 @@ def live_traffic(variant: str, batch: int, split: int, forwards: int = 6):
                 source=f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) around tools/traffic_run.py --forwards {forwards} --split {split}")
 
 
+class PowerSampler:
+    """Best-effort socket power / shader clock of GPU `index` during the timed region (a daemon thread reading the amdgpu hwmon files every 50 ms;
+    nothing is reported when the files are not there).  The conv stack runs within a few % of the board's power cap (profiles/r03_power.txt), which is
+    what bounds `roofline.frac` -- so the line says how close this run was."""
+
+    def __init__(self, index: int):
+        import glob
+
+        self.samples, self._stop, self._thr = [], False, None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.dir = cards[index] if index < len(cards) else None
+        self.pfile = next((os.path.join(self.dir, f) for f in ("power1_average", "power1_input") if self.dir and os.path.exists(os.path.join(self.dir, f))), None)
+        self.ffile = os.path.join(self.dir, "freq1_input") if self.dir and os.path.exists(os.path.join(self.dir, "freq1_input")) else None
+        cap = os.path.join(self.dir, "power1_cap") if self.dir else None
+        self.cap_w = None
+        try:
+            if cap and os.path.exists(cap):
+                self.cap_w = int(open(cap).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+
+    def _run(self):
+        while not self._stop:
+            try:
+                p = int(open(self.pfile).read()) / 1e6
+                f = int(open(self.ffile).read()) / 1e6 if self.ffile else None
+                self.samples.append((p, f))
+            except (OSError, ValueError):
+                return
+            time.sleep(0.05)
+
+    def __enter__(self):
+        if self.pfile:
+            import threading
+
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._thr:
+            self._thr.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        if len(self.samples) < 3:
+            return None
+        p = sorted(x[0] for x in self.samples)
+        out = {"socket_power_w_median": round(p[len(p) // 2], 1), "socket_power_w_max": round(p[-1], 1), "samples": len(p), "source": self.pfile}
+        f = sorted(x[1] for x in self.samples if x[1])
+        if f:
+            out["sclk_mhz_median"] = round(f[len(f) // 2])
+        if self.cap_w:
+            out["power_cap_w"] = round(self.cap_w, 1)
+        return out
+
+
 def _respawn_under_torchrun(n: int):
     """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`
     (one rank per GPU over RCCL) instead of silently measuring one rank."""
@@ -357,17 +415,18 @@ def main():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        eng.join()
-        if gat is not None:
-            for s in range(2):
-                gat.result(s)  # the last two exchanges
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        with PowerSampler(local) as power:
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            eng.join()
+            if gat is not None:
+                for s in range(2):
+                    gat.result(s)  # the last two exchanges
+            torch.cuda.synchronize()
+            if dist.is_initialized():
+                dist.barrier()
+            dt = time.perf_counter() - t0
         if dist.is_initialized():
             t = torch.tensor([dt], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -381,7 +440,7 @@ def main():
         alg = arch.program_algorithmic_bytes(eng.program, B)
         out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, heads_per_img=heads / max(steps * B, 1), overlap=overlap,
                    value=B * world * steps / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,
-                   alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch)
+                   alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch, power=power.summary())
         eng.close()
         return out
 
@@ -411,6 +470,8 @@ def main():
                   "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(main_run["flops_per_image"] / 1e9, 2),
                   "graph": bool(args.graph), "exchange_to_rank0": bool(world > 1 or args.exchange), "overlap_post": main_run["overlap"], "batch_split": nsplit,
                   "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(main_run["net_ms"], 3), "ramp_steps": args.ramp_steps}
+        if main_run["power"]:
+            config["power_during_timed_steps"] = main_run["power"]
         sec_steps = max(50, args.steps // 2)
         if world == 1 and not args.no_secondary:
             if (args.variant, B) != ("vgg_heads_m", 32):

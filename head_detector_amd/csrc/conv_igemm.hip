@@ -219,6 +219,9 @@ const CfgEntry g_cfgs[] = {
     PCFG(16, 8, 128, 4, 2),    // 96  128 px x 128, 8 waves: 72 KiB -> two blocks = 4 waves per SIMD
     QCFG(16, 8, 128, 4, 2),    // 97
     PCFG(16, 8, 256, 4, 4),    // 98  128 px x 256, 16 waves
+    // big register tiles, one wave per SIMD (the hipBLASLt recipe: 0.5 KB of fragment reads per MFMA instead of 1 KB; one block per CU)
+    PCFG(32, 16, 128, 4, 1),   // 99   512 px x 128: 4 waves x (128 px x 128): 256 accumulator registers per lane
+    PCFG(40, 16, 128, 4, 1),   // 100  640 px x 128: 4 waves x (160 px x 128): tiles 80-wide maps exactly
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
