@@ -107,11 +107,12 @@ def tile_names_for(program: "arch.Program", batch: int, nsplit: int = 1, table_p
     if not os.path.exists(path):
         return {}
     table = json.load(open(path))
+    pre = "" if program.precision == "bf16" else program.precision + ":"  # the split-precision modes have their own keys and tile names
     out = {}
     for i, op in enumerate(program.ops):
         if op["kind"] != 1:
             continue
-        name = table.get(tuning_key(op, batch, nsplit), table.get(tuning_key(op, batch)))
+        name = table.get(pre + tuning_key(op, batch, nsplit), table.get(pre + tuning_key(op, batch)))
         if name:
             out[i] = name
     return out
@@ -149,7 +150,7 @@ def main(argv=None):
     ap.add_argument("--precision", default="bf16", choices=sorted(arch.PRECISION_FMT))
     args = ap.parse_args(argv)
     P = arch.build_program(args.variant, _weights_arg(args.weights, args.variant), args.image_size, args.precision)
-    names = tile_names_for(P, args.batch, args.split) if args.precision == "bf16" else {}
+    names = tile_names_for(P, args.batch, args.split) if args.precision != "fp32" else {}
     n = write_pack(args.out, P, _flame_arg(args.flame), names, args.batch)
     print(f"{args.out}: {n / 2 ** 20:.1f} MiB, {len(P.ops)} ops, {len(P.bufs)} buffers, {len(names)} tuned tile choices, {P.flops / 1e9:.2f} GFLOP/image")
 

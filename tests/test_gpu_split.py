@@ -414,3 +414,54 @@ def test_head_detector_facade_in_the_parity_mode(gpu_lib, flame_model):
         assert (ha.bbox.x, ha.bbox.y, ha.bbox.w, ha.bbox.h) == (hb.bbox.x, hb.bbox.y, hb.bbox.w, hb.bbox.h)
         assert abs(ha.score - hb.score) < 1e-5
         assert float(np.abs(np.asarray(ha.vertices_3d) - np.asarray(hb.vertices_3d)).max()) < 2e-3
+
+
+def test_parity_mode_through_the_pack_and_the_c_context(gpu_lib, flame_model, tmp_path):
+    """`pack --precision fp16x3` -> vgh_create -> vgh_ctx_detect (a C client's path to the parity mode) equals the Python engine in fp16x3, bit for bit: the pack
+    carries the split formats of the buffers, the per-op tile names of the parity modes' own table, and the library splits the fp32 weights itself."""
+    from head_detector_amd import _lib, arch, pack
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    variant, S, B = "vgg_heads_m", 320, 2
+    sd = arch.random_state_dict(variant, 11)
+    P = arch.build_program(variant, sd, S, "fp16x3")
+    names = {i: ("s128x64_w32x64_k2_r2" if op["cout_pad"] % 64 == 0 else "s128x32_w32x32") for i, op in enumerate(P.ops) if op["kind"] == 1 and op["ksize"] == 1 and not op["shuffle"]}
+    pk = str(tmp_path / "m_fp16x3.vghpack")
+    pack.write_pack(pk, P, flame_model, names, B)
+    assert pack.read_header(pk)["precision"] == arch.FMT_F16X2
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).to(_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=B * 100)
+    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, use_tuning=False, precision="fp16x3")
+    cfgs = eng.cfg_names()
+    for i, n in names.items():
+        eng.set_cfg(i, cfgs.index(n))
+    _, sc, _ = eng.model(x)
+    conf = float(sc[:, 5, 0].min())
+    ref = eng.detect(x, confidence_threshold=conf, flame=fl)
+    n_ref = ref.num_heads
+    assert n_ref >= B
+    h = C.c_void_p()
+    cfg = _lib.Config(device=torch.cuda.current_device(), pack_path=pk.encode(), max_batch=B)
+    _lib.check(gpu_lib.vgh_create(C.byref(cfg), C.byref(h)))
+    info = _lib.CtxInfo()
+    _lib.check(gpu_lib.vgh_ctx_get_info(h, C.byref(info)))
+    assert info.precision == arch.FMT_F16X2
+    kk, V = 100, fl.num_vertices
+    f32 = dict(dtype=torch.float32, device=_dev())
+    ob, os_, of = torch.zeros(B, kk, 4, **f32), torch.zeros(B, kk, **f32), torch.zeros(B, kk, 413, **f32)
+    oc, nh, hi = torch.zeros(B, dtype=torch.int32, device=_dev()), torch.zeros(1, dtype=torch.int32, device=_dev()), torch.zeros(B * kk, dtype=torch.int32, device=_dev())
+    proj = torch.zeros(B * kk, V, 3, **f32)
+    o = _lib.DetectOut(boxes_dev=ob.data_ptr(), scores_dev=os_.data_ptr(), flame_dev=of.data_ptr(), counts_dev=oc.data_ptr(), n_heads_dev=nh.data_ptr(), head_image_dev=hi.data_ptr(),
+                       head_capacity=B * kk, unpad_dev=None, verts_dev=None, rot_dev=None, rpy_dev=None, proj_dev=proj.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_lib.vgh_ctx_detect(h, x.data_ptr(), _lib.VGH_IMG_U8_NHWC, B, conf, 0.5, C.byref(o), st) == 0, gpu_lib.vgh_ctx_last_error(h)
+    _lib.check(gpu_lib.vgh_ctx_join(h, st))
+    torch.cuda.synchronize()
+    assert torch.equal(oc, ref.counts) and int(nh) == n_ref
+    for b in range(B):
+        n = int(oc[b])
+        assert torch.equal(ob[b, :n], ref.boxes[b, :n]) and torch.equal(of[b, :n], ref.flame_params[b, :n])
+    assert torch.equal(proj[:n_ref], ref.vertices_3d)
+    gpu_lib.vgh_destroy(h)
+    eng.close()
