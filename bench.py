@@ -242,8 +242,17 @@ class PowerSampler:
         import glob
 
         self.samples, self._stop, self._thr = [], False, None
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
-        self.dir = cards[index] if index < len(cards) else None
+        # the box exposes every card's hwmon but only this rank's GPU to HIP: find the card by the PCI address HIP reports for the device
+        self.dir = None
+        try:
+            import ctypes
+
+            hip, buf = ctypes.CDLL("libamdhip64.so"), ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                hw = glob.glob(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/hwmon/hwmon*")
+                self.dir = hw[0] if hw else None
+        except OSError:
+            pass
         self.pfile = next((os.path.join(self.dir, f) for f in ("power1_average", "power1_input") if self.dir and os.path.exists(os.path.join(self.dir, f))), None)
         self.ffile = os.path.join(self.dir, "freq1_input") if self.dir and os.path.exists(os.path.join(self.dir, "freq1_input")) else None
         cap = os.path.join(self.dir, "power1_cap") if self.dir else None

@@ -119,6 +119,7 @@ SYMBOLS = {
     "vgh_conv_split_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "vgh_conv_set_max_blocks_per_xcd": (_I, [_I]),
+    "vgh_conv_set_nt_store": (_I, [_I]),
     "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),
     "vgh_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "vgh_gather_candidates": (_I, [C.POINTER(HeadLevel), _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),

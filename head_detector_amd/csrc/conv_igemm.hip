@@ -50,6 +50,7 @@ static int patch_blocks_per_cu(K kernel, int threads, int lds, std::atomic<int> 
 }
 
 static std::atomic<int> g_max_blocks_per_xcd{0};
+static std::atomic<int> g_nt_store{0};
 
 static int persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int per_cu) {
     // as many blocks per XCD as its 32 CUs keep resident, each looping over tiles; with the batch split over lane streams every
@@ -237,6 +238,11 @@ extern "C" int vgh_conv_set_trace(void* dev_buffer) {
 }
 #endif
 int vgh_conv_num_cfgs() { return kNumCfgs; }
+int vgh_conv_set_nt_store(int on) {
+    g_nt_store.store(on ? 1 : 0, std::memory_order_relaxed);
+    return VGH_OK;
+}
+
 int vgh_conv_set_max_blocks_per_xcd(int blocks) {
     VGH_REQUIRE(blocks >= 0, "conv_set_max_blocks_per_xcd: negative");
     g_max_blocks_per_xcd.store(blocks, std::memory_order_relaxed);
@@ -346,6 +352,7 @@ int vgh_conv_prepare(ConvArgs& a) {
     constexpr int ablate = 0;
 #endif
     a.ablate = ablate;
+    a.nt_out = g_nt_store.load(std::memory_order_relaxed);
     vgh_fastdiv_magic((unsigned)(a.Ho * a.Wo > 0 ? a.Ho * a.Wo : 1), &a.div_howo_m, &a.div_howo_s);
     vgh_fastdiv_magic((unsigned)(a.Wo > 0 ? a.Wo : 1), &a.div_wo_m, &a.div_wo_s);
     const bool al8 = a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_split % 8 == 0 && a.cout_store % 8 == 0 && a.out_pitch % 8 == 0 &&

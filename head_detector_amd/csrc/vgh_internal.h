@@ -72,6 +72,7 @@ struct ConvArgs {
     float lo_scale;   // lo = (v - hi) * lo_scale
     float out_scale;  // undoes the per-op power-of-two weight prescale (fp16), applied to the accumulator before the bias
     int fallback_cfg1;  // 0: a forced tile that cannot run this conv is an error; k + 1: it falls back to tile k (network executor: a table may be stale)
+    int nt_out;          // bf16 output stores carry the non-temporal hint (set by vgh_conv_prepare from vgh_conv_set_nt_store)
     int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
     unsigned long long* trace;  // -DVGH_EXPERIMENTS builds only: per-(block, tile) phase timestamps (s_memtime), or nullptr
 };

@@ -151,6 +151,9 @@ int vgh_conv_split_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast
 /* Cap on the persistent 3x3 kernels' grid: at most `blocks` workgroups per XCD (0 = as many as stay resident, the default).
  * Process-wide.  Leaves CUs to other work; the parity tests use it to drive many tiles through one workgroup. */
 int vgh_conv_set_max_blocks_per_xcd(int blocks);
+/* Process-wide: bf16 conv outputs are stored with the non-temporal hint (evict-first in L2, so the input lines neighbouring tiles re-read survive).
+ * Results do not change. */
+int vgh_conv_set_nt_store(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Head decode: replaces YoloHeadsNDFLHeads.forward's tail (yolo_head_ndfl_heads.py:143-172) and the

@@ -57,6 +57,21 @@ for step in "$@"; do
     pmcflame)
       (cd /tmp && FLAME_NS=8192 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmcf -o f -- python $ROOT/tools/flame_sweep.py > $O/pmcflame.log 2>&1)
       python tools/pmc_flame_summary.py $O/pmcf $O/${TAG}_pmc_flame.txt ;;
+    pmcreq)
+      # which request sizes the L2 -> fabric read counters distinguish on this box, then the request mix of one forward per op (calibrates FETCH_SIZE)
+      rocprofv3 --list-avail 2>/dev/null | grep -o "TCC_EA0_R[A-Z0-9_]*\|TCC_EA_R[A-Z0-9_]*\|TCC_BUBBLE[A-Z0-9_]*\|TCC_MISS[A-Z0-9_]*\|TCC_HIT[A-Z0-9_]*\|TCC_REQ[A-Z0-9_]*\|TCC_READ[A-Z0-9_]*" | sort -u > $O/tcc_counters.txt
+      cat $O/tcc_counters.txt | tr '\n' ' '; echo
+      for c in ${REQ_COUNTERS:-"TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_128B_sum" "TCC_BUBBLE_sum"}; do
+        t=$(echo $c | cut -d' ' -f1)
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $O/pmcreq -o $t -- python $ROOT/tools/traffic_run.py --forwards 2 --split 1 > $O/pmcreq_$t.log 2>&1); tail -2 $O/pmcreq_$t.log | cut -c1-200
+      done ;;
+    pmcknob)
+      # per-op FETCH_SIZE with a library knob set (compare with the pmc step's single-lane pass through tools/pmc_per_op.py)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_knob -o FETCH_SIZE -- python $ROOT/tools/traffic_run.py --forwards 2 --split 1 --knob ${KNOB:-vgh_conv_set_nt_store}=1 > $O/pmc_knob_F.log 2>&1)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_knob -o WRITE_SIZE -- python $ROOT/tools/traffic_run.py --forwards 2 --split 1 --knob ${KNOB:-vgh_conv_set_nt_store}=1 > $O/pmc_knob_W.log 2>&1)
+      python tools/pmc_per_op.py $O/pmc_knob vgg_heads_l 64 2 $O/per_op_knob.txt; tail -1 $O/per_op_knob.txt ;;
+    abknob)
+      timeout 900 python tools/ab_knob.py ${KNOB:-vgh_conv_set_nt_store} --json $O/${TAG}_ab_${KNOB:-vgh_conv_set_nt_store}.json ${KNOB_ARGS:-} > $O/abknob.log 2>&1; grep -v amdgpu $O/abknob.log | tail -${TAILN:-60} ;;
     probe)
       python tools/net_probe.py vgg_heads_l 64 2>&1 | grep -v amdgpu; python tools/net_probe.py vgg_heads_m 32 2>&1 | grep -v amdgpu ;;
     *) echo "unknown step $step" ;;

@@ -1,0 +1,49 @@
+"""Per-op HBM traffic: FETCH_SIZE / WRITE_SIZE of each network dispatch (single-lane PMC passes of tools/gpu_run.sh pmc) next to the op's algorithmic bytes.
+Dispatch order inside a forward is the op order of the program (one launch per op, one lane).  Conventions as tools/pmc_summary.py (KiB; FETCH doubled on gfx950).
+
+    python tools/pmc_per_op.py PMC_DIR VARIANT BATCH FORWARDS [OUT.txt]
+"""
+import csv
+import glob
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from head_detector_amd import arch  # noqa: E402
+
+pmc_dir, variant, batch, forwards = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+out = open(sys.argv[5], "w") if len(sys.argv) > 5 else sys.stdout
+
+
+def is_net(k):
+    return "conv_igemm" in k or "patch_kernel" in k or "patch3_kernel" in k or "stem_kernel" in k or "spp_pool" in k or "stem_ds" in k
+
+
+def load(name):
+    f = sorted(glob.glob(f"{pmc_dir}/**/{name}_counter_collection.csv", recursive=True))[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name and is_net(r["Kernel_Name"])]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return rows
+
+
+P = arch.build_program(variant, arch.random_state_dict(variant, 1), 640)
+ops = [op for op in P.ops]
+fr, wr = load("FETCH_SIZE"), load("WRITE_SIZE")
+per = len(fr) // forwards
+assert per == len(ops) and len(wr) == len(fr), (per, len(ops), len(wr))
+tot = [0.0] * 4
+print(f"# {variant} batch {batch}: HBM bytes per op, mean of {forwards} forwards (MB); excess = measured - algorithmic", file=out)
+print(f"{'op':44s} {'alg_rd':>8s} {'rd':>8s} {'alg_wr':>8s} {'wr':>8s} {'excess':>8s}  kernel", file=out)
+table = []
+for i, op in enumerate(ops):
+    a = arch.op_algorithmic_bytes(P, op, batch)
+    rd = sum(float(fr[f * per + i]["Counter_Value"]) for f in range(forwards)) * 2048 / forwards
+    w = sum(float(wr[f * per + i]["Counter_Value"]) for f in range(forwards)) * 1024 / forwards
+    k = fr[i]["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    k = k[:k.find("(")] if "(" in k else k
+    table.append((op.get("name", str(i)), a["read"], rd, a["write"], w, k))
+    for j, v in enumerate((a["read"], rd, a["write"], w)):
+        tot[j] += v
+for name, ar, rd, aw, w, k in table:
+    print(f"{name:44s} {ar / 1e6:8.1f} {rd / 1e6:8.1f} {aw / 1e6:8.1f} {w / 1e6:8.1f} {(rd + w - ar - aw) / 1e6:8.1f}  {k[-60:]}", file=out)
+print(f"{'total':44s} {tot[0] / 1e6:8.1f} {tot[1] / 1e6:8.1f} {tot[2] / 1e6:8.1f} {tot[3] / 1e6:8.1f} {(tot[1] + tot[3] - tot[0] - tot[2]) / 1e6:8.1f}", file=out)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--forwards", type=int, default=8)
     ap.add_argument("--split", type=int, default=2)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--knob", action="append", default=[], help="process-wide library knob, e.g. vgh_conv_set_nt_store=1")
     args = ap.parse_args()
     import torch
 
@@ -28,6 +29,11 @@ def main():
     from head_detector_amd.engine import VGHeadsEngine
 
     dev = torch.device("cuda", 0)
+    for kv in args.knob:
+        from head_detector_amd import _lib
+
+        name, val = kv.split("=")
+        _lib.check(getattr(_lib.load(), name)(int(val)))
     eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, seed=1, precision=args.precision)
     eng.set_split(args.split)
     x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
