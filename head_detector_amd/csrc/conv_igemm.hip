@@ -83,6 +83,15 @@ void launch_patch3_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, 
 }
 
 template <int BP, int BC, int WP, int WC, int KBS, int NST>
+void launch_stream_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
+    static std::atomic<int> per_cu[kMaxDevices];
+    constexpr int threads = (BP / WP) * (BC / WC) * 64;
+    const int n = patch_blocks_per_cu(conv1x1_stream_kernel<BP, BC, WP, WC, KBS, NST>, threads, lds, per_cu);
+    const int gpx = persistent_blocks_per_xcd(a, chunk, n);
+    hipLaunchKernelGGL((conv1x1_stream_kernel<BP, BC, WP, WC, KBS, NST>), dim3(gpx * 8), dim3(threads), lds, st, a, ntc, total, chunk);
+}
+
+template <int BP, int BC, int WP, int WC, int KBS, int NST>
 void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
     static std::atomic<int> attr_done[kMaxDevices];
     if (lds > 64 * 1024) {
@@ -118,6 +127,9 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
 
 #define QCFG(TW, TH, BC, NWP, NWC) \
     { "q" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, Patch3<TW, TH, BC, NWP, NWC>::LDS, nullptr, 2, TW, TH, launch_patch3_cfg<TW, TH, BC, NWP, NWC> }
+
+#define TCFG(BP, BC, WP, WC, KBS, NST) \
+    { "t" #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, Stream1<BP, BC, WP, WC, KBS, NST>::LDS, launch_stream_cfg<BP, BC, WP, WC, KBS, NST>, 3, 0, 0, nullptr }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -223,6 +235,19 @@ const CfgEntry g_cfgs[] = {
     // big register tiles, one wave per SIMD (the hipBLASLt recipe: 0.5 KB of fragment reads per MFMA instead of 1 KB; one block per CU)
     PCFG(32, 16, 128, 4, 1),   // 99   512 px x 128: 4 waves x (128 px x 128): 256 accumulator registers per lane
     PCFG(40, 16, 128, 4, 1),   // 100  640 px x 128: 4 waves x (160 px x 128): tiles 80-wide maps exactly
+    // persistent streaming tiles for 1x1 / stride-1 convs (conv1x1_stream_kernel: the ring of stages runs across tiles)
+    TCFG(128, 96, 32, 96, 1, 3),   // 101
+    TCFG(128, 64, 32, 64, 1, 3),   // 102
+    TCFG(128, 64, 32, 64, 1, 4),   // 103
+    TCFG(128, 128, 64, 64, 1, 3),  // 104
+    TCFG(64, 64, 32, 32, 1, 3),    // 105
+    TCFG(64, 96, 32, 96, 1, 3),    // 106  2 waves
+    TCFG(128, 192, 64, 96, 1, 3),  // 107  all 192 couts of the merged conv1|conv2 launches in one pass over the pixels
+    TCFG(128, 32, 32, 32, 1, 3),   // 108
+    TCFG(128, 96, 32, 96, 2, 3),   // 109  128 B per pixel per stage: whole lines per request
+    TCFG(128, 64, 32, 64, 2, 3),   // 110
+    TCFG(256, 64, 64, 64, 1, 3),   // 111
+    TCFG(128, 96, 32, 96, 1, 4),   // 112
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
@@ -252,7 +277,8 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     if (cfg < 0 || cfg >= kNumCfgs) return 0;
     const CfgEntry& e = g_cfgs[cfg];
     if (cout_pad % e.BC) return 0;
-    if (e.patch && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    if ((e.patch == 1 || e.patch == 2) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    if (e.patch == 3 && !(ksize == 1 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     return 1;
 }
 const char* vgh_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].name : "?"; }
@@ -261,6 +287,7 @@ int vgh_conv_cfg_cout_tile(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cf
 static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) return 0;
     if (a.grp_cout && a.grp_cout % g_cfgs[cfg].BC) return 0;
+    if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
     return 1;
 }
 
@@ -388,7 +415,7 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
         cfg = t;
     }
     const CfgEntry& e = g_cfgs[cfg];
-    if (e.patch) {
+    if (e.patch == 1 || e.patch == 2) {
         const int ntc = a.cout_pad / e.BC, ntx = (a.W + e.TW - 1) / e.TW, nty = (a.H + e.TH - 1) / e.TH;
         const int64_t total = (int64_t)a.B * nty * ntx * ntc;
         VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");

@@ -426,6 +426,8 @@ class VGHeadsEngine:
             return bool(self.lib.vgh_conv_split_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"], op.get("grp_cout", 0)))
         if not self.lib.vgh_conv_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"]):
             return False
+        if self.cfg_names()[cfg].startswith("t") and (op.get("res_buf", -1) >= 0 or op.get("grp_cout") or op.get("act") == 2):
+            return False  # streaming 1x1 tiles: plain bf16 -> bf16 convs only (the executor would fall back to another tile)
         return not op.get("grp_cout") or op["grp_cout"] % self.lib.vgh_conv_cfg_cout_tile(cfg) == 0
 
     def load_tuning(self, path: Optional[str] = None) -> int:

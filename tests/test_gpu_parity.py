@@ -410,6 +410,41 @@ def test_conv_persistent_multi_tile(gpu_lib, cin, res):
     assert tested >= 20
 
 
+@pytest.mark.parametrize("cin,cout,cap", [(32, 64, 2), (64, 192, 2), (96, 96, 3), (96, 192, 64), (384, 96, 2), (640, 192, 5), (160, 128, 1)])
+def test_conv_stream_tiles_multi_tile(gpu_lib, cin, cout, cap):
+    """Streaming 1x1 tiles ("t": conv1x1_stream_kernel) with MANY tiles per persistent workgroup: the ring of stages running across tiles (operands of
+    tile t+1 in flight under the MFMAs and stores of tile t), the counted waits over loads AND stores (K loops of 1, 2, 3, 5, 12 and 20 steps against
+    3- and 4-stage rings), cout-tile changes between consecutive tiles, a ragged last pixel tile, two output segments and a masked channel tail."""
+    g = torch.Generator().manual_seed(3 * cin + cout)
+    B, H, W = 3, 41, 55  # 6765 pixels: not a multiple of any tile
+    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).float()
+    Wt = torch.randn(cout, 1, 1, cin, generator=g) * (1.5 / np.sqrt(cin)) * (1.0 + 0.5 * torch.arange(cout).float()[:, None, None, None] / cout)
+    b = torch.randn(cout, generator=g)
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    tested = 0
+    try:
+        assert gpu_lib.vgh_conv_set_max_blocks_per_xcd(cap) == 0
+        for cfg, name in enumerate(names):
+            if name[0] != "t" or not gpu_lib.vgh_conv_cfg_ok(cfg, 1, 1, cout, 1, 0):
+                continue
+            for act in (1, 0):
+                out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 1, 1, cfg=cfg, act=act)
+                _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"stream cfg={name} cap={cap} cin={cin} act={act}")
+                assert float((out[..., :o0] + 768.0).abs().max()) == 0.0 and float((out[..., o0 + st :] + 768.0).abs().max()) == 0.0, f"{name}: wrote outside its channels"
+            # two output segments (CSP conv1|conv2) and a masked tail (cout_store < cout_pad)
+            h = cout // 2 // 8 * 8
+            out, ref, st, _ = _run_conv(gpu_lib, x, Wt, b, 1, 1, split=(h, cout - h + 8, 0), cfg=cfg)
+            _assert_close(out[..., cout - h + 8 : cout + 8], ref[..., :h], False, f"stream split seg0 cfg={name}")
+            _assert_close(out[..., 0 : cout - h], ref[..., h:cout], False, f"stream split seg1 cfg={name}")
+            out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 1, 1, cfg=cfg, cout_store=cout - 8)
+            _assert_close(out[..., o0 : o0 + cout - 8], ref[..., : cout - 8], False, f"stream masked tail cfg={name}")
+            assert float((out[..., o0 + cout - 8 :] + 768.0).abs().max()) == 0.0, f"{name}: wrote past cout_store"
+            tested += 1
+    finally:
+        gpu_lib.vgh_conv_set_max_blocks_per_xcd(0)
+    assert tested >= 2
+
+
 def test_conv_silu_epilogue(gpu_lib):
     """VGH_ACT_SILU (north_star's "BN/SiLU fusion"; the VGGHeads graphs themselves are all-ReLU): x * sigmoid(x) with the hardware
     exp (__expf, ~2 ulp fp32 -- far below the bf16 output rounding, and within 1e-6 relative on the fp32 store path) in every

@@ -70,6 +70,17 @@ for step in "$@"; do
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_knob -o FETCH_SIZE -- python $ROOT/tools/traffic_run.py --forwards 2 --split 1 --knob ${KNOB:-vgh_conv_set_nt_store}=1 > $O/pmc_knob_F.log 2>&1)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_knob -o WRITE_SIZE -- python $ROOT/tools/traffic_run.py --forwards 2 --split 1 --knob ${KNOB:-vgh_conv_set_nt_store}=1 > $O/pmc_knob_W.log 2>&1)
       python tools/pmc_per_op.py $O/pmc_knob vgg_heads_l 64 2 $O/per_op_knob.txt; tail -1 $O/per_op_knob.txt ;;
+    tunet)
+      # the streaming 1x1 tiles against the current table, both benchmark buckets (report only unless TUNE_WRITE=1)
+      W=$([ "${TUNE_WRITE:-0}" = 1 ] && echo "" || echo "--no-write")
+      SP=${SPLIT:-1}
+      timeout 900 python tools/tune_conv.py --variant vgg_heads_l --batch 64 --only t --split $SP $W --report $O/${TAG}_tune_t_l64x$SP.json > $O/tunet.log 2>&1
+      timeout 900 python tools/tune_conv.py --variant vgg_heads_m --batch 32 --only t --split $SP $W --report $O/${TAG}_tune_t_m32x$SP.json >> $O/tunet.log 2>&1
+      timeout 900 python tools/tune_conv.py --variant vgg_heads_l --batch 16 --image-size 1280 --only t --split $SP $W --report $O/${TAG}_tune_t_l16_1280x$SP.json >> $O/tunet.log 2>&1
+      grep -v amdgpu $O/tunet.log | tail -${TAILN:-70}; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
+    abtable)
+      # the committed table before this step's retune (tools/_prev_table.json, untracked) against the current one, alternating on one engine
+      timeout 900 python tools/ab_table.py ${PREV_TABLE:-tools/_prev_table.json} head_detector_amd/tuning/conv_cfg.json --rounds ${ROUNDS:-4} > $O/abtable.log 2>&1; grep -v amdgpu $O/abtable.log | tail -8 ;;
     abknob)
       timeout 900 python tools/ab_knob.py ${KNOB:-vgh_conv_set_nt_store} --json $O/${TAG}_ab_${KNOB:-vgh_conv_set_nt_store}.json ${KNOB_ARGS:-} > $O/abknob.log 2>&1; grep -v amdgpu $O/abknob.log | tail -${TAILN:-60} ;;
     probe)

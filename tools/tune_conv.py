@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--split", type=int, default=1, help="measure with the batch split over this many lane streams (vgh_net_set_split)")
     ap.add_argument("--out", default=os.path.join(TUNING_DIR, "conv_cfg.json"))
     ap.add_argument("--report", default=None)
+    ap.add_argument("--only", default=None, help="measure only tiles whose name starts with this prefix (e.g. t: the streaming 1x1 tiles), next to the current table")
+    ap.add_argument("--no-write", action="store_true", help="report only, leave the table alone")
     ap.add_argument("--precision", default="bf16", help="bf16 (throughput tiles) or fp16x3 / bf16x3 (the split-precision tile set; keys get a precision prefix)")
     args = ap.parse_args()
     eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, use_tuning=False, precision=args.precision)
@@ -35,7 +37,14 @@ def main():
     conv_idx = [i for i, op in enumerate(ops) if op["kind"] == 1]
     best = {}
     times = {i: {} for i in conv_idx}
+    if args.only:  # the current table's choice as the reference row of every op
+        eng.load_tuning()
+        runs = [eng.profile_ops(x) for _ in range(args.reps + 1)][1:]
+        for i in conv_idx:
+            times[i]["<table>"] = min(r[i]["ms"] for r in runs)
     for c, name in enumerate(names):
+        if args.only and not name.startswith(args.only):
+            continue
         ok = [i for i in conv_idx if eng.cfg_ok(c, ops[i])]
         if not ok:
             continue
@@ -52,11 +61,19 @@ def main():
             best[key] = (w, times[i][w])
         fl = 2.0 * ops[i]["macs"] * args.batch
         report.append(dict(name=ops[i]["name"], key=key, best=w, ms=times[i][w], tflops=fl / times[i][w] / 1e9, all={k: round(v, 4) for k, v in sorted(times[i].items(), key=lambda kv: kv[1])}))
-    table = {k: v[0] for k, v in best.items()}
-    old = json.load(open(args.out)) if os.path.exists(args.out) else {}
-    old.update(table)
-    os.makedirs(os.path.dirname(args.out), exist_ok=True)
-    json.dump(old, open(args.out, "w"), indent=0, sort_keys=True)
+    table = {k: v[0] for k, v in best.items() if v[0] != "<table>"}
+    if not args.no_write:
+        old = json.load(open(args.out)) if os.path.exists(args.out) else {}
+        old.update(table)
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        json.dump(old, open(args.out, "w"), indent=0, sort_keys=True)
+    if args.only:
+        gain = 0.0
+        for r in report:
+            if r["best"] != "<table>":
+                gain += r["all"]["<table>"] - r["ms"]
+                print(f"  {r['name']:44s} table {r['all']['<table>'] * 1e3:7.1f} us -> {r['best']:28s} {r['ms'] * 1e3:7.1f} us")
+        print(f"  single-stream gain over the table: {gain * 1e3:.1f} us")
     tot = sum(r["ms"] for r in report)
     print(f"{args.variant} B={args.batch} split={args.split}: sum of best conv times {tot:.3f} ms -> {eng.flops_per_image * args.batch / tot / 1e9:.1f} TFLOP/s over convs; {len(table)} shapes")
     if args.report:
