@@ -24,7 +24,7 @@ struct CfgEntry {
     const char* name;
     int BP, BC, threads, lds;
     void (*launch)(const ConvArgs&, int, int, int, int, hipStream_t);
-    int patch, TW, TH;  // patch != 0: conv3x3_patch_kernel (1) / conv3x3_patch3_kernel (2): 3x3, stride 1, fast epilogue only, tile TH x TW
+    int patch, TW, TH;  // 1 / 2: conv3x3_patch_kernel / conv3x3_patch3_kernel (3x3, stride 1, tile TH x TW); 3: conv1x1_stream_kernel; 4: conv3x3_patch_kernel stride 2 (output tile TH x TW); fast epilogue only
     void (*launch_patch)(const ConvArgs&, int, int, int, int, int, int, hipStream_t);
 };
 
@@ -72,6 +72,14 @@ void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, i
     const int n = patch_blocks_per_cu(conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, NWP * NWC * 64, lds, per_cu);
     const int gpx = persistent_blocks_per_xcd(a, chunk, n);
     hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
+}
+
+template <int TW, int TH, int BC, int NWP, int NWC>
+void launch_patch_s2_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
+    static std::atomic<int> per_cu[kMaxDevices];
+    const int n = patch_blocks_per_cu(conv3x3_patch_kernel<TW, TH, BC, NWP, NWC, 0, 1>, NWP * NWC * 64, lds, per_cu);
+    const int gpx = persistent_blocks_per_xcd(a, chunk, n);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC, 0, 1>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
 
 template <int TW, int TH, int BC, int NWP, int NWC>
@@ -128,6 +136,8 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
 #define QCFG(TW, TH, BC, NWP, NWC) \
     { "q" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, Patch3<TW, TH, BC, NWP, NWC>::LDS, nullptr, 2, TW, TH, launch_patch3_cfg<TW, TH, BC, NWP, NWC> }
 
+#define DCFG(TW, TH, BC, NWP, NWC) \
+    { "d" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC, 1>(), nullptr, 4, TW, TH, launch_patch_s2_cfg<TW, TH, BC, NWP, NWC> }
 #define TCFG(BP, BC, WP, WC, KBS, NST) \
     { "t" #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, Stream1<BP, BC, WP, WC, KBS, NST>::LDS, launch_stream_cfg<BP, BC, WP, WC, KBS, NST>, 3, 0, 0, nullptr }
 
@@ -248,6 +258,14 @@ const CfgEntry g_cfgs[] = {
     TCFG(128, 64, 32, 64, 2, 3),   // 110
     TCFG(256, 64, 64, 64, 1, 3),   // 111
     TCFG(128, 96, 32, 96, 1, 4),   // 112
+    // halo-patch tiles for 3x3 / stride-2 convs (conv3x3_patch_kernel<..., S2 = 1>: the input patch de-interleaved into four parity planes).
+    // Measured (profiles/r03_tune_d_*.json): correct and conflict-free, but 10 - 60 % SLOWER than the implicit-GEMM rings on every stride-2 layer
+    // (stage-1 downsample 439 vs 368 us): a 64-pixel tile has 0.3 us of MFMAs per (channel block, kernel row) step against a 1 us L2 round trip for
+    // the next step's weights.  Kept as tuner candidates (the four best shapes; eight more were measured and dropped).
+    DCFG(16, 4, 96, 1, 3),    // 113  64 output px x 96: 3 waves x (64 px x 32)
+    DCFG(16, 4, 64, 2, 2),    // 114  4 waves x (32 px x 32)
+    DCFG(16, 8, 128, 4, 2),   // 115  128 output px: 8 waves x (32 px x 64)
+    DCFG(32, 4, 128, 4, 2),   // 116
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
@@ -279,6 +297,7 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     if (cout_pad % e.BC) return 0;
     if ((e.patch == 1 || e.patch == 2) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 3 && !(ksize == 1 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    if (e.patch == 4 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle)) return 0;
     return 1;
 }
 const char* vgh_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].name : "?"; }
@@ -415,8 +434,8 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
         cfg = t;
     }
     const CfgEntry& e = g_cfgs[cfg];
-    if (e.patch == 1 || e.patch == 2) {
-        const int ntc = a.cout_pad / e.BC, ntx = (a.W + e.TW - 1) / e.TW, nty = (a.H + e.TH - 1) / e.TH;
+    if (e.patch == 1 || e.patch == 2 || e.patch == 4) {
+        const int ntc = a.cout_pad / e.BC, ntx = (a.Wo + e.TW - 1) / e.TW, nty = (a.Ho + e.TH - 1) / e.TH;  // (Ho, Wo) = (H, W) for the stride-1 tiles
         const int64_t total = (int64_t)a.B * nty * ntx * ntc;
         VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
         const int chunk = (int)((total + 7) / 8);

@@ -445,6 +445,32 @@ def test_conv_stream_tiles_multi_tile(gpu_lib, cin, cout, cap):
     assert tested >= 2
 
 
+@pytest.mark.parametrize("cin,H,W", [(64, 41, 57), (96, 40, 64), (32, 33, 35)])
+def test_conv_stride2_patch_tiles_multi_tile(gpu_lib, cin, H, W):
+    """Stride-2 halo-patch tiles ("d": the input patch de-interleaved into four parity planes in LDS) with many tiles per persistent workgroup: odd and
+    even input sizes (the last input row / column is or is not read), ragged output tiles, every cout tile width, all image borders zero-padded."""
+    g = torch.Generator().manual_seed(7 * cin + H)
+    B, Cout = 3, 384
+    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).float()
+    Wt = torch.randn(Cout, 3, 3, cin, generator=g) * (1.5 / np.sqrt(9 * cin)) * (1.0 + 0.5 * torch.arange(Cout).float()[:, None, None, None] / Cout)
+    b = torch.randn(Cout, generator=g)
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    tested = 0
+    try:
+        for cap in (2, 0):
+            assert gpu_lib.vgh_conv_set_max_blocks_per_xcd(cap) == 0
+            for cfg, name in enumerate(names):
+                if name[0] != "d" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 2, Cout, 1, 0):
+                    continue
+                out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 2, cfg=cfg)
+                _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"stride-2 patch cfg={name} cap={cap} cin={cin} {H}x{W}")
+                assert float((out[..., :o0] + 768.0).abs().max()) == 0.0 and float((out[..., o0 + st :] + 768.0).abs().max()) == 0.0, f"{name}: wrote outside its channels"
+                tested += 1
+    finally:
+        gpu_lib.vgh_conv_set_max_blocks_per_xcd(0)
+    assert tested >= 8
+
+
 def test_conv_silu_epilogue(gpu_lib):
     """VGH_ACT_SILU (north_star's "BN/SiLU fusion"; the VGGHeads graphs themselves are all-ReLU): x * sigmoid(x) with the hardware
     exp (__expf, ~2 ulp fp32 -- far below the bf16 output rounding, and within 1e-6 relative on the fp32 store path) in every

@@ -74,9 +74,9 @@ for step in "$@"; do
       # the streaming 1x1 tiles against the current table, both benchmark buckets (report only unless TUNE_WRITE=1)
       W=$([ "${TUNE_WRITE:-0}" = 1 ] && echo "" || echo "--no-write")
       SP=${SPLIT:-1}
-      timeout 900 python tools/tune_conv.py --variant vgg_heads_l --batch 64 --only t --split $SP $W --report $O/${TAG}_tune_t_l64x$SP.json > $O/tunet.log 2>&1
-      timeout 900 python tools/tune_conv.py --variant vgg_heads_m --batch 32 --only t --split $SP $W --report $O/${TAG}_tune_t_m32x$SP.json >> $O/tunet.log 2>&1
-      timeout 900 python tools/tune_conv.py --variant vgg_heads_l --batch 16 --image-size 1280 --only t --split $SP $W --report $O/${TAG}_tune_t_l16_1280x$SP.json >> $O/tunet.log 2>&1
+      timeout 900 python tools/tune_conv.py --variant vgg_heads_l --batch 64 --only ${ONLY:-t} --split $SP $W --report $O/${TAG}_tune_${ONLY:-t}_l64x$SP.json > $O/tunet.log 2>&1
+      timeout 900 python tools/tune_conv.py --variant vgg_heads_m --batch 32 --only ${ONLY:-t} --split $SP $W --report $O/${TAG}_tune_${ONLY:-t}_m32x$SP.json >> $O/tunet.log 2>&1
+      timeout 900 python tools/tune_conv.py --variant vgg_heads_l --batch 16 --image-size 1280 --only ${ONLY:-t} --split $SP $W --report $O/${TAG}_tune_${ONLY:-t}_l16_1280x$SP.json >> $O/tunet.log 2>&1
       grep -v amdgpu $O/tunet.log | tail -${TAILN:-70}; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     abtable)
       # the committed table before this step's retune (tools/_prev_table.json, untracked) against the current one, alternating on one engine
