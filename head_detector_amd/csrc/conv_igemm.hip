@@ -266,6 +266,13 @@ const CfgEntry g_cfgs[] = {
     DCFG(16, 4, 64, 2, 2),    // 114  4 waves x (32 px x 32)
     DCFG(16, 8, 128, 4, 2),   // 115  128 output px: 8 waves x (32 px x 64)
     DCFG(32, 4, 128, 4, 2),   // 116
+    // 64-pixel halo-patch tiles for the 20^2 / 40^2 maps at small batch (M b32: 12 800 pixels = 100 tiles of 128 px per cout tile, i.e. one partial
+    // round of the chip; twice the tiles of half the length fill it better)
+    PCFG(16, 4, 64, 2, 2),    // 117  4 waves x (32 px x 32)
+    PCFG(16, 4, 128, 2, 2),   // 118  4 waves x (32 px x 64)
+    PCFG(16, 4, 128, 2, 4),   // 119  8 waves x (32 px x 32)
+    PCFG(16, 4, 96, 2, 3),    // 120  6 waves x (32 px x 32)
+    PCFG(16, 4, 64, 2, 1),    // 121  2 waves x (32 px x 64)
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };

@@ -444,17 +444,29 @@ class VGHeadsEngine:
             if op["kind"] != 1:
                 continue
             pre = "" if self.precision == "bf16" else self.precision + ":"
-            key = pre + tuning_key(op, self.max_batch, getattr(self, "nsplit", 1))
-            name = table.get(key, table.get(pre + tuning_key(op, self.max_batch)))
+            name = tuning_lookup(table, op, self.max_batch, getattr(self, "nsplit", 1), pre)
             if name in names:
                 self.set_cfg(i, names[name])
                 applied += 1
         return applied
 
 
-def tuning_key(op: dict, batch: int, nsplit: int = 1) -> str:
+def tuning_key(op: dict, batch: int, nsplit: int = 1, bucket: Optional[int] = None) -> str:
     m, n, k = op["gemm"]
-    bucket = 1 if batch <= 2 else (8 if batch <= 16 else 32)
+    if bucket is None:  # b64 (r03): the 20^2 / 40^2 maps of a 32-image batch fill the chip differently from those of 64 images
+        bucket = 1 if batch <= 2 else (8 if batch <= 16 else (32 if batch <= 32 else 64))
     lanes = f"x{nsplit}" if nsplit > 1 else ""  # tile choices measured with the batch split over `nsplit` lane streams
     grp = f"_g{op['grp_cout']}" if op.get("grp_cout") else ""
     return f"b{bucket}{lanes}_m{m}_n{n}_k{k}_ks{op['ksize']}_s{op['stride']}{grp}"
+
+
+def tuning_lookup(table: Dict[str, str], op: dict, batch: int, nsplit: int = 1, prefix: str = "") -> Optional[str]:
+    """Tile name of the measured table for this op: the key of this batch bucket and lane count first, then the same shape measured without lanes,
+    then (batches above 32) the b32 entries, which covered every large batch before the b64 bucket existed."""
+    keys = [tuning_key(op, batch, nsplit), tuning_key(op, batch)]
+    if batch > 32:
+        keys += [tuning_key(op, batch, nsplit, bucket=32), tuning_key(op, batch, bucket=32)]
+    for k in keys:
+        if prefix + k in table:
+            return table[prefix + k]
+    return None

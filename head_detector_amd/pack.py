@@ -101,7 +101,7 @@ def read_header(path: str) -> Dict[str, Any]:
 
 def tile_names_for(program: "arch.Program", batch: int, nsplit: int = 1, table_path: Optional[str] = None) -> Dict[int, str]:
     """Per-op tile choices of the measured table for this batch bucket / lane count (what VGHeadsEngine.load_tuning applies)."""
-    from .engine import TUNING_DIR, tuning_key
+    from .engine import TUNING_DIR, tuning_lookup
 
     path = table_path or os.path.join(TUNING_DIR, "conv_cfg.json")
     if not os.path.exists(path):
@@ -112,7 +112,7 @@ def tile_names_for(program: "arch.Program", batch: int, nsplit: int = 1, table_p
     for i, op in enumerate(program.ops):
         if op["kind"] != 1:
             continue
-        name = table.get(pre + tuning_key(op, batch, nsplit), table.get(pre + tuning_key(op, batch)))
+        name = tuning_lookup(table, op, batch, nsplit, pre)
         if name:
             out[i] = name
     return out

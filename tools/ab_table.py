@@ -18,10 +18,10 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    for variant, B in (("vgg_heads_l", 64), ("vgg_heads_m", 32)):
-        eng = VGHeadsEngine(variant, image_size=640, max_batch=B, seed=1)
+    for variant, B, S in (("vgg_heads_l", 64, 640), ("vgg_heads_m", 32, 640), ("vgg_heads_l", 16, 1280)):
+        eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=1)
         eng.set_split(2)
-        x = torch.randint(0, 256, (B, 640, 640, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+        x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
         res = {t: [] for t in args.tables}
         for r in range(args.rounds):
             for t in args.tables:
@@ -40,7 +40,7 @@ def main():
                 res[t].append(e0.elapsed_time(e1) / args.steps)
         for t in args.tables:
             v = sorted(res[t])
-            print(f"{variant} b{B} {os.path.basename(t)} ({n} ops): min {v[0]:.3f} median {v[len(v) // 2]:.3f} ms/forward = {eng.flops_per_image * B / v[len(v) // 2] / 1e9:.1f} TFLOP/s", flush=True)
+            print(f"{variant} b{B}@{S} {os.path.basename(t)} ({n} ops): min {v[0]:.3f} median {v[len(v) // 2]:.3f} ms/forward = {eng.flops_per_image * B / v[len(v) // 2] / 1e9:.1f} TFLOP/s", flush=True)
         eng.close()
 
 

@@ -80,7 +80,7 @@ for step in "$@"; do
       grep -v amdgpu $O/tunet.log | tail -${TAILN:-70}; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     abtable)
       # the committed table before this step's retune (tools/_prev_table.json, untracked) against the current one, alternating on one engine
-      timeout 900 python tools/ab_table.py ${PREV_TABLE:-tools/_prev_table.json} head_detector_amd/tuning/conv_cfg.json --rounds ${ROUNDS:-4} > $O/abtable.log 2>&1; grep -v amdgpu $O/abtable.log | tail -8 ;;
+      timeout 900 python tools/ab_table.py ${PREV_TABLE:-tools/_prev_table.json} ${NEW_TABLES:-head_detector_amd/tuning/conv_cfg.json} --rounds ${ROUNDS:-4} > $O/abtable.log 2>&1; grep -v amdgpu $O/abtable.log | tail -8 ;;
     abknob)
       timeout 900 python tools/ab_knob.py ${KNOB:-vgh_conv_set_nt_store} --json $O/${TAG}_ab_${KNOB:-vgh_conv_set_nt_store}.json ${KNOB_ARGS:-} > $O/abknob.log 2>&1; grep -v amdgpu $O/abknob.log | tail -${TAILN:-60} ;;
     probe)

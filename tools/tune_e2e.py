@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from head_detector_amd.engine import TUNING_DIR, VGHeadsEngine, tuning_key  # noqa: E402
+from head_detector_amd.engine import TUNING_DIR, VGHeadsEngine, tuning_key, tuning_lookup  # noqa: E402
 
 
 def main():
@@ -57,7 +57,7 @@ def main():
     table = json.load(open(args.out)) if os.path.exists(args.out) else {}
     cur = {}
     for key, g in groups.items():
-        cur[key] = table.get(tuning_key(ops[g["ops"][0]], args.batch, args.split), table.get(key, g["best"]))
+        cur[key] = tuning_lookup(table, ops[g["ops"][0]], args.batch, args.split) or g["best"]
         for i in g["ops"]:
             eng.set_cfg(i, names[cur[key]])
     base = measure()
