@@ -201,6 +201,8 @@ def live_traffic(variant: str, batch: int, split: int, forwards: int = 6):
     import glob
     import tempfile
 
+    from head_detector_amd import arch
+
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
@@ -221,12 +223,20 @@ def live_traffic(variant: str, batch: int, split: int, forwards: int = 6):
             tot, n = 0.0, 0
             for row in csv.DictReader(open(files[0])):
                 k = row["Kernel_Name"]
-                if row["Counter_Name"] == ctr and ("conv_igemm" in k or "patch_kernel" in k or "patch3_kernel" in k or "stem_kernel" in k or "spp_pool" in k):
+                if row["Counter_Name"] == ctr and arch.is_net_kernel(k):
                     tot += float(row["Counter_Value"])
                     n += 1
             if n == 0:
                 return None
             out[ctr] = (tot, n)
+            try:  # every op is one launch per lane: a kernel family missing from arch.NET_KERNEL_MARKERS would show up here as too few dispatches
+                info = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                expected = info["ops_per_forward"] * split * forwards
+            except (IndexError, KeyError, ValueError):
+                expected = None
+            if expected is not None and n != expected:
+                sys.stderr.write(f"[bench] live traffic: {n} network dispatches counted, {expected} expected -- not reporting a partial sum\n")
+                return None
     rd = out["FETCH_SIZE"][0] * 1024 * 2 / forwards
     wr = out["WRITE_SIZE"][0] * 1024 / forwards
     return dict(read_bytes_per_forward=rd, write_bytes_per_forward=wr, launches_per_forward=out["FETCH_SIZE"][1] / forwards, forwards=forwards,
@@ -519,7 +529,7 @@ def main():
         roof = {"bound": "mfma", "achieved": round(main_run["conv_tflops"], 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(main_run["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                 "algorithmic_bytes_per_forward": round(main_run["alg_bytes"]),
-                "kernel": "conv_igemm_kernel<*> + conv3x3_patch_kernel<*> + conv3x3_patch3_kernel<*> + stem / pool (all launches of one forward = one pass of the op program over the batch: "
+                "kernel": "conv_igemm_kernel<*> + conv3x3_patch_kernel<*> + conv3x3_patch3_kernel<*> + conv1x1_stream_kernel<*> + stem / pool (all launches of one forward = one pass of the op program over the batch: "
                           "algorithmic 2*MACs / HIP-event time of the network part; traffic = PMC HBM bytes of one forward)"}
         if traffic is not None:
             tb = traffic["read_bytes_per_forward"] + traffic["write_bytes_per_forward"]

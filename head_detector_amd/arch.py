@@ -561,6 +561,15 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     return P
 
 
+# substrings of the HIP kernel names that run the op program (stem / conv / pool ops): what the PMC tooling (bench.py live_traffic, tools/pmc_*.py)
+# sums over.  Every op is ONE launch per lane, so a forward shows `ops x lanes` such dispatches -- the tools check that count.
+NET_KERNEL_MARKERS = ("conv_igemm", "patch_kernel", "patch3_kernel", "conv1x1_stream", "conv_f32", "stem_kernel", "stem_ds", "spp_pool")
+
+
+def is_net_kernel(kernel_name: str) -> bool:
+    return any(m in kernel_name for m in NET_KERNEL_MARKERS)
+
+
 def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]:
     """HBM bytes one op moves when every tensor is read / written exactly once (SURVEY.md 8(d) "algorithmic bytes"): the input view, the
     residual view and the packed weights read, the stored channels written.  What `roofline.traffic` (PMC FETCH_SIZE / WRITE_SIZE) is

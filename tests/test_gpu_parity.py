@@ -471,6 +471,33 @@ def test_conv_stride2_patch_tiles_multi_tile(gpu_lib, cin, H, W):
     assert tested >= 8
 
 
+def test_conv_non_temporal_stores_change_nothing(gpu_lib):
+    """vgh_conv_set_nt_store: the output stores of every kernel family carry the non-temporal hint -- a cache policy, not a value: outputs are bit-identical."""
+    g = torch.Generator().manual_seed(21)
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    first = {}
+    for i, n in enumerate(names):
+        first.setdefault(n[0] if n[0] in "pqtd" else "i", i)
+    cases = {"i": (3, 1, 64, 128), "p": (3, 1, 64, 128), "q": (3, 1, 64, 128), "t": (1, 1, 96, 96), "d": (3, 2, 64, 96)}
+    try:
+        for fam, cfg in first.items():
+            k, st, cin, cout = cases[fam]
+            if not gpu_lib.vgh_conv_cfg_ok(cfg, k, st, cout, 1, 0):
+                cfg = next(c for c, n in enumerate(names) if (n[0] == fam or (fam == "i" and n[0] not in "pqtd")) and gpu_lib.vgh_conv_cfg_ok(c, k, st, cout, 1, 0))
+            x = torch.randn(2, 24, 40, cin, generator=g).to(torch.bfloat16).float()
+            Wt = torch.randn(cout, k, k, cin, generator=g) * (1.0 / np.sqrt(k * k * cin))
+            b = torch.randn(cout, generator=g)
+            outs = []
+            for on in (0, 1):
+                assert gpu_lib.vgh_conv_set_nt_store(on) == 0
+                out, ref, stc, o0 = _run_conv(gpu_lib, x, Wt, b, k, st, cfg=cfg)
+                _assert_close(out[..., o0 : o0 + stc], ref[..., :stc], False, f"nt={on} {names[cfg]}")
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), names[cfg]
+    finally:
+        gpu_lib.vgh_conv_set_nt_store(0)
+
+
 def test_conv_silu_epilogue(gpu_lib):
     """VGH_ACT_SILU (north_star's "BN/SiLU fusion"; the VGGHeads graphs themselves are all-ReLU): x * sigmoid(x) with the hardware
     exp (__expf, ~2 ulp fp32 -- far below the bf16 output rounding, and within 1e-6 relative on the fp32 store path) in every

@@ -16,7 +16,9 @@ out = open(sys.argv[5], "w") if len(sys.argv) > 5 else sys.stdout
 
 
 def is_net(k):
-    return "conv_igemm" in k or "patch_kernel" in k or "patch3_kernel" in k or "stem_kernel" in k or "spp_pool" in k or "stem_ds" in k
+    from head_detector_amd import arch
+
+    return arch.is_net_kernel(k)
 
 
 def load(name):

@@ -19,7 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def is_net(k):
-    return "conv_igemm" in k or "patch_kernel" in k or "patch3_kernel" in k or "stem_kernel" in k or "spp_pool" in k
+    from head_detector_amd import arch
+
+    return arch.is_net_kernel(k)
 
 
 def load(name):
