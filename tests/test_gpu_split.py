@@ -368,6 +368,14 @@ def test_fp16x3_matrix_core_mode_meets_north_star_tolerances(gpu_lib, flame_mode
     _assert_north_star(r)
 
 
+def test_fp16x3_mode_meets_north_star_tolerances_at_1280(gpu_lib, flame_model):
+    """BASELINE configs[4]'s geometry (VGGHeads_L at 1280 x 1280, 33 600 anchors, a crowd's worth of kept detections) in the parity mode against the
+    unfused fp32 oracle: the longest spatial extents and the most detections any configuration produces, at north_star's bar."""
+    r = network_vs_oracle("vgg_heads_l", "l", "fp16x3", 1280, 1, flame_model, heads_per_image=32.0)
+    _assert_north_star(r)
+    assert r["kept"] >= 24, r
+
+
 @pytest.mark.parametrize("variant,okey,B", [("vgg_heads_m", "m", 2), ("vgg_heads_l", "l", 1)], ids=["m640", "l640"])
 def test_fp32_valu_mode_meets_north_star_tolerances_at_640(gpu_lib, flame_model, variant, okey, B):
     """The fp32 FMA mode (csrc/conv_f32.hip) at 640 x 640 against the oracle (r02 checked it at 160 x 160 only)."""
