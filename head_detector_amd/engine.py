@@ -461,11 +461,11 @@ def tuning_key(op: dict, batch: int, nsplit: int = 1, bucket: Optional[int] = No
 
 
 def tuning_lookup(table: Dict[str, str], op: dict, batch: int, nsplit: int = 1, prefix: str = "") -> Optional[str]:
-    """Tile name of the measured table for this op: the key of this batch bucket and lane count first, then the same shape measured without lanes,
-    then (batches above 32) the b32 entries, which covered every large batch before the b64 bucket existed."""
-    keys = [tuning_key(op, batch, nsplit), tuning_key(op, batch)]
-    if batch > 32:
-        keys += [tuning_key(op, batch, nsplit, bucket=32), tuning_key(op, batch, bucket=32)]
+    """Tile name of the measured table for this op: the key of this batch bucket and lane count first (for batches above 32 then the b32 entry of that
+    lane count: b32 covered every large batch before the b64 bucket existed), then the same without lanes."""
+    b32 = batch > 32
+    keys = [tuning_key(op, batch, nsplit)] + ([tuning_key(op, batch, nsplit, bucket=32)] if b32 else [])  # entries measured with this lane count first
+    keys += [tuning_key(op, batch)] + ([tuning_key(op, batch, bucket=32)] if b32 else [])
     for k in keys:
         if prefix + k in table:
             return table[prefix + k]

@@ -54,6 +54,10 @@ for step in "$@"; do
       tail -2 $O/tune1280.log; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     flame)
       timeout 900 python tools/flame_sweep.py $O/${TAG}_flame_sweep.json > $O/flame.log 2>&1; grep -v amdgpu $O/flame.log | tail -${TAILN:-30} ;;
+    proflame)
+      # per-kernel split of the FLAME decode at FLAME_NS heads (prologue vs vertex kernel)
+      (cd /tmp && FLAME_NS=${FLAME_NS:-512} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/proflame -o f -- python $ROOT/tools/flame_sweep.py > $O/proflame.log 2>&1)
+      f=$(find $O/proflame -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" | cut -c1-260 ;;
     pmcflame)
       (cd /tmp && FLAME_NS=8192 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmcf -o f -- python $ROOT/tools/flame_sweep.py > $O/pmcflame.log 2>&1)
       python tools/pmc_flame_summary.py $O/pmcf $O/${TAG}_pmc_flame.txt ;;
@@ -78,6 +82,12 @@ for step in "$@"; do
       timeout 900 python tools/tune_conv.py --variant vgg_heads_m --batch 32 --only ${ONLY:-t} --split $SP $W --report $O/${TAG}_tune_${ONLY:-t}_m32x$SP.json >> $O/tunet.log 2>&1
       timeout 900 python tools/tune_conv.py --variant vgg_heads_l --batch 16 --image-size 1280 --only ${ONLY:-t} --split $SP $W --report $O/${TAG}_tune_${ONLY:-t}_l16_1280x$SP.json >> $O/tunet.log 2>&1
       grep -v amdgpu $O/tunet.log | tail -${TAILN:-70}; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
+    tunee2e)
+      # per-op report of EVERY tile with two lanes (no table write), then coordinate descent on the whole two-lane forward from the current table
+      V=${E2E_VARIANT:-vgg_heads_l}; B=${E2E_BATCH:-64}; S=${E2E_SIZE:-640}
+      timeout 1200 python tools/tune_conv.py --variant $V --batch $B --image-size $S --split 2 --reps 3 --no-write --report $O/${TAG}_tune_${V}_b${B}x2.json > $O/tunee2e.log 2>&1
+      timeout 1200 python tools/tune_e2e.py --variant $V --batch $B --image-size $S --split 2 --report $O/${TAG}_tune_${V}_b${B}x2.json --topk ${TOPK:-4} --log $O/${TAG}_tune_e2e_${V}_b${B}.json >> $O/tunee2e.log 2>&1
+      grep -v amdgpu $O/tunee2e.log | tail -${TAILN:-30}; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     abtable)
       # the committed table before this step's retune (tools/_prev_table.json, untracked) against the current one, alternating on one engine
       timeout 900 python tools/ab_table.py ${PREV_TABLE:-tools/_prev_table.json} ${NEW_TABLES:-head_detector_amd/tuning/conv_cfg.json} --rounds ${ROUNDS:-4} > $O/abtable.log 2>&1; grep -v amdgpu $O/abtable.log | tail -8 ;;

@@ -27,11 +27,12 @@ def main():
     ap.add_argument("--min-gain", type=float, default=0.002)
     ap.add_argument("--out", default=os.path.join(TUNING_DIR, "conv_cfg.json"))
     ap.add_argument("--log", default=None)
+    ap.add_argument("--image-size", type=int, default=640)
     args = ap.parse_args()
-    eng = VGHeadsEngine(args.variant, image_size=640, max_batch=args.batch, seed=1)
+    eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, seed=1)
     eng.set_split(args.split)
     names = {n: i for i, n in enumerate(eng.cfg_names())}
-    x = torch.randint(0, 256, (args.batch, 640, 640, 3), dtype=torch.uint8).cuda()
+    x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8).cuda()
     ops = eng.program.ops
     report = {r["name"]: r for r in json.load(open(args.report))}
     groups = {}
@@ -45,13 +46,14 @@ def main():
     def measure():
         best = 1e9
         for _ in range(3):
-            eng.forward_net(x)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(12):
+            for _ in range(4):  # back to the steady clock / power state before timing
                 eng.forward_net(x)
             torch.cuda.synchronize()
-            best = min(best, (time.perf_counter() - t0) / 12 * 1e3)
+            t0 = time.perf_counter()
+            for _ in range(16):
+                eng.forward_net(x)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 16 * 1e3)
         return best
 
     table = json.load(open(args.out)) if os.path.exists(args.out) else {}
