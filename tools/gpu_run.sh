@@ -84,9 +84,9 @@ for step in "$@"; do
       grep -v amdgpu $O/tunet.log | tail -${TAILN:-70}; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     tunee2e)
       # per-op report of EVERY tile with two lanes (no table write), then coordinate descent on the whole two-lane forward from the current table
-      V=${E2E_VARIANT:-vgg_heads_l}; B=${E2E_BATCH:-64}; S=${E2E_SIZE:-640}
-      timeout 1200 python tools/tune_conv.py --variant $V --batch $B --image-size $S --split 2 --reps 3 --no-write --report $O/${TAG}_tune_${V}_b${B}x2.json > $O/tunee2e.log 2>&1
-      timeout 1200 python tools/tune_e2e.py --variant $V --batch $B --image-size $S --split 2 --report $O/${TAG}_tune_${V}_b${B}x2.json --topk ${TOPK:-4} --log $O/${TAG}_tune_e2e_${V}_b${B}.json >> $O/tunee2e.log 2>&1
+      V=${E2E_VARIANT:-vgg_heads_l}; B=${E2E_BATCH:-64}; S=${E2E_SIZE:-640}; PR=${E2E_PRECISION:-bf16}
+      timeout 1200 python tools/tune_conv.py --variant $V --batch $B --image-size $S --split 2 --reps 3 --no-write --precision $PR --report $O/${TAG}_tune_${V}_b${B}x2.json > $O/tunee2e.log 2>&1
+      timeout 1200 python tools/tune_e2e.py --variant $V --batch $B --image-size $S --split 2 --precision $PR --report $O/${TAG}_tune_${V}_b${B}x2.json --topk ${TOPK:-4} --log $O/${TAG}_tune_e2e_${V}_b${B}.json >> $O/tunee2e.log 2>&1
       grep -v amdgpu $O/tunee2e.log | tail -${TAILN:-30}; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     abtable)
       # the committed table before this step's retune (tools/_prev_table.json, untracked) against the current one, alternating on one engine

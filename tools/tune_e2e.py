@@ -28,8 +28,10 @@ def main():
     ap.add_argument("--out", default=os.path.join(TUNING_DIR, "conv_cfg.json"))
     ap.add_argument("--log", default=None)
     ap.add_argument("--image-size", type=int, default=640)
+    ap.add_argument("--precision", default="bf16", help="bf16, or fp16x3 / bf16x3 (the parity modes' own tile table; keys get the precision prefix)")
     args = ap.parse_args()
-    eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, seed=1)
+    eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, seed=1, precision=args.precision)
+    pre = "" if args.precision == "bf16" else args.precision + ":"
     eng.set_split(args.split)
     names = {n: i for i, n in enumerate(eng.cfg_names())}
     x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8).cuda()
@@ -59,7 +61,7 @@ def main():
     table = json.load(open(args.out)) if os.path.exists(args.out) else {}
     cur = {}
     for key, g in groups.items():
-        cur[key] = tuning_lookup(table, ops[g["ops"][0]], args.batch, args.split) or g["best"]
+        cur[key] = tuning_lookup(table, ops[g["ops"][0]], args.batch, args.split, pre) or g["best"]
         for i in g["ops"]:
             eng.set_cfg(i, names[cur[key]])
     base = measure()
@@ -89,7 +91,7 @@ def main():
     print(f"final forward: {final:.3f} ms")
     log.append(dict(step="final", ms=final))
     for key, g in groups.items():
-        table[tuning_key(ops[g["ops"][0]], args.batch, args.split)] = cur[key]
+        table[pre + tuning_key(ops[g["ops"][0]], args.batch, args.split)] = cur[key]
     json.dump(table, open(args.out, "w"), indent=0, sort_keys=True)
     if args.log:
         json.dump(log, open(args.log, "w"), indent=1)
