@@ -342,6 +342,47 @@ def test_pack_file_round_trip(tmp_path):
     assert pack.read_header(str(tmp_path / "cli.vghpack"))["has_flame"] == 0
 
 
+def test_tuning_lookup_precedence_and_kernel_name_list():
+    """The measured tile table is keyed by batch bucket and lane count: an entry measured with this lane count wins over one measured without
+    lanes, the b64 bucket falls back to b32 (which covered every large batch before r03), the parity modes carry a precision prefix -- and every
+    tile the committed table names exists in the library.  arch.NET_KERNEL_MARKERS (what the PMC tools sum over) covers every kernel family that
+    runs an op of the program."""
+    import json
+
+    from head_detector_amd import pack
+    from head_detector_amd.engine import TUNING_DIR, tuning_key, tuning_lookup
+
+    P = arch.build_program("vgg_heads_l", arch.random_state_dict("vgg_heads_l", 1), 640)
+    op = next(o for o in P.ops if o["kind"] == 1 and o["ksize"] == 3 and o["stride"] == 1)
+    k64x2, k32x2, k64, k32 = tuning_key(op, 64, 2), tuning_key(op, 64, 2, bucket=32), tuning_key(op, 64), tuning_key(op, 64, bucket=32)
+    assert k64x2.startswith("b64x2_") and k32x2.startswith("b32x2_") and k64.startswith("b64_m") and k32.startswith("b32_m") and tuning_key(op, 32, 2) == k32x2
+    assert tuning_key(op, 16, 2).startswith("b8x2_") and tuning_key(op, 1).startswith("b1_")
+    t = {k32: "d"}
+    assert tuning_lookup(t, op, 64, 2) == "d" and tuning_lookup(t, op, 64, 1) == "d" and tuning_lookup(t, op, 32, 2) == "d" and tuning_lookup(t, op, 16, 2) is None
+    t[k64] = "c"
+    assert tuning_lookup(t, op, 64, 2) == "c" and tuning_lookup(t, op, 32, 2) == "d"
+    t[k32x2] = "b"
+    assert tuning_lookup(t, op, 64, 2) == "b" and tuning_lookup(t, op, 64, 1) == "c" and tuning_lookup(t, op, 32, 2) == "b"
+    t[k64x2] = "a"
+    assert tuning_lookup(t, op, 64, 2) == "a" and tuning_lookup(t, op, 32, 2) == "b"
+    assert tuning_lookup(t, op, 64, 2, "fp16x3:") is None and tuning_lookup({"fp16x3:" + k32x2: "s"}, op, 64, 2, "fp16x3:") == "s"
+    table = json.load(open(os.path.join(TUNING_DIR, "conv_cfg.json")))
+    lib = _lib.load()
+    bf16 = {lib.vgh_conv_cfg_name(i).decode() for i in range(lib.vgh_conv_num_cfgs())}
+    split = {lib.vgh_conv_split_cfg_name(i).decode() for i in range(lib.vgh_conv_split_num_cfgs())}
+    for key, name in table.items():
+        assert name in (split if ":" in key else bf16), (key, name)
+    assert {n[0] for n in bf16} >= set("pqtd") and any(n.startswith("t") for n in table.values())  # halo-patch v2 / v3, streaming 1x1, stride-2 planes
+    # the parity mode's pack carries the tile names of ITS table
+    P3 = arch.build_program("vgg_heads_l", arch.random_state_dict("vgg_heads_l", 1), 640, "fp16x3")
+    n3 = pack.tile_names_for(P3, 32, 2)
+    assert len(n3) > 40 and set(n3.values()) <= split
+    for k in ("conv_igemm_kernel<256, 128, 64, 64, 1, 1, 3, 0>", "conv3x3_patch_kernel<16, 16, 64, 4, 1, 0, 0>", "conv3x3_patch3_kernel<16, 16, 96, 4, 1>", "conv1x1_stream_kernel<128, 96, 32, 96, 1, 3>",
+              "stem_kernel<1, 1, 0>", "stem_ds_kernel<0>", "spp_pool_kernel", "spp_pool_split_kernel<3>", "conv_f32_kernel", "stem_f32_kernel", "spp_pool_f32_kernel"):
+        assert arch.is_net_kernel("void (anonymous namespace)::" + k + "(ConvArgs, int)"), k
+    assert not arch.is_net_kernel("void (anonymous namespace)::flame_mfma_lds_kernel<2, 64>(VertArgs)") and not arch.is_net_kernel("__amd_rocclr_fillBufferAligned")
+
+
 def test_fused_archive_keys_fold_to_the_same_network():
     """an archive exported after QARepVGG fusion (`rbr_reparam` instead of the branch tensors; post_bn kept when only
     partially fused) passes the manifest check and folds to the same conv + bias as the unfused keys."""
