@@ -104,6 +104,7 @@ SYMBOLS = {
     "vgh_net_buffer_bytes": (_I64, [_P, _I]),
     "vgh_net_set_cfg": (_I, [_P, _I, _I]),
     "vgh_net_set_split": (_I, [_P, _I]),
+    "vgh_net_set_lane_lag": (_I, [_I]),
     "vgh_net_set_fuse_stem": (_I, [_P, _I]),
     "vgh_net_set_pred_guard": (_I, [_P, _P]),
     "vgh_net_max_batch": (_I, [_P]),

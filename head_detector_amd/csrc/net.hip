@@ -4,6 +4,7 @@
 // Replaces the TorchScript interpreter call `self.model(image)` (head_detector/detector.py:58-59).
 #include <stdarg.h>
 
+#include <atomic>
 #include <vector>
 
 #include "vgh_internal.h"
@@ -45,7 +46,7 @@ struct vgh_net {
     hipStream_t side[kLanes] = {nullptr, nullptr, nullptr, nullptr};  // picked by ensure_lanes for `lanes_main`
     hipStream_t lanes_main = nullptr;
     bool lanes_ready = false;
-    hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kLanes] = {nullptr, nullptr, nullptr, nullptr}, ev_lag[kLanes] = {nullptr, nullptr, nullptr, nullptr};
     // optional guard (borrowed event): the first op that writes an fp32 prediction buffer waits for it, so a consumer of the
     // PREVIOUS forward's predictions may still be running on another stream while this forward's backbone / neck execute
     hipEvent_t pred_guard = nullptr;
@@ -207,7 +208,11 @@ int vgh_net_lane_streams(vgh_net* n, hipStream_t main, hipStream_t* out) {
 }
 
 // The batch as nsplit independent sub-batches, one per lane stream (lane 0 = the caller's stream); launches are interleaved
-// op by op so the lanes advance together.
+// op by op.  lane_lag = 0: the lanes advance together.  lane_lag = k > 0: lane l starts when lane l-1 has finished its first k ops and
+// stays k ops behind, so that the kernels running side by side are DIFFERENT layers (an HBM-bound 1x1 conv of one lane next to an
+// MFMA-bound 3x3 conv of the other) instead of two copies of the same one.
+static std::atomic<int> g_lane_lag{0};
+
 static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, int B, hipStream_t main) {
     const int L = n->nsplit < B ? n->nsplit : B;
     int at[vgh_net::kLanes + 1];
@@ -215,16 +220,30 @@ static int net_forward_split(vgh_net* n, const void* image_dev, int image_fmt, i
     for (int l = 0; l < L; ++l) at[l + 1] = at[l] + B / L + (l < B % L ? 1 : 0);
     VGH_HIP(hipEventRecord(n->ev_fork, main));
     for (int l = 1; l < L; ++l) VGH_HIP(hipStreamWaitEvent(n->side[l], n->ev_fork, 0));
-    bool guard_pending = n->pred_guard != nullptr;
-    for (const NetOp& op : n->ops) {
-        if (op.d.kind == VGH_OP_FORK) continue;  // head lanes are not combined with the batch split
-        if (guard_pending && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32 == VGH_FMT_F32) {
-            VGH_HIP(hipStreamWaitEvent(main, n->pred_guard, 0));
-            for (int l = 1; l < L; ++l) VGH_HIP(hipStreamWaitEvent(n->side[l], n->pred_guard, 0));
-            guard_pending = false;
+    std::vector<const NetOp*> seq;
+    seq.reserve(n->ops.size());
+    for (const NetOp& op : n->ops)
+        if (op.d.kind != VGH_OP_FORK) seq.push_back(&op);  // head lanes are not combined with the batch split
+    const int N = (int)seq.size();
+    int lag = g_lane_lag.load(std::memory_order_relaxed);
+    if (lag < 0) lag = 0;
+    if (lag > N) lag = N;
+    bool guard_pending[vgh_net::kLanes];
+    for (int l = 0; l < L; ++l) guard_pending[l] = n->pred_guard != nullptr;
+    for (int s = 0; s < N + lag * (L - 1); ++s) {
+        for (int l = 0; l < L; ++l) {
+            const int i = s - l * lag;
+            if (i < 0 || i >= N) continue;
+            const NetOp& op = *seq[i];
+            hipStream_t st = l == 0 ? main : n->side[l];
+            if (lag > 0 && l > 0 && i == 0) VGH_HIP(hipStreamWaitEvent(st, n->ev_lag[l - 1], 0));  // recorded below, `lag` ops into lane l-1
+            if (guard_pending[l] && op.d.kind == VGH_OP_CONV && n->bufs[op.d.out_buf].is_f32 == VGH_FMT_F32) {
+                VGH_HIP(hipStreamWaitEvent(st, n->pred_guard, 0));
+                guard_pending[l] = false;
+            }
+            if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], st)) return rc;
+            if (lag > 0 && l + 1 < L && i == lag - 1) VGH_HIP(hipEventRecord(n->ev_lag[l], st));
         }
-        for (int l = 0; l < L; ++l)
-            if (int rc = net_run_op(n, op, image_dev, image_fmt, at[l + 1] - at[l], at[l], l == 0 ? main : n->side[l])) return rc;
     }
     for (int l = 1; l < L; ++l) {
         VGH_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
@@ -266,6 +285,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     VGH_HIP(hipMemset(n->zeros, 0, 256));
     VGH_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     for (int l = 1; l < vgh_net::kLanes; ++l) VGH_HIP(hipEventCreateWithFlags(&n->ev_join[l], hipEventDisableTiming));  // lane streams: ensure_lanes
+    for (int l = 0; l < vgh_net::kLanes; ++l) VGH_HIP(hipEventCreateWithFlags(&n->ev_lag[l], hipEventDisableTiming));
     // ---- weights: pack on the host, one upload ----
     int64_t wbytes = 0;
     std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0);
@@ -360,6 +380,8 @@ void vgh_net_destroy(vgh_net* n) {
         }
         if (n->ev_join[l]) hipEventDestroy(n->ev_join[l]);
     }
+    for (int l = 0; l < vgh_net::kLanes; ++l)
+        if (n->ev_lag[l]) hipEventDestroy(n->ev_lag[l]);
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     hipFree(n->arena);
     hipFree(n->wblob);
@@ -479,6 +501,12 @@ int vgh_net_forward_graph(vgh_net* n, void* stream) {
 
 void* vgh_net_buffer(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_ptr.size()) ? n->buf_ptr[buf_id] : nullptr; }
 int64_t vgh_net_buffer_bytes(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_bytes.size()) ? n->buf_bytes[buf_id] : -1; }
+
+int vgh_net_set_lane_lag(int ops) {
+    VGH_REQUIRE(ops >= 0, "net_set_lane_lag: negative");
+    g_lane_lag.store(ops, std::memory_order_relaxed);
+    return VGH_OK;
+}
 
 int vgh_net_set_split(vgh_net* n, int nsplit) {
     VGH_REQUIRE(n, "net_set_split: null handle");

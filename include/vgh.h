@@ -99,6 +99,9 @@ int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
  * latency, epilogue store burst, tail -- of one sub-batch hides under the main loops of the others.  Results are identical
  * (images are independent; every op keeps its tile configuration). */
 int vgh_net_set_split(vgh_net* net, int nsplit);
+/* Process-wide: with a batch split, lane l starts when lane l-1 has finished its first `ops` ops and stays that far behind, so that different layers
+ * run side by side (0 = the lanes advance together).  Results do not change. */
+int vgh_net_set_lane_lag(int ops);
 /* Opt-in: the stem (3 -> 48, stride 2) and the first backbone downsample (48 -> 96, stride 2) as ONE kernel (csrc/stem_ds.hip) when the program has that
  * pair in bf16: the 48-channel stem activation then never goes to HBM and its arena buffer is not written.  Results are bit-identical either way.
  * Default off: measured (r03) it removes 1.5 GB of traffic per 64-image forward but is no faster than the two launches (latency-bound small tiles). */

@@ -1262,6 +1262,20 @@ def test_batch_split_lanes_are_invisible(gpu_lib, flame_model):
     # a batch smaller than the number of lanes
     eng.set_split(4)
     assert all(torch.equal(r[:2], q) for r, q in zip(ref, eng.model(x[:2].contiguous())))
+    # lanes running a fixed number of ops apart (vgh_net_set_lane_lag: lane l starts `lag` ops into lane l-1): the same results, with and without overlap mode
+    try:
+        for ns, lag in ((2, 3), (3, 1), (4, 40), (2, 10_000)):
+            eng.set_split(ns)
+            assert gpu_lib.vgh_net_set_lane_lag(lag) == 0
+            for overlap in (False, True):
+                eng.set_overlap(overlap)
+                for _ in range(2):  # the second forward re-records the lag events of the first
+                    got = eng.model(x)
+                assert all(torch.equal(r, q) for r, q in zip(ref, got)), (ns, lag, overlap)
+                d = eng.detect(x, confidence_threshold=conf, flame=fl)
+                assert all(torch.equal(r, q) for r, q in zip(ref_det, (d.boxes, d.counts, d.vertices_3d, d.head_pose))), (ns, lag, overlap)
+    finally:
+        gpu_lib.vgh_net_set_lane_lag(0)
     eng.set_overlap(False)
     eng.close()
 
