@@ -31,16 +31,17 @@ for step in "$@"; do
     bench)
       timeout 1200 python bench.py --per-layer $O/per_layer_l64.json ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -5 $O/bench.err; cut -c1-900 $O/bench.json ;;
     prof)
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $TAG -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-accuracy --no-secondary --traffic off > $O/prof.log 2>&1)
-      f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_bench_l64_kernel_stats.csv && head -14 "$f" | cut -c1-220
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $TAG -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-accuracy --no-secondary --traffic off ${PROF_ARGS:-} > $O/prof.log 2>&1)
+      f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_bench_${PROF_NAME:-l64}_kernel_stats.csv && head -14 "$f" | cut -c1-220
       tail -1 $O/prof.log | cut -c1-300 ;;
     pmc)
-      for L in 1 2; do
+      PV=${PMC_VARIANT:-vgg_heads_l}; PB=${PMC_BATCH:-64}
+      for L in ${PMC_LANES:-1 2}; do
         for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES"; do
           t=$(echo $c | cut -d' ' -f1)
-          (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $O/pmc_x$L -o $t -- python $ROOT/tools/traffic_run.py --forwards $FW --split $L > $O/pmc_x${L}_$t.log 2>&1)
+          (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $O/pmc_${PV}_x$L -o $t -- python $ROOT/tools/traffic_run.py --variant $PV --batch $PB --forwards $FW --split $L > $O/pmc_${PV}_x${L}_$t.log 2>&1)
         done
-        python tools/pmc_summary.py $O/pmc_x$L vgg_heads_l 64 $FW $L $O $TAG
+        python tools/pmc_summary.py $O/pmc_${PV}_x$L $PV $PB $FW $L $O $TAG
       done ;;
     tune)
       timeout 1500 python tools/tune_conv.py --variant vgg_heads_l --batch 64 --report $O/${TAG}_tune_l64.json > $O/tune.log 2>&1
