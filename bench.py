@@ -14,6 +14,7 @@ scaling: configs[3] = 8 x this).  Measured in the same run and reported inside `
     configs[4]  VGGHeads_L @ 1280x1280 crowd (>= 32 heads / image)      -> config.secondary_vgg_heads_l_b16_1280_crowd
     the matrix-core PARITY mode (fp16x3: outputs within north_star's IoU >= 0.999 / 1e-4 of the fp32 reference) and the fp32 VALU mode
                                                                         -> config.parity_mode
+    configs[0]'s shape on the GPU: ONE image per synchronous detect() call (L and M), median / min ms        -> config.latency_one_image_synchronous
 Weights / FLAME constants are seeded synthetic tensors of the exact architecture (no network for the real assets).
 The random-weight network's scores are arbitrary, so the NMS confidence threshold is calibrated ONCE (untimed) so that
 about 3 heads per image survive; nothing is skipped inside the timed region.
@@ -463,6 +464,29 @@ def main():
         eng.close()
         return out
 
+    def one_image_latency(variant: str, calls: int = 150) -> dict:
+        """Wall time of detect() on ONE image including the host wait for its result (network, top-k / NMS, FLAME decode of the survivors; u8 image resident
+        in HBM): what a caller of HeadDetector.__call__ sees per image after the letterbox.  Median / min over `calls` synchronous calls."""
+        eng = VGHeadsEngine(variant, image_size=S, max_batch=1, seed=1)
+        img = torch.randint(0, 256, (1, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(7)).to(dev)
+        unp = torch.tensor([[0.0, 0.0, 1.0]], device=dev)
+        _, sc, _ = eng.model(img)
+        conf = float(sc[0, 2, 0])  # the three best candidates pass the threshold
+        for _ in range(20):
+            eng.detect(img, confidence_threshold=conf, flame=flame, unpad=unp)
+        torch.cuda.synchronize()
+        ts = []
+        heads = 0
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            d = eng.detect(img, confidence_threshold=conf, flame=flame, unpad=unp)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            heads = int(d.num_heads)
+        eng.close()
+        ts.sort()
+        return {"ms_median": round(ts[len(ts) // 2], 3), "ms_min": round(ts[0], 3), "calls": calls, "heads_decoded": heads, "images_per_sec_at_median": round(1e3 / ts[len(ts) // 2], 1)}
+
     def brief(m: dict) -> dict:
         return {"images_per_sec": round(m["value"], 2), "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "net_ms_per_step": round(m["net_ms"], 3),
                 "conv_tflops": round(m["conv_tflops"], 2), "roofline_frac": round(m["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "steps": m["steps"],
@@ -515,6 +539,8 @@ def main():
                 "fp32_valu_mode": {"workload": f"{args.variant} fp32 (v_fma_f32, csrc/conv_f32.hip) batch 8 @ {S}", **brief(pv)}}
             print(f"[bench] parity mode fp16x3 {args.variant} batch 32 @ {S}: {pm['value']:.1f} img/s (target {NORTH_STAR_IMG_PER_S_PER_GPU:.0f}/GPU), net {pm['net_ms']:.3f} ms; "
                   f"fp32 VALU mode batch 8: {pv['value']:.1f} img/s", file=sys.stderr)
+            # BASELINE configs[0]'s shape on the GPU: ONE 640 x 640 image per call, the caller waits for the result (the reference's own API is single-image)
+            config["latency_one_image_synchronous"] = {v: one_image_latency(v) for v in ("vgg_heads_l", "vgg_heads_m")}
         # roofline.traffic: HBM bytes of one forward of the main workload
         traffic = None
         if args.traffic in ("auto", "live") and world == 1 and S == 640 and args.precision == "bf16":
