@@ -66,7 +66,7 @@ static std::atomic<int> g_flame_mode{1};
 static unsigned long long* g_prep_trace = nullptr;  // vgh_flame_set_trace
 #endif
 constexpr int kLdsMinHeads = 1024;  // from here on: LDS-staged tiles with 128-head blocks
-constexpr int kLdsMidHeads = 192;   // ... 64-head blocks (r02: the register-fed kernel ran n = 256 .. 1024 at 0.22 - 0.35 of the fp32 roof)
+constexpr int kLdsMidHeads = 256;   // ... 64-head blocks (r02: the register-fed kernel ran n = 256 .. 1024 at 0.22 - 0.35 of the fp32 roof)
 
 namespace {
 
@@ -826,6 +826,14 @@ __global__ __launch_bounds__((LBH / 64) * 256, WPS) void flame_mfma_lds_kernel(V
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (AS3 void*)(base + LB_A + (piece - NPA) * 256), 16, off, 0, 0, 0);
         }
     };
+    // raw barrier: __syncthreads() carries a fence that drains vmcnt(0) -- the next slab's LDS-DMA loads would be waited for at every barrier and the
+    // double buffer would overlap nothing.  The counted s_waitcnt above the first barrier of a step is the only load wait (r03: -4 ... -6 % on every
+    // LDS-staged decode; bit-identical)
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     issue(0, 0);
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
@@ -835,7 +843,7 @@ __global__ __launch_bounds__((LBH / 64) * 256, WPS) void flame_mfma_lds_kernel(V
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        lds_barrier();
         const float* const sa = fsm + buf * LB_STAGE + half * LBH + hw * 64 + j;              // + pair*2*LBH + t*32
         const float* const sb = fsm + buf * LB_STAGE + LB_A + half * 3 * LB_V + vw * 32 + j;  // + pair*6*LB_V + c*LB_V
         const int pairs = min(LB_KS / 2, npt - st * (LB_KS / 2));
@@ -857,7 +865,7 @@ __global__ __launch_bounds__((LBH / 64) * 256, WPS) void flame_mfma_lds_kernel(V
                     for (int c = 0; c < 3; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u & 1][t], B[u & 1][c], acc[t][c], 0, 0, 0);
             }
         }
-        __syncthreads();  // slab `buf` is rewritten by the loads issued at the top of the next iteration
+        lds_barrier();  // slab `buf` is rewritten by the loads issued at the top of the next iteration
     }
     // head packs of the block's heads into the (now free) slab memory: a straight copy, [head][HP_SIZE]
     float* const s_hp = fsm;

@@ -1450,7 +1450,7 @@ def test_c_only_create_and_detect(gpu_lib, flame_model, tmp_path):
     assert gpu_lib.vgh_create(C.byref(bad), C.byref(h)) != 0 and b"not a readable" in gpu_lib.vgh_last_error()
 
 
-@pytest.mark.parametrize("n,live", [(12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (191, (128, 64)), (192, (300, 100)), (257, (128, 64)), (1023, (128, 64)),
+@pytest.mark.parametrize("n,live", [(12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (191, (128, 64)), (192, (300, 100)), (255, (128, 64)), (256, (300, 100)), (257, (128, 64)), (1023, (128, 64)),
                                     (1024, (300, 100)), (1300, (64, 32)), (1100, (300, 100))])
 def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame_model, n, live):
     """The FP32-MFMA vertex kernels (v_mfma_f32_32x32x2_f32 = an exact k-ordered fmaf chain; register-fed for small / medium batches,
