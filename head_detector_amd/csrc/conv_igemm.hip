@@ -24,7 +24,7 @@ struct CfgEntry {
     const char* name;
     int BP, BC, threads, lds;
     void (*launch)(const ConvArgs&, int, int, int, int, hipStream_t);
-    int patch, TW, TH;  // 1 / 2: conv3x3_patch_kernel / conv3x3_patch3_kernel (3x3, stride 1, tile TH x TW); 3: conv1x1_stream_kernel; 4: conv3x3_patch_kernel stride 2 (output tile TH x TW); fast epilogue only
+    int patch, TW, TH;  // 5: conv3x3_pp_kernel (conv_pp.hip: 8-wave ping-pong, 8 x 8 sub-patch per wave); 1 / 2: conv3x3_patch_kernel / conv3x3_patch3_kernel (3x3, stride 1, tile TH x TW); 3: conv1x1_stream_kernel; 4: conv3x3_patch_kernel stride 2 (output tile TH x TW); fast epilogue only
     void (*launch_patch)(const ConvArgs&, int, int, int, int, int, int, hipStream_t);
 };
 
@@ -140,6 +140,9 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
     { "d" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC, 1>(), nullptr, 4, TW, TH, launch_patch_s2_cfg<TW, TH, BC, NWP, NWC> }
 #define TCFG(BP, BC, WP, WC, KBS, NST) \
     { "t" #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, Stream1<BP, BC, WP, WC, KBS, NST>::LDS, launch_stream_cfg<BP, BC, WP, WC, KBS, NST>, 3, 0, 0, nullptr }
+
+#define GCFG(BC) \
+    { "g8x8x" #BC "_n8", 512, BC, 512, 0, nullptr, 5, 8, 8, nullptr }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -273,6 +276,10 @@ const CfgEntry g_cfgs[] = {
     PCFG(16, 4, 128, 2, 4),   // 119  8 waves x (32 px x 32)
     PCFG(16, 4, 96, 2, 3),    // 120  6 waves x (32 px x 32)
     PCFG(16, 4, 64, 2, 1),    // 121  2 waves x (32 px x 64)
+    // 8-wave ping-pong tiles (conv_pp.hip, r04): 8 sub-patches of 8 x 8 pixels x BC couts per workgroup, one workgroup per CU
+    GCFG(128),  // 122
+    GCFG(96),   // 123
+    GCFG(64),   // 124
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
@@ -302,7 +309,7 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     if (cfg < 0 || cfg >= kNumCfgs) return 0;
     const CfgEntry& e = g_cfgs[cfg];
     if (cout_pad % e.BC) return 0;
-    if ((e.patch == 1 || e.patch == 2) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    if ((e.patch == 1 || e.patch == 2 || e.patch == 5) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 3 && !(ksize == 1 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 4 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle)) return 0;
     return 1;
@@ -313,6 +320,7 @@ int vgh_conv_cfg_cout_tile(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cf
 static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) return 0;
     if (a.grp_cout && a.grp_cout % g_cfgs[cfg].BC) return 0;
+    if (g_cfgs[cfg].patch == 5 && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32)) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
     if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
     return 1;
 }
@@ -441,6 +449,7 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
         cfg = t;
     }
     const CfgEntry& e = g_cfgs[cfg];
+    if (e.patch == 5) return vgh_launch_conv_pp(a, e.BC, g_max_blocks_per_xcd.load(std::memory_order_relaxed), stream);
     if (e.patch == 1 || e.patch == 2 || e.patch == 4) {
         const int ntc = a.cout_pad / e.BC, ntx = (a.Wo + e.TW - 1) / e.TW, nty = (a.Ho + e.TH - 1) / e.TH;  // (Ho, Wo) = (H, W) for the stride-1 tiles
         const int64_t total = (int64_t)a.B * nty * ntx * ntc;

@@ -1,0 +1,375 @@
+// "g" tiles: 3x3 / stride-1 convolution as an 8-wave PING-PONG kernel for gfx950 (r04).
+//
+// Replaces (reference: the 3x3 QARepVGG / ConvBNReLU blocks of the TorchScript blob called at head_detector/detector.py:58-59; definitions
+// yolo_head_training/configs/arch_params/yolo_heads_{m,l}_arch_params.yaml:4-137, yolo_head_training/yolo_head/yolo_head_dfl_head.py:74-135)
+// the same layers as conv3x3_patch_kernel ("p" / "q" tiles in conv_kernels.inc), with another execution structure:
+//
+//   * one 512-thread workgroup per CU, two wave GROUPS (waves 0-3 / 4-7: one wave of each group per SIMD) that run the same instruction
+//     stream ONE BARRIER APART: while a group issues its 16 MFMAs of a tap ("M phase", s_setprio 1), the other group reads the next tap's
+//     fragments from LDS, issues its LDS-DMA prefetches and waits ("L phase").  The matrix pipe of a SIMD always has one wave in its M phase;
+//     the non-MFMA work of a wave is hidden behind its partner's MFMAs instead of colliding with it (two independent blocks per CU, as the
+//     "p" tiles run, meet in random phase: PMC showed 37 % MFMA-busy with 27 % of the wave cycles parked at waitcnt / barrier).
+//   * a wave owns 64 pixels (one 8 x 8 output sub-patch, any image) x BC = 32*TI couts: 128 accumulator registers for TI = 4 and
+//     2*TI + 4 fragment reads per 4*TI MFMAs (0.75 KB of LDS reads per MFMA at TI = 4; the 64 x 64 wave tiles of the "p" kernels read 1 KB).
+//   * the 10 x 10 halo of a wave's sub-patch is PRIVATE to the wave (7 LDS-DMA units per 32-channel block, double buffered, no cross-wave
+//     hand-off); the weights of a tap (BC x 32 channels) are shared by the 8 waves through a 3-stage ring, each wave staging one 1-KiB unit
+//     two taps ahead.  8 x 8 sub-patches tile the 160 / 80 / 40-wide maps exactly; a block takes 8 consecutive sub-patches of the batch.
+//   * the operand stream runs ACROSS tiles: the last channel block of a tile prefetches the halo and the first two taps of the next one.
+//   * epilogue entirely in registers: bias enters as the accumulator's initial value, ReLU, residual, v_cvt_pk_bf16_f32, and
+//     v_permlane32_swap pairs so that every lane stores 16 bytes (32 contiguous bytes per pixel per instruction) -- no LDS round trip.
+//     The two groups' epilogues fall into different barrier slots, each beside the other group's M phase.
+//
+// Barrier slots (g0 = waves 0-3, g1 = waves 4-7; B = s_barrier):
+//     g0:      L(0) B M(0) B L(1) B M(1) B ...            M(n) B [B]
+//     g1:  [B]      B L(0) B M(0) B L(1) B ...  L(n) B M(n) B
+// LDS-DMA rules (MI355X_MICROARCH.md, "Two waves per SIMD" item 7): data staged by another wave is read one barrier AFTER the issuing
+// wave's counted vmcnt; a stage is re-filled only after a barrier that follows the lgkmcnt(0) of its last readers.
+#include <atomic>
+#include <type_traits>
+
+#include "vgh_internal.h"
+
+#define AS3 __attribute__((address_space(3)))
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+namespace {
+
+__device__ __forceinline__ void dma16(const void* base, unsigned voffset, unsigned soffset, char* lds_wave_base) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void barrier_raw() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ float bf_lo(unsigned d) { return __builtin_bit_cast(float, d << 16); }
+__device__ __forceinline__ float bf_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+// lanes 32-63 of `a` trade places with lanes 0-31 of `b`
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+template <int TI>
+struct PPGeo {
+    static constexpr int BC = 32 * TI, NW = 8;
+    static constexpr int XU = 7;           // 16-pixel LDS-DMA units of a wave's 10 x 10 halo (100 of 112 records used)
+    static constexpr int XST = XU * 1024;  // bytes of one halo stage of one wave
+    static constexpr int WST = BC * 64;    // bytes of one weight stage (one tap, one 32-channel block, BC couts)
+    static constexpr int WU = BC / 16;     // 1-KiB units per weight stage (waves >= WU stage into the dummy unit)
+    static constexpr int NWS = 3;          // weight ring
+    static constexpr int WOFF = NW * 2 * XST;
+    static constexpr int DUMMY = WOFF + NWS * WST;
+    static constexpr int LDS = DUMMY + 1024;
+};
+
+struct PPTile {
+    int valid;  // the workgroup has this tile
+    int c0;     // first cout of the tile
+    int spok;   // this wave's sub-patch exists
+    int b, y0, x0;
+};
+
+template <int TI>
+__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk) {
+    using G = PPGeo<TI>;
+    constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w >> 2;
+    const int n32 = lane & 31, hi = lane >> 5;
+    const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
+    const int ncb = a.cblocks;
+    const unsigned wkstride = (unsigned)a.cout_pad * 64u;
+    const int in_pitch = (int)a.in_pitch;
+
+    auto decode = [&](int local, PPTile& t, unsigned (&xo)[7], unsigned& wv) {
+        const int tile = xcd * chunk + local;
+        t.valid = (local < chunk && tile < total_tiles) ? 1 : 0;
+        const int tl = t.valid ? tile : 0;
+        const int g8 = tl / ntc;
+        t.c0 = (tl - g8 * ntc) * BC;
+        const int sp = g8 * 8 + w;
+        t.spok = (t.valid && sp < nsp) ? 1 : 0;
+        const int spc = t.spok ? sp : 0;
+        const int per = nsy * nsx;
+        t.b = spc / per;
+        const int rem = spc - t.b * per;
+        const int sy = rem / nsx;
+        t.y0 = sy * 8;
+        t.x0 = (rem - sy * nsx) * 8;
+        // opaque copy of the lane id: the per-lane halo geometry below is re-materialised per call instead of being hoisted out of the tile loop
+        // and kept alive (or spilled) across the whole K loop
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int hp = u * 16 + (lane_t >> 2);
+            const int hy = hp / 10, hx = hp - hy * 10;
+            const int iy = t.y0 - 1 + hy, ix = t.x0 - 1 + hx;
+            const bool ok = t.spok && hp < 100 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            // source-side swizzle: LDS slot (lane & 3) of halo record (hy, hx) holds channel chunk slot ^ (hy & 3)
+            xo[u] = ok ? 2u * (unsigned)(((t.b * a.H + iy) * a.W + ix) * in_pitch + a.in_coff) + (unsigned)(((lane_t & 3) ^ (hy & 3)) * 16) : OOB;
+        }
+        wv = (t.valid && w < WU) ? (unsigned)(lane_t * 16 + w * 1024) : OOB;
+    };
+
+    PPTile cur, nxt;
+    unsigned xo[7], wv_cur, wv_nxt;  // xo: halo source offsets of the tile whose halo is being prefetched (the current one, the next one in the last channel block)
+    int local = blockIdx.x >> 3;
+    decode(local, cur, xo, wv_cur);
+    if (!cur.valid) return;  // workgroup-uniform: no barrier has been executed yet
+
+    char* const xw = smem + w * (2 * XST);                                          // this wave's two halo stages
+    char* const wdst = (w < WU) ? smem + G::WOFF + w * 1024 : smem + G::DUMMY - 0;  // + stage * WST for real units
+    const int wdst_step = (w < WU) ? WST : 0;
+
+    // fragment byte offsets (LDS): B operand = halo records of this wave, A operand = weight rows
+    //   halo record (hy, hx) at (hy*10 + hx)*64, its 16-byte chunk c at slot c ^ (hy & 3); pixel n32 of MFMA group j sits at sub-patch row 4j + (n32 >> 3),
+    //   column n32 & 7; tap (ky, kx) reads record (row + ky, col + kx): kx and j are immediate offsets (+64, +2560), ky changes the swizzle -> own register
+    int bofs[3][2];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = (n32 >> 3) + ky;
+            bofs[ky][h] = w * (2 * XST) + (r * 10 + (n32 & 7)) * 64 + (((2 * h + hi) ^ (r & 3)) * 16);
+        }
+    int aofs[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) aofs[h] = G::WOFF + n32 * 64 + (((2 * h + hi) ^ ((n32 >> 2) & 3)) * 16);
+
+    const char* wbase_cur = (const char*)a.wpack + (int64_t)cur.c0 * 64;
+
+    // ---- prologue: halo of channel block 0 and the first two taps of the first tile ----
+#pragma unroll
+    for (int u = 0; u < 7; ++u) dma16(a.in, xo[u], 0, xw + u * 1024);
+    dma16(wbase_cur, wv_cur, (unsigned)(0 * ncb) * wkstride, wdst + 0 * wdst_step);
+    dma16(wbase_cur, wv_cur, (unsigned)(1 * ncb) * wkstride, wdst + 1 * wdst_step);
+    wait_vm<0>();
+    barrier_raw();
+    if (grp) barrier_raw();  // the stagger: group 1 runs one barrier behind group 0
+
+    f32x16_t acc[TI][2];
+    int xs = 0;  // halo stage being read (0 / 1): bofs point into it
+    const float act_lo = a.act == VGH_ACT_RELU ? 0.0f : __builtin_nanf("");
+
+    while (true) {
+        const char* wbase_nxt = wbase_cur;
+        // accumulators start at the bias: lane (n32, hi) holds couts c0 + 32 i + 8 q + 4 hi + e of its pixels (register r = 4 q + e)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t bv = *(const f32x4_t*)(a.bias + cur.c0 + i * 32 + q * 8 + hi * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[i][0][q * 4 + e] = bv[e];
+                    acc[i][1][q * 4 + e] = bv[e];
+                }
+            }
+
+        for (int cb = 0; cb < ncb; ++cb) {
+            const bool last = cb == ncb - 1;
+            // prefetch targets of this channel block: halo of (cb + 1) or of the next tile's block 0; weights two taps ahead
+            if (last) {
+                decode(local + gpx, nxt, xo, wv_nxt);
+                wbase_nxt = (const char*)a.wpack + (int64_t)nxt.c0 * 64;
+            }
+            const char* const xsrc = last ? (const char*)a.in : (const char*)a.in + (cb + 1) * 64;
+            const char* const wb_n = last ? wbase_nxt : wbase_cur;
+            const unsigned wv_n = last ? wv_nxt : wv_cur;
+            const int cb_n = last ? 0 : cb + 1;
+            char* const xpre = xw + (xs ^ 1) * XST;
+
+            auto phase = [&](auto tc) {
+                constexpr int T = decltype(tc)::value;
+                constexpr int ky = T / 3, kx = T % 3, st = T % 3;
+                bf16x8_t a0[TI], a1[TI], b0[2], b1[2];
+                // ---- L phase: fragments of tap T, prefetches, counted waits ----
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    a0[i] = *(const bf16x8_t*)(smem + aofs[0] + st * WST + i * 2048);
+                    a1[i] = *(const bf16x8_t*)(smem + aofs[1] + st * WST + i * 2048);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    b0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + j * 2560 + kx * 64);
+                    b1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + j * 2560 + kx * 64);
+                }
+                {
+                    constexpr int TT = T + 2, ws = TT % 3;
+                    if constexpr (TT < 9)
+                        dma16(wbase_cur, wv_cur, (unsigned)(TT * ncb + cb) * wkstride, wdst + ws * wdst_step);
+                    else
+                        dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wdst + ws * wdst_step);
+                }
+                if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                wait_lgkm0();  // this wave's reads of stage st / of its halo are complete before the barrier that releases them for re-filling
+                // the weight unit issued in L(T-1) (tap T+1) has landed; younger: halo unit T-1, this phase's units
+                wait_vm<(T >= 1 && T <= 7 ? 1 : 0) + 1 + (T <= 6 ? 1 : 0)>();
+                barrier_raw();
+                // ---- M phase ----
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                barrier_raw();
+            };
+            phase(std::integral_constant<int, 0>{});
+            phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{});
+            phase(std::integral_constant<int, 3>{});
+            phase(std::integral_constant<int, 4>{});
+            phase(std::integral_constant<int, 5>{});
+            phase(std::integral_constant<int, 6>{});
+            phase(std::integral_constant<int, 7>{});
+            phase(std::integral_constant<int, 8>{});
+            // flip the halo stage
+            const int d = xs ? -XST : XST;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bofs[ky][h] += d;
+            xs ^= 1;
+        }
+
+        // ---- epilogue (registers only): ReLU, + alpha * residual, bf16, half-wave exchange, 16-byte stores ----
+        {
+            const int cbase = cur.c0;
+            bool okpx[2];
+            int64_t opix[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = cur.y0 + 4 * j + (n32 >> 3), x = cur.x0 + (n32 & 7);
+                okpx[j] = cur.spok && y < a.Ho && x < a.Wo;
+                opix[j] = ((int64_t)cur.b * a.Ho + y) * a.Wo + x;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // residual vectors of one 32-pixel group (2 TI x 16 bytes per lane), all in flight before the first use (a conditional load per vector
+                // would make hipcc wait for each one in turn); lanes without an output read the buffer's first bytes
+                u32x4_t rv[TI][2];
+                if (a.res) {
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const int cv = cbase + i * 32 + 16 * m + 8 * hi;
+                            const uint16_t* const p = (okpx[j] && cv < a.cout_store) ? a.res + opix[j] * a.res_pitch + a.res_coff + cv : a.res;
+                            rv[i][m] = *(const u32x4_t*)p;
+                        }
+                }
+                uint16_t* const op = (uint16_t*)a.out + opix[j] * a.out_pitch;
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        // after the exchange this lane holds couts cv .. cv + 7
+                        const int cv = cbase + i * 32 + 16 * m + 8 * hi;
+                        const bool ok = okpx[j] && cv < a.cout_store;
+                        float va[4], vb[4];  // runs q = 2m and q = 2m + 1 of this lane (couts 32 i + 8 q + 4 hi + e)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            va[e] = fmaxf(acc[i][j][(2 * m) * 4 + e], act_lo);
+                            vb[e] = fmaxf(acc[i][j][(2 * m + 1) * 4 + e], act_lo);
+                        }
+                        if (a.res) {
+                            unsigned d0 = rv[i][m][0], d1 = rv[i][m][1], d2 = rv[i][m][2], d3 = rv[i][m][3];
+                            swap32(d0, d2);  // back to the accumulator layout: (d0, d1) = run 2m, (d2, d3) = run 2m + 1 of this lane
+                            swap32(d1, d3);
+                            va[0] += a.alpha * bf_lo(d0);
+                            va[1] += a.alpha * bf_hi(d0);
+                            va[2] += a.alpha * bf_lo(d1);
+                            va[3] += a.alpha * bf_hi(d1);
+                            vb[0] += a.alpha * bf_lo(d2);
+                            vb[1] += a.alpha * bf_hi(d2);
+                            vb[2] += a.alpha * bf_lo(d3);
+                            vb[3] += a.alpha * bf_hi(d3);
+                        }
+                        unsigned pa0 = pack_bf16(va[0], va[1]), pa1 = pack_bf16(va[2], va[3]);
+                        unsigned pb0 = pack_bf16(vb[0], vb[1]), pb1 = pack_bf16(vb[2], vb[3]);
+                        swap32(pa0, pb0);
+                        swap32(pa1, pb1);
+                        if (ok) {
+                            const int ochan = (cv >= a.out_split) ? a.out_coff2 + (cv - a.out_split) : a.out_coff + cv;
+                            const u32x4_t ov = {pa0, pa1, pb0, pb1};
+                            u32x4_t* const dst = (u32x4_t*)(op + ochan);
+                            if (a.nt_out)
+                                __builtin_nontemporal_store(ov, dst);
+                            else
+                                *dst = ov;
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);  // the second group's residual loads stay behind the first group's stores (register budget)
+            }
+        }
+        if (!nxt.valid) break;
+        cur = nxt;
+        wv_cur = wv_nxt;
+        wbase_cur = wbase_nxt;
+        local += gpx;
+    }
+    if (!grp) barrier_raw();  // group 0's share of the last barrier
+}
+
+constexpr int kMaxDev = 16;
+template <int TI>
+int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, int chunk, int max_blocks_per_xcd, hipStream_t st) {
+    static std::atomic<int> done[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    if (!done[dev].load(std::memory_order_acquire)) {
+        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI>, hipFuncAttributeMaxDynamicSharedMemorySize, PPGeo<TI>::LDS));
+        done[dev].store(1, std::memory_order_release);
+    }
+    int gpx = 32;  // one workgroup per CU, 32 CUs per XCD
+    if (max_blocks_per_xcd > 0 && gpx > max_blocks_per_xcd) gpx = max_blocks_per_xcd;
+    if (gpx > chunk) gpx = chunk;
+    hipLaunchKernelGGL((conv3x3_pp_kernel<TI>), dim3(gpx * 8), dim3(512), PPGeo<TI>::LDS, st, a, ntc, nsx, nsy, nsp, total, chunk);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
+}  // namespace
+
+int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4>::LDS : bc == 96 ? PPGeo<3>::LDS : bc == 64 ? PPGeo<2>::LDS : 0; }
+
+int vgh_launch_conv_pp(const ConvArgs& a, int bc, int max_blocks_per_xcd, hipStream_t stream) {
+    VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && !a.split && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 convs only");
+    VGH_REQUIRE(a.cout_pad % bc == 0, "conv: cout_pad %d is not a multiple of the %d-cout ping-pong tile", a.cout_pad, bc);
+    const int nsx = (a.Wo + 7) / 8, nsy = (a.Ho + 7) / 8, ntc = a.cout_pad / bc;
+    const int64_t nsp = (int64_t)a.B * nsy * nsx;
+    const int64_t total = (nsp + 7) / 8 * ntc;
+    VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
+    const int chunk = (int)((total + 7) / 8);
+    switch (bc) {
+        case 128: return launch_pp<4>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        case 96: return launch_pp<3>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        case 64: return launch_pp<2>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+    }
+    VGH_REQUIRE(false, "conv: no ping-pong tile with %d couts", bc);
+    return VGH_OK;
+}

@@ -102,6 +102,9 @@ int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);
 void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, int cin, int fmt, uint16_t* dst, float* out_scale);
 static inline int vgh_fmt_bytes(int fmt) { return fmt == 0 ? 2 : 4; }  // bytes per logical element of an activation buffer
 static inline int vgh_fmt_planes(int fmt) { return fmt >= 2 ? 2 : 1; }
+// conv_pp.hip: the 8-wave ping-pong 3x3 / stride-1 tiles ("g" tiles; bc = 128 / 96 / 64 couts per workgroup); `a` must be prepared
+int vgh_launch_conv_pp(const ConvArgs& a, int bc, int max_blocks_per_xcd, hipStream_t stream);
+int vgh_conv_pp_lds(int bc);
 int vgh_conv_pick_cfg(const ConvArgs& a);
 // validates `a` and fills its derived fields (fast-division constants, fast_epi); vgh_launch_conv calls it itself
 int vgh_conv_prepare(ConvArgs& a);

@@ -384,7 +384,8 @@ def test_conv_all_configs_vs_torch(gpu_lib, case):
 
 @pytest.mark.parametrize("cin,res", [(64, False), (64, True), (32, True), (96, False)])
 def test_conv_persistent_multi_tile(gpu_lib, cin, res):
-    """Halo-patch kernels with MANY tiles per workgroup (grid capped to 2 workgroups per XCD): the tile loop of the "p" kernels and
+    """Halo-patch kernels with MANY tiles per workgroup (grid capped to 2 workgroups per XCD): the tile loop of the "p" kernels,
+    the operand stream of the 8-wave ping-pong "g" kernels running across tiles (conv_pp.hip) and
     the cross-tile pipeline of the "q" kernels (operands of tile t+1 prefetched under tile t, region parity running across tiles,
     counted store waits, cout-tile changes between consecutive tiles of a workgroup, ragged last tiles)."""
     g = torch.Generator().manual_seed(11 + cin)
@@ -399,7 +400,7 @@ def test_conv_persistent_multi_tile(gpu_lib, cin, res):
         for cap in (2, 5):
             assert gpu_lib.vgh_conv_set_max_blocks_per_xcd(cap) == 0
             for cfg, name in enumerate(names):
-                if name[0] not in "pq" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, Cout, 1, 0):
+                if name[0] not in "pqg" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, Cout, 1, 0):
                     continue
                 out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, cfg=cfg, res=r, alpha=0.37 if res else 0.0)
                 _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"multi-tile cfg={name} cap={cap} cin={cin} res={res}")

@@ -94,6 +94,9 @@ for step in "$@"; do
       timeout 900 python tools/ab_table.py ${PREV_TABLE:-tools/_prev_table.json} ${NEW_TABLES:-head_detector_amd/tuning/conv_cfg.json} --rounds ${ROUNDS:-4} > $O/abtable.log 2>&1; grep -v amdgpu $O/abtable.log | tail -8 ;;
     abknob)
       timeout 900 python tools/ab_knob.py ${KNOB:-vgh_conv_set_nt_store} --json $O/${TAG}_ab_${KNOB:-vgh_conv_set_nt_store}.json ${KNOB_ARGS:-} > $O/abknob.log 2>&1; grep -v amdgpu $O/abknob.log | tail -${TAILN:-60} ;;
+    convbench)
+      # single-shape A/B of tile configurations through vgh_conv2d (CB_SHAPES / CB_CFGS / CB_ARGS)
+      timeout 900 python tools/conv_bench.py --shape ${CB_SHAPES:-64,80,80,128,128,3,1} --cfgs ${CB_CFGS:-all} --iters ${CB_ITERS:-30} ${CB_ARGS:-} > $O/convbench${CB_TAG:-}.log 2>&1; grep -v amdgpu $O/convbench${CB_TAG:-}.log | tail -${TAILN:-80} ;;
     probe)
       python tools/net_probe.py vgg_heads_l 64 2>&1 | grep -v amdgpu; python tools/net_probe.py vgg_heads_m 32 2>&1 | grep -v amdgpu ;;
     *) echo "unknown step $step" ;;
