@@ -30,6 +30,12 @@
 #include "vgh_internal.h"
 
 #define AS3 __attribute__((address_space(3)))
+#ifndef PP_RES_PREFETCH
+#define PP_RES_PREFETCH 0  // 1: touch the residual lines of a tile through the LDS-DMA path during its last channel block (A/B knob; measured +-1 %)
+#endif
+#ifndef PP_PRIO
+#define PP_PRIO 1  // s_setprio 1 around: 1 the M phase (MFMAs), 2 the L phase (fragment reads + LDS-DMA issue), 0 nothing (A/B knob)
+#endif
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 namespace {
@@ -55,6 +61,12 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     const bf2 v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, v);
 }
+// ReLU of two packed bf16 values: signed 16-bit max against zero (v_pk_max_i16)
+__device__ __forceinline__ unsigned relu_pk(unsigned d) {
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, d), z));
+}
 // lanes 32-63 of `a` trade places with lanes 0-31 of `b`
 __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -72,7 +84,8 @@ struct PPGeo {
     static constexpr int NWS = 3;          // weight ring
     static constexpr int WOFF = NW * 2 * XST;
     static constexpr int DUMMY = WOFF + NWS * WST;
-    static constexpr int LDS = DUMMY + 1024;
+    static constexpr int BIAS = DUMMY + 1024;  // the layer's bias vector (<= 2048 couts), staged once per workgroup
+    static constexpr int LDS = BIAS + 8192;
 };
 
 struct PPTile {
@@ -86,7 +99,9 @@ template <int TI>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk) {
     using G = PPGeo<TI>;
     constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
-    constexpr unsigned OOB = 0xFFFFFFF0u;
+    // out-of-range marker for buffer offsets (descriptor range 2 GiB): still out of range, and not wrapped past 2^32, after the immediate / scalar
+    // offsets the instructions add (channel offsets of the epilogue, weight k-block offsets < 2^30)
+    constexpr unsigned OOB = 0xC0000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     for (int u = 0; u < 7; ++u) dma16(a.in, xo[u], 0, xw + u * 1024);
     dma16(wbase_cur, wv_cur, (unsigned)(0 * ncb) * wkstride, wdst + 0 * wdst_step);
     dma16(wbase_cur, wv_cur, (unsigned)(1 * ncb) * wkstride, wdst + 1 * wdst_step);
+    dma16(a.bias, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::BIAS + w * 1024);
     wait_vm<0>();
     barrier_raw();
     if (grp) barrier_raw();  // the stagger: group 1 runs one barrier behind group 0
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4_t bv = *(const f32x4_t*)(a.bias + cur.c0 + i * 32 + q * 8 + hi * 4);
+                const f32x4_t bv = *(const f32x4_t*)(smem + G::BIAS + (cur.c0 + i * 32 + q * 8 + hi * 4) * 4);  // LDS: no vmcnt wait behind the previous tile's stores
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     acc[i][0][q * 4 + e] = bv[e];
@@ -187,9 +203,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         for (int cb = 0; cb < ncb; ++cb) {
             const bool last = cb == ncb - 1;
             // prefetch targets of this channel block: halo of (cb + 1) or of the next tile's block 0; weights two taps ahead
+            unsigned rpo = OOB;  // byte offset of this lane's pixel (lane = pixel of the 8 x 8 sub-patch) in the residual tensor, for the L2 touches
             if (last) {
                 decode(local + gpx, nxt, xo, wv_nxt);
                 wbase_nxt = (const char*)a.wpack + (int64_t)nxt.c0 * 64;
+                const int y = cur.y0 + (lane >> 3), x = cur.x0 + (lane & 7);
+                const int64_t ro = ((((int64_t)cur.b * a.Ho + y) * a.Wo + x) * a.res_pitch + a.res_coff + cur.c0) * 2;
+                if (a.res && cur.spok && y < a.Ho && x < a.Wo && ro + 2 * BC <= 0x7fffffff) rpo = (unsigned)ro;
             }
             const char* const xsrc = last ? (const char*)a.in : (const char*)a.in + (cb + 1) * 64;
             const char* const wb_n = last ? wbase_nxt : wbase_cur;
@@ -199,44 +219,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 
             auto phase = [&](auto tc) {
                 constexpr int T = decltype(tc)::value;
+                constexpr bool LAST = PP_RES_PREFETCH != 0;  // the residual touches are issued in every channel block (out of range = no access except in the last one): uniform vmcnt counts
                 constexpr int ky = T / 3, kx = T % 3, st = T % 3;
                 bf16x8_t a0[TI], a1[TI], b0[2], b1[2];
                 // ---- L phase: fragments of tap T, prefetches, counted waits ----
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+                if (!VGH_ABLATE(a, 32)) {
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    a0[i] = *(const bf16x8_t*)(smem + aofs[0] + st * WST + i * 2048);
-                    a1[i] = *(const bf16x8_t*)(smem + aofs[1] + st * WST + i * 2048);
-                }
+                    for (int i = 0; i < TI; ++i) {
+                        a0[i] = *(const bf16x8_t*)(smem + aofs[0] + st * WST + i * 2048);
+                        a1[i] = *(const bf16x8_t*)(smem + aofs[1] + st * WST + i * 2048);
+                    }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    b0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + j * 2560 + kx * 64);
-                    b1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + j * 2560 + kx * 64);
+                    for (int j = 0; j < 2; ++j) {
+                        b0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + j * 2560 + kx * 64);
+                        b1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + j * 2560 + kx * 64);
+                    }
+                } else {  // experiments build: the loop without its fragment traffic (MFMAs on whatever the registers hold)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) asm volatile("" : "=v"(a0[i]), "=v"(a1[i]));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(b0[j]), "=v"(b1[j]));
                 }
-                {
+                if (!VGH_ABLATE(a, 1)) {
                     constexpr int TT = T + 2, ws = TT % 3;
                     if constexpr (TT < 9)
                         dma16(wbase_cur, wv_cur, (unsigned)(TT * ncb + cb) * wkstride, wdst + ws * wdst_step);
                     else
                         dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wdst + ws * wdst_step);
+                    if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                    // last channel block: pull this wave's residual lines into L2 (one lane per pixel, 16 bytes of every 128-byte line, into the
+                    // dummy LDS unit) so that the epilogue's residual loads are L2 hits instead of two exposed HBM round trips per tile
+                    if constexpr (LAST && T < 3) dma16(a.res, rpo, (unsigned)(T == 0 ? 0 : T == 1 ? 128 : BC * 2 - 16), smem + G::DUMMY);
                 }
-                if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
                 wait_lgkm0();  // this wave's reads of stage st / of its halo are complete before the barrier that releases them for re-filling
-                // the weight unit issued in L(T-1) (tap T+1) has landed; younger: halo unit T-1, this phase's units
-                wait_vm<(T >= 1 && T <= 7 ? 1 : 0) + 1 + (T <= 6 ? 1 : 0)>();
-                barrier_raw();
+                // the weight unit issued in L(T-1) (tap T+1) has landed; younger and allowed in flight: halo unit T-1 (+ residual touch T-1), this phase's units
+                wait_vm<(T >= 1 && T <= 7 ? 1 : 0) + (LAST && T >= 1 && T <= 3 ? 1 : 0) + 1 + (T <= 6 ? 1 : 0) + (LAST && T <= 2 ? 1 : 0)>();
+                if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+                if (!VGH_ABLATE(a, 16)) barrier_raw();
                 // ---- M phase ----
-                __builtin_amdgcn_s_setprio(1);
+                if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+                if (!VGH_ABLATE(a, 2)) {
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
+                    for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
+                    for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                barrier_raw();
+                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                }
+                if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                if (!VGH_ABLATE(a, 64)) barrier_raw();
             };
             phase(std::integral_constant<int, 0>{});
             phase(std::integral_constant<int, 1>{});
@@ -256,47 +291,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             xs ^= 1;
         }
 
-        // ---- epilogue (registers only): ReLU, + alpha * residual, bf16, half-wave exchange, 16-byte stores ----
-        {
+        // ---- epilogue (registers only): ReLU, + alpha * residual, bf16, half-wave exchange, 16-byte stores through buffer descriptors (32-bit offsets,
+        //      out-of-range offset = no access: no branch around a load or a store).  ALL residual vectors are requested before the first store: vmcnt is
+        //      one in-order counter, so a residual load issued behind a store could only be awaited together with that store's write acknowledgement ----
+        if (!VGH_ABLATE(a, 8)) {
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x80000000, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, 0x80000000, 0x00020000);
             const int cbase = cur.c0;
-            bool okpx[2];
-            int64_t opix[2];
+            const int dsplit = (a.out_coff2 - a.out_split - a.out_coff) * 2;  // byte shift of the second output segment
+            unsigned ovb[2], rvb[2];  // byte offsets of this lane's pixel + channel (cbase + 8 hi) in the output / residual tensor
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int y = cur.y0 + 4 * j + (n32 >> 3), x = cur.x0 + (n32 & 7);
-                okpx[j] = cur.spok && y < a.Ho && x < a.Wo;
-                opix[j] = ((int64_t)cur.b * a.Ho + y) * a.Wo + x;
+                const bool okpx = cur.spok && y < a.Ho && x < a.Wo;
+                const int opix = (cur.b * a.Ho + y) * a.Wo + x;
+                ovb[j] = okpx ? (unsigned)((opix * (int)a.out_pitch + a.out_coff + cbase + 8 * hi) * 2) : OOB;
+                rvb[j] = okpx ? (unsigned)((opix * (int)a.res_pitch + a.res_coff + cbase + 8 * hi) * 2) : OOB;
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // residual vectors of one 32-pixel group (2 TI x 16 bytes per lane), all in flight before the first use (a conditional load per vector
-                // would make hipcc wait for each one in turn); lanes without an output read the buffer's first bytes
-                u32x4_t rv[TI][2];
-                if (a.res) {
-#pragma unroll
-                    for (int i = 0; i < TI; ++i)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            const int cv = cbase + i * 32 + 16 * m + 8 * hi;
-                            const uint16_t* const p = (okpx[j] && cv < a.cout_store) ? a.res + opix[j] * a.res_pitch + a.res_coff + cv : a.res;
-                            rv[i][m] = *(const u32x4_t*)p;
-                        }
-                }
-                uint16_t* const op = (uint16_t*)a.out + opix[j] * a.out_pitch;
+            // order: residual loads of pixel group 0 -> arithmetic of group 0 (results held) -> residual loads of group 1 -> stores of group 0 ->
+            // arithmetic + stores of group 1: every load is issued ahead of every store, and group 1's vectors land in group 0's dead accumulators
+            u32x4_t rv[TI][2], ov[TI][2];
+            auto load_res = [&](int j) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        // after the exchange this lane holds couts cv .. cv + 7
                         const int cv = cbase + i * 32 + 16 * m + 8 * hi;
-                        const bool ok = okpx[j] && cv < a.cout_store;
-                        float va[4], vb[4];  // runs q = 2m and q = 2m + 1 of this lane (couts 32 i + 8 q + 4 hi + e)
+                        rv[i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (cv < a.cout_store ? rvb[j] : OOB) + (i * 32 + 16 * m) * 2, 0, 0);
+                    }
+            };
+            auto arith = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            va[e] = fmaxf(acc[i][j][(2 * m) * 4 + e], act_lo);
-                            vb[e] = fmaxf(acc[i][j][(2 * m + 1) * 4 + e], act_lo);
-                        }
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        // after the exchange this lane holds couts cv .. cv + 7; before it, runs q = 2m and q = 2m + 1 (couts 32 i + 8 q + 4 hi + e)
+                        unsigned pa0, pa1, pb0, pb1;
                         if (a.res) {
+                            float va[4], vb[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                va[e] = fmaxf(acc[i][j][(2 * m) * 4 + e], act_lo);
+                                vb[e] = fmaxf(acc[i][j][(2 * m + 1) * 4 + e], act_lo);
+                            }
                             unsigned d0 = rv[i][m][0], d1 = rv[i][m][1], d2 = rv[i][m][2], d3 = rv[i][m][3];
                             swap32(d0, d2);  // back to the accumulator layout: (d0, d1) = run 2m, (d2, d3) = run 2m + 1 of this lane
                             swap32(d1, d3);
@@ -308,23 +346,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                             vb[1] += a.alpha * bf_hi(d2);
                             vb[2] += a.alpha * bf_lo(d3);
                             vb[3] += a.alpha * bf_hi(d3);
+                            pa0 = pack_bf16(va[0], va[1]), pa1 = pack_bf16(va[2], va[3]);
+                            pb0 = pack_bf16(vb[0], vb[1]), pb1 = pack_bf16(vb[2], vb[3]);
+                        } else {
+                            // round first, ReLU on the packed pairs: bf16 as int16 is negative exactly when the float is (rounding keeps the sign)
+                            pa0 = pack_bf16(acc[i][j][8 * m + 0], acc[i][j][8 * m + 1]), pa1 = pack_bf16(acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]);
+                            pb0 = pack_bf16(acc[i][j][8 * m + 4], acc[i][j][8 * m + 5]), pb1 = pack_bf16(acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]);
+                            if (a.act == VGH_ACT_RELU) {
+                                pa0 = relu_pk(pa0), pa1 = relu_pk(pa1);
+                                pb0 = relu_pk(pb0), pb1 = relu_pk(pb1);
+                            }
                         }
-                        unsigned pa0 = pack_bf16(va[0], va[1]), pa1 = pack_bf16(va[2], va[3]);
-                        unsigned pb0 = pack_bf16(vb[0], vb[1]), pb1 = pack_bf16(vb[2], vb[3]);
                         swap32(pa0, pb0);
                         swap32(pa1, pb1);
-                        if (ok) {
-                            const int ochan = (cv >= a.out_split) ? a.out_coff2 + (cv - a.out_split) : a.out_coff + cv;
-                            const u32x4_t ov = {pa0, pa1, pb0, pb1};
-                            u32x4_t* const dst = (u32x4_t*)(op + ochan);
+                        ov[i][m] = u32x4_t{pa0, pa1, pb0, pb1};
+                    }
+            };
+            auto store_out = [&](int j) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int cv = cbase + i * 32 + 16 * m + 8 * hi;
+                        if (VGH_ABLATE(a, 128)) {  // experiments: the epilogue's arithmetic without its stores
+                            asm volatile("" ::"v"(ov[i][m]));
+                        } else {
+                            const unsigned vo = (cv < a.cout_store ? ovb[j] : OOB) + (unsigned)(cv >= a.out_split ? dsplit : 0) + (i * 32 + 16 * m) * 2;
                             if (a.nt_out)
-                                __builtin_nontemporal_store(ov, dst);
+                                __builtin_amdgcn_raw_buffer_store_b128(ov[i][m], rs_out, vo, 0, 2);
                             else
-                                *dst = ov;
+                                __builtin_amdgcn_raw_buffer_store_b128(ov[i][m], rs_out, vo, 0, 0);
                         }
                     }
-                __builtin_amdgcn_sched_barrier(0);  // the second group's residual loads stay behind the first group's stores (register budget)
-            }
+            };
+            if (a.res) load_res(0);
+            __builtin_amdgcn_sched_barrier(0);
+            arith(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.res) load_res(1);
+            __builtin_amdgcn_sched_barrier(0);
+            store_out(0);
+            __builtin_amdgcn_sched_barrier(0);
+            arith(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            store_out(1);
         }
         if (!nxt.valid) break;
         cur = nxt;
@@ -355,11 +420,17 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
 
 }  // namespace
 
+// the epilogue addresses the output and residual tensors through buffer descriptors: 32-bit byte offsets
+int vgh_conv_pp_fits(const ConvArgs& a) {
+    const int64_t lim = (1ll << 31) - 4096;
+    return (int64_t)a.P * a.out_pitch * 2 < lim && (!a.res || (int64_t)a.P * a.res_pitch * 2 < lim) && a.cout_pad <= 2048;
+}
 int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4>::LDS : bc == 96 ? PPGeo<3>::LDS : bc == 64 ? PPGeo<2>::LDS : 0; }
 
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int max_blocks_per_xcd, hipStream_t stream) {
     VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && !a.split && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 convs only");
-    VGH_REQUIRE(a.cout_pad % bc == 0, "conv: cout_pad %d is not a multiple of the %d-cout ping-pong tile", a.cout_pad, bc);
+    VGH_REQUIRE(a.cout_pad % bc == 0 && a.cout_pad <= 2048, "conv: cout_pad %d is not a multiple of the %d-cout ping-pong tile (or above 2048)", a.cout_pad, bc);
+    VGH_REQUIRE(vgh_conv_pp_fits(a), "conv: output / residual tensor above 2 GiB (32-bit buffer offsets)");
     const int nsx = (a.Wo + 7) / 8, nsy = (a.Ho + 7) / 8, ntc = a.cout_pad / bc;
     const int64_t nsp = (int64_t)a.B * nsy * nsx;
     const int64_t total = (nsp + 7) / 8 * ntc;
