@@ -54,6 +54,20 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def _physical_cores(fallback: int) -> int:
+    """Physical cores of the host (distinct (physical id, core id) pairs of /proc/cpuinfo); SMT siblings are not counted."""
+    try:
+        seen, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":")[1].strip()))
+        return len(seen) or fallback
+    except OSError:
+        return fallback
+
+
 def _timed(fn, iters: int):
     ts = []
     for _ in range(iters):
@@ -76,7 +90,7 @@ def cpu_baseline(variant: str, image_size: int, flame_model):
     from oracle import net_oracle, postproc_oracle as po
 
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(avail, 32))  # torch's CPU conv stops scaling (and thrashes) far below the box's 256 hardware threads
+    cores = max(1, min(avail, _physical_cores(avail), 64))  # one thread per physical core, at most 64 (torch's CPU conv stops scaling beyond one socket)
     torch.set_num_threads(cores)
     sd = arch.random_state_dict(variant, 1)
     net = net_oracle.YoloHeadsOracle({"vgg_heads_m": "m", "vgg_heads_l": "l"}[variant])
@@ -92,7 +106,7 @@ def cpu_baseline(variant: str, image_size: int, flame_model):
         fo.reproject(consts, torch.cat([r[2] for r in res]))
 
     e2e, n_img = {}, 0
-    for bs, iters in ((1, 10), (8, 2), (32, 1)):
+    for bs, iters in ((1, 10), (8, 3), (32, 3)):
         x = torch.rand(bs, 3, image_size, image_size, generator=torch.Generator().manual_seed(0))
         if bs == 1:
             end_to_end(x)  # warm-up at full size
@@ -326,7 +340,7 @@ def _respawn_under_torchrun(n: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", default="vgg_heads_l")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
@@ -344,6 +358,8 @@ def main():
     ap.add_argument("--tuning", default=None, help="tile table to load instead of head_detector_amd/tuning/conv_cfg.json")
     ap.add_argument("--precision", default="bf16", help="activation format of the main workload (bf16 = the headline; fp16x3 / fp32 are the parity modes)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"], help="roofline.traffic: PMC passes run by this script (live), the committed profile (file)")
+    ap.add_argument("--inner", type=int, default=8, help="forwards (engine calls over one resident batch each) per timed step: the driver's 20-step run then times "
+                    "> 2 s instead of 0.27 s, i.e. one clock / power state covers the region; ms_per_step is per step, config.ms_per_forward per forward")
     ap.add_argument("--ramp-steps", type=int, default=30, help="untimed steps before the W warm-up steps (clock ramp of a cold box; 0 = off)")
     args = ap.parse_args()
     leaked = sorted(k for k in os.environ if k.startswith("VGH_"))
@@ -375,7 +391,7 @@ def main():
     steered = [False]
 
     def run_workload(variant: str, B: int, steps: int, warmup: int, per_layer_path=None, image_size: int = S, heads_per_image: float = args.heads_per_image,
-                     precision: str = "bf16") -> dict:
+                     precision: str = "bf16", inner: int = 1) -> dict:
         """The timed region of the contract for one (variant, batch): W warm-up steps, barrier + synchronize, K steps, synchronize +
         barrier, max over ranks.  HIP events on the engine's stream bracket the network part of every timed step."""
         # post stages of batch s under the network of batch s+1: pays from batch 8 up (measured r02: 2.89 vs 2.95 ms at B=8, 13.25 vs 13.42 at B=64), costs
@@ -402,9 +418,10 @@ def main():
                 hi = mid
             if abs(mean_heads - heads_per_image) < max(0.25, 0.05 * heads_per_image):
                 break
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-        n_heads_all = torch.zeros(max(steps, 1), dtype=torch.int32, device=dev)
+        nfw = steps * inner  # forwards in the timed region
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nfw)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nfw)]
+        n_heads_all = torch.zeros(max(nfw, 1), dtype=torch.int32, device=dev)
         # throughput mode: NMS .. FLAME decode of batch s run on the detector's side stream underneath the network of batch s+1
         eng.set_overlap(overlap)
         eng.set_split(nsplit)
@@ -430,14 +447,14 @@ def main():
 
         for _ in range(args.ramp_steps):  # untimed: a cold box needs a few hundred ms of load before its clocks settle
             step()
-        for _ in range(warmup):
+        for _ in range(warmup * inner):
             step()
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         with PowerSampler(local) as power:
             t0 = time.perf_counter()
-            for i in range(steps):
+            for i in range(nfw):  # K steps of `inner` forwards each
                 step(i)
             eng.join()
             if gat is not None:
@@ -451,15 +468,15 @@ def main():
             t = torch.tensor([dt], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
-        net_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(steps, 1)
+        net_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(nfw, 1)  # per forward
         heads = int(n_heads_all.sum().item())
         if per_layer_path and rank == 0:
             eng.join()
             eng.set_split(1)  # per-op events make sense on one stream only: the table is the single-stream view of every op
             json.dump(eng.profile_ops(images), open(per_layer_path, "w"), indent=0)
         alg = arch.program_algorithmic_bytes(eng.program, B)
-        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, heads_per_img=heads / max(steps * B, 1), overlap=overlap,
-                   value=B * world * steps / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,
+        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,
+                   value=B * world * nfw / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,
                    alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch, power=power.summary())
         eng.close()
         return out
@@ -495,11 +512,11 @@ def main():
         return out
 
     def brief(m: dict) -> dict:
-        return {"images_per_sec": round(m["value"], 2), "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "net_ms_per_step": round(m["net_ms"], 3),
+        return {"images_per_sec": round(m["value"], 2), "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "net_ms_per_step": round(m["net_ms"] * m.get("inner", 1), 3),
                 "conv_tflops": round(m["conv_tflops"], 2), "roofline_frac": round(m["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "steps": m["steps"],
                 "heads_per_image_decoded": round(m["heads_per_img"], 2)}
 
-    main_run = run_workload(args.variant, args.batch, args.steps, args.warmup, args.per_layer, precision=args.precision)
+    main_run = run_workload(args.variant, args.batch, args.steps, args.warmup, args.per_layer, precision=args.precision, inner=max(1, args.inner))
     B = args.batch
 
     # FLAME decode alone (second headline metric): us per head at n = 96
@@ -516,10 +533,13 @@ def main():
     decode_us_per_head = e0.elapsed_time(e1) * 1e3 / (20 * 96)
 
     if rank == 0:
-        config = {"workload": f"{args.variant} {args.precision} batch {B}/GPU @ {S}x{S}, u8 NHWC input resident in HBM, ~{main_run['heads_per_img']:.2f} heads/img decoded",
-                  "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(main_run["flops_per_image"] / 1e9, 2),
+        inner = main_run["inner"]
+        config = {"workload": f"{args.variant} {args.precision} batch {B}/GPU @ {S}x{S}, u8 NHWC input resident in HBM, ~{main_run['heads_per_img']:.2f} heads/img decoded; "
+                              f"one step = {inner} forwards of that batch back to back ({inner * B} images per GPU per step)",
+                  "global_batch": B * world, "forwards_per_step": inner, "images_per_step": inner * B * world,
+                  "ms_per_forward": round(main_run["dt"] / (args.steps * inner) * 1e3, 3), "net_ms_per_forward": round(main_run["net_ms"], 3), "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(main_run["flops_per_image"] / 1e9, 2),
                   "graph": bool(args.graph), "exchange_to_rank0": bool(world > 1 or args.exchange), "overlap_post": main_run["overlap"], "batch_split": nsplit,
-                  "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(main_run["net_ms"], 3), "ramp_steps": args.ramp_steps}
+                  "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "net_ms_per_step": round(main_run["net_ms"] * inner, 3), "ramp_steps": args.ramp_steps}
         if main_run["power"]:
             config["power_during_timed_steps"] = main_run["power"]
         sec_steps = max(50, args.steps // 2)
@@ -553,7 +573,7 @@ def main():
         if args.traffic in ("auto", "live") and world == 1 and S == 640 and args.precision == "bf16":
             traffic = live_traffic(args.variant, B, nsplit)
         if traffic is None and args.traffic in ("auto", "file") and S == 640:
-            for name in (f"r03_traffic_{args.variant[-1]}{B}_x{nsplit}.json",):
+            for name in (f"r04_traffic_{args.variant[-1]}{B}_x{nsplit}.json", f"r03_traffic_{args.variant[-1]}{B}_x{nsplit}.json"):
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath):
                     t = json.load(open(tpath))
@@ -562,13 +582,14 @@ def main():
         roof = {"bound": "mfma", "achieved": round(main_run["conv_tflops"], 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(main_run["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                 "algorithmic_bytes_per_forward": round(main_run["alg_bytes"]),
-                "kernel": "conv_igemm_kernel<*> + conv3x3_patch_kernel<*> + conv3x3_patch3_kernel<*> + conv1x1_stream_kernel<*> + stem / pool (all launches of one forward = one pass of the op program over the batch: "
+                "kernel": "conv3x3_pp_kernel<*> + conv_igemm_kernel<*> + conv3x3_patch_kernel<*> + conv3x3_patch3_kernel<*> + conv1x1_stream_kernel<*> + stem / pool (all launches of one forward = one pass of the op program over the batch: "
                           "algorithmic 2*MACs / HIP-event time of the network part; traffic = PMC HBM bytes of one forward)"}
         if traffic is not None:
             tb = traffic["read_bytes_per_forward"] + traffic["write_bytes_per_forward"]
             roof.update({"traffic": round(tb), "traffic_read_bytes": round(traffic["read_bytes_per_forward"]), "traffic_write_bytes": round(traffic["write_bytes_per_forward"]),
                          "traffic_over_algorithmic": round(tb / main_run["alg_bytes"], 3), "traffic_launches_per_forward": round(traffic["launches_per_forward"], 1),
                          "traffic_hbm_tbps_at_net_time": round(tb / (main_run["net_ms"] * 1e-3) / 1e12, 3), "traffic_source": traffic["source"]})
+            print(f"[bench] roofline.traffic source: {traffic['source']}", file=sys.stderr)
         line = {
             "metric": "images/sec at 640x640 (VGGHeads forward path: net -> top-k/NMS -> FLAME decode)",
             "value": round(main_run["value"], 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -33,6 +33,10 @@
 #ifndef PP_RES_PREFETCH
 #define PP_RES_PREFETCH 0  // 1: touch the residual lines of a tile through the LDS-DMA path during its last channel block (A/B knob; measured +-1 %)
 #endif
+#ifndef PP_XFRONT
+#define PP_XFRONT 1  // 1: the 7 halo units of the next channel block are issued in taps 0-3 (2, 2, 2, 1) instead of one per tap in taps 0-6, so that at the
+                     // epilogue nothing young and slow (an HBM halo fetch) sits in the in-order vmcnt queue ahead of the residual loads
+#endif
 #ifndef PP_PRIO
 #define PP_PRIO 1  // s_setprio 1 around: 1 the M phase (MFMAs), 2 the L phase (fragment reads + LDS-DMA issue), 0 nothing (A/B knob)
 #endif
@@ -248,14 +252,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         dma16(wbase_cur, wv_cur, (unsigned)(TT * ncb + cb) * wkstride, wdst + ws * wdst_step);
                     else
                         dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wdst + ws * wdst_step);
-                    if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                    if constexpr (PP_XFRONT) {
+                        if constexpr (T < 3) {
+                            dma16(xsrc, xo[2 * T], 0, xpre + (2 * T) * 1024);
+                            dma16(xsrc, xo[2 * T + 1], 0, xpre + (2 * T + 1) * 1024);
+                        } else if constexpr (T == 3) {
+                            dma16(xsrc, xo[6], 0, xpre + 6 * 1024);
+                        }
+                    } else {
+                        if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                    }
                     // last channel block: pull this wave's residual lines into L2 (one lane per pixel, 16 bytes of every 128-byte line, into the
                     // dummy LDS unit) so that the epilogue's residual loads are L2 hits instead of two exposed HBM round trips per tile
                     if constexpr (LAST && T < 3) dma16(a.res, rpo, (unsigned)(T == 0 ? 0 : T == 1 ? 128 : BC * 2 - 16), smem + G::DUMMY);
                 }
                 wait_lgkm0();  // this wave's reads of stage st / of its halo are complete before the barrier that releases them for re-filling
-                // the weight unit issued in L(T-1) (tap T+1) has landed; younger and allowed in flight: halo unit T-1 (+ residual touch T-1), this phase's units
-                wait_vm<(T >= 1 && T <= 7 ? 1 : 0) + (LAST && T >= 1 && T <= 3 ? 1 : 0) + 1 + (T <= 6 ? 1 : 0) + (LAST && T <= 2 ? 1 : 0)>();
+                // the weight unit issued first in L(T-1) (tap T+1) has landed; younger and allowed in flight: the rest of L(T-1) and all of L(T)
+                {
+                    constexpr int XN_T = PP_XFRONT ? (T < 3 ? 2 : T == 3 ? 1 : 0) : (T < 7 ? 1 : 0);
+                    constexpr int TP = (T + 8) % 9;  // the previous phase
+                    constexpr int XN_P = PP_XFRONT ? (TP < 3 ? 2 : TP == 3 ? 1 : 0) : (TP < 7 ? 1 : 0);
+                    constexpr int PN_T = (LAST && T < 3) ? 1 : 0, PN_P = (LAST && TP < 3) ? 1 : 0;
+                    wait_vm<XN_P + PN_P + 1 + XN_T + PN_T>();
+                }
                 if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
                 if (!VGH_ABLATE(a, 16)) barrier_raw();
                 // ---- M phase ----

@@ -159,3 +159,84 @@ def test_release_shaped_archives_through_the_pack(gpu_lib, flame_model, tmp_path
             dense = _alias(gpu_lib.vgh_detector_scratch(gpu_lib.vgh_ctx_detector(h), _lib.SCRATCH_SCORES_ALL), tuple(ref_dense.shape), "<f4", _dev()).clone()
             assert float((dense - ref_dense).abs().max()) < 2e-3, what
         gpu_lib.vgh_destroy(h)
+
+
+def _iou(a, b):
+    x1, y1 = torch.maximum(a[..., 0], b[..., 0]), torch.maximum(a[..., 1], b[..., 1])
+    x2, y2 = torch.minimum(a[..., 2], b[..., 2]), torch.minimum(a[..., 3], b[..., 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    return inter / ((a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter)
+
+
+def test_archives_against_the_unfused_oracle_at_north_star_tolerances(gpu_lib, flame_model, tmp_path):
+    """N1 as an ORACLE test: the network the library builds FROM THE ARCHIVE (load_weights -> build_program(fp16x3) -> pack -> vgh_create) against
+    oracle/net_oracle.YoloHeadsOracle loaded from the SAME archive's state dict -- strictly (every key of the unfused archive must be an oracle key and vice versa;
+    head_detector/detector.py:25-30 loads the blob, the oracle is the unfused super_gradients module graph).  Bars: north_star's IoU >= 0.999, scores 1e-5, parameters 1e-4."""
+    from head_detector_amd import _lib, arch, pack
+    from head_detector_amd.detector import load_weights, weight_manifest_diff
+    from head_detector_amd.engine import _alias
+    from oracle import net_oracle
+
+    variant, okey, S, B = "vgg_heads_m", "m", 256, 2
+    sd = arch.random_state_dict(variant, 23)
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(6))
+    full, _ = fused_variants(variant, sd)
+    archives = {}
+    p = str(tmp_path / "unfused.trcd")
+    torch.jit.script(module_from_state_dict({f"model.{k}": v for k, v in sd.items()})).save(p)
+    archives["torchscript unfused"] = (p, True)
+    p = str(tmp_path / "ckpt.pth")
+    torch.save({"net": {k: torch.from_numpy(v) * 0 for k, v in sd.items()}, "ema_net": {k: torch.from_numpy(v) for k, v in sd.items()}}, p)
+    archives["checkpoint ema_net"] = (p, True)
+    p = str(tmp_path / "fused.trcd")
+    torch.jit.script(module_from_state_dict({f"model.{k}": v for k, v in full.items()})).save(p)
+    archives["torchscript fully fused"] = (p, False)  # its keys are rbr_reparam.*: the oracle (unfused graph) is loaded from the archive's unfused twin below
+
+    for what, (path, unfused) in archives.items():
+        got = load_weights(path)
+        assert not any(weight_manifest_diff(variant, got).values()), what
+        oracle = net_oracle.YoloHeadsOracle(okey)
+        if unfused:
+            res = oracle.load_state_dict({k: torch.from_numpy(v) for k, v in got.items()}, strict=False)
+            # strict in both directions up to BatchNorm's bookkeeping counters (no tensor of the archive is ignored, no oracle weight keeps its initial value)
+            assert not [k for k in res.missing_keys if "num_batches_tracked" not in k], (what, res.missing_keys[:5])
+            assert not res.unexpected_keys, (what, res.unexpected_keys[:5])
+        else:
+            oracle.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        with torch.no_grad():
+            ob_, os_, _ = oracle.dense(x)
+        P = arch.build_program(variant, got, S, "fp16x3")
+        pk = str(tmp_path / "a.vghpack")
+        pack.write_pack(pk, P, flame_model, {}, B)
+        h = C.c_void_p()
+        cfg = _lib.Config(device=torch.cuda.current_device(), pack_path=pk.encode(), max_batch=B)
+        _lib.check(gpu_lib.vgh_create(C.byref(cfg), C.byref(h)))
+        kk = 100
+        f32 = dict(dtype=torch.float32, device=_dev())
+        ob, osc, of = torch.zeros(B, kk, 4, **f32), torch.zeros(B, kk, **f32), torch.zeros(B, kk, 413, **f32)
+        oc, nh, hi = torch.zeros(B, dtype=torch.int32, device=_dev()), torch.zeros(1, dtype=torch.int32, device=_dev()), torch.zeros(B * kk, dtype=torch.int32, device=_dev())
+        o = _lib.DetectOut(boxes_dev=ob.data_ptr(), scores_dev=osc.data_ptr(), flame_dev=of.data_ptr(), counts_dev=oc.data_ptr(), n_heads_dev=nh.data_ptr(), head_image_dev=hi.data_ptr(),
+                           head_capacity=B * kk, unpad_dev=None, verts_dev=None, rot_dev=None, rpy_dev=None, proj_dev=None)
+        conf = float(torch.sort(os_[:, :, 0].flatten(), descending=True).values[4 * B])  # a handful of detections per image
+        st = torch.cuda.current_stream().cuda_stream
+        xd = x.to(_dev()).contiguous()
+        assert gpu_lib.vgh_ctx_detect(h, xd.data_ptr(), _lib.VGH_IMG_F32_NCHW, B, conf, 0.5, C.byref(o), st) == 0, gpu_lib.vgh_ctx_last_error(h)
+        _lib.check(gpu_lib.vgh_ctx_join(h, st))
+        torch.cuda.synchronize()
+        det = gpu_lib.vgh_ctx_detector(h)
+        A = ob_.shape[1]
+        dense_b = _alias(gpu_lib.vgh_detector_scratch(det, _lib.SCRATCH_BOXES_ALL), (B, A, 4), "<f4", _dev()).cpu()
+        dense_s = _alias(gpu_lib.vgh_detector_scratch(det, _lib.SCRATCH_SCORES_ALL), (B, A), "<f4", _dev()).cpu()
+        assert float(_iou(dense_b, ob_).min()) >= 0.999, (what, float(_iou(dense_b, ob_).min()))
+        assert float((dense_s - os_[..., 0]).abs().max()) < 1e-5, what
+        # the detections it kept: each is some anchor of the oracle, with that anchor's box and parameters
+        with torch.no_grad():
+            _, _, of_ = oracle.dense(x)
+        assert int(nh) >= B
+        for b in range(B):
+            for i in range(int(oc[b])):
+                a = int((ob_[b] - ob[b, i].cpu()).abs().sum(-1).argmin())
+                assert float(_iou(ob[b, i].cpu(), ob_[b, a])) >= 0.999
+                rel = (of[b, i, :412].cpu() - of_[b, a, :412]).abs() / (of_[b, a, :412].abs() + 1.0)
+                assert float(rel.max()) < 1e-4, (what, float(rel.max()))
+        gpu_lib.vgh_destroy(h)

@@ -1376,10 +1376,12 @@ def test_bf16_mode_accuracy_vs_fp32_mode(gpu_lib, flame_model):
         assert r["param_max_abs_err_live"] < 0.5  # translation is in pixels (|t| ~ 640): 0.5 px
         assert r["log_scale_max_abs_err"] < 5e-2
         assert r["vertex_l2_metric_mean"] < 2e-3 and r["vertex_l2_metric_max"] < 2e-2  # metres in FLAME space (|v| ~ 0.2)
-        # kept_by_both_frac (the share of the fp32 mode's NMS survivors the bf16 mode also keeps at the same threshold) is printed, not pinned: the
-        # random-weight net's scores sit within a few 1e-4 of each other around the calibrated threshold (dense score error 2.3e-4 here), so a change of
-        # summation order in ONE layer -- a retuned tile -- moves it between 0.44 and 0.88 (r02 / r03 tables) while every quantity above stays put
+        # the share of the fp32 mode's NMS survivors the bf16 mode also keeps at the same threshold, pinned WITH A TIE MARGIN: survivors whose
+        # fp32 score clears the threshold by less than 3 x the dense score error are left out -- the random-weight net's scores sit within a few 1e-4 of each
+        # other around any calibrated threshold, so the raw share moved between 0.44 and 0.88 with the summation order of ONE retuned layer (r02 / r03 tables)
         assert 0.0 < r["kept_by_both_frac"] <= 1.0
+        if r["kept_clear_of_threshold"] >= 3:
+            assert r["kept_by_both_clear_frac"] >= 0.75, r
 
 
 def test_c_only_create_and_detect(gpu_lib, flame_model, tmp_path):

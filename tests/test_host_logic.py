@@ -412,3 +412,32 @@ def test_fused_archive_keys_fold_to_the_same_network():
     broken = dict(full)
     del broken[f"{qarep[3].name}.rbr_reparam.bias"]
     assert weight_manifest_diff(variant, broken)["missing"] == [f"{qarep[3].name}.rbr_reparam.bias"]
+
+
+def test_archives_with_unexpected_key_names_are_reported_in_full(tmp_path):
+    """First contact with a released blob whose key names differ from the reconstruction must name EVERY difference before anything is folded:
+    a DataParallel `module.` prefix, a block without its post_bn, BatchNorm bookkeeping counters (ignored), a tensor of another shape."""
+    from head_detector_amd import arch
+    from head_detector_amd.detector import load_weights, weight_manifest_diff
+
+    variant = "vgg_heads_m"
+    sd = arch.random_state_dict(variant, 3)
+    qarep = next(sp.name for sp in arch.layer_specs(variant) if sp.kind == "qarep")
+    bad = {}
+    for k, v in sd.items():
+        if k.startswith(qarep + ".post_bn."):
+            continue  # this block lost its post_bn
+        bad["module." + k if k.startswith("heads.") else k] = v  # the heads carry a DataParallel prefix
+    bad[qarep + ".branch_3x3.bn.num_batches_tracked"] = np.zeros((), np.int64)  # bookkeeping: ignored
+    some = next(k for k in sd if k.endswith("conv.weight") and k.startswith("neck."))
+    bad[some] = np.zeros((3, 3, 1, 1), np.float32)
+    p = str(tmp_path / "odd.pth")
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in bad.items()}, p)
+    diff = weight_manifest_diff(variant, load_weights(p))
+    n_heads = sum(k.startswith("heads.") for k in sd)
+    assert len([k for k in diff["missing"] if k.startswith("heads.")]) == n_heads and len([k for k in diff["unexpected"] if k.startswith("module.heads.")]) == n_heads
+    assert all(k in diff["missing"] for k in sd if k.startswith(qarep + ".post_bn.") and "num_batches_tracked" not in k)
+    assert not any("num_batches_tracked" in k for k in diff["unexpected"])
+    assert any(s.startswith(some + ":") for s in diff["shape"])
+    with pytest.raises(Exception):
+        arch.build_program(variant, load_weights(p), 256)
