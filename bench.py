@@ -360,8 +360,16 @@ def main():
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"], help="roofline.traffic: PMC passes run by this script (live), the committed profile (file)")
     ap.add_argument("--inner", type=int, default=8, help="forwards (engine calls over one resident batch each) per timed step: the driver's 20-step run then times "
                     "> 2 s instead of 0.27 s, i.e. one clock / power state covers the region; ms_per_step is per step, config.ms_per_forward per forward")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="N>1 first-contact kit without GPUs: this script's step closure + DetectionGatherer on gloo ranks with a stand-in "
+                    "engine (tools/dryrun_dist.py); --compact-gather selects the packed-rows exchange")
+    ap.add_argument("--compact-gather", action="store_true", help="N>1: send packed survivor rows (DetectionGatherer(compact_rows=...)) instead of the [B, keep, 418] capacity slab")
     ap.add_argument("--ramp-steps", type=int, default=30, help="untimed steps before the W warm-up steps (clock ramp of a cold box; 0 = off)")
     args = ap.parse_args()
+    if args.dry_run_cpu:  # control flow of the N>1 step on CPU ranks (no GPU, no kernels, no measurement): tools/dryrun_dist.py
+        sys.path.insert(0, os.path.join(ROOT, "tools"))  # spawn'ed ranks inherit sys.path and import the module by name
+        import dryrun_dist as mod
+
+        sys.exit(mod.main(["--gpus", str(max(args.gpus, 2)), "--steps", str(min(args.steps, 20))] + (["--compact"] if args.compact_gather else [])))
     leaked = sorted(k for k in os.environ if k.startswith("VGH_"))
     if leaked:
         sys.exit(f"bench.py: refusing to measure with experiment switches in the environment: {leaked}")
@@ -435,7 +443,7 @@ def main():
         if world > 1 or args.exchange:
             slots = [eng.new_output_slot(flame) for _ in range(2)]
             gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream(),
-                                    always_collective=args.exchange)
+                                    always_collective=args.exchange, compact_rows=B * int(1.5 * heads_per_image + 1) if args.compact_gather else 0)
             ready = [torch.cuda.Event() for _ in range(2)]
             if gat.collective and not steered[0]:
                 # RCCL launches its kernels on a stream of torch's pool; on the hardware queue of the engine stream or of a lane they would

@@ -9,6 +9,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # VGH_LIB_PATH: load another build of the library (tools/ use it for the -DVGH_EXPERIMENTS build, which is never shipped)
 LIB_PATH = os.environ.get("VGH_LIB_PATH") or os.path.join(HERE, "libvgh.so")
+ABI_VERSION = 4  # = VGH_ABI_VERSION of include/vgh.h
 
 VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
@@ -94,6 +95,7 @@ _P, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
     "vgh_version": (C.c_char_p, []),
     "vgh_last_error": (C.c_char_p, []),
+    "vgh_abi_version": (_I, []),
     "vgh_net_create": (_I, [_I, _I, _I, C.POINTER(BufDesc), _I, C.POINTER(OpDesc), _I, _P, _I64, _P, _I64, C.POINTER(_P)]),
     "vgh_net_destroy": (None, [_P]),
     "vgh_net_forward": (_I, [_P, _P, _I, _I, _P]),
@@ -200,6 +202,8 @@ def load() -> C.CDLL:
             raise VghError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.vgh_abi_version() != ABI_VERSION:  # the ctypes structs below mirror include/vgh.h at this revision: another one means other struct sizes
+        raise VghError(f"{LIB_PATH} has ABI revision {lib.vgh_abi_version()}, this binding is written for {ABI_VERSION} (stale build?)")
     _lib = lib
     return lib
 

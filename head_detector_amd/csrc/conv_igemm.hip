@@ -52,7 +52,11 @@ static int patch_blocks_per_cu(K kernel, int threads, int lds, std::atomic<int> 
 static std::atomic<int> g_max_blocks_per_xcd{0};
 static std::atomic<int> g_nt_store{0};
 
-static int persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int per_cu) {
+static int persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int per_cu) { return vgh_conv_persistent_blocks_per_xcd(a, chunk, per_cu); }
+
+}  // namespace
+// persistent workgroups per XCD of a tile-loop kernel (also used by conv_split.hip): resident slots, shared between lanes, capped by the test knob
+int vgh_conv_persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int per_cu) {
     // as many blocks per XCD as its 32 CUs keep resident, each looping over tiles; with the batch split over lane streams every
     // lane's kernel takes its share of the slots so that kernels of different lanes are co-resident (and out of phase)
     int slots = 32 * per_cu / (a.grid_share > 1 ? a.grid_share : 1);
@@ -65,6 +69,8 @@ static int persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int per_cu) {
 #endif
     return chunk < slots ? chunk : slots;
 }
+namespace {
+
 
 template <int TW, int TH, int BC, int NWP, int NWC>
 void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {

@@ -77,8 +77,7 @@ void launch_patch_sp(const ConvArgs& a, int ntc, int ntx, int nty, int total, in
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv3x3_patch_kernel<TW, TH, BC, NWP, NWC, SP>, NWP * NWC * 64, lds) != hipSuccess || n < 1) n = 1;
         per_cu[dev].store(n, std::memory_order_release);
     }
-    const int slots = 32 * n;  // persistent blocks per XCD
-    const int gpx = chunk < slots ? chunk : slots;
+    const int gpx = vgh_conv_persistent_blocks_per_xcd(a, chunk, n);  // as the bf16 patch tiles: lane share + vgh_conv_set_max_blocks_per_xcd (multi-tile tests)
     hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC, SP>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
 template <int TW, int TH, int BC, int NWP, int NWC>

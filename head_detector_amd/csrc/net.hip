@@ -26,7 +26,7 @@ struct NetOp {
     float out_scale = 1.0f;     // split parity modes: accumulator scale of the op (vgh_pack_conv_weights_split_host)
     // automatic tile of the op, resolved ONCE for the arena batch: every forward -- any batch size, any chunk, any lane -- then runs the op
     // on the same tile, so its fp32 summation order (hence every output bit) does not depend on how many images ride along
-    mutable int auto_cfg = -1;
+    int auto_cfg = -1;  // the automatic tile of this op, resolved ONCE at vgh_net_create for the arena batch (chunk- and lane-independent bits)
     uint16_t* wds = nullptr;    // stage-1 downsample only: its weights in the fused stem + downsample kernel's layout (stem_ds.hip)
 };
 
@@ -145,12 +145,6 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
             if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
             a.grid_share = share;
             if (n->bufs[d.in_buf].is_f32 != VGH_FMT_F32) {
-                if (op.auto_cfg < 0) {
-                    ConvArgs ref;
-                    if (int rc = net_conv_args(n, op, n->max_batch, 0, &ref)) return rc;
-                    if (int rc = vgh_conv_prepare(ref)) return rc;
-                    op.auto_cfg = vgh_conv_pick_auto(ref);
-                }
                 a.fallback_cfg1 = op.auto_cfg + 1;
                 return vgh_launch_conv(a, d.force_cfg >= 0 ? d.force_cfg : op.auto_cfg, st);
             }
@@ -256,6 +250,7 @@ extern "C" {
 
 const char* vgh_version(void) { return "vgh 0.1.0 (gfx950)"; }
 const char* vgh_last_error(void) { return g_err; }
+int vgh_abi_version(void) { return VGH_ABI_VERSION; }
 
 int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc* bufs, int n_bufs, const vgh_op_desc* ops, int n_ops,
                    const float* weights_host, int64_t n_weights, const float* biases_host, int64_t n_biases, vgh_net** out) {
@@ -314,7 +309,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     for (int i = 0; i + 1 < n_ops; ++i) {
         const vgh_op_desc &a = ops[i], &d = ops[i + 1];
         if (a.kind != VGH_OP_STEM || d.kind != VGH_OP_CONV) continue;
-        bool ok = d.in_buf == a.out_buf && d.in_coff == a.out_coff && d.ksize == 3 && d.stride == 2 && d.cin == 64 && d.cout_pad == 96 && d.cout_store == 96 && d.res_buf < 0 && !d.shuffle &&
+        bool ok = image_size % 4 == 0 /* vgh_launch_stem_ds tiles 4 x 16 outputs of the 1/4-resolution map */ && d.in_buf == a.out_buf && d.in_coff == a.out_coff && d.ksize == 3 && d.stride == 2 && d.cin == 64 && d.cout_pad == 96 && d.cout_store == 96 && d.res_buf < 0 && !d.shuffle &&
                   d.out_split >= 96 && d.act == VGH_ACT_RELU && d.grp_cout == 0 && bufs[a.out_buf].is_f32 == VGH_FMT_BF16 && bufs[d.out_buf].is_f32 == VGH_FMT_BF16 && d.out_coff % 8 == 0 &&
                   bufs[d.out_buf].pitch % 8 == 0;
         for (int j = 0; ok && j < n_ops; ++j)  // nobody else may read (or write) the stem tensor
@@ -364,6 +359,19 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
         }
         if (n->stem_pair >= 0 && i == n->stem_pair + 1) op.wds = (uint16_t*)(n->wblob + wds_off);
         n->ops.push_back(op);
+    }
+    // the automatic tile of every 16-bit conv, for the arena batch: one choice per op whatever batch / chunk / lane later runs it (bit-identical results across
+    // chunkings), resolved here so that a max_batch whose tensors break the 2 GiB rule of the loaders fails at creation, and no forward ever writes the net
+    for (NetOp& op : n->ops) {
+        if (op.d.kind != VGH_OP_CONV || n->bufs[op.d.in_buf].is_f32 == VGH_FMT_F32) continue;
+        ConvArgs ref;
+        int rc = net_conv_args(n, op, n->max_batch, 0, &ref);
+        if (!rc) rc = vgh_conv_prepare(ref);
+        if (rc) {
+            vgh_net_destroy(n);
+            return rc;
+        }
+        op.auto_cfg = vgh_conv_pick_auto(ref);
     }
     *out = n;
     return VGH_OK;

@@ -27,7 +27,10 @@ template <int SP>
 __device__ __forceinline__ void split_elem(float v, float lo_scale, typename SplitT<SP>::e& h, typename SplitT<SP>::e& l) {
     using E = typename SplitT<SP>::e;
     if constexpr (SP == VGH_FMT_F16X2) {
-        v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+        // saturate at fp16's largest finite value (|v| > 65504 and +-Inf are clipped: documented in DESIGN 3.8); a NaN is NOT a number to clamp --
+        // fminf / fmaxf would turn it into -65504, i.e. hide a numerical fault the bf16 and fp32 paths propagate -- so it passes through into both planes
+        const float c = fminf(fmaxf(v, -65504.0f), 65504.0f);
+        v = (v != v) ? v : c;
         h = fabsf(v) < 6.103515625e-05f ? (E)0.0f : (E)v;
     } else {
         h = (E)v;

@@ -106,6 +106,7 @@ static inline int vgh_fmt_planes(int fmt) { return fmt >= 2 ? 2 : 1; }
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int max_blocks_per_xcd, hipStream_t stream);
 int vgh_conv_pp_lds(int bc);
 int vgh_conv_pp_fits(const ConvArgs& a);
+int vgh_conv_persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int blocks_per_cu);
 int vgh_conv_pick_cfg(const ConvArgs& a);
 // validates `a` and fills its derived fields (fast-division constants, fast_epi); vgh_launch_conv calls it itself
 int vgh_conv_prepare(ConvArgs& a);

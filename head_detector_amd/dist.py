@@ -127,6 +127,7 @@ class GatheredDetections:
     n_heads_per_rank: Optional[torch.Tensor] = None  # [world] int32
     vertex_slabs: Optional[torch.Tensor] = None  # [world, vertex_rows, V, 3]: rank r's first min(n_heads[r], vertex_rows) rows are live
     images_per_rank: Optional[torch.Tensor] = None  # [world] int32: rows [r*B_local, r*B_local + images[r]) of the slabs are real images
+    compact_slabs: Optional[torch.Tensor] = None  # [world, compact_rows, 418] (DetectionGatherer(compact_rows=...)): survivors packed image-major per rank
 
 
 def gather_detections(boxes: torch.Tensor, scores: torch.Tensor, flame_params: torch.Tensor, counts: torch.Tensor, vertices_3d: Optional[torch.Tensor] = None,
@@ -186,8 +187,15 @@ class DetectionGatherer:
     caller's stream wait for them.  Ranks may own different numbers of images (uneven shards): pass ``B_local`` = the largest shard
     and ``local_images`` = this rank's count; rows beyond it carry count 0."""
 
-    def __init__(self, B_local: int, keep: int, num_vertices: int = 0, vertex_rows: int = 0, device=None, dst: int = 0, group=None, slots: int = 2, stream=None, always_collective: bool = False):
+    def __init__(self, B_local: int, keep: int, num_vertices: int = 0, vertex_rows: int = 0, device=None, dst: int = 0, group=None, slots: int = 2, stream=None, always_collective: bool = False,
+                 compact_rows: int = 0):
+        """``compact_rows`` > 0 (SURVEY 8(e) option (ii)): instead of the capacity slab ``[B_local, keep, 418]`` (10.7 MB per rank and step at B = 64, ~3 % of
+        it live) each rank sends its survivors packed image-major into ``[compact_rows, 418]`` -- a fixed cap, so still no size on the host: row r is
+        detection r - first[image] of image = searchsorted(cumsum(counts), r); rows beyond the rank's total are zero and a total above the cap is cut
+        (visible to the consumer through ``counts``).  ``result`` then carries ``compact_slabs [world, compact_rows, 418]`` and ``compact()`` rebuilds the
+        per-image layout."""
         self.group, self.dst = group, dst
+        self.crows = int(compact_rows)
         # always_collective: go through the process group even when it has a single rank (exercises the RCCL calls on a 1-GPU box)
         self.collective = dist.is_initialized() and (dist.get_world_size(group) > 1 or always_collective)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -201,9 +209,10 @@ class DetectionGatherer:
         self.slots = []
         for _ in range(slots):
             sl = dict(
-                send=torch.zeros(B_local, keep, 418, **f32), send_counts=torch.zeros(B_local + 2, **i32),  # [counts | n_heads | images owned]
+                send=torch.zeros(B_local, keep, 418, **f32) if not self.crows else torch.zeros(self.crows, 418, **f32),
+                send_counts=torch.zeros(B_local + 2, **i32),  # [counts | n_heads | images owned]
                 send_verts=torch.zeros(vertex_rows, num_vertices, 3, **f32) if vertex_rows else None,
-                recv=torch.zeros(max(W, 1), B_local, keep, 418, **f32) if self.rank == dst else None,
+                recv=(torch.zeros(max(W, 1), B_local, keep, 418, **f32) if not self.crows else torch.zeros(max(W, 1), self.crows, 418, **f32)) if self.rank == dst else None,
                 recv_counts=torch.zeros(self.world, B_local + 2, **i32),  # all_gather target: every rank has it
                 recv_verts=torch.zeros(max(W, 1), vertex_rows, num_vertices, 3, **f32) if (self.rank == dst and vertex_rows) else None,
                 work=[], done=torch.cuda.Event() if self.cuda else None, busy=False, reader=None)
@@ -235,10 +244,21 @@ class DetectionGatherer:
             self.stream.wait_stream(sl["reader"])
             sl["reader"] = None
         with ctx:
-            # pack into the pre-allocated send buffers (device-side copies, no allocation)
-            sl["send"][:nb, :, 0:4].copy_(boxes[:nb], non_blocking=True)
-            sl["send"][:nb, :, 4].copy_(scores[:nb], non_blocking=True)
-            sl["send"][:nb, :, 5:].copy_(flame_params[:nb], non_blocking=True)
+            # pack into the pre-allocated send buffers (device-side copies; the compact form gathers fixed-shape index tensors: no size visits the host)
+            if not self.crows:
+                sl["send"][:nb, :, 0:4].copy_(boxes[:nb], non_blocking=True)
+                sl["send"][:nb, :, 4].copy_(scores[:nb], non_blocking=True)
+                sl["send"][:nb, :, 5:].copy_(flame_params[:nb], non_blocking=True)
+            else:
+                c = counts[:nb].long().clamp(min=0, max=self.keep)
+                ends = torch.cumsum(c, 0)
+                r = torch.arange(self.crows, device=ends.device)
+                img = torch.searchsorted(ends, r, right=True).clamp(max=nb - 1)  # image of compact row r
+                j = (r - (ends - c)[img]).clamp(min=0, max=self.keep - 1)  # its rank inside the image
+                live = (r < ends[-1]).to(boxes.dtype).unsqueeze(-1)
+                sl["send"][:, 0:4] = boxes[img, j] * live
+                sl["send"][:, 4] = scores[img, j] * live[:, 0]
+                sl["send"][:, 5:] = flame_params[img, j] * live
             sl["send_counts"][:nb].copy_(counts[:nb], non_blocking=True)
             if nb < self.B:
                 sl["send_counts"][nb : self.B].zero_()
@@ -283,8 +303,12 @@ class DetectionGatherer:
             return None
         if self.cuda:
             sl["reader"] = torch.cuda.current_stream(self.device)
-        full = sl["recv"].reshape(self.world * self.B, self.keep, 418)
-        out = GatheredDetections(full[..., :4], full[..., 4], full[..., 5:], sl["recv_counts"][:, : self.B].reshape(-1))
+        if self.crows:
+            out = GatheredDetections(None, None, None, sl["recv_counts"][:, : self.B].reshape(-1))
+            out.compact_slabs = sl["recv"]  # [world, compact_rows, 418]: rank r's survivors image-major, rows beyond its total are zero
+        else:
+            full = sl["recv"].reshape(self.world * self.B, self.keep, 418)
+            out = GatheredDetections(full[..., :4], full[..., 4], full[..., 5:], sl["recv_counts"][:, : self.B].reshape(-1))
         out.n_heads_per_rank = sl["recv_counts"][:, self.B]
         out.images_per_rank = sl["recv_counts"][:, self.B + 1]
         out.vertex_slabs = sl["recv_verts"]  # [world, vertex_rows, V, 3] or None
@@ -296,6 +320,17 @@ class DetectionGatherer:
         imgs = out.images_per_rank.tolist()
         rows = torch.cat([torch.arange(r * self.B, r * self.B + imgs[r]) for r in range(self.world)]).to(out.counts.device)
         cnt = out.counts[rows]
+        if out.compact_slabs is not None:  # rebuild [image, keep, .] from the packed survivor rows (zeros where an image has fewer than keep)
+            full = torch.zeros(self.world * self.B, self.keep, 418, dtype=out.compact_slabs.dtype, device=out.compact_slabs.device)
+            for r in range(self.world):
+                c = out.counts[r * self.B : (r + 1) * self.B].long().clamp(min=0, max=self.keep)
+                ends = torch.cumsum(c, 0)
+                n = min(int(ends[-1]), self.crows)
+                k = torch.arange(n, device=c.device)
+                img = torch.searchsorted(ends, k, right=True)
+                full[r * self.B + img, k - (ends - c)[img]] = out.compact_slabs[r, :n]
+            out = GatheredDetections(full[..., :4], full[..., 4], full[..., 5:], out.counts, n_heads_per_rank=out.n_heads_per_rank, vertex_slabs=out.vertex_slabs,
+                                     images_per_rank=out.images_per_rank)
         verts = hi = None
         if out.vertex_slabs is not None:
             nh = [min(int(n), self.vrows) for n in out.n_heads_per_rank.tolist()]

@@ -36,6 +36,12 @@ extern "C" {
 const char* vgh_version(void);
 const char* vgh_last_error(void);
 
+/* ABI revision of this header: bumped whenever a struct below grows or a function changes meaning (r03 -> 3: vgh_conv_call / vgh_op_desc gained
+ * grp_cout, grp_in_stride, fmt, out_scale and vgh_flame_set_matrix_path became a 0..4 mode; r04 -> 4: this call).  A client built against another
+ * revision passes structs of another size: compare before the first call that takes one (head_detector_amd/_lib.py and tests/c_abi_smoke.c do). */
+#define VGH_ABI_VERSION 4
+int vgh_abi_version(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Network: replaces `self.model(image)` -- the TorchScript blob called at detector.py:58-59 whose
  * graph is YoloHeads.forward (yolo_heads.py:89-112, arch yaml :4-137) + YoloHeadsNDFLHeads.forward

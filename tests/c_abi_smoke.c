@@ -49,6 +49,10 @@ int main(int argc, char** argv) {
         fprintf(stderr, "usage: %s pack images.u8 B conf out_prefix\n", argv[0]);
         return 1;
     }
+    if (vgh_abi_version() != VGH_ABI_VERSION) { /* the header this client was compiled against describes other struct sizes than the library expects */
+        fprintf(stderr, "libvgh.so has ABI revision %d, vgh.h %d\n", vgh_abi_version(), VGH_ABI_VERSION);
+        return 1;
+    }
     B = atoi(argv[3]);
     conf = (float)atof(argv[4]);
     memset(&cfg, 0, sizeof(cfg));

@@ -1,6 +1,10 @@
 """CPU: the N>1 path (batch sharding + gather of detections) with world_size 2 on the gloo backend."""
+import json
 import os
 import socket
+import sys
+
+import pytest
 
 import torch
 import torch.distributed as dist
@@ -162,96 +166,31 @@ def test_gatherer_single_process_and_vertex_cut():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # bench.py's own step closure (make_step) on gloo: the N>1 control flow of the benchmark -- two output slots, wait_slot_free before a
-# slot is rewritten, join_into + submit after every select, the late read of the previous batch -- executed with a stand-in engine
-class _StandInEngine:
-    """Implements the engine surface make_step touches; `select` writes what the real engine would leave in the output slot for this
-    rank's shard of global batch `step` (a function of the global image index only)."""
+# slot is rewritten, join_into + submit after every select, the late read of the previous batch -- executed with the stand-in engine of
+# tools/dryrun_dist.py (the same code `python bench.py --gpus 2 --dry-run-cpu` runs from a shell: the first-contact kit for an 8-GPU lease)
+def _dryrun():
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)  # spawn'ed workers inherit sys.path and import `dryrun_dist` by name
+    import dryrun_dist
 
-    def __init__(self, rank, world, total, keep, V):
-        self.rank, self.world, self.total, self.keep, self.V = rank, world, total, keep, V
-        self.stream = None
-        self.step = -1
-        self.calls = []
-
-    def forward_net(self, images, use_graph=False):
-        self.step += 1
-        self.calls.append("net")
-
-    def candidates(self, B):
-        self.calls.append("cand")
-
-    def select(self, B, confidence_threshold, iou_threshold, flame, unpad, n_heads_out, slot):
-        import types
-
-        b, sc, f, c, v = _shard_outputs(self.step, self.rank, self.world, self.total, self.keep, self.V)
-        nb = b.shape[0]
-        slot["boxes"].fill_(7.0)  # junk beyond the shard, as an engine that owns fewer images than the slab would leave it
-        slot["boxes"][:nb], slot["scores"][:nb], slot["flame"][:nb] = b, sc, f
-        slot["counts"].zero_()
-        slot["counts"][:nb] = c
-        slot["n_heads"][0] = int(c.sum())
-        slot["proj"][: v.shape[0]] = v
-        n_heads_out[0] = int(c.sum())
-        self.calls.append("select")
-        return types.SimpleNamespace(boxes=slot["boxes"], scores=slot["scores"], flame_params=slot["flame"], counts=slot["counts"], n_heads=slot["n_heads"], vertices_cap=slot["proj"])
-
-    def join_into(self, stream):
-        self.calls.append("join_into")
+    return dryrun_dist
 
 
-def _bench_step_worker(rank, world, port, q, total, steps):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import bench
-
-    keep, V = 5, 7
-    B = shard_batch(total, 0, world)[1]
-    assert shard_batch(total, rank, world)[1] - shard_batch(total, rank, world)[0] == B, "bench.py is weak scaling: every rank owns B images"
-    eng = _StandInEngine(rank, world, total, keep, V)
-    mk = lambda: dict(boxes=torch.zeros(B, keep, 4), scores=torch.zeros(B, keep), flame=torch.zeros(B, keep, 413), counts=torch.zeros(B, dtype=torch.int32),  # noqa: E731
-                      n_heads=torch.zeros(1, dtype=torch.int32), proj=torch.zeros(B * keep, V, 3))
-    slots = [mk(), mk()]
-    gat = DetectionGatherer(B, keep, V, vertex_rows=B * keep, device="cpu", dst=0)
-    n_heads_all = torch.zeros(steps, dtype=torch.int32)
-    step = bench.make_step(eng, None, None, None, 0.5, B, slots, gat, True, False, n_heads_all)
-    got = []
-
-    def collect(slot):
-        out = gat.result(slot)
-        if rank == 0:
-            c = gat.compact(out)
-            got.append({k: getattr(c, k).clone().numpy() for k in ("boxes", "scores", "flame_params", "counts", "vertices_3d")})
-
-    for i in range(steps):
-        step(i)
-        if i >= 1:
-            collect((i - 1) & 1)
-    collect((steps - 1) & 1)
-    assert eng.calls == ["net", "cand", "select", "join_into"] * steps
-    if rank == 0:
-        q.put((got, n_heads_all.tolist()))
-    dist.barrier()
-    dist.destroy_process_group()
+@pytest.mark.parametrize("compact", [False, True], ids=["capacity_slab", "compact_rows"])
+def test_bench_step_closure_world2_gloo(compact):
+    _dryrun().run(world=2, total=6, steps=5, compact=compact)
 
 
-def test_bench_step_closure_world2_gloo():
-    world, total, steps = 2, 6, 5
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bench_step_worker, args=(r, world, port, q, total, steps)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got, n_heads = q.get(timeout=180)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert len(got) == steps
-    for s, out in enumerate(got):
-        exp = _shard_outputs(s, 0, 1, total)  # the unsharded global batch
-        for k, e in zip(("boxes", "scores", "flame_params", "counts", "vertices_3d"), exp):
-            assert torch.equal(torch.from_numpy(out[k]), e), (s, k)
-        assert n_heads[s] == int(_shard_outputs(s, 0, world, total)[3].sum())
+def test_dry_run_cli_from_bench():
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "3"], capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ranks"] == 2 and line["gathered_batches_equal_unsharded_expectation"] is True
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus(tmp_path):
