@@ -149,6 +149,8 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
 
 #define GCFG(BC) \
     { "g8x8x" #BC "_n8", 512, BC, 512, 0, nullptr, 5, 8, 8, nullptr }
+#define HCFG(BC) \
+    { "h8x8x" #BC "_n8", 512, BC, 512, 0, nullptr, 6, 8, 8, nullptr }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -286,6 +288,10 @@ const CfgEntry g_cfgs[] = {
     GCFG(128),  // 122
     GCFG(96),   // 123
     GCFG(64),   // 124
+    // the same tiles with ONE barrier per tap (conv3x3_pp_kernel<TI, 2>: the groups run M -> L / L -> M inside a slot, 4-stage weight ring)
+    HCFG(128),  // 125
+    HCFG(96),   // 126
+    HCFG(64),   // 127
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
@@ -315,7 +321,7 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     if (cfg < 0 || cfg >= kNumCfgs) return 0;
     const CfgEntry& e = g_cfgs[cfg];
     if (cout_pad % e.BC) return 0;
-    if ((e.patch == 1 || e.patch == 2 || e.patch == 5) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    if ((e.patch == 1 || e.patch == 2 || e.patch == 5 || e.patch == 6) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 3 && !(ksize == 1 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 4 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle)) return 0;
     return 1;
@@ -326,7 +332,7 @@ int vgh_conv_cfg_cout_tile(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cf
 static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) return 0;
     if (a.grp_cout && a.grp_cout % g_cfgs[cfg].BC) return 0;
-    if (g_cfgs[cfg].patch == 5 && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || !vgh_conv_pp_fits(a))) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
+    if ((g_cfgs[cfg].patch == 5 || g_cfgs[cfg].patch == 6) && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || !vgh_conv_pp_fits(a))) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
     if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
     return 1;
 }
@@ -455,7 +461,7 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
         cfg = t;
     }
     const CfgEntry& e = g_cfgs[cfg];
-    if (e.patch == 5) return vgh_launch_conv_pp(a, e.BC, g_max_blocks_per_xcd.load(std::memory_order_relaxed), stream);
+    if (e.patch == 5 || e.patch == 6) return vgh_launch_conv_pp(a, e.BC, e.patch == 6 ? 2 : 1, g_max_blocks_per_xcd.load(std::memory_order_relaxed), stream);
     if (e.patch == 1 || e.patch == 2 || e.patch == 4) {
         const int ntc = a.cout_pad / e.BC, ntx = (a.Wo + e.TW - 1) / e.TW, nty = (a.Ho + e.TH - 1) / e.TH;  // (Ho, Wo) = (H, W) for the stride-1 tiles
         const int64_t total = (int64_t)a.B * nty * ntx * ntc;

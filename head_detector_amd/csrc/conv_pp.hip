@@ -78,14 +78,14 @@ __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
     b = r[1];
 }
 
-template <int TI>
+template <int TI, int V = 1>
 struct PPGeo {
     static constexpr int BC = 32 * TI, NW = 8;
     static constexpr int XU = 7;           // 16-pixel LDS-DMA units of a wave's 10 x 10 halo (100 of 112 records used)
     static constexpr int XST = XU * 1024;  // bytes of one halo stage of one wave
     static constexpr int WST = BC * 64;    // bytes of one weight stage (one tap, one 32-channel block, BC couts)
     static constexpr int WU = BC / 16;     // 1-KiB units per weight stage (waves >= WU stage into the dummy unit)
-    static constexpr int NWS = 3;          // weight ring
+    static constexpr int NWS = V == 2 ? 4 : 3;  // weight ring (v2: prefetch distance 3 taps, one barrier per tap)
     static constexpr int WOFF = NW * 2 * XST;
     static constexpr int DUMMY = WOFF + NWS * WST;
     static constexpr int BIAS = DUMMY + 1024;  // the layer's bias vector (<= 2048 couts), staged once per workgroup
@@ -99,9 +99,9 @@ struct PPTile {
     int b, y0, x0;
 };
 
-template <int TI>
+template <int TI, int V>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk) {
-    using G = PPGeo<TI>;
+    using G = PPGeo<TI, V>;
     constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
     // out-of-range marker for buffer offsets (descriptor range 2 GiB): still out of range, and not wrapped past 2^32, after the immediate / scalar
     // offsets the instructions add (channel offsets of the epilogue, weight k-block offsets < 2^30)
@@ -180,14 +180,64 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     for (int u = 0; u < 7; ++u) dma16(a.in, xo[u], 0, xw + u * 1024);
     dma16(wbase_cur, wv_cur, (unsigned)(0 * ncb) * wkstride, wdst + 0 * wdst_step);
     dma16(wbase_cur, wv_cur, (unsigned)(1 * ncb) * wkstride, wdst + 1 * wdst_step);
+    if constexpr (V == 2) dma16(wbase_cur, wv_cur, (unsigned)(2 * ncb) * wkstride, wdst + 2 * wdst_step);
     dma16(a.bias, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::BIAS + w * 1024);
     wait_vm<0>();
     barrier_raw();
-    if (grp) barrier_raw();  // the stagger: group 1 runs one barrier behind group 0
+    if constexpr (V == 1) {
+        if (grp) barrier_raw();  // the stagger: group 1 runs one barrier behind group 0
+    }
 
     f32x16_t acc[TI][2];
     int xs = 0;  // halo stage being read (0 / 1): bofs point into it
     const float act_lo = a.act == VGH_ACT_RELU ? 0.0f : __builtin_nanf("");
+
+    // ---- v2 ("h" tiles): ONE barrier per tap.  Per barrier slot s (tap T of the running channel block) the groups run the two halves in opposite order:
+    //         g0 (A):  M(s)  [16 MFMAs on the fragments loaded in slot s-1]  ->  LDS-DMA issue  ->  L(s+1)  [fragment reads for the next slot]
+    //         g1 (B):  L(s)  ->  LDS-DMA issue  ->  M(s)
+    //      so a SIMD's two waves still alternate between the matrix pipe and the LDS / DMA work, but the hand-over inside a slot needs no barrier (a wave's own
+    //      L -> M order is its lgkmcnt); the barrier at the slot's end carries the weight-ring hand-off only.  Weights run THREE taps ahead through a 4-stage ring
+    //      (tap g lives in stage g & 3; 9 = 1 mod 4, so the stage of tap T of the c-th channel block since launch is (c + T) & 3): W(s+3), issued in slot s, is
+    //      waited for at the end of slot s+1 and first read (by A) in slot s+2.  The first slot of a tile has both groups start with their L half. ----
+    bf16x8_t fa0[TI], fa1[TI], fb0[2], fb1[2];  // v2: group A's fragments live across the slot barrier
+    int cbcount = 0;
+    auto load_frags = [&](auto tlc, int sb) __attribute__((always_inline)) {
+        constexpr int TL = decltype(tlc)::value;  // 0 .. 9 (9 = tap 0 of the next channel block: the other halo stage)
+        constexpr int TT = TL % 9, ky = TT / 3, kx = TT % 3;
+        const int rd = ((sb + TL) & 3) * WST;
+        const int xd = TL == 9 ? (xs ? -XST : XST) : 0;
+        if (!VGH_ABLATE(a, 32)) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                fa0[i] = *(const bf16x8_t*)(smem + aofs[0] + rd + i * 2048);
+                fa1[i] = *(const bf16x8_t*)(smem + aofs[1] + rd + i * 2048);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                fb0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + xd + j * 2560 + kx * 64);
+                fb1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + xd + j * 2560 + kx * 64);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) asm volatile("" : "=v"(fa0[i]), "=v"(fa1[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(fb0[j]), "=v"(fb1[j]));
+        }
+    };
+    auto mma = [&]() __attribute__((always_inline)) {
+        if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (!VGH_ABLATE(a, 2)) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    };
 
     while (true) {
         const char* wbase_nxt = wbase_cur;
@@ -203,6 +253,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     acc[i][1][q * 4 + e] = bv[e];
                 }
             }
+
+        if constexpr (V == 2) {
+            if (!grp) load_frags(std::integral_constant<int, 0>{}, cbcount & 3);  // group A enters its first slot with the fragments of tap 0
+        }
 
         for (int cb = 0; cb < ncb; ++cb) {
             const bool last = cb == ncb - 1;
@@ -221,37 +275,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             const int cb_n = last ? 0 : cb + 1;
             char* const xpre = xw + (xs ^ 1) * XST;
 
-            auto phase = [&](auto tc) {
-                constexpr int T = decltype(tc)::value;
-                constexpr bool LAST = PP_RES_PREFETCH != 0;  // the residual touches are issued in every channel block (out of range = no access except in the last one): uniform vmcnt counts
-                constexpr int ky = T / 3, kx = T % 3, st = T % 3;
-                bf16x8_t a0[TI], a1[TI], b0[2], b1[2];
-                // ---- L phase: fragments of tap T, prefetches, counted waits ----
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
-                if (!VGH_ABLATE(a, 32)) {
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) {
-                        a0[i] = *(const bf16x8_t*)(smem + aofs[0] + st * WST + i * 2048);
-                        a1[i] = *(const bf16x8_t*)(smem + aofs[1] + st * WST + i * 2048);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        b0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + j * 2560 + kx * 64);
-                        b1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + j * 2560 + kx * 64);
-                    }
-                } else {  // experiments build: the loop without its fragment traffic (MFMAs on whatever the registers hold)
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) asm volatile("" : "=v"(a0[i]), "=v"(a1[i]));
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(b0[j]), "=v"(b1[j]));
-                }
-                if (!VGH_ABLATE(a, 1)) {
-                    constexpr int TT = T + 2, ws = TT % 3;
+            if constexpr (V == 2) {
+                const int sb = cbcount & 3;
+                auto issue = [&](auto tc) __attribute__((always_inline)) {
+                    constexpr int T = decltype(tc)::value;
+                    constexpr bool LAST = PP_RES_PREFETCH != 0;
+                    if (VGH_ABLATE(a, 1)) return;
+                    constexpr int TT = T + 3;
+                    char* const wd = wdst + ((sb + TT) & 3) * wdst_step;
                     if constexpr (TT < 9)
-                        dma16(wbase_cur, wv_cur, (unsigned)(TT * ncb + cb) * wkstride, wdst + ws * wdst_step);
+                        dma16(wbase_cur, wv_cur, (unsigned)(TT * ncb + cb) * wkstride, wd);
                     else
-                        dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wdst + ws * wdst_step);
+                        dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wd);
                     if constexpr (PP_XFRONT) {
                         if constexpr (T < 3) {
                             dma16(xsrc, xo[2 * T], 0, xpre + (2 * T) * 1024);
@@ -262,45 +297,125 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     } else {
                         if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
                     }
-                    // last channel block: pull this wave's residual lines into L2 (one lane per pixel, 16 bytes of every 128-byte line, into the
-                    // dummy LDS unit) so that the epilogue's residual loads are L2 hits instead of two exposed HBM round trips per tile
                     if constexpr (LAST && T < 3) dma16(a.res, rpo, (unsigned)(T == 0 ? 0 : T == 1 ? 128 : BC * 2 - 16), smem + G::DUMMY);
-                }
-                wait_lgkm0();  // this wave's reads of stage st / of its halo are complete before the barrier that releases them for re-filling
-                // the weight unit issued first in L(T-1) (tap T+1) has landed; younger and allowed in flight: the rest of L(T-1) and all of L(T)
-                {
+                };
+                auto slot = [&](auto tc) __attribute__((always_inline)) {
+                    constexpr int T = decltype(tc)::value;
+                    constexpr bool LAST = PP_RES_PREFETCH != 0;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (grp) {  // group B: fragments of this tap first ...
+                        load_frags(tc, sb);
+                        issue(tc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma();  // ONE copy of the 16 MFMAs for both groups: no accumulator merge at a control-flow join
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!grp) {  // ... group A: the next tap's fragments afterwards
+                        issue(tc);
+                        if (T < 8 || !last) load_frags(std::integral_constant<int, T + 1>{}, sb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    wait_lgkm0();  // this wave's fragment reads are complete before the barrier that releases the stages for re-filling
+                    // the weight unit issued first in the previous slot has landed; younger and allowed in flight: the rest of that slot's units and all of this slot's
                     constexpr int XN_T = PP_XFRONT ? (T < 3 ? 2 : T == 3 ? 1 : 0) : (T < 7 ? 1 : 0);
-                    constexpr int TP = (T + 8) % 9;  // the previous phase
+                    constexpr int TP = (T + 8) % 9;
                     constexpr int XN_P = PP_XFRONT ? (TP < 3 ? 2 : TP == 3 ? 1 : 0) : (TP < 7 ? 1 : 0);
                     constexpr int PN_T = (LAST && T < 3) ? 1 : 0, PN_P = (LAST && TP < 3) ? 1 : 0;
                     wait_vm<XN_P + PN_P + 1 + XN_T + PN_T>();
-                }
-                if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-                if (!VGH_ABLATE(a, 16)) barrier_raw();
-                // ---- M phase ----
-                if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-                if (!VGH_ABLATE(a, 2)) {
+                    barrier_raw();
+                };
+                slot(std::integral_constant<int, 0>{});
+                slot(std::integral_constant<int, 1>{});
+                slot(std::integral_constant<int, 2>{});
+                slot(std::integral_constant<int, 3>{});
+                slot(std::integral_constant<int, 4>{});
+                slot(std::integral_constant<int, 5>{});
+                slot(std::integral_constant<int, 6>{});
+                slot(std::integral_constant<int, 7>{});
+                slot(std::integral_constant<int, 8>{});
+                ++cbcount;
+            } else {
+                auto phase = [&](auto tc) {
+                    constexpr int T = decltype(tc)::value;
+                    constexpr bool LAST = PP_RES_PREFETCH != 0;  // the residual touches are issued in every channel block (out of range = no access except in the last one): uniform vmcnt counts
+                    constexpr int ky = T / 3, kx = T % 3, st = T % 3;
+                    bf16x8_t a0[TI], a1[TI], b0[2], b1[2];
+                    // ---- L phase: fragments of tap T, prefetches, counted waits ----
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+                    if (!VGH_ABLATE(a, 32)) {
 #pragma unroll
-                    for (int i = 0; i < TI; ++i)
+                        for (int i = 0; i < TI; ++i) {
+                            a0[i] = *(const bf16x8_t*)(smem + aofs[0] + st * WST + i * 2048);
+                            a1[i] = *(const bf16x8_t*)(smem + aofs[1] + st * WST + i * 2048);
+                        }
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j) {
+                            b0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + j * 2560 + kx * 64);
+                            b1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + j * 2560 + kx * 64);
+                        }
+                    } else {  // experiments build: the loop without its fragment traffic (MFMAs on whatever the registers hold)
 #pragma unroll
-                    for (int i = 0; i < TI; ++i)
+                        for (int i = 0; i < TI; ++i) asm volatile("" : "=v"(a0[i]), "=v"(a1[i]));
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                }
-                if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-                if (!VGH_ABLATE(a, 64)) barrier_raw();
-            };
-            phase(std::integral_constant<int, 0>{});
-            phase(std::integral_constant<int, 1>{});
-            phase(std::integral_constant<int, 2>{});
-            phase(std::integral_constant<int, 3>{});
-            phase(std::integral_constant<int, 4>{});
-            phase(std::integral_constant<int, 5>{});
-            phase(std::integral_constant<int, 6>{});
-            phase(std::integral_constant<int, 7>{});
-            phase(std::integral_constant<int, 8>{});
+                        for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(b0[j]), "=v"(b1[j]));
+                    }
+                    if (!VGH_ABLATE(a, 1)) {
+                        constexpr int TT = T + 2, ws = TT % 3;
+                        if constexpr (TT < 9)
+                            dma16(wbase_cur, wv_cur, (unsigned)(TT * ncb + cb) * wkstride, wdst + ws * wdst_step);
+                        else
+                            dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wdst + ws * wdst_step);
+                        if constexpr (PP_XFRONT) {
+                            if constexpr (T < 3) {
+                                dma16(xsrc, xo[2 * T], 0, xpre + (2 * T) * 1024);
+                                dma16(xsrc, xo[2 * T + 1], 0, xpre + (2 * T + 1) * 1024);
+                            } else if constexpr (T == 3) {
+                                dma16(xsrc, xo[6], 0, xpre + 6 * 1024);
+                            }
+                        } else {
+                            if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                        }
+                        // last channel block: pull this wave's residual lines into L2 (one lane per pixel, 16 bytes of every 128-byte line, into the
+                        // dummy LDS unit) so that the epilogue's residual loads are L2 hits instead of two exposed HBM round trips per tile
+                        if constexpr (LAST && T < 3) dma16(a.res, rpo, (unsigned)(T == 0 ? 0 : T == 1 ? 128 : BC * 2 - 16), smem + G::DUMMY);
+                    }
+                    wait_lgkm0();  // this wave's reads of stage st / of its halo are complete before the barrier that releases them for re-filling
+                    // the weight unit issued first in L(T-1) (tap T+1) has landed; younger and allowed in flight: the rest of L(T-1) and all of L(T)
+                    {
+                        constexpr int XN_T = PP_XFRONT ? (T < 3 ? 2 : T == 3 ? 1 : 0) : (T < 7 ? 1 : 0);
+                        constexpr int TP = (T + 8) % 9;  // the previous phase
+                        constexpr int XN_P = PP_XFRONT ? (TP < 3 ? 2 : TP == 3 ? 1 : 0) : (TP < 7 ? 1 : 0);
+                        constexpr int PN_T = (LAST && T < 3) ? 1 : 0, PN_P = (LAST && TP < 3) ? 1 : 0;
+                        wait_vm<XN_P + PN_P + 1 + XN_T + PN_T>();
+                    }
+                    if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+                    if (!VGH_ABLATE(a, 16)) barrier_raw();
+                    // ---- M phase ----
+                    if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+                    if (!VGH_ABLATE(a, 2)) {
+#pragma unroll
+                        for (int i = 0; i < TI; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < TI; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                    }
+                    if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                    if (!VGH_ABLATE(a, 64)) barrier_raw();
+                };
+                phase(std::integral_constant<int, 0>{});
+                phase(std::integral_constant<int, 1>{});
+                phase(std::integral_constant<int, 2>{});
+                phase(std::integral_constant<int, 3>{});
+                phase(std::integral_constant<int, 4>{});
+                phase(std::integral_constant<int, 5>{});
+                phase(std::integral_constant<int, 6>{});
+                phase(std::integral_constant<int, 7>{});
+                phase(std::integral_constant<int, 8>{});
+            }
             // flip the halo stage
             const int d = xs ? -XST : XST;
 #pragma unroll
@@ -310,6 +425,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             xs ^= 1;
         }
 
+        if constexpr (V == 2) {
+            // the fragment registers are dead here (group A reloads them after the accumulators are re-initialised, group B at the top of its next slot); hipcc
+            // cannot see that through the two group conditions and would carry 48 registers across the epilogue: fresh (undefined) values end the live ranges
+#pragma unroll
+            for (int i = 0; i < TI; ++i) asm volatile("" : "=v"(fa0[i]), "=v"(fa1[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(fb0[j]), "=v"(fb1[j]));
+        }
         // ---- epilogue (registers only): ReLU, + alpha * residual, bf16, half-wave exchange, 16-byte stores through buffer descriptors (32-bit offsets,
         //      out-of-range offset = no access: no branch around a load or a store).  ALL residual vectors are requested before the first store: vmcnt is
         //      one in-order counter, so a residual load issued behind a store could only be awaited together with that store's write acknowledgement ----
@@ -416,23 +539,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         wbase_cur = wbase_nxt;
         local += gpx;
     }
-    if (!grp) barrier_raw();  // group 0's share of the last barrier
+    if constexpr (V == 1) {
+        if (!grp) barrier_raw();  // group 0's share of the last barrier
+    }
 }
 
 constexpr int kMaxDev = 16;
-template <int TI>
+template <int TI, int V>
 int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, int chunk, int max_blocks_per_xcd, hipStream_t st) {
     static std::atomic<int> done[kMaxDev];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
     if (!done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI>, hipFuncAttributeMaxDynamicSharedMemorySize, PPGeo<TI>::LDS));
+        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (PPGeo<TI, V>::LDS)));
         done[dev].store(1, std::memory_order_release);
     }
     int gpx = 32;  // one workgroup per CU, 32 CUs per XCD
     if (max_blocks_per_xcd > 0 && gpx > max_blocks_per_xcd) gpx = max_blocks_per_xcd;
     if (gpx > chunk) gpx = chunk;
-    hipLaunchKernelGGL((conv3x3_pp_kernel<TI>), dim3(gpx * 8), dim3(512), PPGeo<TI>::LDS, st, a, ntc, nsx, nsy, nsp, total, chunk);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V>), dim3(gpx * 8), dim3(512), (PPGeo<TI, V>::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -444,9 +569,9 @@ int vgh_conv_pp_fits(const ConvArgs& a) {
     const int64_t lim = (1ll << 31) - 4096;
     return (int64_t)a.P * a.out_pitch * 2 < lim && (!a.res || (int64_t)a.P * a.res_pitch * 2 < lim) && a.cout_pad <= 2048;
 }
-int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4>::LDS : bc == 96 ? PPGeo<3>::LDS : bc == 64 ? PPGeo<2>::LDS : 0; }
+int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4, 2>::LDS : bc == 96 ? PPGeo<3, 2>::LDS : bc == 64 ? PPGeo<2, 2>::LDS : 0; }
 
-int vgh_launch_conv_pp(const ConvArgs& a, int bc, int max_blocks_per_xcd, hipStream_t stream) {
+int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_per_xcd, hipStream_t stream) {
     VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && !a.split && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 convs only");
     VGH_REQUIRE(a.cout_pad % bc == 0 && a.cout_pad <= 2048, "conv: cout_pad %d is not a multiple of the %d-cout ping-pong tile (or above 2048)", a.cout_pad, bc);
     VGH_REQUIRE(vgh_conv_pp_fits(a), "conv: output / residual tensor above 2 GiB (32-bit buffer offsets)");
@@ -455,10 +580,13 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int max_blocks_per_xcd, hipStr
     const int64_t total = (nsp + 7) / 8 * ntc;
     VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
     const int chunk = (int)((total + 7) / 8);
-    switch (bc) {
-        case 128: return launch_pp<4>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
-        case 96: return launch_pp<3>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
-        case 64: return launch_pp<2>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+    switch (bc + (version == 2 ? 1 : 0)) {
+        case 128: return launch_pp<4, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        case 96: return launch_pp<3, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        case 64: return launch_pp<2, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        case 129: return launch_pp<4, 2>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        case 97: return launch_pp<3, 2>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        case 65: return launch_pp<2, 2>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
     }
     VGH_REQUIRE(false, "conv: no ping-pong tile with %d couts", bc);
     return VGH_OK;

@@ -103,7 +103,7 @@ void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, i
 static inline int vgh_fmt_bytes(int fmt) { return fmt == 0 ? 2 : 4; }  // bytes per logical element of an activation buffer
 static inline int vgh_fmt_planes(int fmt) { return fmt >= 2 ? 2 : 1; }
 // conv_pp.hip: the 8-wave ping-pong 3x3 / stride-1 tiles ("g" tiles; bc = 128 / 96 / 64 couts per workgroup); `a` must be prepared
-int vgh_launch_conv_pp(const ConvArgs& a, int bc, int max_blocks_per_xcd, hipStream_t stream);
+int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version /* 1: "g" (two barriers per tap), 2: "h" (one) */, int max_blocks_per_xcd, hipStream_t stream);
 int vgh_conv_pp_lds(int bc);
 int vgh_conv_pp_fits(const ConvArgs& a);
 int vgh_conv_persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int blocks_per_cu);

@@ -400,7 +400,7 @@ def test_conv_persistent_multi_tile(gpu_lib, cin, res):
         for cap in (2, 5):
             assert gpu_lib.vgh_conv_set_max_blocks_per_xcd(cap) == 0
             for cfg, name in enumerate(names):
-                if name[0] not in "pqg" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, Cout, 1, 0):
+                if name[0] not in "pqgh" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, Cout, 1, 0):
                     continue
                 out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, cfg=cfg, res=r, alpha=0.37 if res else 0.0)
                 _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"multi-tile cfg={name} cap={cap} cin={cin} res={res}")
