@@ -37,6 +37,14 @@
 #define PP_XFRONT 1  // 1: the 7 halo units of the next channel block are issued in taps 0-3 (2, 2, 2, 1) instead of one per tap in taps 0-6, so that at the
                      // epilogue nothing young and slow (an HBM halo fetch) sits in the in-order vmcnt queue ahead of the residual loads
 #endif
+#ifndef PP_STAGGER
+#define PP_STAGGER 1  // workgroups that own fewer tiles than the busiest one start late by a pseudo-random share of the tile time they have to spare: the launch is
+                      // otherwise in lockstep and every CU stores its 128-KB output tile in the same microseconds (an HBM write burst at ~4.8 TB/s that costs
+                      // ~7 us per tile round on the 80^2 x 128 layers, r04_power_per_phase.txt); the kernel's makespan is set by the busiest workgroups, which do not wait
+#endif
+#ifndef PP_EPI_SAME_SLOT
+#define PP_EPI_SAME_SLOT 1  // g tiles: both groups' epilogues in ONE barrier slot (group 1 defers its end-of-tile barrier) instead of one slot each (A/B knob)
+#endif
 #ifndef PP_PRIO
 #define PP_PRIO 1  // s_setprio 1 around: 1 the M phase (MFMAs), 2 the L phase (fragment reads + LDS-DMA issue), 0 nothing (A/B knob)
 #endif
@@ -62,14 +70,14 @@ __device__ __forceinline__ float bf_lo(unsigned d) { return __builtin_bit_cast(f
 __device__ __forceinline__ float bf_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-    const bf2 v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(unsigned, v);
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2));  // ONE v_cvt_pk_bf16_f32 (element-wise casts became two converts + a v_perm)
 }
-// ReLU of two packed bf16 values: signed 16-bit max against zero (v_pk_max_i16)
-__device__ __forceinline__ unsigned relu_pk(unsigned d) {
+// max of two packed bf16 values against a packed int16 bound (v_pk_max_i16): bound 0 = ReLU (bf16 as int16 is negative exactly when the float is),
+// bound INT16_MIN = identity
+__device__ __forceinline__ unsigned max_pk(unsigned d, unsigned bound) {
     typedef __attribute__((ext_vector_type(2))) short s16x2;
-    const s16x2 z = {0, 0};
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, d), z));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, bound)));
 }
 // lanes 32-63 of `a` trade places with lanes 0-31 of `b`
 __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
@@ -154,6 +162,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     decode(local, cur, xo, wv_cur);
     if (!cur.valid) return;  // workgroup-uniform: no barrier has been executed yet
 
+    if constexpr (PP_STAGGER != 0) {
+        const int my_tiles = (chunk - 1 - (int)(blockIdx.x >> 3)) / gpx + 1, max_tiles = (chunk + gpx - 1) / gpx;
+        if (my_tiles < max_tiles) {
+            const unsigned h = (blockIdx.x * 2654435761u) >> 24;  // 0 .. 255
+            // ~0.85 of one tile time (ncb * 9 taps * two ~350-ns slots ~ 0.63 us per channel block), in s_sleep units of 1024 cycles (~0.5 us)
+            const int naps = (int)((h * (unsigned)(ncb * 11 * (max_tiles - my_tiles))) >> 8);
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     char* const xw = smem + w * (2 * XST);                                          // this wave's two halo stages
     char* const wdst = (w < WU) ? smem + G::WOFF + w * 1024 : smem + G::DUMMY - 0;  // + stage * WST for real units
     const int wdst_step = (w < WU) ? WST : 0;
@@ -404,7 +421,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
                     }
                     if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-                    if (!VGH_ABLATE(a, 64)) barrier_raw();
+                    // the tile's last barrier: group 1 goes straight from its last MFMAs into its epilogue and arrives at this barrier AFTER it, so that
+                    // its epilogue shares a barrier slot with group 0's (which follows group 0's side of this barrier) instead of taking a slot of its own
+                    if (!(PP_EPI_SAME_SLOT && T == 8 && last && grp)) {
+                        if (!VGH_ABLATE(a, 64)) barrier_raw();
+                    }
                 };
                 phase(std::integral_constant<int, 0>{});
                 phase(std::integral_constant<int, 1>{});
@@ -462,15 +483,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         rv[i][m] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, (cv < a.cout_store ? rvb[j] : OOB) + (i * 32 + 16 * m) * 2, 0, 0);
                     }
             };
-            auto arith = [&](auto jc) {
+            // No runtime condition inside the per-vector code (r04: `if (a.res)` / `if (a.act == RELU)` / `if (a.nt_out)` per vector cut the epilogue into ~50 tiny
+            // basic blocks of dependent VALU chains -- cvt -> max -> swap + s_nop -- that hipcc cannot interleave: ~11 cycles per instruction): the residual case and
+            // the address form are wave-uniform branches AROUND the loops, ReLU is a max against a per-launch bound in both number formats.
+            const unsigned relu_lo = a.act == VGH_ACT_RELU ? 0u : 0x80008000u;  // packed int16 bound: 0 = ReLU, INT16_MIN = identity
+            auto arith = [&](auto jc, auto rc) {
                 constexpr int j = decltype(jc)::value;
+                constexpr bool RES = decltype(rc)::value;
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         // after the exchange this lane holds couts cv .. cv + 7; before it, runs q = 2m and q = 2m + 1 (couts 32 i + 8 q + 4 hi + e)
                         unsigned pa0, pa1, pb0, pb1;
-                        if (a.res) {
+                        if constexpr (RES) {
                             float va[4], vb[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -492,46 +518,64 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                             pb0 = pack_bf16(vb[0], vb[1]), pb1 = pack_bf16(vb[2], vb[3]);
                         } else {
                             // round first, ReLU on the packed pairs: bf16 as int16 is negative exactly when the float is (rounding keeps the sign)
-                            pa0 = pack_bf16(acc[i][j][8 * m + 0], acc[i][j][8 * m + 1]), pa1 = pack_bf16(acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]);
-                            pb0 = pack_bf16(acc[i][j][8 * m + 4], acc[i][j][8 * m + 5]), pb1 = pack_bf16(acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]);
-                            if (a.act == VGH_ACT_RELU) {
-                                pa0 = relu_pk(pa0), pa1 = relu_pk(pa1);
-                                pb0 = relu_pk(pb0), pb1 = relu_pk(pb1);
-                            }
+                            pa0 = max_pk(pack_bf16(acc[i][j][8 * m + 0], acc[i][j][8 * m + 1]), relu_lo), pa1 = max_pk(pack_bf16(acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]), relu_lo);
+                            pb0 = max_pk(pack_bf16(acc[i][j][8 * m + 4], acc[i][j][8 * m + 5]), relu_lo), pb1 = max_pk(pack_bf16(acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]), relu_lo);
                         }
                         swap32(pa0, pb0);
                         swap32(pa1, pb1);
                         ov[i][m] = u32x4_t{pa0, pa1, pb0, pb1};
                     }
             };
-            auto store_out = [&](int j) {
+            // the whole cout tile stored, into ONE output segment: the offset of a vector is this lane's base + an immediate
+            const bool simple = cbase + BC <= a.cout_store && (a.out_split >= cbase + BC || a.out_split <= cbase);
+            const unsigned seg = a.out_split <= cbase ? (unsigned)dsplit : 0u;
+            auto store_out = [&](int j, auto sc) {
+                constexpr bool SIMPLE = decltype(sc)::value;
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const int cv = cbase + i * 32 + 16 * m + 8 * hi;
                         if (VGH_ABLATE(a, 128)) {  // experiments: the epilogue's arithmetic without its stores
                             asm volatile("" ::"v"(ov[i][m]));
+                        } else if constexpr (SIMPLE) {
+                            __builtin_amdgcn_raw_buffer_store_b128(ov[i][m], rs_out, ovb[j] + seg + (i * 32 + 16 * m) * 2, 0, 0);
                         } else {
+                            const int cv = cbase + i * 32 + 16 * m + 8 * hi;
                             const unsigned vo = (cv < a.cout_store ? ovb[j] : OOB) + (unsigned)(cv >= a.out_split ? dsplit : 0) + (i * 32 + 16 * m) * 2;
-                            if (a.nt_out)
-                                __builtin_amdgcn_raw_buffer_store_b128(ov[i][m], rs_out, vo, 0, 2);
-                            else
-                                __builtin_amdgcn_raw_buffer_store_b128(ov[i][m], rs_out, vo, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(ov[i][m], rs_out, vo, 0, 0);
                         }
                     }
             };
-            if (a.res) load_res(0);
-            __builtin_amdgcn_sched_barrier(0);
-            arith(std::integral_constant<int, 0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (a.res) load_res(1);
-            __builtin_amdgcn_sched_barrier(0);
-            store_out(0);
-            __builtin_amdgcn_sched_barrier(0);
-            arith(std::integral_constant<int, 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            store_out(1);
+            auto stores = [&](int j) {
+                if (simple)
+                    store_out(j, std::true_type{});
+                else
+                    store_out(j, std::false_type{});
+            };
+            if (a.res) {
+                load_res(0);
+                __builtin_amdgcn_sched_barrier(0);
+                arith(std::integral_constant<int, 0>{}, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                load_res(1);
+                __builtin_amdgcn_sched_barrier(0);
+                stores(0);
+                __builtin_amdgcn_sched_barrier(0);
+                arith(std::integral_constant<int, 1>{}, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                stores(1);
+            } else {
+                arith(std::integral_constant<int, 0>{}, std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                stores(0);
+                __builtin_amdgcn_sched_barrier(0);
+                arith(std::integral_constant<int, 1>{}, std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                stores(1);
+            }
+        }
+        if constexpr (V == 1 && PP_EPI_SAME_SLOT) {
+            if (grp) barrier_raw();  // group 1's deferred end-of-tile barrier (see the last phase)
         }
         if (!nxt.valid) break;
         cur = nxt;
