@@ -60,7 +60,7 @@ struct vgh_flame {
 };
 
 // vgh_flame_set_matrix_path: 0 VALU kernels only, 1 automatic (default), 2 always the register-fed matrix-core kernel, 3 / 4 always the
-// LDS-staged one (3: 128-head blocks, 4: 64-head blocks).  All vertex kernels are bit-identical; tests and tools/flame_sweep.py switch between them.
+// LDS-staged one (3: 128-head blocks, 4: 64-head blocks, 5: 32-head blocks).  All vertex kernels are bit-identical; tests and tools/flame_sweep.py switch between them.
 static std::atomic<int> g_flame_mode{1};
 #ifdef VGH_EXPERIMENTS
 static unsigned long long* g_prep_trace = nullptr;  // vgh_flame_set_trace
@@ -752,16 +752,20 @@ __device__ __forceinline__ void valu_epilogue(const VertArgs& a, f32x16_t (&acc)
 // which is what pins it (and the VALU kernel) near 66 TFLOP/s at n = 8192; here a slab of 32 KB feeds 384 MFMAs (49 FLOP per byte
 // from L2, < 3.2 TB/s at the full fp32 matrix rate) and the MFMA operands are conflict-free ds_read_b32.  Same k-ordered chain per
 // output element, so results are bit-identical to the other FLAME kernels.
-constexpr int LB_V = 128, LB_KS = 16;      // vertices per block, k rows per slab
-constexpr int LB_B = LB_KS * 3 * LB_V;      // floats of a basis slab [k][c][128]
+constexpr int LB_V = 128;                  // vertices per block
+// k rows per slab (floats of a basis slab [k][c][128] = KS * 3 * LB_V): 16 for the 64- / 128-head blocks, 32 for the 32-head blocks (r04: the pieces of a slab
+// -- KS * LBH / 256 coefficient pieces + KS * 384 / 256 basis pieces -- must deal evenly to the waves: 4 + 48 over 4 waves)
+template <int LBH>
+constexpr int lb_ks() { return LBH == 32 ? 32 : 16; }
 
 // LBH = heads per block: 128 (8 waves = 2 head groups x 4 vertex groups; crowd scale) or 64 (4 waves: twice the blocks for the same batch --
 // a few hundred heads then still give every CU work -- at the price of the basis slab feeding half as many MFMAs)
 template <int WPS, int LBH>  // WPS: waves per SIMD the register allocation aims for
-__global__ __launch_bounds__((LBH / 64) * 256, WPS) void flame_mfma_lds_kernel(VertArgs a) {
+__global__ __launch_bounds__((LBH >= 64 ? LBH / 64 : 1) * 256, WPS) void flame_mfma_lds_kernel(VertArgs a) {
 #pragma clang fp contract(off)
-    constexpr int MT = 2;
-    constexpr int NT = (LBH / 64) * 256, NWV = NT / 64;        // threads, waves
+    constexpr int MT = LBH >= 64 ? 2 : 1;                      // 32-head MFMA tiles per wave (LBH = 32: one -- a few dozen heads still make 40 x ceil(n / 32) blocks)
+    constexpr int LB_KS = lb_ks<LBH>(), LB_B = LB_KS * 3 * LB_V;
+    constexpr int NT = (LBH >= 64 ? LBH / 64 : 1) * 256, NWV = NT / 64;  // threads, waves
     constexpr int LB_A = LB_KS * LBH, LB_STAGE = LB_A + LB_B;  // floats per slab: coefficients [k][LBH] + basis
     constexpr int NPA = LB_A / 256, NPT = NPA + LB_B / 256;    // 1 KiB LDS-DMA pieces per slab: coefficient pieces, all pieces
     constexpr int PPW = NPT / NWV;                             // pieces per wave (4 / 7)
@@ -844,7 +848,7 @@ __global__ __launch_bounds__((LBH / 64) * 256, WPS) void flame_mfma_lds_kernel(V
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         lds_barrier();
-        const float* const sa = fsm + buf * LB_STAGE + half * LBH + hw * 64 + j;              // + pair*2*LBH + t*32
+        const float* const sa = fsm + buf * LB_STAGE + half * LBH + hw * (32 * MT) + j;       // + pair*2*LBH + t*32
         const float* const sb = fsm + buf * LB_STAGE + LB_A + half * 3 * LB_V + vw * 32 + j;  // + pair*6*LB_V + c*LB_V
         const int pairs = min(LB_KS / 2, npt - st * (LB_KS / 2));
         float A[2][MT], B[2][3];
@@ -875,12 +879,13 @@ __global__ __launch_bounds__((LBH / 64) * 256, WPS) void flame_mfma_lds_kernel(V
     }
     __syncthreads();
     if (v >= a.Vp) return;
-    valu_epilogue<MT>(a, acc, s_hp, hw * 64, h0, v, half);
+    valu_epilogue<MT>(a, acc, s_hp, hw * (32 * MT), h0, v, half);
 }
 
 template <int WPS, int LBH>
 int launch_mfma_lds(const VertArgs& va, hipStream_t st) {
-    const size_t lds = (size_t)2 * (LB_KS * LBH + LB_B) * sizeof(float) + 1024;  // two slabs + the pair table (<= 256 entries): two blocks per CU
+    constexpr int LB_KS = lb_ks<LBH>(), LB_B = LB_KS * 3 * LB_V;
+    const size_t lds = (size_t)2 * (LB_KS * LBH + LB_B) * sizeof(float) + 1024;  // two slabs + the pair table (<= 256 entries): two blocks per CU (one for LBH = 32)
     static std::atomic<int> attr_done[16];
     int dev = 0;
     VGH_HIP(hipGetDevice(&dev));
@@ -888,7 +893,7 @@ int launch_mfma_lds(const VertArgs& va, hipStream_t st) {
         VGH_HIP(hipFuncSetAttribute((const void*)flame_mfma_lds_kernel<WPS, LBH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[dev].store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL((flame_mfma_lds_kernel<WPS, LBH>), dim3((va.n + LBH - 1) / LBH, (va.V + LB_V - 1) / LB_V), dim3((LBH / 64) * 256), lds, st, va);
+    hipLaunchKernelGGL((flame_mfma_lds_kernel<WPS, LBH>), dim3((va.n + LBH - 1) / LBH, (va.V + LB_V - 1) / LB_V), dim3((LBH >= 64 ? LBH / 64 : 1) * 256), lds, st, va);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -946,7 +951,12 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         const int mode = g_flame_mode.load(std::memory_order_relaxed);
         const int npairs = ((detector_mode ? shape_live + expr_live : f->NB) + f->NP + 1) / 2;
         // crowd scale: operands staged through LDS (its k-pair table holds 256 entries: FLAME has 218; a model with more coefficients keeps the other kernels)
-        const bool lds = even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMidHeads));
+        // r04: 32-head blocks of the LDS-staged kernel (mode 5 only).  Hypothesis: the register-fed kernel keeps at most 63 dword loads (8 KB) in flight per wave
+        // and runs 77 ns per k at n = 96, so 1-KiB LDS-DMA pieces should free it.  Measured (profiles/r04_flame_sweep.json): n = 96 / 192 with all 400
+        // coefficients 63.0 / 64.5 us against 59.4 / 60.2 for the register-fed kernel -- the mid range is bound by its ~30 us of K-independent work (prologue
+        // kernel, two launches, head-pack staging, per-head skinning epilogue), not by loads in flight.  Kept selectable (bit-identical), not automatic.
+        const bool lds32 = even && npairs <= 248 && mode == 5;
+        const bool lds = lds32 || (even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMidHeads)));
         const bool mfma = lds || (even && (mode == 2 || (mode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
         const bool fused = !mfma && !pa.n_dev && m <= 256;  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
@@ -1005,7 +1015,7 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         int rc;
         if (lds) {
             // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
-            rc = (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);
+            rc = lds32 ? launch_mfma_lds<1, 32>(va, st) : (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);
         } else if (mfma) {
             if (pa.n_dev || m <= 512)
                 rc = launch_mfma<1>(va, st);  // one 32-head tile per wave: twice the waves, two resident per SIMD
@@ -1179,7 +1189,7 @@ int vgh_flame_set_trace(void* dev_buffer) {
 #endif
 
 int vgh_flame_set_matrix_path(int mode) {
-    VGH_REQUIRE(mode >= 0 && mode <= 4, "flame_set_matrix_path: mode %d outside 0..4", mode);
+    VGH_REQUIRE(mode >= 0 && mode <= 5, "flame_set_matrix_path: mode %d outside 0..5", mode);
     g_flame_mode.store(mode, std::memory_order_relaxed);
     return VGH_OK;
 }

@@ -257,7 +257,7 @@ int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, i
 /* The vertex stage has interchangeable kernels that produce bit-identical vertices (each output is the same fp32 fmaf chain in ascending
  * k): VALU FMAs, FP32 matrix cores fed from registers (v_mfma_f32_32x32x2_f32), and LDS-staged matrix-core tiles.  mode (process-wide,
  * atomic; for parity tests and A/B measurements): 0 VALU only, 1 automatic by batch size (default), 2 register-fed matrix cores,
- * 3 / 4 the LDS-staged tiles (128- / 64-head blocks) where their tables fit, else automatic. */
+ * 3 / 4 / 5 the LDS-staged tiles (128- / 64- / 32-head blocks) where their tables fit, else automatic. */
 int vgh_flame_set_matrix_path(int mode);
 
 /* ------------------------------------------------------------------------------------------------
