@@ -1,0 +1,120 @@
+"""CPU: the index mathematics of the 8-wave ping-pong 3x3 kernel (head_detector_amd/csrc/conv_pp.hip) restated in numpy and checked against what
+the MFMA needs -- the LDS-DMA placement of a wave's private 10 x 10 halo, the swizzled fragment addresses of every tap, their ds_read_b128 bank behaviour, the
+weight-ring / vmcnt schedule and the half-wave exchange of the register epilogue.  The kernel itself is tested on the GPU (test_conv_all_configs_vs_torch,
+test_conv_persistent_multi_tile); this file pins the layout it is written against, so that a change of one constant fails here, without a GPU, with a name."""
+import numpy as np
+
+XU, PITCH = 7, 10  # 16-record LDS-DMA units of a halo stage; halo records per row (8 + 2)
+
+
+def halo_stage(cb_chunk_of):
+    """LDS image of one halo stage as (record, 16-byte slot) -> (hy, hx, channel chunk) for the 7 units a wave issues: lane l of unit u writes record
+    u * 16 + (l >> 2), slot l & 3, and FETCHES chunk (l & 3) ^ (hy & 3) of halo pixel (hy, hx) (source-side swizzle)."""
+    img = {}
+    for u in range(XU):
+        for lane in range(64):
+            rec = u * 16 + (lane >> 2)
+            hy, hx = divmod(rec, PITCH)
+            slot = lane & 3
+            img[(rec, slot)] = (hy, hx, cb_chunk_of(slot, hy)) if rec < 100 else None
+    return img
+
+
+def frag_byte(lane, j, ky, kx, h):
+    """Byte offset (inside the halo stage) the kernel's B-fragment read uses: bofs[ky][h] + j * 2560 + kx * 64."""
+    n32, hi = lane & 31, lane >> 5
+    r = (n32 >> 3) + ky
+    return (r * PITCH + (n32 & 7)) * 64 + (((2 * h + hi) ^ (r & 3)) * 16) + j * 2560 + kx * 64
+
+
+def test_halo_fragment_reads_fetch_the_im2col_operand():
+    img = halo_stage(lambda slot, hy: slot ^ (hy & 3))
+    for j in range(2):
+        for ky in range(3):
+            for kx in range(3):
+                for h in range(2):
+                    for lane in range(64):
+                        b = frag_byte(lane, j, ky, kx, h)
+                        rec, slot = divmod(b, 64)
+                        slot //= 16
+                        hy, hx, chunk = img[(rec, slot)]
+                        n32, hi = lane & 31, lane >> 5
+                        row, col = 4 * j + (n32 >> 3), n32 & 7  # output pixel of this MFMA column inside the 8 x 8 sub-patch
+                        assert (hy, hx) == (row + ky, col + kx)  # input pixel (row + ky - 1, col + kx - 1) of a pad-1 3x3 conv
+                        assert chunk == 2 * h + hi  # k-slice [8 * (2h + hi), +8) of the 32-channel block: lanes 32-63 hold k 8..15 of the 32x32x16 MFMA
+
+
+def test_fragment_reads_are_bank_conflict_free():
+    # ds_read_b128 services a wave in four 16-lane groups (MI355X_MICROARCH.md, LDS table); within a group the 16 x 16 bytes must cover all 64 banks
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[g + 32 for g in grp] for grp in groups]
+    for j in range(2):
+        for ky in range(3):
+            for kx in range(3):
+                for h in range(2):
+                    for grp in groups:
+                        banks = {(frag_byte(lane, j, ky, kx, h) // 16) % 16 for lane in grp}
+                        assert len(banks) == 16, (j, ky, kx, h)
+    # weights: row = cout (lane & 31), slot = chunk ^ ((cout >> 2) & 3) (vgh_pack_conv_weights_host)
+    for h in range(2):
+        for grp in groups:
+            banks = {(((lane & 31) * 64 + (((2 * h + (lane >> 5)) ^ (((lane & 31) >> 2) & 3)) * 16)) // 16) % 16 for lane in grp}
+            assert len(banks) == 16
+
+
+def test_weight_ring_and_vmcnt_schedule():
+    """g tiles: in L(T) a wave issues [W(T+2), halo units, (residual touch)]; at the end of L(T) it waits until at most n_T of its LDS-DMA loads are outstanding.
+    Simulate the in-order queue over three channel blocks and check (i) the weight unit of tap T+1 has landed at the end of L(T) -- one barrier before any wave
+    reads it in L(T+1) --, (ii) the whole halo of the next block has landed at the end of L(8), (iii) a ring stage is never re-filled before the L phase that
+    follows its last read (3 stages, prefetch distance 2)."""
+    for xfront in (True, False):
+        xn = lambda T: ((2 if T < 3 else 1 if T == 3 else 0) if xfront else (1 if T < 7 else 0))  # noqa: E731
+        issued = []  # in-order queue of (kind, tag)
+        for g in range(3 * 9):
+            cb, T = divmod(g, 9)
+            issued.append(("W", g + 2))
+            issued += [("X", (cb + 1, u)) for u in range(xn(T))]
+            n_T = xn((T + 8) % 9) + 1 + xn(T)  # the kernel's wait_vm<> immediate (without the optional residual touches)
+            landed = issued[: len(issued) - n_T]
+            if g >= 1:
+                assert ("W", g + 1) in landed, (xfront, g)
+            if T == 8:
+                assert sum(1 for k, t in landed if k == "X" and t[0] == cb + 1) == XU
+            # stage (g + 2) % 3 was last read in L(g - 1) (tap g - 1): refilled now, in L(g) -- strictly later
+            assert (g + 2) % 3 == (g - 1) % 3
+        assert sum(xn(T) for T in range(9)) == XU
+
+
+def test_epilogue_half_wave_exchange_gives_eight_contiguous_couts():
+    """Accumulator layout of v_mfma_f32_32x32x16: lane (n32, hi) holds, for register r = 4 q + e, cout 8 q + 4 hi + e of pixel n32.  The epilogue packs runs q = 2m
+    (A) and 2m + 1 (B) to bf16 pairs and applies v_permlane32_swap(vdst = A, src = B): lanes 32-63 of A trade places with lanes 0-31 of B."""
+    cout = lambda hi, q, e: 8 * q + 4 * hi + e  # noqa: E731
+    for m in range(2):
+        A = {hi: [cout(hi, 2 * m, e) for e in range(4)] for hi in (0, 1)}
+        B = {hi: [cout(hi, 2 * m + 1, e) for e in range(4)] for hi in (0, 1)}
+        A[1], B[0] = B[0], A[1]  # the swap
+        for hi in (0, 1):
+            got = A[hi] + B[hi]  # the 16-byte vector {pa0, pa1, pb0, pb1} this lane stores
+            assert got == list(range(16 * m + 8 * hi, 16 * m + 8 * hi + 8))  # at channel offset 16 m + 8 hi: 32 contiguous bytes per pixel per instruction
+        # the residual takes the inverse route: swap32(d0, d2), swap32(d1, d3) on the loaded vector d0..d3 = couts 16m + 8hi + (0,1),(2,3),(4,5),(6,7)
+        d = {hi: [[16 * m + 8 * hi + 2 * i, 16 * m + 8 * hi + 2 * i + 1] for i in range(4)] for hi in (0, 1)}
+        d[1][0], d[0][2] = d[0][2], d[1][0]
+        d[1][1], d[0][3] = d[0][3], d[1][1]
+        for hi in (0, 1):
+            assert d[hi][0] + d[hi][1] == [cout(hi, 2 * m, e) for e in range(4)] and d[hi][2] + d[hi][3] == [cout(hi, 2 * m + 1, e) for e in range(4)]
+
+
+def test_out_of_range_marker_survives_the_offsets_added_to_it():
+    oob = 0xC0000000
+    for add in (0, 224, 2 * 2048, (1 << 30) - 1):  # epilogue immediates, segment shift, the largest weight k-block offset
+        assert 0x80000000 <= oob + add < (1 << 32)  # still beyond the 2 GiB descriptor range, not wrapped to a valid offset (0xFFFFFFF0 + 32 wraps to 16)
+    assert (0xFFFFFFF0 + 32) % (1 << 32) == 16
+
+
+def test_tile_bookkeeping_matches_the_launcher():
+    # 8 x 8 sub-patches tile the maps of the 640 and 1280 configurations exactly; 8 per workgroup; the B = 64 quantisation quoted in DESIGN 3.9
+    for W in (160, 80, 40, 320):
+        assert W % 8 == 0
+    nsp = 64 * (80 // 8) ** 2
+    tiles = (nsp + 7) // 8
+    assert tiles == 800 and np.isclose(tiles / 256, 3.125)

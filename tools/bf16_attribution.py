@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Where does the bf16 mode's box error come from?  CPU emulation (tests/program_ref.py: the lowered program with torch ops, bf16 storage
 rounding switched per op) of VERDICT r01's proposed mixed mode -- fp32 for the last box-tower layers / the prediction convs / the whole
-heads -- against all-fp32, on the 100 highest-scoring anchors of six seeded images, random-init weights.  usage: bf16_attribution.py [variant]"""
+heads -- against all-fp32, on the 100 highest-scoring anchors of six seeded images, random-init weights.  usage: bf16_attribution.py [variant]
+r04: `bf16_attribution.py <variant> fp16` emulates a single-plane fp16 STORAGE mode instead (11-bit significand, saturation at 65504; every op's
+inputs, weights and stored outputs rounded to fp16) next to the bf16 one -- VERDICT r03 item 3; results in DESIGN.md section 4."""
 import sys, time
 import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
 import numpy as np, torch
@@ -40,6 +42,28 @@ policies={
  'fp32 heads, bf16 backbone+neck': lambda op: not op['name'].startswith('heads.'),
  'bf16 heads, fp32 backbone+neck': lambda op: op['name'].startswith('heads.'),
 }
+if len(sys.argv)>2 and sys.argv[2]=='fp16':
+    mode={'m':'bf16'}; amax=[0.0]
+    def _rb(t, flag):
+        if not flag: return t
+        if mode['m']=='bf16': return t.to(torch.bfloat16).float()
+        amax[0]=max(amax[0], float(t.abs().max()))
+        return t.clamp(-65504,65504).half().float()
+    pr.rb=_rb
+    out={'bf16':[], 'fp16':[]}
+    for seed in range(int(os.environ.get('SEEDS','4'))):
+        x=torch.randint(0,256,(1,640,640,3),dtype=torch.uint8,generator=torch.Generator().manual_seed(seed))
+        bref,sref=run(x,lambda op:False)
+        top=torch.topk(sref[0],100).indices
+        for m in ('bf16','fp16'):
+            mode['m']=m
+            b,s_=run(x,lambda op:True)
+            i=iou(b[0,top],bref[0,top]); d=iou(b[0],bref[0])
+            out[m].append((float(i.min()),float(i.median()),float((s_[0,top]-sref[0,top]).abs().max()),float(d.min())))
+    for k,v in out.items():
+        a=np.array(v); print(f"{variant} {k} storage everywhere: top-100 IoU min {a[:,0].min():.5f} (per seed {np.round(a[:,0],5)}) median {np.median(a[:,1]):.6f} score err {a[:,2].max():.2e} dense IoU min {a[:,3].min():.5f}")
+    print('largest |value| the fp16 rounding saw:', amax[0])
+    sys.exit(0)
 res={k:[] for k in policies}
 for seed in range(6):
     x=torch.randint(0,256,(1,640,640,3),dtype=torch.uint8,generator=torch.Generator().manual_seed(seed))
