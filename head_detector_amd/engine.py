@@ -453,21 +453,25 @@ class VGHeadsEngine:
         return applied
 
 
-def tuning_key(op: dict, batch: int, nsplit: int = 1, bucket: Optional[int] = None) -> str:
+def tuning_key(op: dict, batch: int, nsplit: int = 1, bucket: Optional[int] = None, res: Optional[bool] = None) -> str:
     m, n, k = op["gemm"]
     if bucket is None:  # b64 (r03): the 20^2 / 40^2 maps of a 32-image batch fill the chip differently from those of 64 images
         bucket = 1 if batch <= 2 else (8 if batch <= 16 else (32 if batch <= 32 else 64))
     lanes = f"x{nsplit}" if nsplit > 1 else ""  # tile choices measured with the batch split over `nsplit` lane streams
     grp = f"_g{op['grp_cout']}" if op.get("grp_cout") else ""
-    return f"b{bucket}{lanes}_m{m}_n{n}_k{k}_ks{op['ksize']}_s{op['stride']}{grp}"
+    # r04: a conv with a residual input has another epilogue (16 more 1-KiB loads per wave through the per-CU path): its own entry, the plain key as fallback
+    rs = "_res" if (op.get("res_buf", -1) >= 0 if res is None else res) else ""
+    return f"b{bucket}{lanes}_m{m}_n{n}_k{k}_ks{op['ksize']}_s{op['stride']}{grp}{rs}"
 
 
 def tuning_lookup(table: Dict[str, str], op: dict, batch: int, nsplit: int = 1, prefix: str = "") -> Optional[str]:
     """Tile name of the measured table for this op: the key of this batch bucket and lane count first (for batches above 32 then the b32 entry of that
     lane count: b32 covered every large batch before the b64 bucket existed), then the same without lanes."""
     b32 = batch > 32
-    keys = [tuning_key(op, batch, nsplit)] + ([tuning_key(op, batch, nsplit, bucket=32)] if b32 else [])  # entries measured with this lane count first
-    keys += [tuning_key(op, batch)] + ([tuning_key(op, batch, bucket=32)] if b32 else [])
+    keys = []
+    for r in ((None, False) if op.get("res_buf", -1) >= 0 else (None,)):  # the residual entry first, then the plain one
+        keys += [tuning_key(op, batch, nsplit, res=r)] + ([tuning_key(op, batch, nsplit, bucket=32, res=r)] if b32 else [])  # entries measured with this lane count first
+        keys += [tuning_key(op, batch, res=r)] + ([tuning_key(op, batch, bucket=32, res=r)] if b32 else [])
     for k in keys:
         if prefix + k in table:
             return table[prefix + k]
