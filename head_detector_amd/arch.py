@@ -348,6 +348,9 @@ def _stack(parts: List[Tuple[np.ndarray, np.ndarray]], pad_to: int = 1) -> Tuple
     return np.concatenate(ws), np.concatenate(bs), offs
 
 
+STEM_PITCH_BF16 = 48  # 64 restores the zero-padded stem tensor of r01 - r03 (tools/ab_stem_pitch.py measures one against the other)
+
+
 def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640, precision: str = "bf16", head_lanes: bool = False) -> Program:
     """precision: 'bf16' (throughput mode: bf16 activations/weights, fp32 accumulate); 'fp16x3' (matrix-core parity mode: two fp16 planes
     per value, three MFMAs per product, csrc/conv_split.hip); 'bf16x3' (the same with bf16 planes: 16 significand bits, kept for the
@@ -363,8 +366,12 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     W, b = F["backbone.stem.conv"]
     assert v["stem"] == 48
     wo, bo = P._push_w(np.transpose(W, (0, 2, 3, 1)), b)  # [48][ky][kx][ci]
-    stem_buf = P.buf("stem", S // 2, S // 2, 64)
-    P.ops.append(dict(name="backbone.stem.conv", kind=0, in_buf=-1, in_coff=0, cin=3, out_buf=stem_buf, out_coff=0, cout_pad=64, cout_store=64, out_split=64,
+    # bf16 throughput mode: the stem tensor is stored at its own 48-channel pitch (96-byte pixels); the stage-1 downsample still reads 64-channel K
+    # windows, whose last 16 channels (the next pixel's first 16) meet the 16 zero weight columns _ohwi pads in below -- the executor verifies that at
+    # vgh_net_create.  The parity modes keep the 64-channel pitch with stored zeros (a split pixel is [hi | lo] planes: no such window).
+    stem_pitch = STEM_PITCH_BF16 if precision == "bf16" else 64
+    stem_buf = P.buf("stem", S // 2, S // 2, stem_pitch)
+    P.ops.append(dict(name="backbone.stem.conv", kind=0, in_buf=-1, in_coff=0, cin=3, out_buf=stem_buf, out_coff=0, cout_pad=64, cout_store=stem_pitch, out_split=64,
                       out_coff2=0, res_buf=-1, res_coff=0, alpha=0.0, ksize=3, stride=2, act=1, shuffle=0, w_off=wo, b_off=bo, force_cfg=-1,
                       macs=float((S // 2) ** 2) * 48 * 27, gemm=((S // 2) ** 2, 48, 27)))
     x = View(stem_buf, 0, 64)
@@ -577,9 +584,9 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     kind = op["kind"]
     if kind == 3:
         return dict(read=0.0, write=0.0)
-    if kind == 0:  # stem: u8 image in, 64-channel (48 live + 16 zero) activation out
+    if kind == 0:  # stem: u8 image in; 48 channels out (bf16 mode), or 48 + 16 stored zeros (parity modes: 64-channel pitch)
         ob = P.bufs[op["out_buf"]]
-        return dict(read=float(batch * P.image_size * P.image_size * 3), write=float(batch * ob["h"] * ob["w"] * 64 * FMT_BYTES[ob["is_f32"]]))
+        return dict(read=float(batch * P.image_size * P.image_size * 3), write=float(batch * ob["h"] * ob["w"] * op["cout_store"] * FMT_BYTES[ob["is_f32"]]))
     ib = P.bufs[op["in_buf"]]
     eb_in = FMT_BYTES[ib["is_f32"]]
     if kind == 2:  # SPP pools: C channels in, 3 x C out
@@ -588,7 +595,7 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     ob = P.bufs[op["out_buf"]]
     eb_out = FMT_BYTES[ob["is_f32"]]
     groups = op["cout_pad"] // op["grp_cout"] if op.get("grp_cout") else 1
-    rd = batch * ib["h"] * ib["w"] * op["cin"] * groups * eb_in
+    rd = batch * ib["h"] * ib["w"] * min(op["cin"], ib["pitch"] - op["in_coff"]) * groups * eb_in  # a K window wider than the pitch (stem tensor) re-reads its neighbour
     out_px = batch * ob["h"] * ob["w"]
     store = op["cout_store"] if not op["shuffle"] else op["cout_pad"] // 4
     wr = out_px * store * eb_out
@@ -608,7 +615,7 @@ def program_algorithmic_bytes(P: "Program", batch: int, fused_stem: Optional[boo
             b["write"] = 0.0
         if fused_stem and i > 0 and P.ops[i - 1]["kind"] == 0 and op["kind"] == 1 and op["in_buf"] == P.ops[i - 1]["out_buf"]:
             ib = P.bufs[op["in_buf"]]
-            b["read"] -= batch * ib["h"] * ib["w"] * op["cin"] * FMT_BYTES[ib["is_f32"]]
+            b["read"] -= batch * ib["h"] * ib["w"] * min(op["cin"], ib["pitch"] - op["in_coff"]) * FMT_BYTES[ib["is_f32"]]
         tot["read"] += b["read"]
         tot["write"] += b["write"]
     return tot

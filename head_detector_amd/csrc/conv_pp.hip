@@ -42,6 +42,9 @@
                       // otherwise in lockstep and every CU stores its 128-KB output tile in the same microseconds (an HBM write burst at ~4.8 TB/s that costs
                       // ~7 us per tile round on the 80^2 x 128 layers, r04_power_per_phase.txt); the kernel's makespan is set by the busiest workgroups, which do not wait
 #endif
+#ifndef PP_BAR_TAIL
+#define PP_BAR_TAIL 0  // g tiles: MFMAs of an M phase issued AFTER the slot's closing barrier (0: the barrier follows the whole run)
+#endif
 #ifndef PP_EPI_SAME_SLOT
 #define PP_EPI_SAME_SLOT 1  // g tiles: both groups' epilogues in ONE barrier slot (group 1 defers its end-of-tile barrier) instead of one slot each (A/B knob)
 #endif
@@ -165,7 +168,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     if constexpr (PP_STAGGER != 0) {
         const int my_tiles = (chunk - 1 - (int)(blockIdx.x >> 3)) / gpx + 1, max_tiles = (chunk + gpx - 1) / gpx;
         if (my_tiles < max_tiles) {
-            const unsigned h = (blockIdx.x * 2654435761u) >> 24;  // 0 .. 255
+            // PP_STAGGER == 2: one nap per PIXEL GROUP -- the ntc workgroups that run the cout tiles of the same eight sub-patches (consecutive tiles, same XCD)
+            // start together, so that the halo one of them pulls into the XCD's L2 is still there when its siblings ask for it
+            const unsigned key = PP_STAGGER == 2 ? (unsigned)((xcd * chunk + (int)(blockIdx.x >> 3)) / ntc) * 8u + (unsigned)xcd : blockIdx.x;
+            const unsigned h = (key * 2654435761u) >> 24;  // 0 .. 255
             // ~0.85 of one tile time (ncb * 9 taps * two ~350-ns slots ~ 0.63 us per channel block), in s_sleep units of 1024 cycles (~0.5 us)
             const int naps = (int)((h * (unsigned)(ncb * 11 * (max_tiles - my_tiles))) >> 8);
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
@@ -410,21 +416,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     if (!VGH_ABLATE(a, 16)) barrier_raw();
                     // ---- M phase ----
                     if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+                    // the slot's closing barrier sits PP_BAR_TAIL MFMAs before the end of the run: the wave arrives while the matrix pipe still has work queued, the
+                    // other group (long since waiting) is released ~one barrier latency later and starts its own run while this wave issues its tail -- the hand-over
+                    // no longer drains the pipe (skeleton without loads / reads / epilogue: 672 cycles per 16-MFMA slot against 512, r04_power_per_phase.txt ablate 41).
+                    // The tile's last barrier: group 1 goes straight from its last MFMAs into its epilogue and arrives at this barrier AFTER it, so that
+                    // its epilogue shares a barrier slot with group 0's (which follows group 0's side of this barrier) instead of taking a slot of its own
+                    const bool closing = !(PP_EPI_SAME_SLOT && T == 8 && last && grp);
+                    constexpr int NM = TI * 4, BAR_AT = NM - (PP_BAR_TAIL < NM ? PP_BAR_TAIL : NM - 1);
                     if (!VGH_ABLATE(a, 2)) {
 #pragma unroll
-                        for (int i = 0; i < TI; ++i)
+                        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                        for (int i = 0; i < TI; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                                for (int j = 0; j < 2; ++j) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? a1[i] : a0[i], h ? b1[j] : b0[j], acc[i][j], 0, 0, 0);
+                                    if (PP_BAR_TAIL > 0 && (h * TI + i) * 2 + j + 1 == BAR_AT) {
+                                        __builtin_amdgcn_sched_barrier(0);
+                                        if (closing && !VGH_ABLATE(a, 64)) barrier_raw();
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                }
+                    } else if (PP_BAR_TAIL > 0) {
+                        if (closing && !VGH_ABLATE(a, 64)) barrier_raw();
                     }
                     if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-                    // the tile's last barrier: group 1 goes straight from its last MFMAs into its epilogue and arrives at this barrier AFTER it, so that
-                    // its epilogue shares a barrier slot with group 0's (which follows group 0's side of this barrier) instead of taking a slot of its own
-                    if (!(PP_EPI_SAME_SLOT && T == 8 && last && grp)) {
-                        if (!VGH_ABLATE(a, 64)) barrier_raw();
+                    if constexpr (PP_BAR_TAIL == 0) {
+                        if (closing && !VGH_ABLATE(a, 64)) barrier_raw();
                     }
                 };
                 phase(std::integral_constant<int, 0>{});

@@ -28,6 +28,9 @@ struct NetOp {
     // on the same tile, so its fp32 summation order (hence every output bit) does not depend on how many images ride along
     int auto_cfg = -1;  // the automatic tile of this op, resolved ONCE at vgh_net_create for the arena batch (chunk- and lane-independent bits)
     uint16_t* wds = nullptr;    // stage-1 downsample only: its weights in the fused stem + downsample kernel's layout (stem_ds.hip)
+    // the input view is WIDER than the buffer's pitch (the 48-channel stem tensor read as 64-channel K blocks): channels past the pitch are the next
+    // pixel's first ones; vgh_net_create has verified that every weight row is exactly zero there (finite x 0 adds +-0 to the accumulator)
+    int overhang_ok = 0;
 };
 
 struct vgh_net {
@@ -115,7 +118,7 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->nkb = d.ksize * d.ksize * a->cblocks;
     const int eh = d.shuffle ? 2 * a->Ho : a->Ho, ew = d.shuffle ? 2 * a->Wo : a->Wo;
     VGH_REQUIRE(ob.h == eh && ob.w == ew, "net: op output buffer %d is %dx%d, conv produces %dx%d", d.out_buf, ob.h, ob.w, eh, ew);
-    VGH_REQUIRE(d.in_coff + d.cin + (d.grp_cout ? (d.cout_pad / d.grp_cout - 1) * d.grp_in_stride : 0) <= ib.pitch, "net: conv reads past the input pitch (buf %d)", d.in_buf);
+    VGH_REQUIRE(op.overhang_ok || d.in_coff + d.cin + (d.grp_cout ? (d.cout_pad / d.grp_cout - 1) * d.grp_in_stride : 0) <= ib.pitch, "net: conv reads past the input pitch (buf %d)", d.in_buf);
     return VGH_OK;
 }
 
@@ -137,7 +140,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
             if (ob.is_f32 == VGH_FMT_F32)  // fp32 parity mode
                 return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)bp(d.out_buf), ob.pitch, d.out_coff, st);
             return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)bp(d.out_buf), (int64_t)ob.pitch * vgh_fmt_planes(ob.is_f32), d.out_coff,
-                                   ob.is_f32, ob.pitch, st);
+                                   d.cout_store, ob.is_f32, ob.pitch, st);
         }
         case VGH_OP_CONV: {
             if (fused && op_index == n->stem_pair + 1) return VGH_OK;  // ran inside the stem's launch
@@ -291,6 +294,15 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             VGH_REQUIRE(d.in_buf >= 0 && d.in_buf < n_bufs && d.out_buf >= 0 && d.out_buf < n_bufs && d.res_buf < n_bufs, "net_create: op %d buffer ids", i);
             const int64_t we = (int64_t)d.cout_pad * d.ksize * d.ksize * d.cin;
             VGH_REQUIRE(d.w_off >= 0 && d.w_off + we <= n_weights && d.b_off >= 0 && d.b_off + d.cout_pad <= n_biases, "net_create: op %d weight range", i);
+            if (d.in_coff + d.cin > bufs[d.in_buf].pitch && !d.grp_cout) {
+                // a K window wider than the pitch is legal only over all-zero weight columns, in the single-plane bf16 format (a split pixel's lo plane follows its hi plane)
+                const int live = bufs[d.in_buf].pitch - d.in_coff;
+                VGH_REQUIRE(live > 0 && bufs[d.in_buf].is_f32 == VGH_FMT_BF16, "net_create: op %d reads past the pitch of buffer %d", i, d.in_buf);
+                const float* w = weights_host + d.w_off;
+                for (int64_t r = 0; r < (int64_t)d.cout_pad * d.ksize * d.ksize; ++r)
+                    for (int c = live; c < d.cin; ++c)
+                        VGH_REQUIRE(w[r * d.cin + c] == 0.0f, "net_create: op %d reads %d channels of a %d-channel pitch with a non-zero weight at input channel %d", i, d.cin, bufs[d.in_buf].pitch, c);
+            }
             woff[i] = wbytes;
             const int wf = bufs[d.in_buf].is_f32;  // weight image: bf16 (2 B), dense fp32 (4 B) or the three 16-bit segments of the split modes (6 B)
             wbytes += align_up(we * (wf == VGH_FMT_BF16 ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
@@ -353,6 +365,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             op.wpack = (uint16_t*)(n->wblob + woff[i]);
             op.wf32 = (float*)(n->wblob + woff[i]);  // same storage: bf16 image (throughput mode) or dense fp32 (parity mode)
             op.bias = (float*)(n->wblob + boff[i]);
+            op.overhang_ok = (!ops[i].grp_cout && ops[i].in_coff + ops[i].cin > bufs[ops[i].in_buf].pitch) ? 1 : 0;  // zero weight columns verified above
         } else if (ops[i].kind == VGH_OP_STEM) {
             op.wf32 = (float*)(n->wblob + woff[i]);
             op.bias = (float*)(n->wblob + boff[i]);

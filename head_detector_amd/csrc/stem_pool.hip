@@ -17,7 +17,10 @@ constexpr int SIN = 2 * ST + 1;   // 33x33 input patch
 constexpr int STEM_CO = 48, STEM_CP = 64;
 
 // SP != 0 (split parity modes, STAGE = 0 only): the exact fp32 result leaves as a hi and a lo 16-bit plane (split_fmt.h)
-template <int FMT, int STAGE, int SP = 0>
+// NCH (STAGE = 1): 16-byte chunks stored per pixel -- 8: the 48 channels + 16 zero channels of a 64-channel pitch (the K padding of the next conv);
+// 6: the 48 channels alone at a 48-channel pitch (r04: 96-byte pixels, the next conv reads a 64-channel window whose last 16 channels are the
+// neighbouring pixel's first 16 and meet all-zero weight rows -- net.hip checks that -- so the 210 MB of zeros per 64 images are neither written nor read)
+template <int FMT, int STAGE, int SP = 0, int NCH = 8>
 __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ image, int H, int W, const float* __restrict__ wgt /*[27][48]*/,
                                                    const float* __restrict__ bias /*[48]*/, uint16_t* __restrict__ out, int64_t out_pitch,
                                                    int out_coff, int plane, float lo_scale) {
@@ -160,13 +163,15 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ i
         }
         return;
     }
-    stage[tid * 8 + (6 ^ (tid & 7))] = z;
-    stage[tid * 8 + (7 ^ (tid & 7))] = z;
+    if constexpr (NCH == 8) {
+        stage[tid * 8 + (6 ^ (tid & 7))] = z;
+        stage[tid * 8 + (7 ^ (tid & 7))] = z;
+    }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NCH; ++it) {
         const int e = it * 256 + tid;
-        const int p = e >> 3, ch = e & 7;
+        const int p = e / NCH, ch = e - p * NCH;  // consecutive lanes write consecutive 16-byte chunks: whole lines also across the 96-byte pixels of NCH = 6
         const int oy = ty + (p / ST), ox = tx + (p % ST);
         if (oy < Ho && ox < Wo)
             *(bf16x8_t*)(out + (((int64_t)b * Ho + oy) * Wo + ox) * out_pitch + out_coff + ch * 8) = stage[p * 8 + (ch ^ (p & 7))];
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(256) void spp_pool_split_kernel(uint16_t* __restric
 }  // namespace
 
 int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w, const float* bias, uint16_t* out, int64_t out_pitch,
-                    int out_coff, int fmt, int plane, hipStream_t stream) {
+                    int out_coff, int store_ch, int fmt, int plane, hipStream_t stream) {
+    VGH_REQUIRE(store_ch == 64 || (store_ch == 48 && fmt == VGH_FMT_BF16), "stem: stores 64 channels (48 + 16 zeros), or 48 in the bf16 mode; got %d", store_ch);
     VGH_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: image size must be even");
     VGH_REQUIRE(out_pitch % 8 == 0 && out_coff % 8 == 0 && plane % 8 == 0, "stem: output alignment");
     VGH_REQUIRE(image_fmt == VGH_IMG_F32_NCHW || image_fmt == VGH_IMG_U8_NHWC, "stem: unknown image format %d", image_fmt);
@@ -295,6 +301,8 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
     const bool u8 = image_fmt == VGH_IMG_U8_NHWC;
 #define VGH_STEM_LAUNCH(FMT, STAGE, SP, LO) \
     hipLaunchKernelGGL((stem_kernel<FMT, STAGE, SP>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff, plane, LO)
+#define VGH_STEM_LAUNCH48(FMT) \
+    hipLaunchKernelGGL((stem_kernel<FMT, 1, 0, 6>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff, plane, 1.0f)
     if (fmt == VGH_FMT_F16X2) {
         if (u8) VGH_STEM_LAUNCH(VGH_IMG_U8_NHWC, 0, VGH_FMT_F16X2, 2048.0f);
         else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, VGH_FMT_F16X2, 2048.0f);
@@ -303,6 +311,12 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
         else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, VGH_FMT_BF16X2, 1.0f);
     } else {
         VGH_REQUIRE(fmt == VGH_FMT_BF16, "stem: output format %d", fmt);
+        if (store_ch == 48) {
+            if (u8) VGH_STEM_LAUNCH48(VGH_IMG_U8_NHWC);
+            else VGH_STEM_LAUNCH48(VGH_IMG_F32_NCHW);
+            VGH_HIP(hipGetLastError());
+            return VGH_OK;
+        }
 #ifdef VGH_EXPERIMENTS
         static const int stage = getenv("VGH_STEM_STAGE") ? atoi(getenv("VGH_STEM_STAGE")) : 1;  // A/B switch: 0 = direct per-lane stores
         if (!stage) {
@@ -316,6 +330,7 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
         }
     }
 #undef VGH_STEM_LAUNCH
+#undef VGH_STEM_LAUNCH48
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }

@@ -135,7 +135,8 @@ static inline uint16_t vgh_f32_to_bf16_host(float f) {
 // ---- other launchers --------------------------------------------------------------------
 // fmt / plane: VGH_FMT_BF16 (plane unused) or a split format: then out_pitch is the physical pitch and `plane` the elements from hi to lo
 int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w /*[64][27] dev*/,
-                    const float* bias /*[64] dev*/, uint16_t* out, int64_t out_pitch, int out_coff, int fmt, int plane, hipStream_t stream);
+                    const float* bias /*[64] dev*/, uint16_t* out, int64_t out_pitch, int out_coff, int store_ch /*64, or 48 (bf16 only)*/, int fmt, int plane,
+                    hipStream_t stream);
 // stem_ds.hip: stem + stage-1 downsample in one kernel (bit-identical to vgh_launch_stem + the 3x3 / stride-2 / 64 -> 96 implicit-GEMM conv)
 int vgh_launch_stem_ds(const void* image, int image_fmt, int B, int H, int W, const float* wstem, const float* bstem, const uint16_t* wds, const float* bds, uint16_t* out,
                        int64_t out_pitch, int out_coff, hipStream_t stream);

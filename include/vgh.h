@@ -68,9 +68,11 @@ typedef struct vgh_buf_desc {
 
 typedef struct vgh_op_desc {
     int32_t kind;
-    int32_t in_buf, in_coff, cin;        /* cin padded to a multiple of 32 (zero channels)             */
+    int32_t in_buf, in_coff, cin;        /* cin padded to a multiple of 32 (zero channels).  in_coff + cin may exceed the buffer's pitch (bf16 buffers,   */
+                                         /*   dense convs): the window then runs on into the next pixel, and vgh_net_create REQUIRES every weight of the   */
+                                         /*   input channels past the pitch to be exactly zero (the 48-channel stem tensor read as two 32-channel K blocks) */
     int32_t out_buf, out_coff, cout_pad; /* rows of the weight matrix, multiple of 32                  */
-    int32_t cout_store;                  /* channels written; [cout_real, cout_store) are exact zeros  */
+    int32_t cout_store;                  /* channels written; [cout_real, cout_store) are exact zeros (VGH_OP_STEM: 64, or 48 = no padding, bf16 only) */
     int32_t out_split, out_coff2;        /* channels >= out_split go to out_coff2 + (c - out_split)    */
     int32_t res_buf, res_coff;           /* residual added AFTER the activation (YoloNASBottleneck),   */
     float alpha;                         /*   out = act(conv + b) + alpha * res;  res_buf < 0: none    */

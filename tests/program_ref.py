@@ -33,7 +33,8 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None, f64: bool = F
         y = torch.relu(F.conv2d(up(x), up(W), up(b), stride=2, padding=1)).permute(0, 2, 3, 1).float()
         out = bufs[op["out_buf"]]
         out[..., op["out_coff"] : op["out_coff"] + 48] = rb(y, bf16)
-        out[..., op["out_coff"] + 48 : op["out_coff"] + 64] = 0
+        if op["cout_store"] > 48:  # 64-channel pitch (parity modes): 16 stored zeros; the bf16 mode stores the 48 channels at a 48-channel pitch
+            out[..., op["out_coff"] + 48 : op["out_coff"] + 64] = 0
         return
     if kind == 2:  # SPP pools
         buf = bufs[op["in_buf"]]
@@ -54,7 +55,13 @@ def run_op(P, op, bufs, image, bf16: bool, w_all=None, b_all=None, f64: bool = F
             ys.append(F.conv2d(up(rb(xg, bf16)), up(rb(W[g * gc : (g + 1) * gc], bf16)), None, stride=op["stride"], padding=k // 2))
         y = torch.cat(ys, 1) + up(b)[None, :, None, None]
     else:
-        x = bufs[op["in_buf"]][..., op["in_coff"] : op["in_coff"] + cin].permute(0, 3, 1, 2)
+        x = bufs[op["in_buf"]][..., op["in_coff"] : op["in_coff"] + cin]
+        if x.shape[-1] < cin:
+            # a K window wider than the pitch (the 48-channel stem tensor read as 64 channels): the engine's window runs on into the next pixel and meets
+            # all-zero weight columns (checked here, and by vgh_net_create); zeros stand in for those finite values
+            assert float(W[:, x.shape[-1] :].abs().max()) == 0.0
+            x = torch.cat([x, torch.zeros(*x.shape[:-1], cin - x.shape[-1], dtype=x.dtype)], -1)
+        x = x.permute(0, 3, 1, 2)
         y = F.conv2d(up(rb(x, bf16)), up(rb(W, bf16)), None, stride=op["stride"], padding=k // 2) + up(b)[None, :, None, None]
     if op["act"] == 1:
         y = torch.relu(y)

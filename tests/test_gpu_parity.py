@@ -638,6 +638,47 @@ def test_fused_stem_downsample_is_bit_identical(gpu_lib, variant, S, B, fmt):
     eng.close()
 
 
+def test_stem_tensor_at_its_48_channel_pitch(gpu_lib, monkeypatch):
+    """bf16 mode (r04): the stem tensor is stored as 96-byte pixels and the stage-1 downsample reads 64-channel K windows over it -- the last 16 channels of
+    a window are the next pixel's first 16 and meet all-zero weight columns.  (i) the stem buffer holds the 48 channels of the fp32 reference, nothing else;
+    (ii) the downsample equals the torch conv on the 48 real channels (also at the last pixel of the last image, whose window runs into the arena's slack)
+    for a batch below the arena batch after a larger one has left its data behind; (iii) vgh_net_create refuses a non-zero weight in a padded column."""
+    from head_detector_amd import _lib, arch
+    from head_detector_amd.engine import VGHeadsEngine
+
+    S, B = 160, 3
+    sd = arch.random_state_dict("vgg_heads_l", 5)
+    eng = VGHeadsEngine("vgg_heads_l", state_dict=sd, image_size=S, max_batch=B, use_tuning=False)
+    P = eng.program
+    assert P.bufs[0]["pitch"] == 48 and P.ops[0]["cout_store"] == 48 and P.ops[1]["cin"] == 64
+    g = torch.Generator().manual_seed(11)
+    big = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g)
+    x = torch.randint(0, 256, (2, S, S, 3), dtype=torch.uint8, generator=g)
+    eng.forward_net(big.to(_dev()))  # image 2's stem pixels stay in the arena behind the 2-image batch
+    eng.forward_net(x.to(_dev()))
+    stem = eng.buffer("stem", 2).float().cpu()
+    assert stem.shape == (2, S // 2, S // 2, 48)
+    bufs = pr.alloc(P, 2)
+    pr.run_op(P, P.ops[0], bufs, x, True)
+    assert torch.equal(stem, bufs[0])
+    pr.run_op(P, P.ops[1], bufs, x, True)
+    ds = eng.buffer("backbone.stage1.ds", 2).float().cpu()
+    ref = bufs[P.ops[1]["out_buf"]]
+    assert float(ref.abs().max()) > 0 and not ((ds - ref).abs() > 2e-2 + 1.0 / 64 * ref.abs()).any(), "stage-1 downsample over the 48-channel pitch"  # bf16: 2 ulps
+    eng.close()
+
+    real = arch.build_program
+
+    def poisoned(*a, **k):
+        Q = real(*a, **k)
+        Q.weights[1].reshape(-1, 64)[5, 50] = 0.25  # stage-1 downsample: a weight on input channel 50, which the 48-channel tensor does not have
+        return Q
+
+    monkeypatch.setattr(arch, "build_program", poisoned)
+    with pytest.raises(_lib.VghError, match="non-zero weight at input channel 50"):
+        VGHeadsEngine("vgg_heads_l", state_dict=sd, image_size=S, max_batch=1, use_tuning=False)
+
+
 def test_u8_nhwc_input_equals_f32_nchw(gpu_lib):
     """The fused /255 (detector.py:51) must reproduce the float path exactly."""
     from head_detector_amd.engine import VGHeadsEngine

@@ -50,9 +50,16 @@ def test_lowering_reproduces_unfused_oracle(variant):
             scale = float(b.abs().max()) + 1e-6
             err = float((a - b).abs().max()) / scale
             assert err < 2e-4, (variant, name, err)
-    # padded channels must be exact zeros (they are K-padding of downstream convs)
-    stem = bufs[0]
-    assert float(stem[..., 48:].abs().max()) == 0.0
+    # the K padding of the stage-1 downsample: in the bf16 program the stem tensor has a 48-channel pitch and the conv's 64-channel window meets 16 all-zero
+    # weight columns; in the parity programs the pitch is 64 and the padded channels are stored zeros
+    assert P.bufs[0]["pitch"] == 48 and P.ops[1]["cin"] == 64 and P.ops[1]["in_buf"] == 0
+    w_all, _ = P.arrays()
+    ds = P.ops[1]
+    Wds = w_all[ds["w_off"] : ds["w_off"] + ds["cout_pad"] * 9 * 64].reshape(-1, 64)
+    assert float(np.abs(Wds[:, 48:]).max()) == 0.0 and float(np.abs(Wds[:, :48]).max()) > 0.0
+    P32 = arch.build_program(variant, sd, S, precision="fp16x3")
+    assert P32.bufs[0]["pitch"] == 64 and P32.ops[0]["cout_store"] == 64
+    assert float(pr.run_program(P32, x, bf16=False)[0][..., 48:].abs().max()) == 0.0
 
 
 def test_u8_input_equals_float_input_in_program_ref():

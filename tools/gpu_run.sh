@@ -7,7 +7,7 @@
 #         tune       retune the L b64 / M b32 tile tables             tune1280   retune the L b16 @1280 bucket
 #         tunesplit  tile table of the fp16x3 parity mode (L b32)
 #         flame      FLAME decode sweep (tools/flame_sweep.py)        pmcflame   MFMA-busy of the FLAME kernels at n = 8192
-#         probe      whole-net time of both benchmark buckets (two lanes)
+#         probe      whole-net time of both benchmark buckets (two lanes)      py         python $PY_CMD (any tools/ script)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
@@ -97,6 +97,9 @@ for step in "$@"; do
     convbench)
       # single-shape A/B of tile configurations through vgh_conv2d (CB_SHAPES / CB_CFGS / CB_ARGS)
       timeout 900 python tools/conv_bench.py --shape ${CB_SHAPES:-64,80,80,128,128,3,1} --cfgs ${CB_CFGS:-all} --iters ${CB_ITERS:-30} ${CB_ARGS:-} > $O/convbench${CB_TAG:-}.log 2>&1; grep -v amdgpu $O/convbench${CB_TAG:-}.log | tail -${TAILN:-80} ;;
+    py)
+      # any tools/ script:  PY_CMD="tools/ab_stem_pitch.py --rounds 4"  (log named by PY_TAG)
+      timeout ${PY_TIMEOUT:-900} python ${PY_CMD} > $O/py${PY_TAG:-}.log 2>&1; echo "py rc=$?" >> $O/py${PY_TAG:-}.log; grep -v amdgpu $O/py${PY_TAG:-}.log | tail -${TAILN:-40} ;;
     probe)
       python tools/net_probe.py vgg_heads_l 64 2>&1 | grep -v amdgpu; python tools/net_probe.py vgg_heads_m 32 2>&1 | grep -v amdgpu ;;
     *) echo "unknown step $step" ;;
