@@ -45,6 +45,9 @@
 #ifndef PP_BAR_TAIL
 #define PP_BAR_TAIL 0  // g tiles: MFMAs of an M phase issued AFTER the slot's closing barrier (0: the barrier follows the whole run)
 #endif
+#ifndef PP_INIT_IN_EPILOGUE
+#define PP_INIT_IN_EPILOGUE 1  // the next tile's bias enters the accumulators between the last stores of the epilogue (1) or at the tile top (0) (A/B knob)
+#endif
 #ifndef PP_EPI_SAME_SLOT
 #define PP_EPI_SAME_SLOT 1  // g tiles: both groups' epilogues in ONE barrier slot (group 1 defers its end-of-tile barrier) instead of one slot each (A/B knob)
 #endif
@@ -103,6 +106,10 @@ struct PPGeo {
     static constexpr int LDS = BIAS + 8192;
 };
 
+struct PPHalo {  // wave-uniform part of a sub-patch's halo addressing
+    int base;        // byte offset of halo record (0, 0) = input pixel (y0 - 1, x0 - 1) in the input view
+    int y0m1, x0m1;  // its pixel coordinates (range checks)
+};
 struct PPTile {
     int valid;  // the workgroup has this tile
     int c0;     // first cout of the tile
@@ -128,7 +135,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     const unsigned wkstride = (unsigned)a.cout_pad * 64u;
     const int in_pitch = (int)a.in_pitch;
 
-    auto decode = [&](int local, PPTile& t, unsigned (&xo)[7], unsigned& wv) {
+    // a tile's wave-uniform part: cout tile, this wave's sub-patch, and what the per-lane halo offsets are built from (PPHalo)
+    auto decode_tile = [&](int local, PPTile& t, PPHalo& hb, unsigned& wv) {
         const int tile = xcd * chunk + local;
         t.valid = (local < chunk && tile < total_tiles) ? 1 : 0;
         const int tl = t.valid ? tile : 0;
@@ -143,26 +151,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         const int sy = rem / nsx;
         t.y0 = sy * 8;
         t.x0 = (rem - sy * nsx) * 8;
-        // opaque copy of the lane id: the per-lane halo geometry below is re-materialised per call instead of being hoisted out of the tile loop
-        // and kept alive (or spilled) across the whole K loop
+        // byte offset of halo record (0, 0) = input pixel (y0 - 1, x0 - 1): wave-uniform (scalar) and possibly "negative" -- only in-range records add up to an
+        // offset that is used
+        hb.base = 2 * (((t.b * a.H + t.y0 - 1) * a.W + t.x0 - 1) * in_pitch + a.in_coff);
+        hb.y0m1 = t.spok ? t.y0 - 1 : -64;  // a missing sub-patch: every record out of range
+        hb.x0m1 = t.x0 - 1;
+        wv = (t.valid && w < WU) ? (unsigned)(lane * 16 + w * 1024) : OOB;
+    };
+    // source offset of this lane's 16 bytes of LDS-DMA unit u of the halo: record hp = 16 u + lane / 4 = halo pixel (hp / 10, hp % 10), two 24-bit multiply-adds
+    // (hy < 12, hx < 10, row pitch < 2^24 bytes: vgh_conv_pp_fits) instead of the 32-bit multiplies of a full pixel address.  Recomputed per tile -- kept, the
+    // lane geometry would cost registers across the whole K loop; the opaque lane copy stops hipcc from hoisting it -- and, for the NEXT tile, just in time in the
+    // L phase that issues the unit (r04 trace: decoding all seven units at the top of the last channel block cost every SIMD ~2 000 cycles per tile with all
+    // eight waves in it at once; inside an L phase the other group's MFMAs cover it)
+    const unsigned rowb = 2u * (unsigned)(a.W * in_pitch), pixb = 2u * (unsigned)in_pitch;
+    auto unit_off = [&](int u, const PPHalo& hb) -> unsigned {
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            const int hp = u * 16 + (lane_t >> 2);
-            const int hy = hp / 10, hx = hp - hy * 10;
-            const int iy = t.y0 - 1 + hy, ix = t.x0 - 1 + hx;
-            const bool ok = t.spok && hp < 100 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            // source-side swizzle: LDS slot (lane & 3) of halo record (hy, hx) holds channel chunk slot ^ (hy & 3)
-            xo[u] = ok ? 2u * (unsigned)(((t.b * a.H + iy) * a.W + ix) * in_pitch + a.in_coff) + (unsigned)(((lane_t & 3) ^ (hy & 3)) * 16) : OOB;
-        }
-        wv = (t.valid && w < WU) ? (unsigned)(lane_t * 16 + w * 1024) : OOB;
+        const unsigned hp = (unsigned)(u * 16) + ((unsigned)lane_t >> 2);
+        const unsigned hy = __umul24(hp, 205u) >> 11;  // hp / 10 for hp < 1029
+        const unsigned hx = hp - hy * 10u;
+        const bool ok = hp < 100u && (unsigned)(hb.y0m1 + (int)hy) < (unsigned)a.H && (unsigned)(hb.x0m1 + (int)hx) < (unsigned)a.W;
+        // source-side swizzle: LDS slot (lane & 3) of halo record (hy, hx) holds channel chunk slot ^ (hy & 3)
+        const unsigned rel = __umul24(hy, rowb) + __umul24(hx, pixb) + ((((unsigned)lane_t & 3u) ^ (hy & 3u)) << 4);
+        return ok ? (unsigned)hb.base + rel : OOB;
     };
 
     PPTile cur, nxt;
+    PPHalo hb_nxt;
     unsigned xo[7], wv_cur, wv_nxt;  // xo: halo source offsets of the tile whose halo is being prefetched (the current one, the next one in the last channel block)
     int local = blockIdx.x >> 3;
-    decode(local, cur, xo, wv_cur);
+    decode_tile(local, cur, hb_nxt, wv_cur);
+#pragma unroll
+    for (int u = 0; u < 7; ++u) xo[u] = unit_off(u, hb_nxt);
     if (!cur.valid) return;  // workgroup-uniform: no barrier has been executed yet
 
     if constexpr (PP_STAGGER != 0) {
@@ -262,21 +282,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         if constexpr (PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
 
+    // accumulators start at the bias: lane (n32, hi) holds couts c0 + 32 i + 8 q + 4 hi + e of its pixels (register r = 4 q + e).  From LDS (no vmcnt wait behind
+    // the previous tile's stores); the first tile's here, every later tile's between the stores of the previous tile's epilogue (r04 trace: 128 v_mov + 16 LDS
+    // reads per wave at the tile top were ~1 200 cycles per SIMD and tile with the matrix pipe idle; the epilogue waits on the store path anyway)
+    // (a macro, not a lambda: an accumulator array captured by a lambda with several call sites loses its registers -- hipcc puts it in scratch)
+#define PP_INIT_ROWS(i, q, c0n)                                                                                     \
+    do {                                                                                                            \
+        const f32x4_t bv_ = *(const f32x4_t*)(smem + G::BIAS + ((c0n) + (i) * 32 + (q) * 8 + hi * 4) * 4);         \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                          \
+            acc[i][0][(q) * 4 + e_] = bv_[e_];                                                                      \
+            acc[i][1][(q) * 4 + e_] = bv_[e_];                                                                      \
+        }                                                                                                           \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) PP_INIT_ROWS(i, q, cur.c0);
+    int trace_no = -1;  // tile counter of this workgroup; -DVGH_EXPERIMENTS: per-tile marks of thread 0 (group 0) -- tile top, first channel block done, K loop done, epilogue done
     while (true) {
         const char* wbase_nxt = wbase_cur;
-        // accumulators start at the bias: lane (n32, hi) holds couts c0 + 32 i + 8 q + 4 hi + e of its pixels (register r = 4 q + e)
+        ++trace_no;
+        VGH_MARK(a, trace_no, 0);
+        if constexpr (!PP_INIT_IN_EPILOGUE) {
+            if (trace_no > 0) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4_t bv = *(const f32x4_t*)(smem + G::BIAS + (cur.c0 + i * 32 + q * 8 + hi * 4) * 4);  // LDS: no vmcnt wait behind the previous tile's stores
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[i][0][q * 4 + e] = bv[e];
-                    acc[i][1][q * 4 + e] = bv[e];
-                }
+                    for (int q = 0; q < 4; ++q) PP_INIT_ROWS(i, q, cur.c0);
             }
-
+        }
         if constexpr (V == 2) {
             if (!grp) load_frags(std::integral_constant<int, 0>{}, cbcount & 3);  // group A enters its first slot with the fragments of tap 0
         }
@@ -286,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             // prefetch targets of this channel block: halo of (cb + 1) or of the next tile's block 0; weights two taps ahead
             unsigned rpo = OOB;  // byte offset of this lane's pixel (lane = pixel of the 8 x 8 sub-patch) in the residual tensor, for the L2 touches
             if (last) {
-                decode(local + gpx, nxt, xo, wv_nxt);
+                decode_tile(local + gpx, nxt, hb_nxt, wv_nxt);  // its halo offsets: unit by unit in the L phases below
                 wbase_nxt = (const char*)a.wpack + (int64_t)nxt.c0 * 64;
                 const int y = cur.y0 + (lane >> 3), x = cur.x0 + (lane & 7);
                 const int64_t ro = ((((int64_t)cur.b * a.Ho + y) * a.Wo + x) * a.res_pitch + a.res_coff + cur.c0) * 2;
@@ -312,13 +346,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wd);
                     if constexpr (PP_XFRONT) {
                         if constexpr (T < 3) {
+                            if (last) xo[2 * T] = unit_off(2 * T, hb_nxt), xo[2 * T + 1] = unit_off(2 * T + 1, hb_nxt);
                             dma16(xsrc, xo[2 * T], 0, xpre + (2 * T) * 1024);
                             dma16(xsrc, xo[2 * T + 1], 0, xpre + (2 * T + 1) * 1024);
                         } else if constexpr (T == 3) {
+                            if (last) xo[6] = unit_off(6, hb_nxt);
                             dma16(xsrc, xo[6], 0, xpre + 6 * 1024);
                         }
                     } else {
-                        if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                        if constexpr (T < 7) {
+                            if (last) xo[T] = unit_off(T, hb_nxt);
+                            dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                        }
                     }
                     if constexpr (LAST && T < 3) dma16(a.res, rpo, (unsigned)(T == 0 ? 0 : T == 1 ? 128 : BC * 2 - 16), smem + G::DUMMY);
                 };
@@ -391,13 +430,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                             dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wdst + ws * wdst_step);
                         if constexpr (PP_XFRONT) {
                             if constexpr (T < 3) {
+                                if (last) xo[2 * T] = unit_off(2 * T, hb_nxt), xo[2 * T + 1] = unit_off(2 * T + 1, hb_nxt);
                                 dma16(xsrc, xo[2 * T], 0, xpre + (2 * T) * 1024);
                                 dma16(xsrc, xo[2 * T + 1], 0, xpre + (2 * T + 1) * 1024);
                             } else if constexpr (T == 3) {
+                                if (last) xo[6] = unit_off(6, hb_nxt);
                                 dma16(xsrc, xo[6], 0, xpre + 6 * 1024);
                             }
                         } else {
-                            if constexpr (T < 7) dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                            if constexpr (T < 7) {
+                                if (last) xo[T] = unit_off(T, hb_nxt);
+                                dma16(xsrc, xo[T], 0, xpre + T * 1024);
+                            }
                         }
                         // last channel block: pull this wave's residual lines into L2 (one lane per pixel, 16 bytes of every 128-byte line, into the
                         // dummy LDS unit) so that the epilogue's residual loads are L2 hits instead of two exposed HBM round trips per tile
@@ -462,7 +506,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 #pragma unroll
                 for (int h = 0; h < 2; ++h) bofs[ky][h] += d;
             xs ^= 1;
+            if (cb == 0) VGH_MARK(a, trace_no, 1);
         }
+        VGH_MARK(a, trace_no, 2);
 
         if constexpr (V == 2) {
             // the fragment registers are dead here (group A reloads them after the accumulators are re-initialised, group B at the top of its next slot); hipcc
@@ -580,18 +626,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                 stores(0);
                 __builtin_amdgcn_sched_barrier(0);
                 arith(std::integral_constant<int, 1>{}, std::true_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                stores(1);
             } else {
                 arith(std::integral_constant<int, 0>{}, std::false_type{});
                 __builtin_amdgcn_sched_barrier(0);
                 stores(0);
                 __builtin_amdgcn_sched_barrier(0);
                 arith(std::integral_constant<int, 1>{}, std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                stores(1);
             }
+            // the tile's last stores (pixel group 1): both groups' accumulators are dead and every store instruction waits its turn on the CU's store path, so
+            // the next tile's bias goes into accumulator rows 32 i + 16 m .. + 15 between the stores (plain code, not inside store_out: see PP_INIT_ROWS)
+            __builtin_amdgcn_sched_barrier(0);
+#define PP_TAIL_STORES(SIMPLE)                                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                               \
+        const int cv = cbase + i * 32 + 16 * m + 8 * hi;                                                                                          \
+        const unsigned vo = (SIMPLE) ? ovb[1] + seg : (cv < a.cout_store ? ovb[1] : OOB) + (unsigned)(cv >= a.out_split ? dsplit : 0);            \
+        if (VGH_ABLATE(a, 128))                                                                                                                   \
+            asm volatile("" ::"v"(ov[i][m]));                                                                                                     \
+        else                                                                                                                                      \
+            __builtin_amdgcn_raw_buffer_store_b128(ov[i][m], rs_out, vo + (i * 32 + 16 * m) * 2, 0, 0);                                           \
+        if constexpr (PP_INIT_IN_EPILOGUE) {                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                                    \
+            PP_INIT_ROWS(i, 2 * m, nxt.c0);                                                                                                       \
+            PP_INIT_ROWS(i, 2 * m + 1, nxt.c0);                                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                                                    \
+        }                                                                                                                                         \
+    }
+            if (simple) {  // wave-uniform branch AROUND the loop (no runtime condition per vector)
+                PP_TAIL_STORES(true)
+            } else {
+                PP_TAIL_STORES(false)
+            }
+#undef PP_TAIL_STORES
+        } else if constexpr (PP_INIT_IN_EPILOGUE) {  // experiments build, epilogue ablated: the next tile still starts from its bias
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) PP_INIT_ROWS(i, q, nxt.c0);
         }
+        VGH_MARK(a, trace_no, 3);
         if constexpr (V == 1 && PP_EPI_SAME_SLOT) {
             if (grp) barrier_raw();  // group 1's deferred end-of-tile barrier (see the last phase)
         }
@@ -629,14 +701,15 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
 // the epilogue addresses the output and residual tensors through buffer descriptors: 32-bit byte offsets
 int vgh_conv_pp_fits(const ConvArgs& a) {
     const int64_t lim = (1ll << 31) - 4096;
-    return (int64_t)a.P * a.out_pitch * 2 < lim && (!a.res || (int64_t)a.P * a.res_pitch * 2 < lim) && a.cout_pad <= 2048;
+    return (int64_t)a.P * a.out_pitch * 2 < lim && (!a.res || (int64_t)a.P * a.res_pitch * 2 < lim) && a.cout_pad <= 2048 &&
+           (int64_t)a.W * a.in_pitch * 2 < (1 << 24);  // one input row in 24 bits: the halo offsets are 24-bit multiply-adds
 }
 int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4, 2>::LDS : bc == 96 ? PPGeo<3, 2>::LDS : bc == 64 ? PPGeo<2, 2>::LDS : 0; }
 
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_per_xcd, hipStream_t stream) {
     VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && !a.split && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 convs only");
     VGH_REQUIRE(a.cout_pad % bc == 0 && a.cout_pad <= 2048, "conv: cout_pad %d is not a multiple of the %d-cout ping-pong tile (or above 2048)", a.cout_pad, bc);
-    VGH_REQUIRE(vgh_conv_pp_fits(a), "conv: output / residual tensor above 2 GiB (32-bit buffer offsets)");
+    VGH_REQUIRE(vgh_conv_pp_fits(a), "conv: output / residual tensor above 2 GiB (32-bit buffer offsets), or an input row above 16 MiB");
     const int nsx = (a.Wo + 7) / 8, nsy = (a.Ho + 7) / 8, ntc = a.cout_pad / bc;
     const int64_t nsp = (int64_t)a.B * nsy * nsx;
     const int64_t total = (nsp + 7) / 8 * ntc;

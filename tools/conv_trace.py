@@ -78,6 +78,21 @@ def main():
             gap = (t[sel & (ntile > k_ + 1), k_ + 1, 0] - t[sel & (ntile > k_ + 1), k_, 3]) if k_ + 1 < ntile.max() else np.array([0])
             print(f"  tile {k_:2d} ({int(sel.sum()):4d} blocks): top->ready {d01.mean():7.0f} (max {d01.max():6d})  K loop {d12.mean():7.0f} (min {d12.min():6d} max {d12.max():6d})  "
                   f"epilogue {d23.mean():7.0f} (max {d23.max():6d})  ->next {gap.mean():6.0f}")
+        # s_memtime ticks are shader cycles (tools/micro/barrier_handoff: 1024.1 ticks per 32 back-to-back 32x32x16 MFMAs per SIMD): the busiest blocks' tick count
+        # over the launch's wall time is the clock the kernel actually ran at; for the g / h tiles (marks: tile top, first channel block done, K loop done,
+        # epilogue done) the steady K loop gives cycles per barrier slot against the 128 * BC / 32 matrix-pipe cycles a slot holds
+        nmax = int(ntile.max())
+        blk = t[ntile == nmax]
+        cyc = float((blk[:, nmax - 1, 3] - blk[:, 0, 0]).mean())
+        line = f"  busiest blocks ({blk.shape[0]}, {nmax} tiles): {cyc:.0f} cycles tile top -> last epilogue = {cyc / us_last / 1e3:.3f} GHz effective over the traced launch"
+        if name[0] in "gh" and Cin > 32 and k == 3:
+            bc = int(name.split("x")[2].split("_")[0])
+            slots = 18 * (Cin // 32 - 1)
+            per_slot = float((t[:, 0, 2] - t[:, 0, 1]).mean()) / slots
+            tile = float((t[ntile > 1][:, 1, 0] - t[ntile > 1][:, 0, 0]).mean()) if (ntile > 1).any() else cyc
+            line += (f"; steady K loop {per_slot:.0f} cycles / slot vs {4 * bc} of MFMA = {4 * bc / per_slot:.2f} busy; whole tile {tile:.0f} cycles, "
+                     f"{2 * 9 * (Cin // 32) * 4 * bc / tile:.2f} busy")
+        print(line)
 
 
 if __name__ == "__main__":
