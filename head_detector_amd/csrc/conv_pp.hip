@@ -45,6 +45,11 @@
 #ifndef PP_BAR_TAIL
 #define PP_BAR_TAIL 0  // g tiles: MFMAs of an M phase issued AFTER the slot's closing barrier (0: the barrier follows the whole run)
 #endif
+#ifndef PP_RELAX_FIRST_WAIT
+#define PP_RELAX_FIRST_WAIT 0  // 1: the first counted wait of a tile allows for the previous tile's 4 TI output stores.  Measured r04 (pp_ab r5e): 3 - 5 % SLOWER and the
+                               // tile top unchanged in the trace -- the stall behind the epilogue is not this vmcnt wait but the CU's one vector-memory path: the next
+                               // tile's LDS-DMA loads queue behind 128 KB of stores at 16 B/clk whatever the counters allow
+#endif
 #ifndef PP_INIT_IN_EPILOGUE
 #define PP_INIT_IN_EPILOGUE 1  // the next tile's bias enters the accumulators between the last stores of the epilogue (1) or at the tile top (0) (A/B knob)
 #endif
@@ -106,6 +111,10 @@ struct PPGeo {
     static constexpr int LDS = BIAS + 8192;
 };
 
+struct PPDiv {  // n / d == (umulhi(n, m) + n) >> s for n < 2^30 (vgh_fastdiv_magic): the three divisions of a tile decode
+    unsigned m_ntc, s_ntc, m_per, s_per, m_nsx, s_nsx;
+};
+__device__ __forceinline__ int pp_div(int n, unsigned m, unsigned s) { return (int)((__umulhi((unsigned)n, m) + (unsigned)n) >> s); }
 struct PPHalo {  // wave-uniform part of a sub-patch's halo addressing
     int base;        // byte offset of halo record (0, 0) = input pixel (y0 - 1, x0 - 1) in the input view
     int y0m1, x0m1;  // its pixel coordinates (range checks)
@@ -118,7 +127,7 @@ struct PPTile {
 };
 
 template <int TI, int V>
-__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk) {
+__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk, const PPDiv dv) {
     using G = PPGeo<TI, V>;
     constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
     // out-of-range marker for buffer offsets (descriptor range 2 GiB): still out of range, and not wrapped past 2^32, after the immediate / scalar
@@ -140,15 +149,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         const int tile = xcd * chunk + local;
         t.valid = (local < chunk && tile < total_tiles) ? 1 : 0;
         const int tl = t.valid ? tile : 0;
-        const int g8 = tl / ntc;
+        const int g8 = pp_div(tl, dv.m_ntc, dv.s_ntc);  // tl / ntc
         t.c0 = (tl - g8 * ntc) * BC;
         const int sp = g8 * 8 + w;
         t.spok = (t.valid && sp < nsp) ? 1 : 0;
         const int spc = t.spok ? sp : 0;
         const int per = nsy * nsx;
-        t.b = spc / per;
+        t.b = pp_div(spc, dv.m_per, dv.s_per);  // spc / per
         const int rem = spc - t.b * per;
-        const int sy = rem / nsx;
+        const int sy = pp_div(rem, dv.m_nsx, dv.s_nsx);  // rem / nsx
         t.y0 = sy * 8;
         t.x0 = (rem - sy * nsx) * 8;
         // byte offset of halo record (0, 0) = input pixel (y0 - 1, x0 - 1): wave-uniform (scalar) and possibly "negative" -- only in-range records add up to an
@@ -454,7 +463,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         constexpr int TP = (T + 8) % 9;  // the previous phase
                         constexpr int XN_P = PP_XFRONT ? (TP < 3 ? 2 : TP == 3 ? 1 : 0) : (TP < 7 ? 1 : 0);
                         constexpr int PN_T = (LAST && T < 3) ? 1 : 0, PN_P = (LAST && TP < 3) ? 1 : 0;
-                        wait_vm<XN_P + PN_P + 1 + XN_T + PN_T>();
+                        constexpr int NW = XN_P + PN_P + 1 + XN_T + PN_T;
+                        if constexpr (T == 0 && PP_RELAX_FIRST_WAIT != 0) {
+                            // first phase of a tile that follows another one: the awaited unit (tap 1, issued in the previous tile's last phase) is also older
+                            // than that tile's 4 TI output stores -- vmcnt is one in-order counter, so without them in the count this wait sat out the whole
+                            // store drain of the epilogue (~5 000 cycles, r04_pp_trace.txt) before the tile's first MFMA
+                            // (a workgroup's first tile takes the relaxed count too: its prologue has waited for everything)
+                            if (cb == 0 && !VGH_ABLATE(a, 8 | 128))
+                                wait_vm<NW + 4 * TI>();
+                            else
+                                wait_vm<NW>();
+                        } else {
+                            wait_vm<NW>();
+                        }
                     }
                     if constexpr (PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
                     if (!VGH_ABLATE(a, 16)) barrier_raw();
@@ -691,7 +712,11 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
     int gpx = 32;  // one workgroup per CU, 32 CUs per XCD
     if (max_blocks_per_xcd > 0 && gpx > max_blocks_per_xcd) gpx = max_blocks_per_xcd;
     if (gpx > chunk) gpx = chunk;
-    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V>), dim3(gpx * 8), dim3(512), (PPGeo<TI, V>::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk);
+    PPDiv dv;
+    vgh_fastdiv_magic((unsigned)ntc, &dv.m_ntc, &dv.s_ntc);
+    vgh_fastdiv_magic((unsigned)(nsy * nsx), &dv.m_per, &dv.s_per);
+    vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V>), dim3(gpx * 8), dim3(512), (PPGeo<TI, V>::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
