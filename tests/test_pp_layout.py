@@ -118,3 +118,31 @@ def test_tile_bookkeeping_matches_the_launcher():
     nsp = 64 * (80 // 8) ** 2
     tiles = (nsp + 7) // 8
     assert tiles == 800 and np.isclose(tiles / 256, 3.125)
+
+
+def test_just_in_time_halo_offsets_equal_the_full_pixel_address():
+    """conv_pp.hip::unit_off builds a halo record's source offset from a wave-uniform base (byte offset of input pixel (y0 - 1, x0 - 1), "negative" on the top / left
+    border) plus two 24-bit multiply-adds of the lane's (hy, hx), with hy = (hp * 205) >> 11 for hp / 10, in 32-bit wrap-around arithmetic.  Against the full address
+    ((b H + iy) W + ix) pitch + coff of every in-range record, for sub-patches on every border, a view inside a concat buffer, and the largest row the launcher admits."""
+    assert all((hp * 205) >> 11 == hp // 10 for hp in range(112))
+    M32 = 1 << 32
+    for H, W, pitch, coff in ((160, 160, 384, 96), (20, 20, 2048, 512), (8, 320, 768, 0), (40, 8191, 1024, 0)):
+        assert 2 * W * pitch < (1 << 24)  # vgh_conv_pp_fits: one input row in 24 bits
+        rowb, pixb = 2 * W * pitch, 2 * pitch
+        nb = min(4, ((1 << 31) - 1) // (2 * H * W * pitch))  # the loaders' 2 GiB rule (vgh_conv_prepare)
+        for b in (0, nb - 1):
+            for y0 in (0, 8, (H - 1) // 8 * 8):
+                for x0 in (0, 8, (W - 1) // 8 * 8):
+                    base = 2 * (((b * H + y0 - 1) * W + x0 - 1) * pitch + coff)  # int; < 0 for b = 0, y0 = 0
+                    for u in range(XU):
+                        for lane in range(64):
+                            hp = u * 16 + (lane >> 2)
+                            hy = (hp * 205) >> 11
+                            hx = hp - hy * 10
+                            iy, ix = y0 - 1 + hy, x0 - 1 + hx
+                            ok = hp < 100 and 0 <= iy < H and 0 <= ix < W
+                            rel = hy * rowb + hx * pixb + (((lane & 3) ^ (hy & 3)) << 4)
+                            assert hy < (1 << 24) and rowb < (1 << 24) and hx < (1 << 24) and pixb < (1 << 24)  # v_mul_u32_u24 operands
+                            if ok:
+                                full = 2 * (((b * H + iy) * W + ix) * pitch + coff) + (((lane & 3) ^ (hy & 3)) << 4)
+                                assert (base % M32 + rel) % M32 == full and full < (1 << 31)
