@@ -270,6 +270,25 @@ def test_c_abi_argument_validation_reports_errors_without_a_gpu():
     assert lib.vgh_conv_num_cfgs() > 70 and lib.vgh_conv_cfg_name(19).decode().startswith("p8x40")
 
 
+def test_ping_pong_tiles_qualify_only_for_their_conv_class():
+    """vgh_conv_cfg_ok (host logic, no GPU): the g / h tiles of csrc/conv_pp.hip take 3x3 / stride-1 bf16 convs with the 16-byte epilogue whose cout_pad is a
+    multiple of their cout tile -- what the tuner and the table loader rely on when a key names one."""
+    from head_detector_amd import _lib
+
+    lib = _lib.load()
+    names = [lib.vgh_conv_cfg_name(i).decode() for i in range(lib.vgh_conv_num_cfgs())]
+    for fam in "gh":
+        for bc in (128, 96, 64):
+            c = names.index(f"{fam}8x8x{bc}_n8")
+            assert lib.vgh_conv_cfg_cout_tile(c) == bc
+            assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc, 1, 0) == 1
+            assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc + 32, 1, 0) == 0  # cout_pad not a multiple of the tile
+            assert lib.vgh_conv_cfg_ok(c, 3, 2, 3 * bc, 1, 0) == 0  # stride 2
+            assert lib.vgh_conv_cfg_ok(c, 1, 1, 3 * bc, 1, 0) == 0  # 1x1
+            assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc, 0, 0) == 0  # fp32 / unaligned store
+            assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc, 1, 1) == 0  # ConvTranspose pixel shuffle
+
+
 def test_save_meshes_matches_reference_obj_bytes(tmp_path):
     """PredictionResult.save_meshes writes byte-for-byte what the reference's MeshSaver / save_meshes wrote for the same vertices and
     triangles (tests/golden/mesh_obj.npz, produced by running head_detector/detection_result.py:22-35,73-78)."""
