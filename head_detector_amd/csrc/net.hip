@@ -60,7 +60,7 @@ struct vgh_net {
     // stem + stage-1 downsample as ONE kernel (stem_ds.hip: the 48-channel stem activation stays in LDS): index of the stem op when the pair
     // qualifies (bf16 mode, the architecture's 3x3 / stride-2 / 64 -> 96 conv as the stem tensor's only reader), else -1; results are bit-identical
     int stem_pair = -1;
-    int fuse_stem = 0;  // opt-in (vgh_net_set_fuse_stem): measured r03, the fused kernel saves 1.5 GB of HBM traffic per L b64 forward but no time
+    int fuse_stem = 0;  // opt-in (vgh_net_set_fuse_stem): measured r03, the fused kernel saves 1.5 GB of HBM traffic per L b64 forward but no time (EXPERIMENTS.md 8c)
 };
 
 static inline int64_t buf_image_bytes(const vgh_buf_desc& b) { return (int64_t)b.h * b.w * b.pitch * vgh_fmt_bytes(b.is_f32); }
