@@ -43,6 +43,7 @@ struct vgh_flame {
     int device, V, Vp, NB, NJ, NP, K, Kp;  // NP = 9*(NJ-1); K = NB + NP; Kp = K rounded up to 8
     int max_heads;
     float* basis;    // [K][3][Vp]
+    float* basis8;   // [Kp / 8][3][2][Vp][4]: basis8[((g * 3 + c) * 2 + (k & 1)) * Vp + v][(k >> 1) & 3] = basis[k = 8g + ..][c][v]; rows K .. Kp - 1 zero
     float* vt;       // [3][Vp]
     float* wts;      // [NJ][Vp]
     float* J0;       // [3*NJ]
@@ -116,7 +117,10 @@ struct PrepScratch {
 // the 5 skinning transforms + 6D rotation + clamp(scale) + translation + un-pad triple -> hp[HP_SIZE] (LDS).  `emit`: also write
 // the caller-visible per-head outputs (rotation matrix, joints, roll/pitch/yaw).  The arithmetic is the same wherever it runs
 // (stand-alone prologue kernel for large batches, or the vertex kernel's own prologue for small ones).
-__device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, PrepScratch& S, float* coef, int cstride, float* hp, bool emit) {
+// `betas_out` false: the raw betas are not copied to coef (the caller reads them in place); `pose_row0` >= 0: the pose features go to rows pose_row0 .. of coef
+// instead of rows NB .. (a compact coefficient tile).
+__device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, PrepScratch& S, float* coef, int cstride, float* hp, bool emit, const bool betas_out = true,
+                                          const int pose_row0 = -1) {
 // every rounding is spelled out (explicit fmaf where a fused multiply-add is meant): the function is inlined into several kernels and
 // must not be contracted differently from one to the next, or a head's vertices would depend on the batch it is decoded in
 #pragma clang fp contract(off)
@@ -138,7 +142,7 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
 #pragma unroll 4
     for (int l = lane; l < NB; l += 64) {
         const float v = p ? p[l] : a.betas[(int64_t)h * NB + l];
-        coef[(int64_t)l * cstride] = v;
+        if (betas_out) coef[(int64_t)l * cstride] = v;
         if (!(l < a.live0_end || (l >= a.live1_begin && l < a.live1_end))) continue;
         const f32x4_t* const row = (const f32x4_t*)(a.JS + (int64_t)l * (MAXJ * 3));
         f32x4_t w[MAXJ * 3 / 4];
@@ -196,8 +200,9 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     PMARK(a, h, lane, 3);
     // pose_feature = (rot_mats[:,1:] - I).view(-1)
     const int NP = 9 * (NJ - 1);
-    if (lane < NP) coef[(int64_t)(NB + lane) * cstride] = S.R[9 + lane] - ((lane % 9) % 4 == 0 ? 1.0f : 0.0f);
-    if (lane >= NP && NB + lane < a.Kp) coef[(int64_t)(NB + lane) * cstride] = 0.0f;
+    const int prow0 = pose_row0 >= 0 ? pose_row0 : NB;
+    if (lane < NP) coef[(int64_t)(prow0 + lane) * cstride] = S.R[9 + lane] - ((lane % 9) % 4 == 0 ? 1.0f : 0.0f);
+    if (lane >= NP && NB + lane < a.Kp) coef[(int64_t)(prow0 + lane) * cstride] = 0.0f;
     // batch_rigid_transform: chain along parents, A_j = [Rg_j | tg_j - Rg_j J_j].  Twelve lanes own one entry each (lanes 0-8: the
     // 3x3 of Rg_j, lanes 9-11: tg_j), the chain state lives in LDS (a per-lane array indexed by the runtime `parents` would sit in
     // scratch memory: ~100 dependent global round trips, the bulk of the old single-lane prologue's ~45 us)
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(HB * 64) void flame_prep_multi_kernel(PrepArgs a) {
 
 struct VertArgs {
     const float* basis;  // [K][3][Vp]
+    const float* basis8; // [Kp / 8][3][2][Vp][4]: the same values, k-interleaved (c3 tiles) or null
     const float* vt;     // [3][Vp]
     const float* wts;    // [NJ][Vp]
     const float* coef;   // [Kp][npad]
@@ -907,6 +913,259 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
     return VGH_OK;
 }
 
+// ---- component-split matrix-core kernel ("c3" tiles, r04) -------------------------------------------------------------------
+// Why: between a handful and ~100 heads the register-fed kernel above is neither MFMA- nor bandwidth-bound, it is ONE WAVE'S CHAIN long: a wave owns
+// 32 heads x 32 vertices x (x, y, z) = 3 matrix instructions of 64 cycles and 4 operand dwords per k-pair, 218 pairs, on a single SIMD, while (n = 96: 471 waves
+// on 1 024 SIMDs) most of the chip has nothing to do; measured 72 ns per k.  Here a block is NV vertices x 32 heads and its three compute waves take ONE
+// coordinate plane each: a third of the chain per wave and three times the waves; NV = 16 (MFMA columns 16 .. 31 mirror 0 .. 15, the matrix pipe is not what
+// is short) doubles the blocks again so that 32 heads already reach every CU.  The coefficient tile of the block's heads sits in LDS ([k][head], row stride 33:
+// k-major staging writes and head-major operand reads both spread over the banks), so the only vector-memory stream of the K loop is the basis: one dword per
+// lane and k-pair, 48 pairs in flight per wave, ONE pair sequence over the three live ranges (no drain between them).  The shape / expression coefficients are
+// the raw parameters, read in place (any head_row indirection included); the pose features and head packs come from the prologue.  The price of the split is an
+// exchange: the blend results meet in LDS ([component][register][lane], conflict-free both ways; the buffer aliases the coefficient tile) and the epilogue --
+// flame_vertex_kernel's skinning / rigid / un-pad statements, one (head, vertex) per lane, so the bits are the same -- is dealt slot by slot (a slot = one
+// accumulator register = 2 heads x 32 vertices) to ALL waves of the block.
+//   NPW = 0: pose features and head packs come from the prologue kernel (coef scratch rows NB .., headpack).
+//   NPW > 0 ("fused", n <= NPW heads): NPW extra waves run prep_head for one head each WHILE the compute waves stream the shape / expression range; the
+//            pose-feature pairs and the epilogue wait for them at one barrier.  One launch, no dependent kernel boundary, the prologue's ~7 us under the stream.
+#ifdef VGH_EXPERIMENTS
+#define C3MARK(i) do { if (pa.trace && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) pa.trace[8 + (i)] = wall_clock64(); } while (0)
+#else
+#define C3MARK(i) do { } while (0)
+#endif
+
+template <int NV, int NPW>
+__global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, PrepArgs pa) {
+#pragma clang fp contract(off)
+    constexpr int NW = 3 + NPW;
+    constexpr int NH = NPW > 0 ? NPW : 32;  // head packs held by the block
+    constexpr int AS = NPW > 0 ? 33 : 32;   // row stride of the coefficient tile: 32 = what an LDS-DMA instruction writes (8 rows x 128 bytes; the two half-waves of an
+                                            // operand read then cover the 64 banks); 33 for the fused variant's k-major register staging
+    constexpr int UQ = 14;                  // k-groups (4 pairs, one 16-byte load per lane) per burst, two bursts in flight: 112 pairs = half of the longest chain
+    static_assert(NV == 32 || NV == 16, "NV");
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    // live k-groups (8 consecutive k = 4 MFMA pairs = one row block of the interleaved basis copy): the groups that hold a pair of the shape, expression or pose
+    // range, in ascending k; gi -> g.  A pair is live when its k lies in one of the ranges (even bounds: a pair is in or out as a whole).
+    const int g0e = (a.r0_end + 7) >> 3;  // r0 starts at 0
+    const int g1b = a.r1_end > a.r1_begin ? max(a.r1_begin >> 3, g0e) : g0e, g1e = a.r1_end > a.r1_begin ? max((a.r1_end + 7) >> 3, g1b) : g0e;
+    const int g2b = max(a.r2_begin >> 3, g1e), g2e = max((a.r2_end + 7) >> 3, g2b);
+    const int c0 = g0e, c01 = c0 + (g1e - g1b), ng = c01 + (g2e - g2b);
+    auto gof = [&](int gi) { return gi < c0 ? gi : gi < c01 ? g1b + (gi - c0) : g2b + (gi - c01); };
+    auto live = [&](int k) { return k < a.r0_end || (k >= a.r1_begin && k < a.r1_end) || (k >= a.r2_begin && k < a.r2_end); };
+    float* const s_A = fsm;  // [ng * 8][AS] coefficients of heads h0 .. h0 + 31: row gi * 8 + (k & 7); after the blend s_x [3][16][64]
+    float* const s_x = fsm;
+    float* const s_hp = fsm + ((max(ng * 8 * AS, 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h0 = blockIdx.y * 32;
+    if (a.n_dev) a.n = min(a.n, *a.n_dev);
+    if (h0 >= a.n) return;
+    const int j = lane & 31, half = lane >> 5;
+    const int v = blockIdx.x * NV + (j & (NV - 1));  // < Vp (a multiple of 32)
+    const int64_t plane = a.Vp;
+    C3MARK(0);
+    if constexpr (NPW == 0) {
+        // ---- coefficient tile and head packs straight into LDS (LDS-DMA, 1 KiB per instruction, everything in flight at once): 8 rows of the prologue kernel's
+        //      transposed scratch coef[k][head] (128 bytes per row and tile) = one live k-group per instruction; head packs as they lie ----
+        if (!VGH_ABLATE(a, 4)) {
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (unsigned)((int64_t)a.Kp * a.npad * 4), 0x00020000);
+            for (int gi = wv; gi < ng; gi += NW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(s_A + gi * 256), 16, (unsigned)((gof(gi) * 8 + (lane >> 3)) * a.npad + h0 + (lane & 7) * 4) * 4u, 0, 0, 0);
+            const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(a.headpack + (int64_t)h0 * HP_SIZE), 0, (unsigned)(32 * HP_SIZE * 4), 0x00020000);
+            for (int g = wv; g < 32 * HP_SIZE / 256; g += NW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (AS3 void*)(s_hp + g * 256), 16, (unsigned)(g * 256 + lane * 4) * 4u, 0, 0, 0);
+        }
+    }
+    float wj[MAXJ];  // skinning weights of this lane's vertex (every wave takes epilogue slots)
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) wj[q] = q < a.NJ ? a.wts[(int64_t)q * plane + v] : 0.0f;
+    // ---- blend operands: the k-interleaved basis copy [k / 8][c][k & 1][Vp][4]: 16 bytes of a lane = its vertex at k = 8g + half + {0, 2, 4, 6} -- the B operands of
+    //      the four pairs of group g.  One vector-memory instruction per 4 pairs, so that 28 instructions in flight are half of the longest chain (what bounds this
+    //      kernel is how much of its chain a wave has in flight: with dword loads and 48 pairs in flight the K loop ran 111 ns per pair, a 64-cycle MFMA apart) ----
+    const f32x4_t* const bl = (const f32x4_t*)a.basis8 + ((int64_t)(wv < 3 ? wv : 0) * 2 + half) * plane + v;  // + g * 6 * plane
+    f32x4_t B0[UQ], B1[UQ];
+    f32x16_t acc;
+    auto fetch = [&](f32x4_t (&B)[UQ], int g0) {
+        if (g0 >= ng) return;
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) {
+            const int gi = (g0 + u < ng) ? g0 + u : ng - 1;  // past the end: a valid, unused group
+            if (VGH_ABLATE(a, 1)) B[u] = f32x4_t{(float)lane, (float)u, 1.0f, 2.0f};
+            else B[u] = bl[(int64_t)gof(gi) * 6 * plane];
+        }
+    };
+    {
+        const float tv = a.vt[(wv < 3 ? wv : 0) * plane + v];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = tv;
+    }
+    if (wv < 3) fetch(B0, 0);  // the basis stream starts under the staging of the tile
+    if constexpr (NPW > 0) {
+        // fused: the raw betas of the block's heads, read in place.  Every compute wave stages the whole (small) tile itself -- identical values from every
+        // writer, so a wave needs nothing but its own writes to have landed and no hand-over exists that the prologue waves (busy until the pose barrier) would
+        // have to attend.  A lane owns head lane % NPW and k = lane / NPW + (64 / NPW) i: all loads of a range are independent (batches of 8 in flight).
+        if (wv < 3 && !VGH_ABLATE(a, 4)) {
+            constexpr int KPI = 64 / NPW;
+            const int hh = lane & (NPW - 1), ks = lane / NPW;
+            const float* src = nullptr;
+            if (hh < a.n) {
+                const int64_t prow = pa.head_row ? pa.head_row[hh] : hh;
+                src = pa.params ? pa.params + prow * VGH_NUM_FLAME_PARAMS : pa.betas + (int64_t)hh * pa.NB;
+            }
+            auto stage = [&](int kb, int ke) {
+                for (int k0 = kb; k0 < ke; k0 += KPI * 8) {
+                    float t[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = k0 + i * KPI + ks;
+                        t[i] = (src && k < ke) ? src[k] : 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = k0 + i * KPI + ks;
+                        const int g = k >> 3;
+                        if (k < ke) s_A[((g < g0e ? g : c0 + (g - g1b)) * 8 + (k & 7)) * AS + hh] = t[i];
+                    }
+                }
+            };
+            stage(a.r0_begin, a.r0_end);
+            stage(a.r1_begin, a.r1_end);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UQ) : "memory");  // in order: everything ahead of the first basis burst (the LDS-DMA of the tile) has landed
+        __syncthreads();
+    }
+    C3MARK(1);
+    if (wv < 3) {
+        // blend: pairs (k, k + 1) per MFMA in ascending k over the live groups: the chain of flame_mfma_kernel for one component
+        const float* const sa = s_A + half * AS + j;  // + (gi * 8 + 2i) * AS
+        auto consume = [&](const f32x4_t (&B)[UQ], int g0) {
+#pragma unroll
+            for (int u = 0; u < UQ; ++u) {
+                if (g0 + u < ng) {  // wave-uniform
+                    const int k0 = gof(g0 + u) * 8;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (live(k0 + 2 * i)) {  // wave-uniform
+                            const float av = (NPW == 0 || j < NH) ? sa[((g0 + u) * 8 + 2 * i) * AS] : 0.0f;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B[u][i], acc, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
+        bool synced = NPW == 0;  // fused: the first burst that holds a pose group waits for the prologue waves (pose rows of the tile, head packs)
+        for (int g = 0; g < ng; g += 2 * UQ) {
+            fetch(B1, g + UQ);
+            if (!synced && g + UQ > c01) {
+                __syncthreads();
+                synced = true;
+            }
+            consume(B0, g);
+            fetch(B0, g + 2 * UQ);
+            if (!synced && g + 2 * UQ > c01) {
+                __syncthreads();
+                synced = true;
+            }
+            consume(B1, g + UQ);
+        }
+        if (!synced) __syncthreads();
+        C3MARK(2);
+    } else if constexpr (NPW > 0) {
+        const int hh = wv - 3;
+        PrepScratch* const scr = (PrepScratch*)(s_hp + NH * HP_SIZE);
+        if (hh < a.n) {
+            prep_head(pa, hh, lane, scr[hh], s_A + hh, AS, s_hp + hh * HP_SIZE, blockIdx.x == 0, false, c01 * 8);  // NB = 8 g2b: the pose rows start a group
+        } else {
+            for (int q = lane; q < (ng - c01) * 8; q += 64) s_A[(c01 * 8 + q) * AS + hh] = 0.0f;
+            for (int e = lane; e < HP_SIZE; e += 64) s_hp[hh * HP_SIZE + e] = 0.0f;
+        }
+        __syncthreads();  // the pose barrier of the compute waves
+    }
+    __syncthreads();  // every wave is done with the coefficient tile: its memory becomes the exchange buffer
+    if (wv < 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_x[((wv * 16) + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    C3MARK(3);
+    // ---- epilogue: flame_vertex_kernel's statements per (head, vertex), slots dealt round-robin to the waves ----
+    const bool vok = j < NV && v < a.V;
+    if (VGH_ABLATE(a, 2)) {
+        if (a.proj && tid == 0) a.proj[((int64_t)h0 * a.V + v) * 3] = s_x[lane];
+        return;
+    }
+    for (int r = wv; r < 16; r += NW) {
+        const int hlo = (r & 3) + 8 * (r >> 2);  // head of the lower half-wave; the upper one has hlo + 4
+        if (h0 + hlo >= a.n) continue;           // wave-uniform: neither half has a live head
+        const int hh = hlo + 4 * half;
+        const float* const hp = s_hp + min(hh, NH - 1) * HP_SIZE;
+        const float px = s_x[(0 * 16 + r) * 64 + lane], py = s_x[(1 * 16 + r) * 64 + lane], pz = s_x[(2 * 16 + r) * 64 + lane];
+        float T[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) T[q] = 0.0f;
+#pragma unroll
+        for (int jn = 0; jn < MAXJ; ++jn)
+            if (jn < a.NJ) {  // wave-uniform
+                const f32x4_t A0 = *(const f32x4_t*)(hp + HP_A + jn * 12), A1 = *(const f32x4_t*)(hp + HP_A + jn * 12 + 4), A2 = *(const f32x4_t*)(hp + HP_A + jn * 12 + 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    T[q] = fmaf(wj[jn], A0[q], T[q]);
+                    T[4 + q] = fmaf(wj[jn], A1[q], T[4 + q]);
+                    T[8 + q] = fmaf(wj[jn], A2[q], T[8 + q]);
+                }
+            }
+        const float vx = fmaf(T[0], px, fmaf(T[1], py, fmaf(T[2], pz, T[3])));
+        const float vy = fmaf(T[4], px, fmaf(T[5], py, fmaf(T[6], pz, T[7])));
+        const float vz = fmaf(T[8], px, fmaf(T[9], py, fmaf(T[10], pz, T[11]))) + a.z_offset;
+        if (vok && h0 + hh < a.n) {
+            const int64_t obase = ((int64_t)(h0 + hh) * a.V + v) * 3;
+            if (a.verts) *(f32x3_t*)(a.verts + obase) = f32x3_t{vx, vy, vz};  // 12 bytes per lane, contiguous across a half-wave
+            if (a.proj) {
+                const f32x4_t R0 = *(const f32x4_t*)(hp + HP_R), R1 = *(const f32x4_t*)(hp + HP_R + 4), R2 = *(const f32x4_t*)(hp + HP_R + 8), R3 = *(const f32x4_t*)(hp + HP_R + 12);
+                // R0 = R[0..3], R1 = R[4..7], R2 = {R[8], s, t0, t1}, R3 = {t2, u0, u1, u2}
+                const float sc = R2[1];
+                float qx = (R0[0] * vx + R0[1] * vy + R0[2] * vz) * sc + R2[2];
+                float qy = (R0[3] * vx + R1[0] * vy + R1[1] * vz) * sc + R2[3];
+                float qz = (R1[2] * vx + R1[3] * vy + R2[0] * vz) * sc + R3[0];
+                if (a.do_unpad) {  // detector.py:67-69
+                    qx = (qx - R3[1]) / R3[3];
+                    qy = (qy - R3[2]) / R3[3];
+                    qz = qz / R3[3];
+                }
+                *(f32x3_t*)(a.proj + obase) = f32x3_t{qx, qy, qz};
+            }
+        }
+    }
+    C3MARK(4);
+}
+
+template <int NV, int NPW>
+int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
+    constexpr int NH = NPW > 0 ? NPW : 32;
+    const int ngmax = (va.Kp + 7) / 8;  // live groups <= all groups
+    const int g0e = (va.r0_end + 7) >> 3;
+    const int g1b = va.r1_end > va.r1_begin ? std::max(va.r1_begin >> 3, g0e) : g0e, g1e = va.r1_end > va.r1_begin ? std::max((va.r1_end + 7) >> 3, g1b) : g0e;
+    const int g2b = std::max(va.r2_begin >> 3, g1e), g2e = std::max((va.r2_end + 7) >> 3, g2b);
+    const int nrows8 = std::min(ngmax, g0e + (g1e - g1b) + (g2e - g2b)) * 8;
+    const int tile = (std::max(nrows8 * (NPW > 0 ? 33 : 32), 3 * 16 * 64) + 3) & ~3;
+    const size_t lds = ((size_t)tile + (size_t)NH * HP_SIZE) * sizeof(float) + (NPW > 0 ? NPW * sizeof(PrepScratch) : 0);
+    static std::atomic<int> attr_done[16];
+    int dev = 0;
+    VGH_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
+        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NV, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_done[dev].store(1, std::memory_order_release);
+    }
+    if (lds > 96 * 1024) {
+        vgh_set_error("flame c3 tiles: %zu bytes of LDS for %d coefficient rows", lds, nrows8);
+        return VGH_ERR_INVALID;
+    }
+    const int vgroups = (va.V + NV - 1) / NV, hgroups = NPW > 0 ? 1 : (va.n + 31) / 32;
+    hipLaunchKernelGGL((flame_c3_kernel<NV, NPW>), dim3(vgroups, hgroups), dim3((3 + NPW) * 64), lds, st, va, pa);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
 int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, hipStream_t st);
 
 int run_decode(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, int expr_live, bool detector_mode, float* verts, float* proj, void* stream) {
@@ -958,7 +1217,11 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         const bool lds32 = even && npairs <= 248 && mode == 5;
         const bool lds = lds32 || (even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMidHeads)));
         const bool mfma = lds || (even && (mode == 2 || (mode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
-        const bool fused = !mfma && !pa.n_dev && m <= 256;  // the vertex kernel computes its own heads' prologue
+        // c3 tiles (component-split waves, coefficient tile in LDS): modes 6 / 7 force them with 32 / 16 vertices per block and the prologue kernel, modes 8 / 9
+        // add the fused variant (prologue waves inside the block) for m <= 8
+        const bool c3 = even && mode >= 6 && mode <= 9 && f->K - f->NB <= 64 && (f->NB & 7) == 0;  // the pose rows start a k-group
+        const bool c3_fused = c3 && mode >= 8 && !pa.n_dev && m <= 8 && (verts || proj);
+        const bool fused = c3_fused || (!c3 && !mfma && !pa.n_dev && m <= 256);  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
             constexpr int HB = 16;
             if (m >= 512) {  // coalesced coefficient rows (measured: 16 waves per block cost 17 us vs 9.5 us at n = 96, but 92 vs 112 us at n = 8192); the
@@ -980,6 +1243,7 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         if (!verts && !proj) continue;
         VertArgs va;
         va.basis = f->basis;
+        va.basis8 = f->basis8;
         va.vt = f->vt;
         va.wts = f->wts;
         va.coef = f->coef;
@@ -1013,7 +1277,14 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         if (getenv("VGH_FLAME_ABLATE")) va.ablate = atoi(getenv("VGH_FLAME_ABLATE"));
 #endif
         int rc;
-        if (lds) {
+        if (c3_fused) {
+            if (mode == 8)
+                rc = m <= 1 ? launch_c3<32, 1>(va, pa, st) : m <= 2 ? launch_c3<32, 2>(va, pa, st) : m <= 4 ? launch_c3<32, 4>(va, pa, st) : launch_c3<32, 8>(va, pa, st);
+            else
+                rc = m <= 1 ? launch_c3<16, 1>(va, pa, st) : m <= 2 ? launch_c3<16, 2>(va, pa, st) : m <= 4 ? launch_c3<16, 4>(va, pa, st) : launch_c3<16, 8>(va, pa, st);
+        } else if (c3) {
+            rc = (mode == 7 || mode == 9) ? launch_c3<16, 0>(va, pa, st) : launch_c3<32, 0>(va, pa, st);
+        } else if (lds) {
             // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
             rc = lds32 ? launch_mfma_lds<1, 32>(va, st) : (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);
         } else if (mfma) {
@@ -1065,7 +1336,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
     f->Kp = (f->K + 7) / 8 * 8;
     f->max_heads = max_heads > 0 ? max_heads : 1024;
     const int Vp = f->Vp, K = f->K;
-    std::vector<float> basis((size_t)K * 3 * Vp, 0.0f), vt((size_t)3 * Vp, 0.0f), wts((size_t)NJ * Vp, 0.0f);
+    std::vector<float> basis((size_t)K * 3 * Vp, 0.0f), vt((size_t)3 * Vp, 0.0f), wts((size_t)NJ * Vp, 0.0f), basis8((size_t)f->Kp * 3 * Vp, 0.0f);
     for (int v = 0; v < V; ++v)
         for (int c = 0; c < 3; ++c) {
             vt[(size_t)c * Vp + v] = v_template[(size_t)v * 3 + c];
@@ -1073,6 +1344,9 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
             for (int l = 0; l < NB; ++l) basis[((size_t)l * 3 + c) * Vp + v] = sd[l];
             for (int pz = 0; pz < f->NP; ++pz) basis[((size_t)(NB + pz) * 3 + c) * Vp + v] = posedirs[(size_t)pz * 3 * V + (size_t)v * 3 + c];
         }
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < 3; ++c)
+            for (int v = 0; v < V; ++v) basis8[((((size_t)(k >> 3) * 3 + c) * 2 + (k & 1)) * Vp + v) * 4 + ((k >> 1) & 3)] = basis[((size_t)k * 3 + c) * Vp + v];
     for (int v = 0; v < V; ++v)
         for (int j = 0; j < NJ; ++j) wts[(size_t)j * Vp + v] = lbs_weights[(size_t)v * NJ + j];
     // fold the joint regressor into the shape basis (fp64)
@@ -1098,6 +1372,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
     VGH_HIP(hipMalloc((void**)&f->dst, (vec).size() * sizeof((vec)[0])));                         \
     VGH_HIP(hipMemcpy(f->dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice))
     UP(basis, basis);
+    UP(basis8, basis8);
     UP(vt, vt);
     UP(wts, wts);
     UP(J0, J0);
@@ -1116,6 +1391,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
 void vgh_flame_destroy(vgh_flame* f) {
     if (!f) return;
     hipFree(f->basis);
+    hipFree(f->basis8);
     hipFree(f->vt);
     hipFree(f->wts);
     hipFree(f->J0);
@@ -1189,7 +1465,7 @@ int vgh_flame_set_trace(void* dev_buffer) {
 #endif
 
 int vgh_flame_set_matrix_path(int mode) {
-    VGH_REQUIRE(mode >= 0 && mode <= 5, "flame_set_matrix_path: mode %d outside 0..5", mode);
+    VGH_REQUIRE(mode >= 0 && mode <= 9, "flame_set_matrix_path: mode %d outside 0..9", mode);
     g_flame_mode.store(mode, std::memory_order_relaxed);
     return VGH_OK;
 }

@@ -1494,13 +1494,14 @@ def test_c_only_create_and_detect(gpu_lib, flame_model, tmp_path):
     assert gpu_lib.vgh_create(C.byref(bad), C.byref(h)) != 0 and b"not a readable" in gpu_lib.vgh_last_error()
 
 
-@pytest.mark.parametrize("n,live", [(5, (128, 64)), (12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (191, (128, 64)), (192, (300, 100)), (255, (128, 64)), (256, (300, 100)), (257, (128, 64)), (1023, (128, 64)),
+@pytest.mark.parametrize("n,live", [(1, (128, 64)), (2, (300, 100)), (3, (64, 32)), (4, (128, 64)), (7, (300, 100)), (8, (128, 64)), (5, (128, 64)), (12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (191, (128, 64)), (192, (300, 100)), (255, (128, 64)), (256, (300, 100)), (257, (128, 64)), (1023, (128, 64)),
                                     (1024, (300, 100)), (1300, (64, 32)), (1100, (300, 100))])
 def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame_model, n, live):
     """The FP32-MFMA vertex kernels (v_mfma_f32_32x32x2_f32 = an exact k-ordered fmaf chain; register-fed for small / medium batches,
     LDS-staged 128 x 128 tiles at crowd scale) and the VALU kernel produce the SAME bits for every vertex (unrotated and projected /
     un-padded), for partial head tiles, every live-coefficient split -- so which one runs is a pure speed choice -- and all stay
-    within the f64-oracle bar.  Modes of vgh_flame_set_matrix_path: 0 VALU, 1 automatic, 2 register-fed, 3 / 4 / 5 LDS-staged (128- / 64- / 32-head blocks)."""
+    within the f64-oracle bar.  Modes of vgh_flame_set_matrix_path: 0 VALU, 1 automatic, 2 register-fed, 3 / 4 / 5 LDS-staged (128- / 64- / 32-head blocks),
+    6 / 7 / 8 the component-split tiles (one / two head tiles per block; 8: prologue waves inside the block up to 8 heads)."""
     from head_detector_amd.flame import FLAMELayer
     from oracle import flame_oracle as fo
 
@@ -1509,12 +1510,12 @@ def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame
     unpad = torch.tensor([[3.0, 7.0, 1.3]], device=_dev()).expand(n, 3).contiguous()
     outs = {}
     try:
-        for mode in (1, 0, 2, 3, 4, 5):
+        for mode in (1, 0, 2, 3, 4, 5, 6, 7, 8, 9):
             assert gpu_lib.vgh_flame_set_matrix_path(mode) == 0
             outs[mode] = [t.clone() for t in fl.decode(p, unpad=unpad, shape_live=live[0], expr_live=live[1])]
     finally:
         gpu_lib.vgh_flame_set_matrix_path(1)
-    for mode in (1, 2, 3, 4, 5):
+    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         for a, b in zip(outs[mode], outs[0]):
             assert torch.equal(a, b), mode
     _, _, q = fo.reproject(fo.FlameConstants(flame_model, torch.float64), p.cpu().double())

@@ -18,12 +18,17 @@ def main():
     dev = torch.device("cuda", 0)
     fl = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=8192)
     lib = _lib.load()
-    mode = int(os.environ.get("FLAME_MODE", "1"))  # vgh_flame_set_matrix_path: 0 VALU, 1 automatic, 2 register-fed MFMA, 3 / 4 LDS-staged MFMA
-    _lib.check(lib.vgh_flame_set_matrix_path(mode))
+    # vgh_flame_set_matrix_path: 0 VALU, 1 automatic, 2 register-fed MFMA, 3 / 4 / 5 LDS-staged MFMA, 6 / 7 / 8 component-split tiles; FLAME_MODES = several in one process
+    modes = tuple(int(x) for x in os.environ.get("FLAME_MODES", os.environ.get("FLAME_MODE", "1")).split(","))
     ns = tuple(int(x) for x in os.environ.get("FLAME_NS", "1,8,64,96,256,512,1024,8192").split(","))
+    lives = {"m": ("M heads 64+32", (64, 32)), "l": ("L heads 128+64", (128, 64)), "all": ("all 300+100", (300, 100))}
     rows = []
-    for live, (sl, el) in (("M heads 64+32", (64, 32)), ("L heads 128+64", (128, 64)), ("all 300+100", (300, 100))):
+    for mode, lk in ((m, k) for k in os.environ.get("FLAME_LIVES", "m,l,all").split(",") for m in modes):
+        live, (sl, el) = lives[lk]
+        _lib.check(lib.vgh_flame_set_matrix_path(mode))
         for n in ns:
+            if mode in (8, 9) and n > 8:
+                continue  # modes 8 / 9 differ from 6 / 7 up to 8 heads only
             p = torch.randn(n, 413, device=dev)
             p[:, sl:300] = 0
             p[:, 300 + el:400] = 0
