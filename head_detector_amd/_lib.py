@@ -9,7 +9,7 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # VGH_LIB_PATH: load another build of the library (tools/ use it for the -DVGH_EXPERIMENTS build, which is never shipped)
 LIB_PATH = os.environ.get("VGH_LIB_PATH") or os.path.join(HERE, "libvgh.so")
-ABI_VERSION = 4  # = VGH_ABI_VERSION of include/vgh.h
+ABI_VERSION = 5  # = VGH_ABI_VERSION of include/vgh.h
 
 VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2

@@ -929,21 +929,34 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
 //   NPW > 0 ("fused", n <= NPW heads): NPW extra waves run prep_head for one head each WHILE the compute waves stream the shape / expression range; the
 //            pose-feature pairs and the epilogue wait for them at one barrier.  One launch, no dependent kernel boundary, the prologue's ~7 us under the stream.
 #ifdef VGH_EXPERIMENTS
-#define C3MARK(i) do { if (pa.trace && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) pa.trace[8 + (i)] = wall_clock64(); } while (0)
+#define C3MARK(i) do { if (pa.trace && bx == 1 && by == 0 && threadIdx.x == 0) pa.trace[8 + (i)] = wall_clock64(); } while (0)
 #else
 #define C3MARK(i) do { } while (0)
 #endif
 
-template <int NV, int NPW>
-__global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, PrepArgs pa) {
+//   NPW > 0 ("fused", n <= NPW heads, 3 + NPW waves): NPW extra waves run prep_head for one head each WHILE the compute waves stream the shape / expression
+//            groups (raw betas read in place); the pose groups and the epilogue wait for them at one barrier.  One launch, the prologue's ~8 us under the stream.
+//   NPW = 0 (3 compute waves + NHL helpers that stage and take epilogue slots; 5 helpers for a single head tile, 1 from two tiles on so that two blocks share a
+//            CU): coefficients and head packs come from the prologue KERNEL launched before.
+//   (r04, measured and removed: the prologue in the first blocks of the SAME launch, released to the vertex blocks by per-head flags -- agent-scope release /
+//    acquire = buffer_wbl2 / buffer_inv of a whole L2 and hundreds of polling waves: the flag of a lone head became visible 14 us into the launch, EXPERIMENTS 8d)
+template <int NPW, int NHL>
+__global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs a, PrepArgs pa) {
 #pragma clang fp contract(off)
-    constexpr int NW = 3 + NPW;
+    static_assert((NPW > 0) != (NHL > 0), "either prologue waves or helper waves");
+    constexpr int NW = 3 + NPW + NHL;
     constexpr int NH = NPW > 0 ? NPW : 32;  // head packs held by the block
     constexpr int AS = NPW > 0 ? 33 : 32;   // row stride of the coefficient tile: 32 = what an LDS-DMA instruction writes (8 rows x 128 bytes; the two half-waves of an
                                             // operand read then cover the 64 banks); 33 for the fused variant's k-major register staging
-    constexpr int UQ = 14;                  // k-groups (4 pairs, one 16-byte load per lane) per burst, two bursts in flight: 112 pairs = half of the longest chain
-    static_assert(NV == 32 || NV == 16, "NV");
+    constexpr int UQ = NPW == 8 ? 9 : 14;   // k-groups (4 pairs, one 16-byte load per lane) per burst, THREE bursts in flight = 168 of the longest chain's 220 pairs
+                                            // (11 waves leave 168 registers per lane: 9 groups per burst):
+                                            // a burst is asked for two consume times (2 x 56 MFMAs) ahead, more than a load takes under this traffic
     extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (a.n_dev) a.n = min(a.n, *a.n_dev);
+    const int vgroups = (a.V + 31) >> 5;
+    const int bid = (int)blockIdx.x;
+    const int by = bid / vgroups, bx = bid - by * vgroups;
     // live k-groups (8 consecutive k = 4 MFMA pairs = one row block of the interleaved basis copy): the groups that hold a pair of the shape, expression or pose
     // range, in ascending k; gi -> g.  A pair is live when its k lies in one of the ranges (even bounds: a pair is in or out as a whole).
     const int g0e = (a.r0_end + 7) >> 3;  // r0 starts at 0
@@ -955,33 +968,17 @@ __global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, Pr
     float* const s_A = fsm;  // [ng * 8][AS] coefficients of heads h0 .. h0 + 31: row gi * 8 + (k & 7); after the blend s_x [3][16][64]
     float* const s_x = fsm;
     float* const s_hp = fsm + ((max(ng * 8 * AS, 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int h0 = blockIdx.y * 32;
-    if (a.n_dev) a.n = min(a.n, *a.n_dev);
+    const int h0 = by * 32;
     if (h0 >= a.n) return;
     const int j = lane & 31, half = lane >> 5;
-    const int v = blockIdx.x * NV + (j & (NV - 1));  // < Vp (a multiple of 32)
+    const int v = bx * 32 + j;  // < Vp (a multiple of 32)
     const int64_t plane = a.Vp;
     C3MARK(0);
-    if constexpr (NPW == 0) {
-        // ---- coefficient tile and head packs straight into LDS (LDS-DMA, 1 KiB per instruction, everything in flight at once): 8 rows of the prologue kernel's
-        //      transposed scratch coef[k][head] (128 bytes per row and tile) = one live k-group per instruction; head packs as they lie ----
-        if (!VGH_ABLATE(a, 4)) {
-            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (unsigned)((int64_t)a.Kp * a.npad * 4), 0x00020000);
-            for (int gi = wv; gi < ng; gi += NW)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(s_A + gi * 256), 16, (unsigned)((gof(gi) * 8 + (lane >> 3)) * a.npad + h0 + (lane & 7) * 4) * 4u, 0, 0, 0);
-            const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(a.headpack + (int64_t)h0 * HP_SIZE), 0, (unsigned)(32 * HP_SIZE * 4), 0x00020000);
-            for (int g = wv; g < 32 * HP_SIZE / 256; g += NW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (AS3 void*)(s_hp + g * 256), 16, (unsigned)(g * 256 + lane * 4) * 4u, 0, 0, 0);
-        }
-    }
-    float wj[MAXJ];  // skinning weights of this lane's vertex (every wave takes epilogue slots)
-#pragma unroll
-    for (int q = 0; q < MAXJ; ++q) wj[q] = q < a.NJ ? a.wts[(int64_t)q * plane + v] : 0.0f;
     // ---- blend operands: the k-interleaved basis copy [k / 8][c][k & 1][Vp][4]: 16 bytes of a lane = its vertex at k = 8g + half + {0, 2, 4, 6} -- the B operands of
     //      the four pairs of group g.  One vector-memory instruction per 4 pairs, so that 28 instructions in flight are half of the longest chain (what bounds this
     //      kernel is how much of its chain a wave has in flight: with dword loads and 48 pairs in flight the K loop ran 111 ns per pair, a 64-cycle MFMA apart) ----
     const f32x4_t* const bl = (const f32x4_t*)a.basis8 + ((int64_t)(wv < 3 ? wv : 0) * 2 + half) * plane + v;  // + g * 6 * plane
-    f32x4_t B0[UQ], B1[UQ];
+    f32x4_t B0[UQ], B1[UQ], B2[UQ];
     f32x16_t acc;
     auto fetch = [&](f32x4_t (&B)[UQ], int g0) {
         if (g0 >= ng) return;
@@ -989,15 +986,35 @@ __global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, Pr
         for (int u = 0; u < UQ; ++u) {
             const int gi = (g0 + u < ng) ? g0 + u : ng - 1;  // past the end: a valid, unused group
             if (VGH_ABLATE(a, 1)) B[u] = f32x4_t{(float)lane, (float)u, 1.0f, 2.0f};
-            else B[u] = bl[(int64_t)gof(gi) * 6 * plane];
+            else B[u] = bl[(int64_t)(VGH_ABLATE(a, 8) ? (gi & 1) : gof(gi)) * 6 * plane];  // ablation 8: every load an L2 hit
         }
     };
+    // LDS-DMA of the tile, 1 KiB per instruction = 8 rows of the transposed scratch coef[k][head] (128 bytes per row and tile) = one live k-group
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (unsigned)((int64_t)a.Kp * a.npad * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(a.headpack + (int64_t)h0 * HP_SIZE), 0, (unsigned)(32 * HP_SIZE * 4), 0x00020000);
+    auto dma_group = [&](int gi) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(s_A + gi * 256), 16, (unsigned)((gof(gi) * 8 + (lane >> 3)) * a.npad + h0 + (lane & 7) * 4) * 4u, 0, 0, 0);
+    };
+    auto dma_packs = [&](int first, int step) {  // head packs as they lie
+        for (int g = first; g < 32 * HP_SIZE / 256; g += step) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (AS3 void*)(s_hp + g * 256), 16, (unsigned)(g * 256 + lane * 4) * 4u, 0, 0, 0);
+    };
+    // rows of a live group whose k is outside the live ranges (group 37 when the shape range ends before 300, the tail of a range that is not a multiple of 8,
+    // the pad behind the pose features) are cleared: their pairs then add fma(0, b, acc) = acc, and the K loop runs without a branch per pair
+    auto zero_dead_rows = [&](int gi) {
+        if (gi < 0 || gi >= ng) return;
+        const int k0 = gof(gi) * 8;
+        if (live(k0) && live(k0 + 7)) return;
+        for (int r = lane >> 5; r < 8; r += 2)
+            if (!live(k0 + r)) s_A[(gi * 8 + r) * AS + (lane & 31)] = 0.0f;
+    };
+    float wj[MAXJ];  // skinning weights of this lane's vertex (every wave takes epilogue slots)
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) wj[q] = q < a.NJ ? a.wts[(int64_t)q * plane + v] : 0.0f;
     {
         const float tv = a.vt[(wv < 3 ? wv : 0) * plane + v];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = tv;
     }
-    if (wv < 3) fetch(B0, 0);  // the basis stream starts under the staging of the tile
     if constexpr (NPW > 0) {
         // fused: the raw betas of the block's heads, read in place.  Every compute wave stages the whole (small) tile itself -- identical values from every
         // writer, so a wave needs nothing but its own writes to have landed and no hand-over exists that the prologue waves (busy until the pose barrier) would
@@ -1011,62 +1028,98 @@ __global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, Pr
                 src = pa.params ? pa.params + prow * VGH_NUM_FLAME_PARAMS : pa.betas + (int64_t)hh * pa.NB;
             }
             auto stage = [&](int kb, int ke) {
-                for (int k0 = kb; k0 < ke; k0 += KPI * 8) {
-                    float t[8];
+                constexpr int NB_ = 32;  // loads in flight per lane
+                for (int k0 = kb; k0 < ke; k0 += KPI * NB_) {
+                    float t[NB_];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < NB_; ++i) {
                         const int k = k0 + i * KPI + ks;
                         t[i] = (src && k < ke) ? src[k] : 0.0f;
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < NB_; ++i) {
                         const int k = k0 + i * KPI + ks;
                         const int g = k >> 3;
                         if (k < ke) s_A[((g < g0e ? g : c0 + (g - g1b)) * 8 + (k & 7)) * AS + hh] = t[i];
                     }
                 }
             };
+            zero_dead_rows(c0 - 1);
+            if (c01 > c0) {
+                zero_dead_rows(c0);
+                zero_dead_rows(c01 - 1);
+            }
             stage(a.r0_begin, a.r0_end);
             stage(a.r1_begin, a.r1_end);
         }
+        if (wv < 3) {  // the basis stream starts behind the tile's loads (in-order return: whatever is issued first is waited for first)
+            fetch(B0, 0);
+            fetch(B1, UQ);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UQ) : "memory");  // in order: everything ahead of the first basis burst (the LDS-DMA of the tile) has landed
+        if (!VGH_ABLATE(a, 4)) {
+            for (int gi = wv; gi < ng; gi += NW) dma_group(gi);
+            dma_packs(wv, NW);
+        }
+        asm volatile("" ::: "memory");  // the counted wait below counts on this order
+        if (wv < 3) {  // the basis stream starts behind the tile's LDS-DMA (in-order return) and stays in flight across the barrier
+            fetch(B0, 0);
+            fetch(B1, UQ);
+            if (ng > UQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UQ) : "memory");  // (a second burst exists)
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UQ) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int gi = wv; gi < ng; gi += NW) zero_dead_rows(gi);  // behind this wave's own LDS-DMA of the group
         __syncthreads();
     }
     C3MARK(1);
     if (wv < 3) {
         // blend: pairs (k, k + 1) per MFMA in ascending k over the live groups: the chain of flame_mfma_kernel for one component
         const float* const sa = s_A + half * AS + j;  // + (gi * 8 + 2i) * AS
+        auto read_a = [&](int gi, float (&A)[4]) {
+            const float* const p = sa + gi * 8 * AS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[i] = (NPW == 0 || j < NH) ? p[2 * i * AS] : 0.0f;
+        };
+        // the A operands of a group are read while the previous group's four MFMAs run (one wave-uniform branch per group; a read right in front of its MFMA
+        // behind a branch per pair cost ~150 cycles per 64-cycle MFMA)
         auto consume = [&](const f32x4_t (&B)[UQ], int g0) {
+            if (g0 >= ng) return;
+            float Ac[4], An[4];
+            read_a(g0, Ac);
 #pragma unroll
             for (int u = 0; u < UQ; ++u) {
+                if (u + 1 < UQ) read_a(min(g0 + u + 1, ng - 1), An);  // never past this burst: the next one may still wait for its rows (pose barrier)
                 if (g0 + u < ng) {  // wave-uniform
-                    const int k0 = gof(g0 + u) * 8;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (live(k0 + 2 * i)) {  // wave-uniform
-                            const float av = (NPW == 0 || j < NH) ? sa[((g0 + u) * 8 + 2 * i) * AS] : 0.0f;
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, B[u][i], acc, 0, 0, 0);
-                        }
+                        if (VGH_ABLATE(a, 16)) acc[0] = fmaf(Ac[i], B[u][i], acc[0]);  // ablation 16: no matrix chain, the loads still feed a result
+                        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[i], B[u][i], acc, 0, 0, 0);
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Ac[i] = An[i];
             }
         };
         bool synced = NPW == 0;  // fused: the first burst that holds a pose group waits for the prologue waves (pose rows of the tile, head packs)
-        for (int g = 0; g < ng; g += 2 * UQ) {
-            fetch(B1, g + UQ);
-            if (!synced && g + UQ > c01) {
+        auto pose_sync = [&](int gend) {
+            if (!synced && gend > c01) {
                 __syncthreads();
                 synced = true;
             }
+        };
+        for (int g = 0; g < ng; g += 3 * UQ) {
+            fetch(B2, g + 2 * UQ);
+            pose_sync(g + UQ);
             consume(B0, g);
-            fetch(B0, g + 2 * UQ);
-            if (!synced && g + 2 * UQ > c01) {
-                __syncthreads();
-                synced = true;
-            }
+            fetch(B0, g + 3 * UQ);
+            pose_sync(g + 2 * UQ);
             consume(B1, g + UQ);
+            fetch(B1, g + 4 * UQ);
+            pose_sync(g + 3 * UQ);
+            consume(B2, g + 2 * UQ);
         }
         if (!synced) __syncthreads();
         C3MARK(2);
@@ -1074,7 +1127,7 @@ __global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, Pr
         const int hh = wv - 3;
         PrepScratch* const scr = (PrepScratch*)(s_hp + NH * HP_SIZE);
         if (hh < a.n) {
-            prep_head(pa, hh, lane, scr[hh], s_A + hh, AS, s_hp + hh * HP_SIZE, blockIdx.x == 0, false, c01 * 8);  // NB = 8 g2b: the pose rows start a group
+            prep_head(pa, hh, lane, scr[hh], s_A + hh, AS, s_hp + hh * HP_SIZE, bx == 0, false, c01 * 8);  // NB = 8 g2b: the pose rows start a group
         } else {
             for (int q = lane; q < (ng - c01) * 8; q += 64) s_A[(c01 * 8 + q) * AS + hh] = 0.0f;
             for (int e = lane; e < HP_SIZE; e += 64) s_hp[hh * HP_SIZE + e] = 0.0f;
@@ -1089,7 +1142,7 @@ __global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, Pr
     __syncthreads();
     C3MARK(3);
     // ---- epilogue: flame_vertex_kernel's statements per (head, vertex), slots dealt round-robin to the waves ----
-    const bool vok = j < NV && v < a.V;
+    const bool vok = v < a.V;
     if (VGH_ABLATE(a, 2)) {
         if (a.proj && tid == 0) a.proj[((int64_t)h0 * a.V + v) * 3] = s_x[lane];
         return;
@@ -1139,9 +1192,9 @@ __global__ __launch_bounds__((3 + NPW) * 64) void flame_c3_kernel(VertArgs a, Pr
     C3MARK(4);
 }
 
-template <int NV, int NPW>
+template <int NPW, int NHL>
 int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
-    constexpr int NH = NPW > 0 ? NPW : 32;
+    constexpr int NH = NPW > 0 ? NPW : 32, NW = 3 + NPW + NHL;
     const int ngmax = (va.Kp + 7) / 8;  // live groups <= all groups
     const int g0e = (va.r0_end + 7) >> 3;
     const int g1b = va.r1_end > va.r1_begin ? std::max(va.r1_begin >> 3, g0e) : g0e, g1e = va.r1_end > va.r1_begin ? std::max((va.r1_end + 7) >> 3, g1b) : g0e;
@@ -1153,15 +1206,15 @@ int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
     int dev = 0;
     VGH_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NV, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NPW, NHL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done[dev].store(1, std::memory_order_release);
     }
     if (lds > 96 * 1024) {
         vgh_set_error("flame c3 tiles: %zu bytes of LDS for %d coefficient rows", lds, nrows8);
         return VGH_ERR_INVALID;
     }
-    const int vgroups = (va.V + NV - 1) / NV, hgroups = NPW > 0 ? 1 : (va.n + 31) / 32;
-    hipLaunchKernelGGL((flame_c3_kernel<NV, NPW>), dim3(vgroups, hgroups), dim3((3 + NPW) * 64), lds, st, va, pa);
+    const int vgroups = (va.V + 31) / 32, hgroups = NPW > 0 ? 1 : (va.n + 31) / 32;
+    hipLaunchKernelGGL((flame_c3_kernel<NPW, NHL>), dim3(vgroups * hgroups), dim3(NW * 64), lds, st, va, pa);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -1217,10 +1270,17 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         const bool lds32 = even && npairs <= 248 && mode == 5;
         const bool lds = lds32 || (even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMidHeads)));
         const bool mfma = lds || (even && (mode == 2 || (mode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
-        // c3 tiles (component-split waves, coefficient tile in LDS): modes 6 / 7 force them with 32 / 16 vertices per block and the prologue kernel, modes 8 / 9
-        // add the fused variant (prologue waves inside the block) for m <= 8
-        const bool c3 = even && mode >= 6 && mode <= 9 && f->K - f->NB <= 64 && (f->NB & 7) == 0;  // the pose rows start a k-group
-        const bool c3_fused = c3 && mode >= 8 && !pa.n_dev && m <= 8 && (verts || proj);
+        // c3 tiles (component-split waves, coefficient tile in LDS; K - NB pose features in one k-group run, NB a multiple of 8 so that the pose rows start a
+        // group): mode 6 always with the prologue kernel, mode 7 the same with the fused variant (prologue waves inside the block) up to 8 heads.  Automatic
+        // (measured, profiles/r04_flame_sweep.json; us per call, all 400 / L-live / M-live coefficients; old = the kernels above):
+        //   n = 1: 22.4 / 18.2 / 16.5 (old 33.4 / 19.2 / 16.2)    n = 8: 27.2 / 21.3 / 18.4 (52.7 / 36.6 / 30.9)    n = 32: 28.8 / 23.0 / 20.2 (58.0 / 42.0 / 36.4)
+        //   n = 96: 43.0 / 34.9 / 28.2 (59.0 / 43.3 / 37.3)       n = 128: 56.6 / 44.4 / 35.8 (59.8 / 43.8 / 37.9)  n = 192: 68.8 / 53.3 / 42.0 (60.5 / 44.9 / 38.9)
+        //   n = 256: 82.2 / 62.3 / 49.4 (100.4 / 71.9 / 58.9: the 64-head LDS-staged blocks start there)            n = 512: 145.8 / 107.4 / 83.3 (146.4 / 101.5 / 80.2)
+        // -> up to 112 heads and from 256 to 383; with a device-side count the launch is capacity-sized (dead tile rows exit at once): up to a capacity of 128.
+        const bool c3_ok = even && f->K - f->NB <= 64 && (f->NB & 7) == 0 && f->basis8;
+        const bool c3_auto = mode == 1 && (pa.n_dev ? m <= 128 : (m <= 112 || (m >= 256 && m < 384))) && !(m <= 2 && npairs < 100);  // (1 - 2 heads of the M set: the VALU kernel)
+        const bool c3 = c3_ok && (mode == 6 || mode == 7 || c3_auto);
+        const bool c3_fused = c3 && mode != 6 && !pa.n_dev && m <= 8 && (verts || proj);
         const bool fused = c3_fused || (!c3 && !mfma && !pa.n_dev && m <= 256);  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
             constexpr int HB = 16;
@@ -1278,12 +1338,9 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
 #endif
         int rc;
         if (c3_fused) {
-            if (mode == 8)
-                rc = m <= 1 ? launch_c3<32, 1>(va, pa, st) : m <= 2 ? launch_c3<32, 2>(va, pa, st) : m <= 4 ? launch_c3<32, 4>(va, pa, st) : launch_c3<32, 8>(va, pa, st);
-            else
-                rc = m <= 1 ? launch_c3<16, 1>(va, pa, st) : m <= 2 ? launch_c3<16, 2>(va, pa, st) : m <= 4 ? launch_c3<16, 4>(va, pa, st) : launch_c3<16, 8>(va, pa, st);
+            rc = m <= 1 ? launch_c3<1, 0>(va, pa, st) : m <= 2 ? launch_c3<2, 0>(va, pa, st) : m <= 4 ? launch_c3<4, 0>(va, pa, st) : launch_c3<8, 0>(va, pa, st);
         } else if (c3) {
-            rc = (mode == 7 || mode == 9) ? launch_c3<16, 0>(va, pa, st) : launch_c3<32, 0>(va, pa, st);
+            rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : launch_c3<0, 1>(va, pa, st);
         } else if (lds) {
             // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
             rc = lds32 ? launch_mfma_lds<1, 32>(va, st) : (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);
@@ -1465,7 +1522,7 @@ int vgh_flame_set_trace(void* dev_buffer) {
 #endif
 
 int vgh_flame_set_matrix_path(int mode) {
-    VGH_REQUIRE(mode >= 0 && mode <= 9, "flame_set_matrix_path: mode %d outside 0..9", mode);
+    VGH_REQUIRE(mode >= 0 && mode <= 7, "flame_set_matrix_path: mode %d outside 0..7", mode);
     g_flame_mode.store(mode, std::memory_order_relaxed);
     return VGH_OK;
 }

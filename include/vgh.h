@@ -37,9 +37,10 @@ const char* vgh_version(void);
 const char* vgh_last_error(void);
 
 /* ABI revision of this header: bumped whenever a struct below grows or a function changes meaning (r03 -> 3: vgh_conv_call / vgh_op_desc gained
- * grp_cout, grp_in_stride, fmt, out_scale and vgh_flame_set_matrix_path became a 0..4 mode; r04 -> 4: this call).  A client built against another
+ * grp_cout, grp_in_stride, fmt, out_scale and vgh_flame_set_matrix_path became a 0..4 mode; r04 -> 4: this call; -> 5: modes 0..7 of
+ * vgh_flame_set_matrix_path).  A client built against another
  * revision passes structs of another size: compare before the first call that takes one (head_detector_amd/_lib.py and tests/c_abi_smoke.c do). */
-#define VGH_ABI_VERSION 4
+#define VGH_ABI_VERSION 5
 int vgh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -257,9 +258,13 @@ int vgh_flame_decode_indirect(vgh_flame* f, const float* params_dev, const int32
  * axis-angle per joint -> verts_dev [n,V,3] (NO z offset, NO global rotation), joints_dev [n,NJ,3] or NULL. */
 int vgh_flame_lbs(vgh_flame* f, const float* betas_dev, const float* pose_dev, int n, float* verts_dev, float* joints_dev, void* stream);
 /* The vertex stage has interchangeable kernels that produce bit-identical vertices (each output is the same fp32 fmaf chain in ascending
- * k): VALU FMAs, FP32 matrix cores fed from registers (v_mfma_f32_32x32x2_f32), and LDS-staged matrix-core tiles.  mode (process-wide,
- * atomic; for parity tests and A/B measurements): 0 VALU only, 1 automatic by batch size (default), 2 register-fed matrix cores,
- * 3 / 4 / 5 the LDS-staged tiles (128- / 64- / 32-head blocks) where their tables fit, else automatic. */
+ * k): VALU FMAs, FP32 matrix cores fed from registers (v_mfma_f32_32x32x2_f32), LDS-staged matrix-core tiles, and (r04) component-split
+ * matrix-core tiles (one coordinate plane per wave, coefficient tile in LDS; prologue waves inside the block up to 8 heads).  mode
+ * (process-wide, atomic; for parity tests and A/B measurements): 0 VALU only, 1 automatic by batch size (default), 2 register-fed matrix
+ * cores, 3 / 4 / 5 the LDS-staged tiles (128- / 64- / 32-head blocks) where their tables fit, else automatic, 6 / 7 the component-split
+ * tiles always (6: with the prologue kernel at every batch size; 7: fused up to 8 heads) where the model fits them (even ranges, NB a
+ * multiple of 8), else automatic.  The meaning of 1 changed in r04 (it now picks the component-split tiles up to 112 heads); the set of
+ * values grew from 0..5 to 0..7: VGH_ABI_VERSION 5. */
 int vgh_flame_set_matrix_path(int mode);
 
 /* ------------------------------------------------------------------------------------------------

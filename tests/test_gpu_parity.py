@@ -1510,12 +1510,12 @@ def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame
     unpad = torch.tensor([[3.0, 7.0, 1.3]], device=_dev()).expand(n, 3).contiguous()
     outs = {}
     try:
-        for mode in (1, 0, 2, 3, 4, 5, 6, 7, 8, 9):
+        for mode in (1, 0, 2, 3, 4, 5, 6, 7):
             assert gpu_lib.vgh_flame_set_matrix_path(mode) == 0
             outs[mode] = [t.clone() for t in fl.decode(p, unpad=unpad, shape_live=live[0], expr_live=live[1])]
     finally:
         gpu_lib.vgh_flame_set_matrix_path(1)
-    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+    for mode in (1, 2, 3, 4, 5, 6, 7):
         for a, b in zip(outs[mode], outs[0]):
             assert torch.equal(a, b), mode
     _, _, q = fo.reproject(fo.FlameConstants(flame_model, torch.float64), p.cpu().double())
