@@ -67,6 +67,7 @@ static std::atomic<int> g_flame_mode{1};
 static unsigned long long* g_prep_trace = nullptr;  // vgh_flame_set_trace
 #endif
 constexpr int kLdsMinHeads = 1024;  // from here on: LDS-staged tiles with 128-head blocks
+constexpr int kC3MaxHeads = 2048;   // ... component-split tiles up to here (r04; automatic mode, direct batches)
 constexpr int kLdsMidHeads = 256;   // ... 64-head blocks (r02: the register-fed kernel ran n = 256 .. 1024 at 0.22 - 0.35 of the fp32 roof)
 
 namespace {
@@ -151,7 +152,11 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
 #pragma unroll
         for (int o = 0; o < MAXJ * 3; ++o) s[o] = fmaf(w[o >> 2][o & 3], v, s[o]);
     }
-    const float j0 = lane < NJ * 3 ? a.J0[lane] : 0.0f;
+    // the joint sums end up three per lane group of 8 (below): outputs jbase .. jbase + 2 in the lanes with lane % 8 == 0
+    const int jbase = ((lane & 32) ? 12 : 0) + ((lane & 16) ? 6 : 0) + ((lane & 8) ? 3 : 0);
+    float j0[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) j0[q] = ((lane & 7) == 0 && jbase + q < NJ * 3) ? a.J0[jbase + q] : 0.0f;
     if (p && lane < 13) S.tail[lane] = p[400 + lane];
     if (lane < NJ) S.par[lane] = a.parents[lane];
     if (lane < 3) S.unpad[lane] = a.unpad ? a.unpad[urow * 3 + lane] : (lane == 2 ? 1.0f : 0.0f);
@@ -168,15 +173,36 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     __builtin_amdgcn_wave_barrier();
     PMARK(a, h, lane, 1);
     {
-        float mine = 0.0f;
+        // 24 sums over the 64 lanes.  The addition tree of every output is the xor butterfly's (level by level the same two partial sums, own + partner's), but
+        // on the first three levels the partners split the outputs between them -- a lane keeps half and sends the other half -- so that 12 + 6 + 3 + 3 x 3 = 30
+        // cross-lane moves do what 24 x 6 = 144 did (r04: 1.85 -> 0.5 us of every prologue; same bits)
+        static_assert(MAXJ * 3 == 24, "the halving below is written for 24 outputs");
+        const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+        float t12[12], t6[6], t3[3];
 #pragma unroll
-        for (int o = 0; o < MAXJ * 3; ++o) {
-            float v = s[o];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            mine = lane == o ? v : mine;
+        for (int q = 0; q < 12; ++q) {
+            const float keep = b5 ? s[q + 12] : s[q], send = b5 ? s[q] : s[q + 12];
+            t12[q] = keep + __shfl_xor(send, 32);
         }
-        if (lane < NJ * 3) S.J[lane] = j0 + mine;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float keep = b4 ? t12[q + 6] : t12[q], send = b4 ? t12[q] : t12[q + 6];
+            t6[q] = keep + __shfl_xor(send, 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float keep = b3 ? t6[q + 3] : t6[q], send = b3 ? t6[q] : t6[q + 3];
+            t3[q] = keep + __shfl_xor(send, 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) t3[q] += __shfl_xor(t3[q], off);
+        if ((lane & 7) == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (jbase + q < NJ * 3) S.J[jbase + q] = j0[q] + t3[q];
+        }
     }
     PMARK(a, h, lane, 2);
     // smplx batch_rodrigues per joint
@@ -936,27 +962,36 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
 
 //   NPW > 0 ("fused", n <= NPW heads, 3 + NPW waves): NPW extra waves run prep_head for one head each WHILE the compute waves stream the shape / expression
 //            groups (raw betas read in place); the pose groups and the epilogue wait for them at one barrier.  One launch, the prologue's ~8 us under the stream.
-//   NPW = 0 (3 compute waves + NHL helpers that stage and take epilogue slots; 5 helpers for a single head tile, 1 from two tiles on so that two blocks share a
-//            CU): coefficients and head packs come from the prologue KERNEL launched before.
+//   NPW = 0 (3 VG compute waves + NHL helpers that stage and take epilogue slots; VG = 1: 5 helpers for a single head tile, 1 from two tiles on so that two blocks
+//            share a CU): coefficients and head packs come from the prologue KERNEL launched before.
+//   VG = 4 (a few hundred heads and more): a block is 128 vertices x 32 heads, its TWELVE compute waves (four vertex groups x three planes, three chains per SIMD:
+//            the matrix pipe of a CU stays busy from one block) share ONE coefficient tile -- 56 KB of LDS per 12 waves instead of per 3, operands still one
+//            16-byte basis load per lane and 4 pairs; vertex blocks of one head tile run on one XCD (40 blocks per tile row, 40 % 8 = 0) and share its L2.
 //   (r04, measured and removed: the prologue in the first blocks of the SAME launch, released to the vertex blocks by per-head flags -- agent-scope release /
 //    acquire = buffer_wbl2 / buffer_inv of a whole L2 and hundreds of polling waves: the flag of a lone head became visible 14 us into the launch, EXPERIMENTS 8d)
-template <int NPW, int NHL>
-__global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs a, PrepArgs pa) {
+template <int NPW, int NHL, int VG>
+__global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(VertArgs a, PrepArgs pa) {
 #pragma clang fp contract(off)
-    static_assert((NPW > 0) != (NHL > 0), "either prologue waves or helper waves");
-    constexpr int NW = 3 + NPW + NHL;
+    static_assert(!(NPW > 0 && NHL > 0) && (VG == 1 || NPW == 0), "prologue waves or helper waves; the fused variant has one vertex group");
+    constexpr int NCW = 3 * VG;             // compute waves: wave w = vertex group w / 3, coordinate plane w % 3
+    constexpr int NW = NCW + NPW + NHL;
     constexpr int NH = NPW > 0 ? NPW : 32;  // head packs held by the block
     constexpr int AS = NPW > 0 ? 33 : 32;   // row stride of the coefficient tile: 32 = what an LDS-DMA instruction writes (8 rows x 128 bytes; the two half-waves of an
                                             // operand read then cover the 64 banks); 33 for the fused variant's k-major register staging
-    constexpr int UQ = NPW == 8 ? 9 : 14;   // k-groups (4 pairs, one 16-byte load per lane) per burst, THREE bursts in flight = 168 of the longest chain's 220 pairs
+    constexpr int UQ = NW >= 11 ? 9 : 14;   // k-groups (4 pairs, one 16-byte load per lane) per burst, THREE bursts in flight = 168 of the longest chain's 220 pairs
                                             // (11 waves leave 168 registers per lane: 9 groups per burst):
                                             // a burst is asked for two consume times (2 x 56 MFMAs) ahead, more than a load takes under this traffic
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.n_dev) a.n = min(a.n, *a.n_dev);
-    const int vgroups = (a.V + 31) >> 5;
-    const int bid = (int)blockIdx.x;
-    const int by = bid / vgroups, bx = bid - by * vgroups;
+    // block -> (head tile by, vertex block bx) so that the tiles of ONE vertex block run on one XCD and share its L2 copy of the basis rows: workgroups go to the
+    // XCDs round-robin (XCD = blockIdx.x % 8); inside an XCD's sequence the vertex blocks bx = x, x + 8, ... of a tile row come first, then the next row
+    const int vgroups = (a.V + 31) >> 5, vblocks = (vgroups + VG - 1) / VG, vb8 = (vblocks + 7) >> 3;
+    const int bid = (int)blockIdx.x, bq = bid >> 3;
+    const int by = bq / vb8, bx = (bq - by * vb8) * 8 + (bid & 7);
+    if (bx >= vblocks) return;  // (the row is padded to a multiple of 8 blocks)
+    const int cvg = wv < NCW ? wv / 3 : 0, cpl = wv < NCW ? wv - cvg * 3 : 0;  // this wave's vertex group inside the block and its coordinate plane
+    const bool cw = wv < NCW && bx * VG + cvg < vgroups;                       // a compute wave with vertices (the last block of a tile row may have idle groups)
     // live k-groups (8 consecutive k = 4 MFMA pairs = one row block of the interleaved basis copy): the groups that hold a pair of the shape, expression or pose
     // range, in ascending k; gi -> g.  A pair is live when its k lies in one of the ranges (even bounds: a pair is in or out as a whole).
     const int g0e = (a.r0_end + 7) >> 3;  // r0 starts at 0
@@ -965,23 +1000,23 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
     const int c0 = g0e, c01 = c0 + (g1e - g1b), ng = c01 + (g2e - g2b);
     auto gof = [&](int gi) { return gi < c0 ? gi : gi < c01 ? g1b + (gi - c0) : g2b + (gi - c01); };
     auto live = [&](int k) { return k < a.r0_end || (k >= a.r1_begin && k < a.r1_end) || (k >= a.r2_begin && k < a.r2_end); };
-    float* const s_A = fsm;  // [ng * 8][AS] coefficients of heads h0 .. h0 + 31: row gi * 8 + (k & 7); after the blend s_x [3][16][64]
+    float* const s_A = fsm;  // [ng * 8][AS] coefficients of heads h0 .. h0 + 31: row gi * 8 + (k & 7); after the blend s_x [VG][3][16][64]
     float* const s_x = fsm;
-    float* const s_hp = fsm + ((max(ng * 8 * AS, 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
+    float* const s_hp = fsm + ((max(ng * 8 * AS, VG * 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
     const int h0 = by * 32;
     if (h0 >= a.n) return;
     const int j = lane & 31, half = lane >> 5;
-    const int v = bx * 32 + j;  // < Vp (a multiple of 32)
+    const int v = min(bx * VG + cvg, vgroups - 1) * 32 + j;  // < Vp (a multiple of 32); helper / prologue waves: the (one) vertex group, idle compute waves: a valid one
     const int64_t plane = a.Vp;
     C3MARK(0);
     // ---- blend operands: the k-interleaved basis copy [k / 8][c][k & 1][Vp][4]: 16 bytes of a lane = its vertex at k = 8g + half + {0, 2, 4, 6} -- the B operands of
     //      the four pairs of group g.  One vector-memory instruction per 4 pairs, so that 28 instructions in flight are half of the longest chain (what bounds this
     //      kernel is how much of its chain a wave has in flight: with dword loads and 48 pairs in flight the K loop ran 111 ns per pair, a 64-cycle MFMA apart) ----
-    const f32x4_t* const bl = (const f32x4_t*)a.basis8 + ((int64_t)(wv < 3 ? wv : 0) * 2 + half) * plane + v;  // + g * 6 * plane
+    const f32x4_t* const bl = (const f32x4_t*)a.basis8 + ((int64_t)cpl * 2 + half) * plane + v;  // + g * 6 * plane
     f32x4_t B0[UQ], B1[UQ], B2[UQ];
     f32x16_t acc;
     auto fetch = [&](f32x4_t (&B)[UQ], int g0) {
-        if (g0 >= ng) return;
+        if (g0 >= ng || !cw) return;
 #pragma unroll
         for (int u = 0; u < UQ; ++u) {
             const int gi = (g0 + u < ng) ? g0 + u : ng - 1;  // past the end: a valid, unused group
@@ -1011,7 +1046,7 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
 #pragma unroll
     for (int q = 0; q < MAXJ; ++q) wj[q] = q < a.NJ ? a.wts[(int64_t)q * plane + v] : 0.0f;
     {
-        const float tv = a.vt[(wv < 3 ? wv : 0) * plane + v];
+        const float tv = a.vt[cpl * plane + v];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = tv;
     }
@@ -1019,7 +1054,7 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
         // fused: the raw betas of the block's heads, read in place.  Every compute wave stages the whole (small) tile itself -- identical values from every
         // writer, so a wave needs nothing but its own writes to have landed and no hand-over exists that the prologue waves (busy until the pose barrier) would
         // have to attend.  A lane owns head lane % NPW and k = lane / NPW + (64 / NPW) i: all loads of a range are independent (batches of 8 in flight).
-        if (wv < 3 && !VGH_ABLATE(a, 4)) {
+        if (cw && !VGH_ABLATE(a, 4)) {
             constexpr int KPI = 64 / NPW;
             const int hh = lane & (NPW - 1), ks = lane / NPW;
             const float* src = nullptr;
@@ -1052,7 +1087,7 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
             stage(a.r0_begin, a.r0_end);
             stage(a.r1_begin, a.r1_end);
         }
-        if (wv < 3) {  // the basis stream starts behind the tile's loads (in-order return: whatever is issued first is waited for first)
+        if (cw) {  // the basis stream starts behind the tile's loads (in-order return: whatever is issued first is waited for first)
             fetch(B0, 0);
             fetch(B1, UQ);
         }
@@ -1063,7 +1098,7 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
             dma_packs(wv, NW);
         }
         asm volatile("" ::: "memory");  // the counted wait below counts on this order
-        if (wv < 3) {  // the basis stream starts behind the tile's LDS-DMA (in-order return) and stays in flight across the barrier
+        if (cw) {  // the basis stream starts behind the tile's LDS-DMA (in-order return) and stays in flight across the barrier
             fetch(B0, 0);
             fetch(B1, UQ);
             if (ng > UQ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * UQ) : "memory");  // (a second burst exists)
@@ -1075,7 +1110,7 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
         __syncthreads();
     }
     C3MARK(1);
-    if (wv < 3) {
+    if (wv < NCW) {
         // blend: pairs (k, k + 1) per MFMA in ascending k over the live groups: the chain of flame_mfma_kernel for one component
         const float* const sa = s_A + half * AS + j;  // + (gi * 8 + 2i) * AS
         auto read_a = [&](int gi, float (&A)[4]) {
@@ -1086,7 +1121,7 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
         // the A operands of a group are read while the previous group's four MFMAs run (one wave-uniform branch per group; a read right in front of its MFMA
         // behind a branch per pair cost ~150 cycles per 64-cycle MFMA)
         auto consume = [&](const f32x4_t (&B)[UQ], int g0) {
-            if (g0 >= ng) return;
+            if (g0 >= ng || !cw) return;
             float Ac[4], An[4];
             read_a(g0, Ac);
 #pragma unroll
@@ -1124,7 +1159,7 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
         if (!synced) __syncthreads();
         C3MARK(2);
     } else if constexpr (NPW > 0) {
-        const int hh = wv - 3;
+        const int hh = wv - NCW;
         PrepScratch* const scr = (PrepScratch*)(s_hp + NH * HP_SIZE);
         if (hh < a.n) {
             prep_head(pa, hh, lane, scr[hh], s_A + hh, AS, s_hp + hh * HP_SIZE, bx == 0, false, c01 * 8);  // NB = 8 g2b: the pose rows start a group
@@ -1135,24 +1170,27 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
         __syncthreads();  // the pose barrier of the compute waves
     }
     __syncthreads();  // every wave is done with the coefficient tile: its memory becomes the exchange buffer
-    if (wv < 3) {
+    if (wv < NCW) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_x[((wv * 16) + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; ++r) s_x[((wv * 16) + r) * 64 + lane] = acc[r];  // wv = vertex group * 3 + plane
     }
     __syncthreads();
     C3MARK(3);
     // ---- epilogue: flame_vertex_kernel's statements per (head, vertex), slots dealt round-robin to the waves ----
-    const bool vok = v < a.V;
+    // VG = 1: slots dealt round-robin to all waves (every wave's lanes hold the one vertex group's weights); VG > 1: a compute wave takes every third slot of
+    // its own vertex group
+    const bool vok = v < a.V && (VG == 1 || cw);
     if (VGH_ABLATE(a, 2)) {
         if (a.proj && tid == 0) a.proj[((int64_t)h0 * a.V + v) * 3] = s_x[lane];
         return;
     }
-    for (int r = wv; r < 16; r += NW) {
+    const float* const s_xg = s_x + cvg * (3 * 16 * 64);
+    for (int r = (VG == 1 ? wv : cpl); r < (VG == 1 || cw ? 16 : 0); r += (VG == 1 ? NW : 3)) {
         const int hlo = (r & 3) + 8 * (r >> 2);  // head of the lower half-wave; the upper one has hlo + 4
         if (h0 + hlo >= a.n) continue;           // wave-uniform: neither half has a live head
         const int hh = hlo + 4 * half;
         const float* const hp = s_hp + min(hh, NH - 1) * HP_SIZE;
-        const float px = s_x[(0 * 16 + r) * 64 + lane], py = s_x[(1 * 16 + r) * 64 + lane], pz = s_x[(2 * 16 + r) * 64 + lane];
+        const float px = s_xg[(0 * 16 + r) * 64 + lane], py = s_xg[(1 * 16 + r) * 64 + lane], pz = s_xg[(2 * 16 + r) * 64 + lane];
         float T[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) T[q] = 0.0f;
@@ -1192,29 +1230,29 @@ __global__ __launch_bounds__((3 + NPW + NHL) * 64) void flame_c3_kernel(VertArgs
     C3MARK(4);
 }
 
-template <int NPW, int NHL>
+template <int NPW, int NHL, int VG = 1>
 int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
-    constexpr int NH = NPW > 0 ? NPW : 32, NW = 3 + NPW + NHL;
+    constexpr int NH = NPW > 0 ? NPW : 32, NW = 3 * VG + NPW + NHL;
     const int ngmax = (va.Kp + 7) / 8;  // live groups <= all groups
     const int g0e = (va.r0_end + 7) >> 3;
     const int g1b = va.r1_end > va.r1_begin ? std::max(va.r1_begin >> 3, g0e) : g0e, g1e = va.r1_end > va.r1_begin ? std::max((va.r1_end + 7) >> 3, g1b) : g0e;
     const int g2b = std::max(va.r2_begin >> 3, g1e), g2e = std::max((va.r2_end + 7) >> 3, g2b);
     const int nrows8 = std::min(ngmax, g0e + (g1e - g1b) + (g2e - g2b)) * 8;
-    const int tile = (std::max(nrows8 * (NPW > 0 ? 33 : 32), 3 * 16 * 64) + 3) & ~3;
+    const int tile = (std::max(nrows8 * (NPW > 0 ? 33 : 32), VG * 3 * 16 * 64) + 3) & ~3;
     const size_t lds = ((size_t)tile + (size_t)NH * HP_SIZE) * sizeof(float) + (NPW > 0 ? NPW * sizeof(PrepScratch) : 0);
     static std::atomic<int> attr_done[16];
     int dev = 0;
     VGH_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NPW, NHL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NPW, NHL, VG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done[dev].store(1, std::memory_order_release);
     }
     if (lds > 96 * 1024) {
         vgh_set_error("flame c3 tiles: %zu bytes of LDS for %d coefficient rows", lds, nrows8);
         return VGH_ERR_INVALID;
     }
-    const int vgroups = (va.V + 31) / 32, hgroups = NPW > 0 ? 1 : (va.n + 31) / 32;
-    hipLaunchKernelGGL((flame_c3_kernel<NPW, NHL>), dim3(vgroups * hgroups), dim3(NW * 64), lds, st, va, pa);
+    const int vblocks = ((va.V + 31) / 32 + VG - 1) / VG, hgroups = NPW > 0 ? 1 : (va.n + 31) / 32;
+    hipLaunchKernelGGL((flame_c3_kernel<NPW, NHL, VG>), dim3((vblocks + 7) / 8 * 8 * hgroups), dim3(NW * 64), lds, st, va, pa);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -1273,18 +1311,20 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         // c3 tiles (component-split waves, coefficient tile in LDS; K - NB pose features in one k-group run, NB a multiple of 8 so that the pose rows start a
         // group): mode 6 always with the prologue kernel, mode 7 the same with the fused variant (prologue waves inside the block) up to 8 heads.  Automatic
         // (measured, profiles/r04_flame_sweep.json; us per call, all 400 / L-live / M-live coefficients; old = the kernels above):
-        //   n = 1: 22.4 / 18.2 / 16.5 (old 33.4 / 19.2 / 16.2)    n = 8: 27.2 / 21.3 / 18.4 (52.7 / 36.6 / 30.9)    n = 32: 28.8 / 23.0 / 20.2 (58.0 / 42.0 / 36.4)
-        //   n = 96: 43.0 / 34.9 / 28.2 (59.0 / 43.3 / 37.3)       n = 128: 56.6 / 44.4 / 35.8 (59.8 / 43.8 / 37.9)  n = 192: 68.8 / 53.3 / 42.0 (60.5 / 44.9 / 38.9)
-        //   n = 256: 82.2 / 62.3 / 49.4 (100.4 / 71.9 / 58.9: the 64-head LDS-staged blocks start there)            n = 512: 145.8 / 107.4 / 83.3 (146.4 / 101.5 / 80.2)
-        // -> up to 112 heads and from 256 to 383; with a device-side count the launch is capacity-sized (dead tile rows exit at once): up to a capacity of 128.
+        //   n = 1: 22.4 / 18.2 / 16.5 (old 33.4 / 19.2 / 16.2)    n = 8: 27.0 / 21.3 / 18.4 (52.7 / 36.6 / 30.9)    n = 32: 27.7 / 23.0 / 20.2 (58.0 / 42.0 / 36.4)
+        //   n = 96: 39.1 / 30.4 / 25.4 (59.0 / 43.3 / 37.3)       n = 128: 49.9 / 35.9 / 28.3 (59.8 / 43.8 / 37.9)  n = 192: 51.3 / 37.2 / 30.0 (60.5 / 44.9 / 38.9)
+        //   n = 256: 82.7 / 56.9 / 44.1 (100.4 / 71.9 / 58.9)     n = 512: 122.4 / 83.4 / 63.8 (146.4 / 101.5 / 80.2)  n = 1024: 193.3 / 127.8 / 95.0 (249.7 / 163.3 / 123.4)
+        //   n = 2048: 364 / 237 / 173 (387 / 245 / 180)   n = 3072: 536 / 348 / 253 (469 / 298 / 218: the 128-head LDS-staged blocks take over)   n = 8192: 1 400 / 900 / 653 (1 192 / 766 / 569)
+        // -> direct batches up to kC3MaxHeads; with a device-side count the launch is capacity-sized (dead tile rows exit at once): up to a capacity of 128.
         const bool c3_ok = even && f->K - f->NB <= 64 && (f->NB & 7) == 0 && f->basis8;
-        const bool c3_auto = mode == 1 && (pa.n_dev ? m <= 128 : (m <= 112 || (m >= 256 && m < 384))) && !(m <= 2 && npairs < 100);  // (1 - 2 heads of the M set: the VALU kernel)
+        const bool c3_auto = mode == 1 && (pa.n_dev ? m <= 128 : m <= kC3MaxHeads) && !(m <= 2 && npairs < 100);  // (1 - 2 heads of the M set: the VALU kernel)
         const bool c3 = c3_ok && (mode == 6 || mode == 7 || c3_auto);
         const bool c3_fused = c3 && mode != 6 && !pa.n_dev && m <= 8 && (verts || proj);
         const bool fused = c3_fused || (!c3 && !mfma && !pa.n_dev && m <= 256);  // the vertex kernel computes its own heads' prologue
         if (!fused || (!verts && !proj)) {
             constexpr int HB = 16;
-            if (m >= 512) {  // coalesced coefficient rows (measured: 16 waves per block cost 17 us vs 9.5 us at n = 96, but 92 vs 112 us at n = 8192); the
+            if (m >= (c3 ? 4096 : 512)) {  // (the c3 tiles fetch the rows by LDS-DMA either way: the one-wave-per-block prologue is ~5 us shorter below a few thousand heads)
+                            // coalesced coefficient rows (measured: 16 waves per block cost 17 us vs 9.5 us at n = 96, but 92 vs 112 us at n = 8192); the
                             // padded heads of the last block stay inside the scratch (npad is a multiple of 128)
                 const size_t lds = (size_t)HB * sizeof(PrepScratch) + (size_t)HB * HP_SIZE * 4 + (size_t)f->Kp * HB * 4;
                 static std::atomic<int> attr_done[16];
@@ -1340,7 +1380,9 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         if (c3_fused) {
             rc = m <= 1 ? launch_c3<1, 0>(va, pa, st) : m <= 2 ? launch_c3<2, 0>(va, pa, st) : m <= 4 ? launch_c3<4, 0>(va, pa, st) : launch_c3<8, 0>(va, pa, st);
         } else if (c3) {
-            rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : launch_c3<0, 1>(va, pa, st);
+            // one head tile: 3 + 5 waves; up to 96 heads: 3 + 1 (two blocks per CU; n = 112: 51.1 vs 50.1 us for the 128-vertex blocks); beyond: 128-vertex blocks of 12 compute waves (64-vertex blocks of 6 measured
+            // slower than both everywhere)
+            rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : m <= 96 ? launch_c3<0, 1>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);
         } else if (lds) {
             // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
             rc = lds32 ? launch_mfma_lds<1, 32>(va, st) : (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);

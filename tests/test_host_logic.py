@@ -467,3 +467,34 @@ def test_archives_with_unexpected_key_names_are_reported_in_full(tmp_path):
     assert any(s.startswith(some + ":") for s in diff["shape"])
     with pytest.raises(Exception):
         arch.build_program(variant, load_weights(p), 256)
+
+
+def test_flame_prologue_joint_reduction_tree_is_the_xor_butterfly():
+    """CPU spec of the cross-lane reduction in csrc/flame.hip::prep_head (J = J0 + JS beta: 24 sums over 64 lanes): on the first three levels the xor partners split
+    the outputs between them (keep half, send half), then three outputs per lane go through a plain butterfly -- 30 cross-lane moves instead of 144.  Every output's
+    addition tree must be the butterfly's (level by level own + partner's partial sum), i.e. the same fp32 bits, or a head's vertices would change with the kernel
+    revision.  Also specifies where the sums land: outputs jbase .. jbase + 2 in the lanes with lane % 8 == 0, jbase = 12 b5 + 6 b4 + 3 b3."""
+    import numpy as np
+
+    f32 = np.float32
+    lanes = np.arange(64)
+    for seed in range(4):
+        s = (np.random.default_rng(seed).standard_normal((24, 64)) * 10.0 ** (seed - 2)).astype(f32)
+        ref = np.zeros(24, f32)
+        for o in range(24):
+            v = s[o].copy()
+            for off in (32, 16, 8, 4, 2, 1):
+                v = (v + v[lanes ^ off]).astype(f32)
+            ref[o] = v[o]
+        t, n = s, 24
+        for bit in (32, 16, 8):  # keep half / send half
+            n //= 2
+            up = (lanes & bit) != 0
+            t = np.stack([(np.where(up, t[q + n], t[q]) + np.where(up, t[q], t[q + n])[lanes ^ bit]).astype(f32) for q in range(n)])
+        for off in (4, 2, 1):
+            t = np.stack([(t[q] + t[q][lanes ^ off]).astype(f32) for q in range(3)])
+        out = np.zeros(24, f32)
+        for lane in range(0, 64, 8):
+            jbase = (12 if lane & 32 else 0) + (6 if lane & 16 else 0) + (3 if lane & 8 else 0)
+            out[jbase : jbase + 3] = t[:, lane]
+        assert np.array_equal(out, ref)
