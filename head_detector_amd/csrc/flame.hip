@@ -1315,9 +1315,10 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         //   n = 96: 39.1 / 30.4 / 25.4 (59.0 / 43.3 / 37.3)       n = 128: 49.9 / 35.9 / 28.3 (59.8 / 43.8 / 37.9)  n = 192: 51.3 / 37.2 / 30.0 (60.5 / 44.9 / 38.9)
         //   n = 256: 82.7 / 56.9 / 44.1 (100.4 / 71.9 / 58.9)     n = 512: 122.4 / 83.4 / 63.8 (146.4 / 101.5 / 80.2)  n = 1024: 193.3 / 127.8 / 95.0 (249.7 / 163.3 / 123.4)
         //   n = 2048: 364 / 237 / 173 (387 / 245 / 180)   n = 3072: 536 / 348 / 253 (469 / 298 / 218: the 128-head LDS-staged blocks take over)   n = 8192: 1 400 / 900 / 653 (1 192 / 766 / 569)
-        // -> direct batches up to kC3MaxHeads; with a device-side count the launch is capacity-sized (dead tile rows exit at once): up to a capacity of 128.
+        // -> direct batches up to kC3MaxHeads; with a device-side count the launch is capacity-sized and the dead tile rows exit at once: any capacity the
+        //    register-fed kernel took (the live count of a detector batch is a few hundred at most: 4-wave blocks up to a capacity of 128, 128-vertex blocks beyond).
         const bool c3_ok = even && f->K - f->NB <= 64 && (f->NB & 7) == 0 && f->basis8;
-        const bool c3_auto = mode == 1 && (pa.n_dev ? m <= 128 : m <= kC3MaxHeads) && !(m <= 2 && npairs < 100);  // (1 - 2 heads of the M set: the VALU kernel)
+        const bool c3_auto = mode == 1 && (pa.n_dev ? m <= 16384 : m <= kC3MaxHeads) && !(m <= 2 && npairs < 100);  // (1 - 2 heads of the M set: the VALU kernel)
         const bool c3 = c3_ok && (mode == 6 || mode == 7 || c3_auto);
         const bool c3_fused = c3 && mode != 6 && !pa.n_dev && m <= 8 && (verts || proj);
         const bool fused = c3_fused || (!c3 && !mfma && !pa.n_dev && m <= 256);  // the vertex kernel computes its own heads' prologue
@@ -1382,7 +1383,8 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         } else if (c3) {
             // one head tile: 3 + 5 waves; up to 96 heads: 3 + 1 (two blocks per CU; n = 112: 51.1 vs 50.1 us for the 128-vertex blocks); beyond: 128-vertex blocks of 12 compute waves (64-vertex blocks of 6 measured
             // slower than both everywhere)
-            rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : m <= 96 ? launch_c3<0, 1>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);
+            if (pa.n_dev) rc = m <= 128 ? launch_c3<0, 1>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);  // (capacity, not the live count)
+            else rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : m <= 96 ? launch_c3<0, 1>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);
         } else if (lds) {
             // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
             rc = lds32 ? launch_mfma_lds<1, 32>(va, st) : (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);
