@@ -1020,8 +1020,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
 #pragma unroll
         for (int u = 0; u < UQ; ++u) {
             const int gi = (g0 + u < ng) ? g0 + u : ng - 1;  // past the end: a valid, unused group
-            if (VGH_ABLATE(a, 1)) B[u] = f32x4_t{(float)lane, (float)u, 1.0f, 2.0f};
-            else B[u] = bl[(int64_t)(VGH_ABLATE(a, 8) ? (gi & 1) : gof(gi)) * 6 * plane];  // ablation 8: every load an L2 hit
+            B[u] = bl[(int64_t)gof(gi) * 6 * plane];
         }
     };
     // LDS-DMA of the tile, 1 KiB per instruction = 8 rows of the transposed scratch coef[k][head] (128 bytes per row and tile) = one live k-group
@@ -1053,43 +1052,53 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     if constexpr (NPW > 0) {
         // fused: the raw betas of the block's heads, read in place.  Every compute wave stages the whole (small) tile itself -- identical values from every
         // writer, so a wave needs nothing but its own writes to have landed and no hand-over exists that the prologue waves (busy until the pose barrier) would
-        // have to attend.  A lane owns head lane % NPW and k = lane / NPW + (64 / NPW) i: all loads of a range are independent (batches of 8 in flight).
-        if (cw && !VGH_ABLATE(a, 4)) {
-            constexpr int KPI = 64 / NPW;
-            const int hh = lane & (NPW - 1), ks = lane / NPW;
-            const float* src = nullptr;
-            if (hh < a.n) {
-                const int64_t prow = pa.head_row ? pa.head_row[hh] : hh;
-                src = pa.params ? pa.params + prow * VGH_NUM_FLAME_PARAMS : pa.betas + (int64_t)hh * pa.NB;
+        // have to attend.  A lane owns head lane % NPW and the live coefficients e = lane / NPW + (64 / NPW) i of the two ranges taken as one sequence; a batch
+        // of 32 loads per lane (everything up to 4 heads, two batches at 8) is issued, THEN the first two basis bursts, and only then the values are written:
+        // one memory round trip from the kernel top to the first MFMA (the loads of a range, a wait, its writes, the next range, then the basis cost 5.2 us)
+        constexpr int KPI = 64 / NPW, NB_ = 32;
+        const int hh = lane & (NPW - 1), ks = lane / NPW;
+        const int n0 = a.r0_end - a.r0_begin, nlive = n0 + (a.r1_end - a.r1_begin);
+        // every lane loads, from a valid address (a head slot past the batch reads the last head's row -- MFMA rows are independent and those rows are never
+        // stored; an index past the sequence re-reads its last element): a load under a per-lane condition makes hipcc wait vmcnt(0) per load
+        const float* src;
+        {
+            const int hs = min(hh, a.n - 1);
+            const int64_t prow = pa.head_row ? pa.head_row[hs] : hs;
+            src = pa.params ? pa.params + prow * VGH_NUM_FLAME_PARAMS : pa.betas + (int64_t)hs * pa.NB;
+        }
+        auto kof_e = [&](int e) { return e < n0 ? a.r0_begin + e : a.r1_begin + (e - n0); };
+        auto stage_load = [&](float (&t)[NB_], int e0) {
+#pragma unroll
+            for (int i = 0; i < NB_; ++i) {
+                const int e = e0 + i * KPI + ks;
+                t[i] = src[kof_e(min(e, nlive - 1))];
             }
-            auto stage = [&](int kb, int ke) {
-                constexpr int NB_ = 32;  // loads in flight per lane
-                for (int k0 = kb; k0 < ke; k0 += KPI * NB_) {
-                    float t[NB_];
+        };
+        auto stage_write = [&](const float (&t)[NB_], int e0) {
 #pragma unroll
-                    for (int i = 0; i < NB_; ++i) {
-                        const int k = k0 + i * KPI + ks;
-                        t[i] = (src && k < ke) ? src[k] : 0.0f;
-                    }
-#pragma unroll
-                    for (int i = 0; i < NB_; ++i) {
-                        const int k = k0 + i * KPI + ks;
-                        const int g = k >> 3;
-                        if (k < ke) s_A[((g < g0e ? g : c0 + (g - g1b)) * 8 + (k & 7)) * AS + hh] = t[i];
-                    }
+            for (int i = 0; i < NB_; ++i) {
+                const int e = e0 + i * KPI + ks;
+                if (e < nlive) {
+                    const int k = kof_e(e), g = k >> 3;
+                    s_A[((g < g0e ? g : c0 + (g - g1b)) * 8 + (k & 7)) * AS + hh] = t[i];
                 }
-            };
+            }
+        };
+        if (cw && !VGH_ABLATE(a, 4)) {
             zero_dead_rows(c0 - 1);
             if (c01 > c0) {
                 zero_dead_rows(c0);
                 zero_dead_rows(c01 - 1);
             }
-            stage(a.r0_begin, a.r0_end);
-            stage(a.r1_begin, a.r1_end);
-        }
-        if (cw) {  // the basis stream starts behind the tile's loads (in-order return: whatever is issued first is waited for first)
-            fetch(B0, 0);
+            float t[NB_];
+            stage_load(t, 0);
+            fetch(B0, 0);  // the basis stream starts behind the tile's loads (in-order return: whatever is issued first is waited for first)
             fetch(B1, UQ);
+            stage_write(t, 0);
+            for (int e0 = KPI * NB_; e0 < nlive; e0 += KPI * NB_) {
+                stage_load(t, e0);
+                stage_write(t, e0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
@@ -1130,8 +1139,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
                 if (g0 + u < ng) {  // wave-uniform
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (VGH_ABLATE(a, 16)) acc[0] = fmaf(Ac[i], B[u][i], acc[0]);  // ablation 16: no matrix chain, the loads still feed a result
-                        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[i], B[u][i], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[i], B[u][i], acc, 0, 0, 0);
                     }
                 }
 #pragma unroll
