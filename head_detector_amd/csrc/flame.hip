@@ -42,6 +42,7 @@ constexpr int HP_SIZE = 128;                 // floats per head
 struct vgh_flame {
     int device, V, Vp, NB, NJ, NP, K, Kp;  // NP = 9*(NJ-1); K = NB + NP; Kp = K rounded up to 8
     int max_heads;
+    int ncu;  // compute units of the device (rounds of blocks: the c3 block size choice)
     float* basis;    // [K][3][Vp]
     float* basis8;   // [Kp / 8][3][2][Vp][4]: basis8[((g * 3 + c) * 2 + (k & 1)) * Vp + v][(k >> 1) & 3] = basis[k = 8g + ..][c][v]; rows K .. Kp - 1 zero
     float* vt;       // [3][Vp]
@@ -964,7 +965,7 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
 //            groups (raw betas read in place); the pose groups and the epilogue wait for them at one barrier.  One launch, the prologue's ~8 us under the stream.
 //   NPW = 0 (3 VG compute waves + NHL helpers that stage and take epilogue slots; VG = 1: 5 helpers for a single head tile, 1 from two tiles on so that two blocks
 //            share a CU): coefficients and head packs come from the prologue KERNEL launched before.
-//   VG = 4 (a few hundred heads and more): a block is 128 vertices x 32 heads, its TWELVE compute waves (four vertex groups x three planes, three chains per SIMD:
+//   VG = 4 / 5 (a few hundred heads and more): a block is 128 (160) vertices x 32 heads, its TWELVE (fifteen) compute waves (vertex groups x three planes, three - four chains per SIMD:
 //            the matrix pipe of a CU stays busy from one block) share ONE coefficient tile -- 56 KB of LDS per 12 waves instead of per 3, operands still one
 //            16-byte basis load per lane and 4 pairs; vertex blocks of one head tile run on one XCD (40 blocks per tile row, 40 % 8 = 0) and share its L2.
 //   (r04, measured and removed: the prologue in the first blocks of the SAME launch, released to the vertex blocks by per-head flags -- agent-scope release /
@@ -978,7 +979,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     constexpr int NH = NPW > 0 ? NPW : 32;  // head packs held by the block
     constexpr int AS = NPW > 0 ? 33 : 32;   // row stride of the coefficient tile: 32 = what an LDS-DMA instruction writes (8 rows x 128 bytes; the two half-waves of an
                                             // operand read then cover the 64 banks); 33 for the fused variant's k-major register staging
-    constexpr int UQ = NW >= 11 ? 9 : 14;   // k-groups (4 pairs, one 16-byte load per lane) per burst, THREE bursts in flight = 168 of the longest chain's 220 pairs
+    constexpr int UQ = NW >= 14 ? 5 : NW >= 11 ? 9 : 14;   // k-groups (4 pairs, one 16-byte load per lane) per burst, THREE bursts in flight = 168 of the longest chain's 220 pairs
                                             // (11 waves leave 168 registers per lane: 9 groups per burst):
                                             // a burst is asked for two consume times (2 x 56 MFMAs) ahead, more than a load takes under this traffic
     extern __shared__ __attribute__((aligned(16))) float fsm[];
@@ -1392,7 +1393,14 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
             // one head tile: 3 + 5 waves; up to 96 heads: 3 + 1 (two blocks per CU; n = 112: 51.1 vs 50.1 us for the 128-vertex blocks); beyond: 128-vertex blocks of 12 compute waves (64-vertex blocks of 6 measured
             // slower than both everywhere)
             if (pa.n_dev) rc = m <= 128 ? launch_c3<0, 1>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);  // (capacity, not the live count)
-            else rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : m <= 96 ? launch_c3<0, 1>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);
+            else if (m <= 96) rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : launch_c3<0, 1>(va, pa, st);
+            else {
+                // 128- or 160-vertex blocks (12 / 15 compute waves, one block per CU): whichever needs fewer ROUNDS of blocks over the CUs, a round of the larger
+                // block costing 1.3 of the smaller's (measured: n = 256 59.7 vs 82.9 us, 384 100.8 vs 86.0, 512 103.2 vs 118.3, 768 146.1 vs 154.0, 1 024 a tie)
+                const int vgroups = (f->V + 31) / 32, hg = (m + 31) / 32, ncu = f->ncu > 0 ? f->ncu : 256;
+                const int r4 = (hg * ((vgroups + 3) / 4) + ncu - 1) / ncu, r5 = (hg * ((vgroups + 4) / 5) + ncu - 1) / ncu;
+                rc = 13 * r5 < 10 * r4 ? launch_c3<0, 0, 5>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);
+            }
         } else if (lds) {
             // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
             rc = lds32 ? launch_mfma_lds<1, 32>(va, st) : (mode == 4 || (mode == 1 && m < kLdsMinHeads)) ? launch_mfma_lds<2, 64>(va, st) : launch_mfma_lds<4, 128>(va, st);
@@ -1444,6 +1452,7 @@ int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template,
     f->K = NB + f->NP;
     f->Kp = (f->K + 7) / 8 * 8;
     f->max_heads = max_heads > 0 ? max_heads : 1024;
+    VGH_HIP(hipDeviceGetAttribute(&f->ncu, hipDeviceAttributeMultiprocessorCount, device));
     const int Vp = f->Vp, K = f->K;
     std::vector<float> basis((size_t)K * 3 * Vp, 0.0f), vt((size_t)3 * Vp, 0.0f), wts((size_t)NJ * Vp, 0.0f), basis8((size_t)f->Kp * 3 * Vp, 0.0f);
     for (int v = 0; v < V; ++v)
