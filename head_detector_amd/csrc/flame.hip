@@ -121,6 +121,8 @@ struct PrepScratch {
 // (stand-alone prologue kernel for large batches, or the vertex kernel's own prologue for small ones).
 // `betas_out` false: the raw betas are not copied to coef (the caller reads them in place); `pose_row0` >= 0: the pose features go to rows pose_row0 .. of coef
 // instead of rows NB .. (a compact coefficient tile).
+// WIDE (the one-wave-per-block prologue kernel, which has the registers): the joint regression's loads of 7 x 64 coefficients are issued as ONE batch.
+template <bool WIDE = false>
 __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, PrepScratch& S, float* coef, int cstride, float* hp, bool emit, const bool betas_out = true,
                                           const int pose_row0 = -1) {
 // every rounding is spelled out (explicit fmaf where a fused multiply-add is meant): the function is inlined into several kernels and
@@ -141,6 +143,33 @@ __device__ __forceinline__ void prep_head(const PrepArgs& a, int h, int lane, Pr
     float s[MAXJ * 3];
 #pragma unroll
     for (int o = 0; o < MAXJ * 3; ++o) s[o] = 0.0f;
+    if constexpr (WIDE) {
+        // the same fmaf chains (a lane's l ascending; a coefficient outside the live ranges enters as 0: fma(w, 0, s) = s), but every load of a chunk of 7 x 64
+        // coefficients -- the value and its six 16-byte row pieces, from clamped (always valid) addresses -- is in flight before the first FMA: one memory round
+        // trip for FLAME's 400 betas where the loop below takes two and a wait per divergent `continue` (r04: 3.8 - 4.3 -> ~2 us of the prologue kernel)
+        constexpr int CH = 7;
+        const float* const bsrc = p ? p : a.betas + (int64_t)h * NB;
+        for (int c0 = 0; c0 < NB; c0 += 64 * CH) {
+            float v[CH];
+            f32x4_t w[CH][MAXJ * 3 / 4];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int lc = min(c0 + i * 64 + lane, NB - 1);
+                v[i] = bsrc[lc];
+                const f32x4_t* const row = (const f32x4_t*)(a.JS + (int64_t)lc * (MAXJ * 3));
+#pragma unroll
+                for (int q = 0; q < MAXJ * 3 / 4; ++q) w[i][q] = row[q];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int l = c0 + i * 64 + lane;
+                if (betas_out && l < NB) coef[(int64_t)l * cstride] = v[i];
+                const float vv = (l < NB && (l < a.live0_end || (l >= a.live1_begin && l < a.live1_end))) ? v[i] : 0.0f;
+#pragma unroll
+                for (int o = 0; o < MAXJ * 3; ++o) s[o] = fmaf(w[i][o >> 2][o & 3], vv, s[o]);
+            }
+        }
+    } else
 #pragma unroll 4
     for (int l = lane; l < NB; l += 64) {
         const float v = p ? p[l] : a.betas[(int64_t)h * NB + l];
@@ -337,7 +366,7 @@ __global__ __launch_bounds__(64) void flame_prep_kernel(PrepArgs a) {
     __shared__ float s_hp[HP_SIZE];  // the head pack is assembled here and leaves as one coalesced store
     const int h = blockIdx.x, lane = threadIdx.x;
     if (a.n_dev && h >= *a.n_dev) return;
-    prep_head(a, h, lane, S, a.coef + h, a.npad, s_hp, true);
+    prep_head<true>(a, h, lane, S, a.coef + h, a.npad, s_hp, true);
     float* const hpg = a.headpack + (int64_t)h * HP_SIZE;
     for (int e = lane; e < HP_SIZE; e += 64) hpg[e] = s_hp[e];
 }
@@ -1056,7 +1085,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         // have to attend.  A lane owns head lane % NPW and the live coefficients e = lane / NPW + (64 / NPW) i of the two ranges taken as one sequence; a batch
         // of 32 loads per lane (everything up to 4 heads, two batches at 8) is issued, THEN the first two basis bursts, and only then the values are written:
         // one memory round trip from the kernel top to the first MFMA (the loads of a range, a wait, its writes, the next range, then the basis cost 5.2 us)
-        constexpr int KPI = 64 / NPW, NB_ = 32;
+        constexpr int KPI = 64 / NPW, NB_ = NPW == 1 ? 7 : NPW == 2 ? 14 : NPW == 4 ? 28 : 32;  // loads per lane and batch: FLAME's 400 betas in one batch up to 4 heads
         const int hh = lane & (NPW - 1), ks = lane / NPW;
         const int n0 = a.r0_end - a.r0_begin, nlive = n0 + (a.r1_end - a.r1_begin);
         // every lane loads, from a valid address (a head slot past the batch reads the last head's row -- MFMA rows are independent and those rows are never
