@@ -985,7 +985,7 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
 //   NPW > 0 ("fused", n <= NPW heads): NPW extra waves run prep_head for one head each WHILE the compute waves stream the shape / expression range; the
 //            pose-feature pairs and the epilogue wait for them at one barrier.  One launch, no dependent kernel boundary, the prologue's ~7 us under the stream.
 #ifdef VGH_EXPERIMENTS
-#define C3MARK(i) do { if (pa.trace && bx == 1 && by == 0 && threadIdx.x == 0) pa.trace[8 + (i)] = wall_clock64(); } while (0)
+#define C3MARK(i) do { if (pa.trace && bx == 1 && by == 0 && threadIdx.x == 0) { pa.trace[8 + (i)] = wall_clock64(); if ((i) == 1 || (i) == 2) pa.trace[13 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)  /* [14], [15]: shader-clock ticks around the K loop */
 #else
 #define C3MARK(i) do { } while (0)
 #endif
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         const float vz = fmaf(T[8], px, fmaf(T[9], py, fmaf(T[10], pz, T[11]))) + a.z_offset;
         if (vok && h0 + hh < a.n) {
             const int64_t obase = ((int64_t)(h0 + hh) * a.V + v) * 3;
-            if (a.verts) *(f32x3_t*)(a.verts + obase) = f32x3_t{vx, vy, vz};  // 12 bytes per lane, contiguous across a half-wave
+            if (a.verts) { if (VG > 1) __builtin_nontemporal_store(f32x3_t{vx, vy, vz}, (f32x3_t*)(a.verts + obase)); else *(f32x3_t*)(a.verts + obase) = f32x3_t{vx, vy, vz}; }  // 12 bytes per lane, contiguous across a half-wave
             if (a.proj) {
                 const f32x4_t R0 = *(const f32x4_t*)(hp + HP_R), R1 = *(const f32x4_t*)(hp + HP_R + 4), R2 = *(const f32x4_t*)(hp + HP_R + 8), R3 = *(const f32x4_t*)(hp + HP_R + 12);
                 // R0 = R[0..3], R1 = R[4..7], R2 = {R[8], s, t0, t1}, R3 = {t2, u0, u1, u2}
@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
                     qy = (qy - R3[2]) / R3[3];
                     qz = qz / R3[3];
                 }
-                *(f32x3_t*)(a.proj + obase) = f32x3_t{qx, qy, qz};
+                if (VG > 1) __builtin_nontemporal_store(f32x3_t{qx, qy, qz}, (f32x3_t*)(a.proj + obase)); else *(f32x3_t*)(a.proj + obase) = f32x3_t{qx, qy, qz};
             }
         }
     }

@@ -37,4 +37,4 @@ for mode in (int(x) for x in os.environ.get("FLAME_MODES", "6,7").split(",")):
             torch.cuda.synchronize()
             t = tr.cpu().tolist()
             print(f"mode {mode} n={n} live {sl}+{el}: prologue " + " ".join(f"{pn[i]} {(t[i + 1] - t[i]) / 100:.2f}" for i in range(6)) + f" (total {(t[6] - t[0]) / 100:.2f} us)"
-                  + " | c3 " + " ".join(f"{cn[i]} {(t[9 + i] - t[8 + i]) / 100:.2f}" for i in range(4)) + f" (total {(t[12] - t[8]) / 100:.2f} us; top - prologue start {(t[8] - t[0]) / 100:.2f} us)")
+                  + " | c3 " + " ".join(f"{cn[i]} {(t[9 + i] - t[8 + i]) / 100:.2f}" for i in range(4)) + f" (total {(t[12] - t[8]) / 100:.2f} us; top - prologue start {(t[8] - t[0]) / 100:.2f} us; K loop {t[15] - t[14]} shader cycles = {(t[15] - t[14]) / max(1, (t[10] - t[9]) * 10):.2f} GHz)")
