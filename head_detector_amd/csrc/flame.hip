@@ -999,16 +999,17 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
 //            16-byte basis load per lane and 4 pairs; vertex blocks of one head tile run on one XCD (40 blocks per tile row, 40 % 8 = 0) and share its L2.
 //   (r04, measured and removed: the prologue in the first blocks of the SAME launch, released to the vertex blocks by per-head flags -- agent-scope release /
 //    acquire = buffer_wbl2 / buffer_inv of a whole L2 and hundreds of polling waves: the flag of a lone head became visible 14 us into the launch, EXPERIMENTS 8d)
-template <int NPW, int NHL, int VG>
+template <int NPW, int NHL, int VG, int MT = 1>
 __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(VertArgs a, PrepArgs pa) {
 #pragma clang fp contract(off)
-    static_assert(!(NPW > 0 && NHL > 0) && (VG == 1 || NPW == 0), "prologue waves or helper waves; the fused variant has one vertex group");
+    static_assert(!(NPW > 0 && NHL > 0) && (VG == 1 || NPW == 0) && (MT == 1 || (NPW == 0 && NHL == 0 && VG > 1)), "prologue waves or helper waves; the fused variant has one vertex group; two head tiles per wave only in the large blocks");
     constexpr int NCW = 3 * VG;             // compute waves: wave w = vertex group w / 3, coordinate plane w % 3
     constexpr int NW = NCW + NPW + NHL;
-    constexpr int NH = NPW > 0 ? NPW : 32;  // head packs held by the block
+    constexpr int NH = NPW > 0 ? NPW : 32 * MT;  // head packs held by the block (MT = 2: each compute wave runs TWO head tiles' chains on one basis operand -- half the
+                                                 // operand bytes per MFMA: a CU's L1 fill rate, ~16 B/clk, is what a block of twelve one-tile waves runs into)
     constexpr int AS = NPW > 0 ? 33 : 32;   // row stride of the coefficient tile: 32 = what an LDS-DMA instruction writes (8 rows x 128 bytes; the two half-waves of an
                                             // operand read then cover the 64 banks); 33 for the fused variant's k-major register staging
-    constexpr int UQ = NW >= 14 ? 5 : NW >= 11 ? 9 : 14;   // k-groups (4 pairs, one 16-byte load per lane) per burst, THREE bursts in flight = 168 of the longest chain's 220 pairs
+    constexpr int UQ = NW >= 14 ? 5 : NW >= 11 ? (MT == 2 ? 7 : 9) : 14;   // k-groups (4 pairs, one 16-byte load per lane) per burst, THREE bursts in flight = 168 of the longest chain's 220 pairs
                                             // (11 waves leave 168 registers per lane: 9 groups per burst):
                                             // a burst is asked for two consume times (2 x 56 MFMAs) ahead, more than a load takes under this traffic
     extern __shared__ __attribute__((aligned(16))) float fsm[];
@@ -1030,10 +1031,10 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     const int c0 = g0e, c01 = c0 + (g1e - g1b), ng = c01 + (g2e - g2b);
     auto gof = [&](int gi) { return gi < c0 ? gi : gi < c01 ? g1b + (gi - c0) : g2b + (gi - c01); };
     auto live = [&](int k) { return k < a.r0_end || (k >= a.r1_begin && k < a.r1_end) || (k >= a.r2_begin && k < a.r2_end); };
-    float* const s_A = fsm;  // [ng * 8][AS] coefficients of heads h0 .. h0 + 31: row gi * 8 + (k & 7); after the blend s_x [VG][3][16][64]
+    float* const s_A = fsm;  // [ng][MT][8][AS] coefficients of heads h0 + 32 t .. + 31: row (gi * MT + t) * 8 + (k & 7); after the blend s_x [VG][MT][3][16][64]
     float* const s_x = fsm;
-    float* const s_hp = fsm + ((max(ng * 8 * AS, VG * 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
-    const int h0 = by * 32;
+    float* const s_hp = fsm + ((max(ng * MT * 8 * AS, VG * MT * 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
+    const int h0 = by * (32 * MT);
     if (h0 >= a.n) return;
     const int j = lane & 31, half = lane >> 5;
     const int v = min(bx * VG + cvg, vgroups - 1) * 32 + j;  // < Vp (a multiple of 32); helper / prologue waves: the (one) vertex group, idle compute waves: a valid one
@@ -1044,7 +1045,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     //      kernel is how much of its chain a wave has in flight: with dword loads and 48 pairs in flight the K loop ran 111 ns per pair, a 64-cycle MFMA apart) ----
     const f32x4_t* const bl = (const f32x4_t*)a.basis8 + ((int64_t)cpl * 2 + half) * plane + v;  // + g * 6 * plane
     f32x4_t B0[UQ], B1[UQ], B2[UQ];
-    f32x16_t acc;
+    f32x16_t acc[MT];
     auto fetch = [&](f32x4_t (&B)[UQ], int g0) {
         if (g0 >= ng || !cw) return;
 #pragma unroll
@@ -1055,12 +1056,14 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     };
     // LDS-DMA of the tile, 1 KiB per instruction = 8 rows of the transposed scratch coef[k][head] (128 bytes per row and tile) = one live k-group
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (unsigned)((int64_t)a.Kp * a.npad * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(a.headpack + (int64_t)h0 * HP_SIZE), 0, (unsigned)(32 * HP_SIZE * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(a.headpack + (int64_t)h0 * HP_SIZE), 0, (unsigned)(NH * HP_SIZE * 4), 0x00020000);
     auto dma_group = [&](int gi) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(s_A + gi * 256), 16, (unsigned)((gof(gi) * 8 + (lane >> 3)) * a.npad + h0 + (lane & 7) * 4) * 4u, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (AS3 void*)(s_A + (gi * MT + t) * 256), 16, (unsigned)((gof(gi) * 8 + (lane >> 3)) * a.npad + h0 + t * 32 + (lane & 7) * 4) * 4u, 0, 0, 0);
     };
     auto dma_packs = [&](int first, int step) {  // head packs as they lie
-        for (int g = first; g < 32 * HP_SIZE / 256; g += step) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (AS3 void*)(s_hp + g * 256), 16, (unsigned)(g * 256 + lane * 4) * 4u, 0, 0, 0);
+        for (int g = first; g < NH * HP_SIZE / 256; g += step) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_h, (AS3 void*)(s_hp + g * 256), 16, (unsigned)(g * 256 + lane * 4) * 4u, 0, 0, 0);
     };
     // rows of a live group whose k is outside the live ranges (group 37 when the shape range ends before 300, the tail of a range that is not a multiple of 8,
     // the pad behind the pose features) are cleared: their pairs then add fma(0, b, acc) = acc, and the K loop runs without a branch per pair
@@ -1069,7 +1072,10 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         const int k0 = gof(gi) * 8;
         if (live(k0) && live(k0 + 7)) return;
         for (int r = lane >> 5; r < 8; r += 2)
-            if (!live(k0 + r)) s_A[(gi * 8 + r) * AS + (lane & 31)] = 0.0f;
+            if (!live(k0 + r)) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) s_A[((gi * MT + t) * 8 + r) * AS + (lane & 31)] = 0.0f;
+            }
     };
     float wj[MAXJ];  // skinning weights of this lane's vertex (every wave takes epilogue slots)
 #pragma unroll
@@ -1077,7 +1083,9 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     {
         const float tv = a.vt[cpl * plane + v];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = tv;
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = tv;
     }
     if constexpr (NPW > 0) {
         // fused: the raw betas of the block's heads, read in place.  Every compute wave stages the whole (small) tile itself -- identical values from every
@@ -1151,17 +1159,20 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     C3MARK(1);
     if (wv < NCW) {
         // blend: pairs (k, k + 1) per MFMA in ascending k over the live groups: the chain of flame_mfma_kernel for one component
-        const float* const sa = s_A + half * AS + j;  // + (gi * 8 + 2i) * AS
-        auto read_a = [&](int gi, float (&A)[4]) {
-            const float* const p = sa + gi * 8 * AS;
+        const float* const sa = s_A + half * AS + j;  // + ((gi * MT + t) * 8 + 2i) * AS
+        auto read_a = [&](int gi, float (&A)[MT][4]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) A[i] = (NPW == 0 || j < NH) ? p[2 * i * AS] : 0.0f;
+            for (int t = 0; t < MT; ++t) {
+                const float* const p = sa + (gi * MT + t) * 8 * AS;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) A[t][i] = (NPW == 0 || j < NH) ? p[2 * i * AS] : 0.0f;
+            }
         };
         // the A operands of a group are read while the previous group's four MFMAs run (one wave-uniform branch per group; a read right in front of its MFMA
         // behind a branch per pair cost ~150 cycles per 64-cycle MFMA)
         auto consume = [&](const f32x4_t (&B)[UQ], int g0) {
             if (g0 >= ng || !cw) return;
-            float Ac[4], An[4];
+            float Ac[MT][4], An[MT][4];
             read_a(g0, Ac);
 #pragma unroll
             for (int u = 0; u < UQ; ++u) {
@@ -1169,11 +1180,14 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
                 if (g0 + u < ng) {  // wave-uniform
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[i], B[u][i], acc, 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[t][i], B[u][i], acc[t], 0, 0, 0);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Ac[i] = An[i];
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Ac[t][i] = An[t][i];
             }
         };
         bool synced = NPW == 0;  // fused: the first burst that holds a pose group waits for the prologue waves (pose rows of the tile, head packs)
@@ -1210,7 +1224,9 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     __syncthreads();  // every wave is done with the coefficient tile: its memory becomes the exchange buffer
     if (wv < NCW) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_x[((wv * 16) + r) * 64 + lane] = acc[r];  // wv = vertex group * 3 + plane
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_x[(((cvg * MT + t) * 3 + cpl) * 16 + r) * 64 + lane] = acc[t][r];
     }
     __syncthreads();
     C3MARK(3);
@@ -1222,9 +1238,10 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         if (a.proj && tid == 0) a.proj[((int64_t)h0 * a.V + v) * 3] = s_x[lane];
         return;
     }
-    const float* const s_xg = s_x + cvg * (3 * 16 * 64);
-    for (int r = (VG == 1 ? wv : cpl); r < (VG == 1 || cw ? 16 : 0); r += (VG == 1 ? NW : 3)) {
-        const int hlo = (r & 3) + 8 * (r >> 2);  // head of the lower half-wave; the upper one has hlo + 4
+    for (int sl = (VG == 1 ? wv : cpl); sl < (VG == 1 || cw ? 16 * MT : 0); sl += (VG == 1 ? NW : 3)) {
+        const int t = sl >> 4, r = sl & 15;
+        const float* const s_xg = s_x + (cvg * MT + t) * (3 * 16 * 64);
+        const int hlo = t * 32 + (r & 3) + 8 * (r >> 2);  // head of the lower half-wave; the upper one has hlo + 4
         if (h0 + hlo >= a.n) continue;           // wave-uniform: neither half has a live head
         const int hh = hlo + 4 * half;
         const float* const hp = s_hp + min(hh, NH - 1) * HP_SIZE;
@@ -1268,29 +1285,29 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     C3MARK(4);
 }
 
-template <int NPW, int NHL, int VG = 1>
+template <int NPW, int NHL, int VG = 1, int MT = 1>
 int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
-    constexpr int NH = NPW > 0 ? NPW : 32, NW = 3 * VG + NPW + NHL;
+    constexpr int NH = NPW > 0 ? NPW : 32 * MT, NW = 3 * VG + NPW + NHL;
     const int ngmax = (va.Kp + 7) / 8;  // live groups <= all groups
     const int g0e = (va.r0_end + 7) >> 3;
     const int g1b = va.r1_end > va.r1_begin ? std::max(va.r1_begin >> 3, g0e) : g0e, g1e = va.r1_end > va.r1_begin ? std::max((va.r1_end + 7) >> 3, g1b) : g0e;
     const int g2b = std::max(va.r2_begin >> 3, g1e), g2e = std::max((va.r2_end + 7) >> 3, g2b);
     const int nrows8 = std::min(ngmax, g0e + (g1e - g1b) + (g2e - g2b)) * 8;
-    const int tile = (std::max(nrows8 * (NPW > 0 ? 33 : 32), VG * 3 * 16 * 64) + 3) & ~3;
+    const int tile = (std::max(nrows8 * MT * (NPW > 0 ? 33 : 32), VG * MT * 3 * 16 * 64) + 3) & ~3;
     const size_t lds = ((size_t)tile + (size_t)NH * HP_SIZE) * sizeof(float) + (NPW > 0 ? NPW * sizeof(PrepScratch) : 0);
     static std::atomic<int> attr_done[16];
     int dev = 0;
     VGH_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NPW, NHL, VG>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NPW, NHL, VG, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev].store(1, std::memory_order_release);
     }
-    if (lds > 96 * 1024) {
+    if (lds > 160 * 1024) {
         vgh_set_error("flame c3 tiles: %zu bytes of LDS for %d coefficient rows", lds, nrows8);
         return VGH_ERR_INVALID;
     }
-    const int vblocks = ((va.V + 31) / 32 + VG - 1) / VG, hgroups = NPW > 0 ? 1 : (va.n + 31) / 32;
-    hipLaunchKernelGGL((flame_c3_kernel<NPW, NHL, VG>), dim3((vblocks + 7) / 8 * 8 * hgroups), dim3(NW * 64), lds, st, va, pa);
+    const int vblocks = ((va.V + 31) / 32 + VG - 1) / VG, hgroups = NPW > 0 ? 1 : (va.n + 32 * MT - 1) / (32 * MT);
+    hipLaunchKernelGGL((flame_c3_kernel<NPW, NHL, VG, MT>), dim3((vblocks + 7) / 8 * 8 * hgroups), dim3(NW * 64), lds, st, va, pa);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -1424,11 +1441,14 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
             if (pa.n_dev) rc = m <= 128 ? launch_c3<0, 1>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);  // (capacity, not the live count)
             else if (m <= 96) rc = m <= 32 ? launch_c3<0, 5>(va, pa, st) : launch_c3<0, 1>(va, pa, st);
             else {
-                // 128- or 160-vertex blocks (12 / 15 compute waves, one block per CU): whichever needs fewer ROUNDS of blocks over the CUs, a round of the larger
-                // block costing 1.3 of the smaller's (measured: n = 256 59.7 vs 82.9 us, 384 100.8 vs 86.0, 512 103.2 vs 118.3, 768 146.1 vs 154.0, 1 024 a tie)
+                // one block per CU: 128 vertices x 32 heads (12 compute waves), 160 x 32 (15 waves) or 128 x 64 (12 waves, two head tiles' chains per wave on one
+                // basis operand) -- whichever needs the least time in ROUNDS of blocks over the CUs, a round costing 1.0 / 1.3 / 1.72 of the first's (measured,
+                // all 400 coefficients: n = 256 59.7 vs 82.9 us for 160- vs 128-vertex blocks, 384 100.8 vs 86.0, 512 103.2 vs 118.3 (64-head blocks 134.2),
+                // 1 024 189.4 vs 190.2 (196.8), 2 048 361.9 vs 364.3 (323.5))
                 const int vgroups = (f->V + 31) / 32, hg = (m + 31) / 32, ncu = f->ncu > 0 ? f->ncu : 256;
-                const int r4 = (hg * ((vgroups + 3) / 4) + ncu - 1) / ncu, r5 = (hg * ((vgroups + 4) / 5) + ncu - 1) / ncu;
-                rc = 13 * r5 < 10 * r4 ? launch_c3<0, 0, 5>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);
+                const int r4 = (hg * ((vgroups + 3) / 4) + ncu - 1) / ncu, r5 = (hg * ((vgroups + 4) / 5) + ncu - 1) / ncu, r2 = ((hg + 1) / 2 * ((vgroups + 3) / 4) + ncu - 1) / ncu;
+                const int c4 = 100 * r4, c5 = 130 * r5, c2 = 172 * r2;
+                rc = c2 < c4 && c2 < c5 ? launch_c3<0, 0, 4, 2>(va, pa, st) : c5 < c4 ? launch_c3<0, 0, 5>(va, pa, st) : launch_c3<0, 0, 4>(va, pa, st);
             }
         } else if (lds) {
             // 128-head blocks at crowd scale; 64-head blocks (twice the blocks) below it and in mode 4
