@@ -97,6 +97,28 @@ def test_flame_layer_forward_general_pose(flame_layer, flame_model):
     assert (out_zj.cpu().double() - fo.flame_forward(c64, d, zero_rot=True, zero_jaw=True)).abs().max() < 5e-6
 
 
+@pytest.mark.parametrize("n", [1, 6, 40, 130, 300])
+def test_flame_general_lbs_is_bit_identical_across_vertex_kernels(gpu_lib, flame_model, n):
+    """vgh_flame_lbs (FLAMELayer.forward's core: betas + a full pose per joint, no 413-vector) through every vertex-kernel family: the component-split tiles read the raw
+    betas in place (fused, up to 8 heads) or from the prologue's scratch, with 5-waves-helper, 4-wave and 12 / 15-wave blocks depending on n -- same bits as the VALU kernel."""
+    from head_detector_amd.flame import FLAMELayer
+    from head_detector_amd.head_info import FlameParams
+
+    consts = {"shape": 300, "expression": 100, "rotation": 6, "jaw": 3, "eyeballs": 6, "neck": 3, "translation": 3, "scale": 1}
+    layer = FLAMELayer(consts=consts, model=flame_model, device=_dev(), max_heads=512)
+    x = torch.randn(n, sum(consts.values()), generator=torch.Generator().manual_seed(100 + n)) * 0.3
+    fp = FlameParams.from_3dmm(x, consts)
+    outs = {}
+    try:
+        for mode in (0, 1, 2, 6, 7):
+            assert gpu_lib.vgh_flame_set_matrix_path(mode) == 0
+            outs[mode] = layer.forward(fp, zero_rot=False).clone()
+    finally:
+        gpu_lib.vgh_flame_set_matrix_path(1)
+    for mode in (1, 2, 6, 7):
+        assert torch.equal(outs[mode], outs[0]), mode
+
+
 # ======================================================================================================
 # top-k (K7), NMS (K8)
 # ======================================================================================================
