@@ -498,3 +498,53 @@ def test_flame_prologue_joint_reduction_tree_is_the_xor_butterfly():
             jbase = (12 if lane & 32 else 0) + (6 if lane & 16 else 0) + (3 if lane & 8 else 0)
             out[jbase : jbase + 3] = t[:, lane]
         assert np.array_equal(out, ref)
+
+
+def test_flame_c3_live_groups_tile_rows_and_interleaved_basis_layout():
+    """CPU spec of the index arithmetic of csrc/flame.hip::flame_c3_kernel: (1) the live k-groups (8 consecutive k) of the shape / expression / pose ranges in ascending
+    order and gi -> g; (2) walking them group by group, pair by pair, with the kernel's `live` test visits exactly the even k of the three ranges in ascending order --
+    the fmaf chain every FLAME vertex kernel must reproduce -- and the rows it does NOT visit inside a live group are the ones `zero_dead_rows` clears; (3) the
+    coefficient tile row of a k (gi * 8 + k % 8) agrees with the fused variant's staging map; (4) the k-interleaved basis copy: the 16 bytes a lane (j, half) loads for
+    group g hold k = 8g + half + {0, 2, 4, 6} of its vertex, and the layout is a bijection."""
+    import numpy as np
+
+    NB, K, Kp, Vp = 400, 436, 440, 64
+
+    def groups(r0e, r1b, r1e, r2b, r2e):
+        g0e = (r0e + 7) >> 3
+        g1b, g1e = (max(r1b >> 3, g0e), max((r1e + 7) >> 3, max(r1b >> 3, g0e))) if r1e > r1b else (g0e, g0e)
+        g2b = max(r2b >> 3, g1e)
+        g2e = max((r2e + 7) >> 3, g2b)
+        c0, c01 = g0e, g0e + (g1e - g1b)
+        ng = c01 + (g2e - g2b)
+        gof = lambda gi: gi if gi < c0 else g1b + (gi - c0) if gi < c01 else g2b + (gi - c01)  # noqa: E731
+        return g0e, g1b, c0, c01, ng, gof
+
+    for shape_live, expr_live in ((64, 32), (128, 64), (300, 100), (300, 0), (0, 100), (0, 0), (296, 4), (4, 36)):
+        r0e, r1b, r1e, r2b, r2e = shape_live, 300, 300 + expr_live, NB, K
+        live = lambda k: k < r0e or r1b <= k < r1e or r2b <= k < r2e  # noqa: E731
+        g0e, g1b, c0, c01, ng, gof = groups(r0e, r1b, r1e, r2b, r2e)
+        gs = [gof(gi) for gi in range(ng)]
+        assert gs == sorted(set(gs)) and all(0 <= g < Kp // 8 for g in gs)  # ascending, no group twice, inside the padded basis
+        want = [k for k in range(0, K, 2) if live(k)]
+        visited = [gof(gi) * 8 + 2 * i for gi in range(ng) for i in range(4) if live(gof(gi) * 8 + 2 * i)]
+        assert visited == want  # the chain order
+        assert all(any(live(g * 8 + r) for r in range(8)) for g in gs)  # no dead group is staged
+        assert all(live(k) == live(k + 1) for k in range(0, Kp, 2))  # a pair is in or out as a whole (even bounds)
+        for k in want:  # tile row of k: the fused staging map == the enumeration
+            g = k >> 3
+            gi_stage = g if g < g0e else c0 + (g - g1b)
+            assert k >= r2b or gof(gi_stage) == g
+        assert c01 * 8 + (K - NB) <= ng * 8 and gof(c01) * 8 == NB  # the pose rows start a group right behind the betas' groups
+    # (4) basis8[((g * 3 + c) * 2 + (k & 1)) * Vp + v][(k >> 1) & 3]
+    idx = np.full(Kp * 3 * Vp, -1, np.int64)
+    for k in range(Kp):
+        for c in range(3):
+            v = np.arange(Vp)
+            flat = ((((k >> 3) * 3 + c) * 2 + (k & 1)) * Vp + v) * 4 + ((k >> 1) & 3)
+            assert (idx[flat] == -1).all()
+            idx[flat] = (k * 3 + c) * Vp + v
+    assert (idx >= 0).all()  # a bijection onto the padded basis
+    for g, c, half, j in ((0, 0, 0, 0), (5, 2, 1, 17), (54, 1, 0, 63)):
+        base = (((g * 3 + c) * 2 + half) * Vp + j) * 4
+        assert [int(idx[base + i]) for i in range(4)] == [((8 * g + half + 2 * i) * 3 + c) * Vp + j for i in range(4)]
