@@ -15,6 +15,10 @@
 //  * a block owns (256 x 4 vertices) x HT heads: every basis value fetched feeds HT FMAs (coefficients
 //    broadcast from LDS), the skinning / rigid / un-pad epilogue runs in registers and results leave with
 //    16-byte stores.  Exact fp32 FMA chains in fixed k order.
+//  * (r02 - r04) the blend is a [heads x K] . [K x 3V] contraction, and gfx950's fp32 matrix instructions are exact ascending fmaf chains over their k
+//    (tools/micro/mfma_f32_chain.hip): the matrix-core kernels below -- register-fed, LDS-staged 128-head tiles, and from r04 the component-split "c3" tiles
+//    that run 1 ... 2 048 heads (one coordinate plane per wave, coefficient tile in LDS, k-interleaved basis copy, prologue waves inside the block up to 8 heads)
+//    -- produce the VALU kernel's bits, so which one runs is a pure speed choice (run_decode_on; vgh_flame_set_matrix_path for tests and A/B).
 #include <math.h>
 #include <stdlib.h>
 
