@@ -1036,8 +1036,13 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     auto gof = [&](int gi) { return gi < c0 ? gi : gi < c01 ? g1b + (gi - c0) : g2b + (gi - c01); };
     auto live = [&](int k) { return k < a.r0_end || (k >= a.r1_begin && k < a.r1_end) || (k >= a.r2_begin && k < a.r2_end); };
     float* const s_A = fsm;  // [ng][MT][8][AS] coefficients of heads h0 + 32 t .. + 31: row (gi * MT + t) * 8 + (k & 7); after the blend s_x [VG][MT][3][16][64]
-    float* const s_x = fsm;
-    float* const s_hp = fsm + ((max(ng * MT * 8 * AS, VG * MT * 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
+    // the exchange buffer aliases the tile (one barrier between them), except in the large one-tile blocks (VG > 1, MT = 1): there it has its own memory behind
+    // the head packs, so that a vertex group's three waves hand over among themselves (an LDS counter) and start their epilogue while other groups' chains still run
+    constexpr bool XOWN = VG > 1 && MT == 1;
+    float* const s_hp = fsm + ((max(ng * MT * 8 * AS, XOWN ? 0 : VG * MT * 3 * 16 * 64) + 3) & ~3);  // [NH][HP_SIZE] head packs, head-major (16-byte broadcast reads)
+    float* const s_x = XOWN ? s_hp + NH * HP_SIZE : fsm;
+    int* const s_cnt = (int*)(s_x + VG * MT * 3 * 16 * 64);  // XOWN: one arrival counter per vertex group
+    if (XOWN && threadIdx.x < VG) s_cnt[threadIdx.x] = 0;     // (ahead of the staging barrier)
     const int h0 = by * (32 * MT);
     if (h0 >= a.n) return;
     const int j = lane & 31, half = lane >> 5;
@@ -1225,14 +1230,24 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         }
         __syncthreads();  // the pose barrier of the compute waves
     }
-    __syncthreads();  // every wave is done with the coefficient tile: its memory becomes the exchange buffer
-    if (wv < NCW) {
+    if constexpr (XOWN) {
+        if (cw) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+            for (int r = 0; r < 16; ++r) s_x[((cvg * 3 + cpl) * 16 + r) * 64 + lane] = acc[0][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&s_cnt[cvg], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&s_cnt[cvg], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 3) __builtin_amdgcn_s_sleep(1);  // the group's three planes are in
+        }
+    } else {
+        __syncthreads();  // every wave is done with the coefficient tile: its memory becomes the exchange buffer
+        if (wv < NCW) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_x[(((cvg * MT + t) * 3 + cpl) * 16 + r) * 64 + lane] = acc[t][r];
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_x[(((cvg * MT + t) * 3 + cpl) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     C3MARK(3);
     // ---- epilogue: flame_vertex_kernel's statements per (head, vertex), slots dealt round-robin to the waves ----
     // VG = 1: slots dealt round-robin to all waves (every wave's lanes hold the one vertex group's weights); VG > 1: a compute wave takes every third slot of
@@ -1297,8 +1312,9 @@ int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
     const int g1b = va.r1_end > va.r1_begin ? std::max(va.r1_begin >> 3, g0e) : g0e, g1e = va.r1_end > va.r1_begin ? std::max((va.r1_end + 7) >> 3, g1b) : g0e;
     const int g2b = std::max(va.r2_begin >> 3, g1e), g2e = std::max((va.r2_end + 7) >> 3, g2b);
     const int nrows8 = std::min(ngmax, g0e + (g1e - g1b) + (g2e - g2b)) * 8;
-    const int tile = (std::max(nrows8 * MT * (NPW > 0 ? 33 : 32), VG * MT * 3 * 16 * 64) + 3) & ~3;
-    const size_t lds = ((size_t)tile + (size_t)NH * HP_SIZE) * sizeof(float) + (NPW > 0 ? NPW * sizeof(PrepScratch) : 0);
+    const int tile = (std::max(nrows8 * MT * (NPW > 0 ? 33 : 32), VG > 1 && MT == 1 ? 0 : VG * MT * 3 * 16 * 64) + 3) & ~3;
+    constexpr bool XOWN = VG > 1 && MT == 1;  // the exchange buffer has its own memory (+ a counter per vertex group)
+    const size_t lds = ((size_t)tile + (size_t)NH * HP_SIZE + (XOWN ? VG * 3 * 16 * 64 + 16 : 0)) * sizeof(float) + (NPW > 0 ? NPW * sizeof(PrepScratch) : 0);
     static std::atomic<int> attr_done[16];
     int dev = 0;
     VGH_HIP(hipGetDevice(&dev));
