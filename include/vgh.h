@@ -227,6 +227,8 @@ int vgh_topk_nms(const float* boxes_dev, const float* scores_dev, const float* f
  * stream they are given, and a decode queued on a different stream than the previous one is ordered after it on the device
  * (event wait, no host sync) -- calls from several streams are safe, they just do not overlap.  Not safe for concurrent
  * calls from several host threads; use one handle per thread.
+ * Device memory of a handle: two copies of the blend basis (K x 3 x V floats each: the planar one and, since r04, a k-interleaved one for
+ * the component-split tiles; 2 x 26.5 MB for FLAME) + the scratch (max_heads x (K + 128) floats).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vgh_flame vgh_flame;
 int vgh_flame_create(int device, int V, int NB, int NJ, const float* v_template, const float* shapedirs, const float* posedirs,
