@@ -337,6 +337,9 @@ static int cfg_ok_for(int cfg, const ConvArgs& a) {
     return 1;
 }
 
+// for net.hip: can tile `cfg` run the PREPARED launch `a` (the only batch-dependent term is the ping-pong tiles' 2 GiB rule, vgh_conv_pp_fits)
+int vgh_conv_cfg_ok_for(int cfg, const ConvArgs& a) { return a.split ? 1 : cfg_ok_for(cfg, a); }
+
 namespace {
 // Tile choice for shapes without a measured entry in tuning/conv_cfg.json: a class table distilled from the per-op tuning
 // reports (tools/gen_heuristic.py).  Class = (kernel size, stride, pixel-count bucket, largest of {128,96,64,32} dividing

@@ -556,7 +556,22 @@ int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {
     VGH_REQUIRE(n && op_index >= 0 && op_index < (int)n->ops.size(), "net_set_cfg: bad op index");
     const bool split_net = vgh_fmt_planes(n->bufs[n->ops[op_index].d.kind == VGH_OP_CONV ? n->ops[op_index].d.in_buf : 0].is_f32) > 1;
     VGH_REQUIRE(cfg >= -1 && cfg < (split_net ? vgh_conv_split_num_cfgs() : vgh_conv_num_cfgs()), "net_set_cfg: bad cfg");
-    n->ops[op_index].d.force_cfg = cfg;
+    NetOp& op = n->ops[op_index];
+    if (cfg >= 0 && op.d.kind == VGH_OP_CONV && !split_net && n->bufs[op.d.in_buf].is_f32 == VGH_FMT_BF16) {
+        // eligibility is decided ONCE, for the arena batch: a tile that fits a small chunk but not max_batch (the ping-pong tiles' 2 GiB rule depends on the
+        // pixel count) would otherwise run some batch sizes and silently fall back on others -- two summation orders for one op, against the "same bits for
+        // any chunk" invariant of NetOp::auto_cfg.  Such a tile is replaced by the automatic one for every batch, and the replacement is logged.
+        ConvArgs ref;
+        int rc = net_conv_args(n, op, n->max_batch, 0, &ref);
+        if (!rc) rc = vgh_conv_prepare(ref);
+        if (rc) return rc;
+        if (!vgh_conv_cfg_ok_for(cfg, ref)) {
+            fprintf(stderr, "[vgh] net_set_cfg: op %d: tile %s cannot run this op at max_batch=%d; its automatic tile %s runs it at every batch size\n", op_index, vgh_conv_cfg_name(cfg),
+                    n->max_batch, vgh_conv_cfg_name(op.auto_cfg));
+            cfg = -1;
+        }
+    }
+    op.d.force_cfg = cfg;
     return VGH_OK;
 }
 

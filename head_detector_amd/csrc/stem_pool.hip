@@ -134,12 +134,20 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ i
             continue;
         }
         bf16x8_t o0, o1;
+        // ReLU through fmaxf also turns a NaN into 0.  The 48-channel pitch (NCH = 6) additionally needs FINITE stores: the stage-1 downsample reads 16 channels of the
+        // NEXT pixel / image over zero weight columns (net.hip), and Inf x 0 would carry one image's fault into its neighbour -- only a float image can overflow (a u8
+        // image bounds |out| by sum|w| + |b|), so only that instantiation pays the clamp to bf16's largest finite value
+        auto act = [](float v) {
+            v = fmaxf(v, 0.0f);
+            if constexpr (FMT == VGH_IMG_F32_NCHW && NCH == 6) v = fminf(v, 3.3895313892515355e38f);
+            return v;
+        };
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            o0[2 * c] = (__bf16)fmaxf(acc[c][0] + bias[cg * 16 + 2 * c], 0.0f);
-            o0[2 * c + 1] = (__bf16)fmaxf(acc[c][1] + bias[cg * 16 + 2 * c + 1], 0.0f);
-            o1[2 * c] = (__bf16)fmaxf(acc[4 + c][0] + bias[cg * 16 + 8 + 2 * c], 0.0f);
-            o1[2 * c + 1] = (__bf16)fmaxf(acc[4 + c][1] + bias[cg * 16 + 8 + 2 * c + 1], 0.0f);
+            o0[2 * c] = (__bf16)act(acc[c][0] + bias[cg * 16 + 2 * c]);
+            o0[2 * c + 1] = (__bf16)act(acc[c][1] + bias[cg * 16 + 2 * c + 1]);
+            o1[2 * c] = (__bf16)act(acc[4 + c][0] + bias[cg * 16 + 8 + 2 * c]);
+            o1[2 * c + 1] = (__bf16)act(acc[4 + c][1] + bias[cg * 16 + 8 + 2 * c + 1]);
         }
         if (STAGE) {
             stage[tid * 8 + ((2 * cg) ^ (tid & 7))] = o0;

@@ -108,6 +108,7 @@ int vgh_conv_pp_lds(int bc);
 int vgh_conv_pp_fits(const ConvArgs& a);
 int vgh_conv_persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int blocks_per_cu);
 int vgh_conv_pick_cfg(const ConvArgs& a);
+int vgh_conv_cfg_ok_for(int cfg, const ConvArgs& a);  // `a` prepared; bf16 tiles only (split launches validate in conv_split.hip)
 // validates `a` and fills its derived fields (fast-division constants, fast_epi); vgh_launch_conv calls it itself
 int vgh_conv_prepare(ConvArgs& a);
 // automatic tile of a PREPARED descriptor: index into the bf16 table (a.split == 0) or into conv_split.hip's table

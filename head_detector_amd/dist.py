@@ -127,6 +127,7 @@ class GatheredDetections:
     n_heads_per_rank: Optional[torch.Tensor] = None  # [world] int32
     vertex_slabs: Optional[torch.Tensor] = None  # [world, vertex_rows, V, 3]: rank r's first min(n_heads[r], vertex_rows) rows are live
     images_per_rank: Optional[torch.Tensor] = None  # [world] int32: rows [r*B_local, r*B_local + images[r]) of the slabs are real images
+    dropped_rows_per_rank: Optional[torch.Tensor] = None  # [world] int32 (compact exchange): survivors of rank r that did not fit its compact_rows cap (0 = nothing was cut)
     compact_slabs: Optional[torch.Tensor] = None  # [world, compact_rows, 418] (DetectionGatherer(compact_rows=...)): survivors packed image-major per rank
 
 
@@ -191,9 +192,11 @@ class DetectionGatherer:
                  compact_rows: int = 0):
         """``compact_rows`` > 0 (SURVEY 8(e) option (ii)): instead of the capacity slab ``[B_local, keep, 418]`` (10.7 MB per rank and step at B = 64, ~3 % of
         it live) each rank sends its survivors packed image-major into ``[compact_rows, 418]`` -- a fixed cap, so still no size on the host: row r is
-        detection r - first[image] of image = searchsorted(cumsum(counts), r); rows beyond the rank's total are zero and a total above the cap is cut
-        (visible to the consumer through ``counts``).  ``result`` then carries ``compact_slabs [world, compact_rows, 418]`` and ``compact()`` rebuilds the
-        per-image layout."""
+        detection r - first[image] of image = searchsorted(cumsum(counts), r); rows beyond the rank's total are exact zeros (``masked_fill``, not a multiply:
+        a NaN in a dead NMS tail row stays out).  A total above the cap is cut at the cap AND the per-image counts that travel are clamped to the rows
+        actually shipped, so ``counts`` never marks a row live that was not sent; the number of cut rows travels too (``dropped_rows_per_rank``; ``overflowed()``
+        is the check a caller asserts on).  A rank that owns no image (``local_images=0``) still posts every collective with an all-zero slab.  ``result``
+        then carries ``compact_slabs [world, compact_rows, 418]`` and ``compact()`` rebuilds the per-image layout."""
         self.group, self.dst = group, dst
         self.crows = int(compact_rows)
         # always_collective: go through the process group even when it has a single rank (exercises the RCCL calls on a 1-GPU box)
@@ -210,10 +213,13 @@ class DetectionGatherer:
         for _ in range(slots):
             sl = dict(
                 send=torch.zeros(B_local, keep, 418, **f32) if not self.crows else torch.zeros(self.crows, 418, **f32),
-                send_counts=torch.zeros(B_local + 2, **i32),  # [counts | n_heads | images owned]
+                send_counts=torch.zeros(B_local + 3, **i32),  # [counts | n_heads | images owned | compact rows cut at the cap]
+                # compact exchange: index / gather scratch allocated once (the steady-state loop allocates nothing for the payload)
+                pack=(dict(flat=torch.zeros(self.crows, dtype=torch.int64, device=self.device), dead=torch.zeros(self.crows, dtype=torch.bool, device=self.device),
+                           b=torch.zeros(self.crows, 4, **f32), s=torch.zeros(self.crows, **f32), f=torch.zeros(self.crows, 413, **f32)) if self.crows else None),
                 send_verts=torch.zeros(vertex_rows, num_vertices, 3, **f32) if vertex_rows else None,
                 recv=(torch.zeros(max(W, 1), B_local, keep, 418, **f32) if not self.crows else torch.zeros(max(W, 1), self.crows, 418, **f32)) if self.rank == dst else None,
-                recv_counts=torch.zeros(self.world, B_local + 2, **i32),  # all_gather target: every rank has it
+                recv_counts=torch.zeros(self.world, B_local + 3, **i32),  # all_gather target: every rank has it
                 recv_verts=torch.zeros(max(W, 1), vertex_rows, num_vertices, 3, **f32) if (self.rank == dst and vertex_rows) else None,
                 work=[], done=torch.cuda.Event() if self.cuda else None, busy=False, reader=None)
             self.slots.append(sl)
@@ -249,17 +255,32 @@ class DetectionGatherer:
                 sl["send"][:nb, :, 0:4].copy_(boxes[:nb], non_blocking=True)
                 sl["send"][:nb, :, 4].copy_(scores[:nb], non_blocking=True)
                 sl["send"][:nb, :, 5:].copy_(flame_params[:nb], non_blocking=True)
+            elif nb == 0:  # a rank without images (uneven shards): nothing to pack, but every collective below is still posted
+                sl["send"].zero_()
+                sl["send_counts"][: self.B].zero_()
+                sl["send_counts"][self.B + 2] = 0
             else:
+                pk = sl["pack"]
                 c = counts[:nb].long().clamp(min=0, max=self.keep)
                 ends = torch.cumsum(c, 0)
+                first = ends - c
                 r = torch.arange(self.crows, device=ends.device)
-                img = torch.searchsorted(ends, r, right=True).clamp(max=nb - 1)  # image of compact row r
-                j = (r - (ends - c)[img]).clamp(min=0, max=self.keep - 1)  # its rank inside the image
-                live = (r < ends[-1]).to(boxes.dtype).unsqueeze(-1)
-                sl["send"][:, 0:4] = boxes[img, j] * live
-                sl["send"][:, 4] = scores[img, j] * live[:, 0]
-                sl["send"][:, 5:] = flame_params[img, j] * live
-            sl["send_counts"][:nb].copy_(counts[:nb], non_blocking=True)
+                img = torch.searchsorted(ends, r, right=True).clamp(min=0, max=nb - 1)  # image of compact row r
+                j = (r - first[img]).clamp(min=0, max=self.keep - 1)  # its rank inside the image
+                torch.add(img * int(boxes.shape[1]), j, out=pk["flat"])
+                torch.ge(r, ends[nb - 1 : nb], out=pk["dead"])  # rows beyond the rank's total
+                torch.index_select(boxes[:nb].reshape(-1, 4), 0, pk["flat"], out=pk["b"])
+                torch.index_select(scores[:nb].reshape(-1), 0, pk["flat"], out=pk["s"])
+                torch.index_select(flame_params[:nb].reshape(-1, flame_params.shape[-1]), 0, pk["flat"], out=pk["f"])
+                sl["send"][:, 0:4] = pk["b"].masked_fill_(pk["dead"].unsqueeze(-1), 0.0)
+                sl["send"][:, 4] = pk["s"].masked_fill_(pk["dead"], 0.0)
+                sl["send"][:, 5:] = pk["f"].masked_fill_(pk["dead"].unsqueeze(-1), 0.0)
+                # the counts that travel describe the rows that travel: an image whose detections straddle the cap keeps the part that fitted
+                shipped = (ends.clamp(max=self.crows) - first.clamp(max=self.crows)).to(torch.int32)
+                sl["send_counts"][:nb].copy_(shipped, non_blocking=True)
+                sl["send_counts"][self.B + 2] = (ends[nb - 1] - self.crows).clamp(min=0).to(torch.int32)
+            if not self.crows:
+                sl["send_counts"][:nb].copy_(counts[:nb], non_blocking=True)
             if nb < self.B:
                 sl["send_counts"][nb : self.B].zero_()
             if n_heads is not None:
@@ -311,8 +332,14 @@ class DetectionGatherer:
             out = GatheredDetections(full[..., :4], full[..., 4], full[..., 5:], sl["recv_counts"][:, : self.B].reshape(-1))
         out.n_heads_per_rank = sl["recv_counts"][:, self.B]
         out.images_per_rank = sl["recv_counts"][:, self.B + 1]
+        out.dropped_rows_per_rank = sl["recv_counts"][:, self.B + 2]
         out.vertex_slabs = sl["recv_verts"]  # [world, vertex_rows, V, 3] or None
         return out
+
+    @staticmethod
+    def overflowed(out: GatheredDetections) -> bool:
+        """Did any rank cut survivors at its ``compact_rows`` cap in this exchange (reads one small device tensor: a host sync)?"""
+        return out.dropped_rows_per_rank is not None and bool((out.dropped_rows_per_rank > 0).any())
 
     def compact(self, out: GatheredDetections) -> GatheredDetections:
         """Host-side trimming of ``result`` into the layout of ``gather_detections`` (reads the counts: one sync): the padding rows
@@ -330,7 +357,7 @@ class DetectionGatherer:
                 img = torch.searchsorted(ends, k, right=True)
                 full[r * self.B + img, k - (ends - c)[img]] = out.compact_slabs[r, :n]
             out = GatheredDetections(full[..., :4], full[..., 4], full[..., 5:], out.counts, n_heads_per_rank=out.n_heads_per_rank, vertex_slabs=out.vertex_slabs,
-                                     images_per_rank=out.images_per_rank)
+                                     images_per_rank=out.images_per_rank, dropped_rows_per_rank=out.dropped_rows_per_rank)
         verts = hi = None
         if out.vertex_slabs is not None:
             nh = [min(int(n), self.vrows) for n in out.n_heads_per_rank.tolist()]

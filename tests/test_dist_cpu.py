@@ -164,6 +164,75 @@ def test_gatherer_single_process_and_vertex_cut():
     assert g.compact(out).head_image is None  # head list and vertex rows no longer line up
 
 
+def test_compact_exchange_clamps_counts_at_the_cap_and_keeps_dead_rows_zero():
+    """with compact_rows set, (1) survivors beyond the cap are cut AND the travelling counts are clamped to the rows shipped (no all-zero
+    row is ever reported as a detection) with the number of cut rows visible; (2) NaN / Inf in the dead tail rows of the engine's slabs never reach the
+    message (masked_fill, not 0 * NaN); (3) a rank that owns no image still goes through submit."""
+    keep, B = 5, 3
+    g = DetectionGatherer(B, keep, device="cpu", compact_rows=5)
+    gen = torch.Generator().manual_seed(5)
+    b, sc, f = torch.rand(B, keep, 4, generator=gen), torch.rand(B, keep, generator=gen), torch.rand(B, keep, 413, generator=gen)
+    c = torch.tensor([3, 3, 3], dtype=torch.int32)
+    b[:, 3:], sc[:, 3:], f[:, 3:] = float("nan"), float("inf"), float("nan")  # what NMS leaves beyond an image's count is undefined
+    g.submit(0, b, sc, f, c)
+    out = g.result(0)
+    assert out.counts.tolist() == [3, 2, 0] and int(out.dropped_rows_per_rank[0]) == 4 and g.overflowed(out)
+    full = g.compact(out)
+    assert torch.equal(full.boxes[0, :3], b[0, :3]) and torch.equal(full.boxes[1, :2], b[1, :2]) and torch.equal(full.flame_params[1, :2], f[1, :2])
+    assert torch.isfinite(out.compact_slabs).all() and float(full.boxes[1, 2:].abs().sum()) == 0.0 and float(full.boxes[2].abs().sum()) == 0.0
+    # below the cap: nothing cut, rows beyond the total are exact zeros although the gathered tail slots hold NaN
+    c2 = torch.tensor([1, 0, 2], dtype=torch.int32)
+    g.wait_slot_free(1)
+    g.submit(1, b, sc, f, c2)
+    out2 = g.result(1)
+    assert out2.counts.tolist() == [1, 0, 2] and int(out2.dropped_rows_per_rank[0]) == 0 and not g.overflowed(out2)
+    assert torch.isfinite(out2.compact_slabs).all() and float(out2.compact_slabs[0, 3:].abs().sum()) == 0.0
+    assert torch.equal(out2.compact_slabs[0, 1, :4], b[2, 0]) and torch.equal(out2.compact_slabs[0, 2, 5:], f[2, 1])
+    # a rank without images
+    g.wait_slot_free(0)
+    g.submit(0, b, sc, f, c, local_images=0)
+    out3 = g.result(0)
+    assert out3.counts.tolist() == [0, 0, 0] and int(out3.images_per_rank[0]) == 0 and float(out3.compact_slabs.abs().sum()) == 0.0 and not g.overflowed(out3)
+
+
+def _empty_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keep, total = 5, 2  # 2 images over 3 ranks: rank 2 owns none (shard_batch) and must still post its collectives
+    lo, hi = shard_batch(total, rank, world)
+    g = DetectionGatherer(1, keep, device="cpu", dst=0, compact_rows=4)
+    if hi > lo:
+        b, sc, f, c, _ = _shard_outputs(0, rank, world, total, keep)
+    else:
+        b, sc, f, c = torch.zeros(0, keep, 4), torch.zeros(0, keep), torch.zeros(0, keep, 413), torch.zeros(0, dtype=torch.int32)
+    pad = lambda t: torch.cat([t, torch.full((1 - (hi - lo), *t.shape[1:]), 7, dtype=t.dtype)])
+    g.submit(0, pad(b), pad(sc), pad(f), pad(c), None, None, None, local_images=hi - lo)
+    out = g.result(0)
+    if rank == 0:
+        full = g.compact(out)
+        q.put({"images": out.images_per_rank.tolist(), "counts": full.counts.numpy(), "boxes": full.boxes.numpy()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_exchange_with_a_rank_that_owns_no_image_world3_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = _shard_outputs(0, 0, 1, 2)
+    cnt = torch.minimum(exp[3], torch.tensor(4, dtype=torch.int32))  # one image per rank, cap 4 rows
+    assert got["images"] == [1, 1, 0] and got["counts"].tolist() == cnt.tolist()
+    for i in range(2):
+        assert torch.equal(torch.from_numpy(got["boxes"])[i, : int(cnt[i])], exp[0][i, : int(cnt[i])])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # bench.py's own step closure (make_step) on gloo: the N>1 control flow of the benchmark -- two output slots, wait_slot_free before a
 # slot is rewritten, join_into + submit after every select, the late read of the previous batch -- executed with the stand-in engine of

@@ -100,6 +100,7 @@ def step_worker(rank, world, port, q, total, steps, compact=False):
     def collect(slot):
         out = gat.result(slot)
         if rank == 0:
+            assert not gat.overflowed(out), "dry run: a rank cut survivors at its compact_rows cap"
             c = gat.compact(out)
             got.append({k: getattr(c, k).clone().numpy() for k in ("boxes", "scores", "flame_params", "counts", "vertices_3d")})
 

@@ -100,6 +100,9 @@ for step in "$@"; do
     py)
       # any tools/ script:  PY_CMD="tools/ab_stem_pitch.py --rounds 4"  (log named by PY_TAG)
       timeout ${PY_TIMEOUT:-900} python ${PY_CMD} > $O/py${PY_TAG:-}.log 2>&1; echo "py rc=$?" >> $O/py${PY_TAG:-}.log; grep -v amdgpu $O/py${PY_TAG:-}.log | tail -${TAILN:-40} ;;
+    benchm)
+      # BASELINE configs[1] (VGGHeads_M b32) as the MAIN workload of bench.py: its own line, per-layer table and (PROF_ARGS / PMC_VARIANT) kernel stats / PMC passes
+      timeout 900 python bench.py --variant vgg_heads_m --batch 32 --no-secondary --no-cpu-baseline --no-accuracy --per-layer $O/${TAG}_per_layer_m32.json ${BENCH_ARGS:-} > $O/bench_m32.json 2> $O/bench_m32.err; echo "benchm rc=$?"; tail -3 $O/bench_m32.err; cut -c1-700 $O/bench_m32.json ;;
     probe)
       python tools/net_probe.py vgg_heads_l 64 2>&1 | grep -v amdgpu; python tools/net_probe.py vgg_heads_m 32 2>&1 | grep -v amdgpu ;;
     *) echo "unknown step $step" ;;
