@@ -238,8 +238,12 @@ def fold_state_dict(variant: str, sd: Dict[str, np.ndarray]) -> Dict[str, Tuple[
         elif sp.kind in ("conv", "cbr"):
             p = n if sp.kind == "conv" else f"{n}.seq"
             w = need(f"{p}.conv.weight", (sp.cout, sp.cin, sp.k, sp.k))
-            s, t = _bn_affine(sd, f"{p}.bn")
-            out[n] = (w * s[:, None, None, None], t)
+            if f"{p}.conv.bias" in sd and f"{p}.bn.running_var" not in sd:
+                # u8: the exporter already merged the eval-mode BatchNorm into the conv (an ONNX export that kept the conv's name): nothing left to fold
+                out[n] = (w, need(f"{p}.conv.bias", (sp.cout,)))
+            else:
+                s, t = _bn_affine(sd, f"{p}.bn")
+                out[n] = (w * s[:, None, None, None], t)
         elif sp.kind == "plain":
             out[n] = (need(f"{n}.weight", (sp.cout, sp.cin, sp.k, sp.k)), need(f"{n}.bias", (sp.cout,)))
         elif sp.kind == "convT":

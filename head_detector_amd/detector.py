@@ -36,11 +36,24 @@ REPO_ID = "okupyn/vgg_heads"
 
 
 def load_weights(path: str) -> Dict[str, np.ndarray]:
-    """state_dict of a released TorchScript archive (.trcd) or of a torch checkpoint -> {name: ndarray} with the
+    """state_dict of a released TorchScript archive (.trcd), of a torch checkpoint, or the initializers of an ONNX export (.onnx) -> {name: ndarray} with the
     ``model.`` prefix of ConvertableCompletePipelineModel stripped (exportable_mesh_model.py:421-427).  A training checkpoint's
     EMA weights win over the raw ones (they are what the export pipeline serialises)."""
     if not os.path.exists(path):
         raise FileNotFoundError(path)
+    if path.lower().endswith(".onnx"):
+        # the reference also publishes ONNX exports (README.md:23,199): their graph.initializer tensors, read by a protobuf wire reader of our own
+        # (onnx_wire.py: the `onnx` package is not a dependency); same key convention as the archive's state_dict
+        from . import onnx_wire
+
+        tensors, _ = onnx_wire.load_initializers(path)
+        out = {}
+        for k, v in tensors.items():
+            if v.dtype.kind not in "fiu" or v.dtype == np.bool_:
+                continue
+            k = k[len("model."):] if k.startswith("model.") else k
+            out[k] = np.ascontiguousarray(v, dtype=np.float32)
+        return out
     try:
         sd = torch.jit.load(path, map_location="cpu").state_dict()
     except (RuntimeError, ValueError) as jit_err:  # not a TorchScript archive: a plain checkpoint?
@@ -74,6 +87,15 @@ def weight_manifest_diff(variant: str, sd: Dict[str, np.ndarray]) -> Dict[str, l
                     del want[k]
             want[f"{spec.name}.rbr_reparam.weight"] = (spec.cout, spec.cin, 3, 3)
             want[f"{spec.name}.rbr_reparam.bias"] = (spec.cout,)
+    # u8: a Conv + BatchNorm block whose BN the exporter merged (torch.onnx.export folds eval-mode BN into the conv when it keeps the conv's name): `<block>.conv.weight`
+    # + `<block>.conv.bias` and no BN tensors -- arch.fold_state_dict takes that form as already folded
+    for spec in arch.layer_specs(variant):
+        if spec.kind in ("conv", "cbr"):
+            pfx = spec.name if spec.kind == "conv" else f"{spec.name}.seq"
+            if f"{pfx}.conv.bias" in sd and f"{pfx}.bn.running_var" not in sd:
+                for k in [k for k in want if k.startswith(pfx + ".bn.")]:
+                    del want[k]
+                want[f"{pfx}.conv.bias"] = (spec.cout,)
     ignore = re.compile(r"(num_batches_tracked|anchor_points|stride_tensor|proj_conv|max_batch)")
     have = {k: tuple(np.asarray(v).shape) for k, v in sd.items() if not ignore.search(k)}
     # an UNFUSED block may still carry an unused rbr_reparam conv (SG keeps the attribute around): not an error

@@ -447,7 +447,7 @@ class VGHeadsEngine:
                 continue
             pre = "" if self.precision == "bf16" else self.precision + ":"
             name = tuning_lookup(table, op, self.max_batch, getattr(self, "nsplit", 1), pre)
-            if name in names:
+            if name in names and self.cfg_ok(names[name], op):  # a stale entry (a tile that cannot run this op) is skipped here, not replaced -- and logged -- by the library
                 self.set_cfg(i, names[name])
                 applied += 1
         return applied

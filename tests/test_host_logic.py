@@ -469,6 +469,80 @@ def test_archives_with_unexpected_key_names_are_reported_in_full(tmp_path):
         arch.build_program(variant, load_weights(p), 256)
 
 
+def _bn_folded_by_exporter(variant, sd):
+    """The state dict as torch.onnx.export leaves a Conv + BatchNorm block whose BN it merged but whose conv kept its name: `<block>.conv.weight`, `<block>.conv.bias`, no BN keys."""
+    out = dict(sd)
+    for sp in arch.layer_specs(variant):
+        if sp.kind in ("conv", "cbr"):
+            pfx = sp.name if sp.kind == "conv" else f"{sp.name}.seq"
+            s_, t_ = arch._bn_affine(sd, f"{pfx}.bn")
+            out[f"{pfx}.conv.weight"] = (sd[f"{pfx}.conv.weight"].astype(np.float64) * s_[:, None, None, None]).astype(np.float32)
+            out[f"{pfx}.conv.bias"] = t_.astype(np.float32)
+            for k in list(out):
+                if k.startswith(pfx + ".bn."):
+                    del out[k]
+    return out
+
+
+def test_onnx_initializer_ingest_without_the_onnx_package(tmp_path):
+    """N4 (ingest half; /root/reference/README.md:199 publishes ONNX weights): ModelProto.graph.initializer read by head_detector_amd/onnx_wire.py -- raw_data f32,
+    packed float_data, fp16 / bf16 raw data, proto2-style unpacked dims -- through load_weights -> weight_manifest_diff -> fold_state_dict: the same folded network as
+    the state dict the file was written from; an export whose Conv + BN blocks arrive merged folds to the same network too; malformed files fail with a reason."""
+    from head_detector_amd import onnx_wire
+    from head_detector_amd.detector import load_weights, weight_manifest_diff
+
+    variant = "vgg_heads_m"
+    sd = arch.random_state_dict(variant, 4)
+    keys = list(sd)
+    how = {keys[1]: "float_data", keys[2]: "dims_unpacked", keys[5]: "float_data"}
+    extra = {"anchor_points": np.arange(6, dtype=np.int64).reshape(3, 2), "onnx::Reshape_991": np.array([1, -1], dtype=np.int64), "scalar_eps": np.array(1e-6, dtype=np.float64)}
+    p = str(tmp_path / "vgg_heads_m.onnx")
+    onnx_wire.write_model(p, {**sd, **extra}, how, prefix="model.")
+    tensors, nodes = onnx_wire.load_initializers(p)
+    assert nodes == [] and tensors["model.onnx::Reshape_991"].tolist() == [1, -1] and tensors["model.scalar_eps"].shape == () and tensors["model.anchor_points"].dtype == np.int64
+    got = load_weights(p)
+    assert set(sd) <= set(got)
+    for k in sd:
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], sd[k]), k
+    diff = weight_manifest_diff(variant, got)
+    assert not diff["missing"] and not diff["shape"] and sorted(diff["unexpected"]) == ["onnx::Reshape_991", "scalar_eps"]  # anchor_points is on the ignore list
+    F, G = arch.fold_state_dict(variant, sd), arch.fold_state_dict(variant, got)
+    assert all(np.array_equal(F[k][0], G[k][0]) for k in F)
+    # half-precision exports: values are the 16-bit roundings of the source
+    p16 = str(tmp_path / "half.onnx")
+    onnx_wire.write_model(p16, {k: (v.astype(np.float16) if i % 2 else v) for i, (k, v) in enumerate(sd.items())}, {k: "bf16" for i, k in enumerate(keys) if i % 2 == 0}, prefix="model.")
+    g16 = load_weights(p16)
+    for i, k in enumerate(keys):
+        ref = sd[k].astype(np.float16).astype(np.float32) if i % 2 else torch.from_numpy(sd[k]).bfloat16().float().numpy()
+        assert np.array_equal(g16[k], ref), k
+    # Conv + BN merged by the exporter
+    folded = _bn_folded_by_exporter(variant, sd)
+    pf = str(tmp_path / "folded.onnx")
+    onnx_wire.write_model(pf, folded, prefix="model.")
+    gf = load_weights(pf)
+    assert not any(weight_manifest_diff(variant, gf).values())
+    H = arch.fold_state_dict(variant, gf)
+    for k in F:
+        if F[k][1] is not None:
+            assert np.abs(H[k][0] - F[k][0]).max() <= 1e-6 * (np.abs(F[k][0]).max() + 1e-30) and np.abs(H[k][1] - F[k][1]).max() <= 1e-6 * (np.abs(F[k][1]).max() + 1), k
+    # malformed input
+    raw = open(p, "rb").read()
+    (tmp_path / "cut.onnx").write_bytes(raw[: len(raw) // 2])
+    with pytest.raises(onnx_wire.OnnxWireError, match="runs past the end|truncated"):
+        load_weights(str(tmp_path / "cut.onnx"))
+    (tmp_path / "nograph.onnx").write_bytes(onnx_wire._vi(1, 8))
+    with pytest.raises(onnx_wire.OnnxWireError, match="no ModelProto.graph"):
+        load_weights(str(tmp_path / "nograph.onnx"))
+    ext = onnx_wire._ld(7, onnx_wire._ld(5, onnx_wire._ld(1, onnx_wire._enc_varint(4)) + onnx_wire._vi(2, 1) + onnx_wire._ld(8, b"w") + onnx_wire._vi(14, 1)))
+    (tmp_path / "ext.onnx").write_bytes(ext)
+    with pytest.raises(onnx_wire.OnnxWireError, match="external file"):
+        load_weights(str(tmp_path / "ext.onnx"))
+    short = onnx_wire._ld(7, onnx_wire._ld(5, onnx_wire._ld(1, onnx_wire._enc_varint(4)) + onnx_wire._vi(2, 1) + onnx_wire._ld(9, b"\0" * 8) + onnx_wire._ld(8, b"w")))
+    (tmp_path / "short.onnx").write_bytes(short)
+    with pytest.raises(onnx_wire.OnnxWireError, match="want 4 elements"):
+        load_weights(str(tmp_path / "short.onnx"))
+
+
 def test_flame_prologue_joint_reduction_tree_is_the_xor_butterfly():
     """CPU spec of the cross-lane reduction in csrc/flame.hip::prep_head (J = J0 + JS beta: 24 sums over 64 lanes): on the first three levels the xor partners split
     the outputs between them (keep half, send half), then three outputs per lane go through a plain butterfly -- 30 cross-lane moves instead of 144.  Every output's
