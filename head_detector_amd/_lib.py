@@ -9,17 +9,17 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # VGH_LIB_PATH: load another build of the library (tools/ use it for the -DVGH_EXPERIMENTS build, which is never shipped)
 LIB_PATH = os.environ.get("VGH_LIB_PATH") or os.path.join(HERE, "libvgh.so")
-ABI_VERSION = 5  # = VGH_ABI_VERSION of include/vgh.h
+ABI_VERSION = 6  # = VGH_ABI_VERSION of include/vgh.h
 
 VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
 VGH_IMG_F32_NCHW, VGH_IMG_U8_NHWC = 0, 1
-VGH_FMT_BF16, VGH_FMT_F32, VGH_FMT_BF16X2, VGH_FMT_F16X2 = 0, 1, 2, 3
+VGH_FMT_BF16, VGH_FMT_F32, VGH_FMT_BF16X2, VGH_FMT_F16X2, VGH_FMT_FP8 = 0, 1, 2, 3, 4
 NUM_FLAME_PARAMS = 413
 
 
 class BufDesc(C.Structure):
-    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("pitch", C.c_int32), ("is_f32", C.c_int32)]
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("pitch", C.c_int32), ("is_f32", C.c_int32), ("scale", C.c_float)]
 
 
 class OpDesc(C.Structure):
@@ -55,6 +55,7 @@ class ConvCall(C.Structure):
         ("force_cfg", C.c_int32),
         ("grp_cout", C.c_int32), ("grp_in_stride", C.c_int32),
         ("fmt", C.c_int32), ("out_scale", C.c_float),
+        ("out_fp8", C.c_int32), ("gscale_dev", C.c_void_p),
     ]
 
 
@@ -114,6 +115,7 @@ SYMBOLS = {
     "vgh_conv2d": (_I, [C.POINTER(ConvCall), _P]),
     "vgh_pack_conv_weights": (_I, [_P, _I, _I, _I, _P]),
     "vgh_pack_conv_weights_split": (_I, [_P, _I, _I, _I, _I, _P, C.POINTER(_F)]),
+    "vgh_pack_conv_weights_fp8": (_I, [_P, _I, _I, _I, _P, _P]),
     "vgh_conv_num_cfgs": (_I, []),
     "vgh_conv_cfg_name": (C.c_char_p, [_I]),
     "vgh_conv_cfg_cout_tile": (_I, [_I]),

@@ -42,9 +42,12 @@ VARIANTS: Dict[str, dict] = {
     ),
 }
 # activation storage formats (VGH_FMT_* of include/vgh.h; the buffer field keeps its historical name is_f32) per precision mode
-FMT_BF16, FMT_F32, FMT_BF16X2, FMT_F16X2 = 0, 1, 2, 3
-PRECISION_FMT = {"bf16": FMT_BF16, "fp32": FMT_F32, "bf16x3": FMT_BF16X2, "fp16x3": FMT_F16X2}
-FMT_BYTES = {FMT_BF16: 2, FMT_F32: 4, FMT_BF16X2: 4, FMT_F16X2: 4}  # bytes per logical element
+FMT_BF16, FMT_F32, FMT_BF16X2, FMT_F16X2, FMT_FP8 = 0, 1, 2, 3, 4
+# "fp8" (r05) is the bf16 program with OCP-e4m3 LINKS: a tensor written by one 3x3 / stride-1 conv and read by one (bottleneck cv1 -> cv2, the middle layers of the
+# FLAME shape / expression branches) is stored as e4m3 bytes with a calibrated per-tensor scale, and its consumer runs v_mfma_f32_32x32x64_f8f6f4 (csrc/conv_pp.hip)
+PRECISION_FMT = {"bf16": FMT_BF16, "fp32": FMT_F32, "bf16x3": FMT_BF16X2, "fp16x3": FMT_F16X2, "fp8": FMT_BF16}
+FMT_BYTES = {FMT_BF16: 2, FMT_F32: 4, FMT_BF16X2: 4, FMT_F16X2: 4, FMT_FP8: 1}  # bytes per logical element
+FP8_MAX, FP8_HEADROOM = 448.0, 2.0  # scale of an e4m3 link = calibrated max|activation| * headroom / 448
 TR_OUTS = (("rotation", 6), ("jaw", 3), ("translation", 3), ("scale", 1))  # order of the transform branches in the prediction buffer
 STRIDES = (8, 16, 32)
 
@@ -283,8 +286,9 @@ class Program:
     flops: float = 0.0  # algorithmic 2*MACs per image (fused-conv accounting)
     precision: str = "bf16"
 
-    def buf(self, name: str, h: int, w: int, pitch: int, f32: bool = False) -> int:
-        self.bufs.append(dict(name=name, h=h, w=w, pitch=pitch, is_f32=int(f32)))
+    def buf(self, name: str, h: int, w: int, pitch: int, f32: bool = False, fp8_scale: Optional[float] = None) -> int:
+        """fp8_scale: the buffer is an e4m3 link (FMT_FP8), value = stored * fp8_scale."""
+        self.bufs.append(dict(name=name, h=h, w=w, pitch=pitch, is_f32=int(f32)) if fp8_scale is None else dict(name=name, h=h, w=w, pitch=pitch, is_f32=FMT_FP8, scale=float(fp8_scale)))
         return len(self.bufs) - 1
 
     def _push_w(self, W: np.ndarray, b: np.ndarray) -> Tuple[int, int]:
@@ -355,11 +359,33 @@ def _stack(parts: List[Tuple[np.ndarray, np.ndarray]], pad_to: int = 1) -> Tuple
 STEM_PITCH_BF16 = 48  # 64 restores the zero-padded stem tensor of r01 - r03 (tools/ab_stem_pitch.py measures one against the other)
 
 
-def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640, precision: str = "bf16", head_lanes: bool = False) -> Program:
+def fp8_link_names(variant: str, image_size: int = 640, fp8_min_px: int = 40) -> Dict[str, Tuple[str, int]]:
+    """e4m3 link buffer of the "fp8" program -> (buffer of the bf16 program that holds the same tensor, its leading channels): what a calibration forward of the
+    bf16 engine has to look at (engine.calibrate_fp8)."""
+    P = build_program(variant, random_state_dict(variant, 0), image_size, "fp8", fp8_scales={}, fp8_min_px=fp8_min_px)
+    out = {}
+    for bf in P.bufs:
+        if bf["is_f32"] == FMT_FP8:
+            out[bf["name"]] = (bf["name"][:-1], bf["live"]) if bf["name"].endswith("q") else (bf["name"], bf["live"])
+    return out
+
+
+def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640, precision: str = "bf16", head_lanes: bool = False,
+                  fp8_scales: Optional[Dict[str, float]] = None, fp8_min_px: int = 40) -> Program:
     """precision: 'bf16' (throughput mode: bf16 activations/weights, fp32 accumulate); 'fp16x3' (matrix-core parity mode: two fp16 planes
     per value, three MFMAs per product, csrc/conv_split.hip); 'bf16x3' (the same with bf16 planes: 16 significand bits, kept for the
-    comparison); 'fp32' (VALU parity mode: no 16-bit format anywhere)."""
+    comparison); 'fp32' (VALU parity mode: no 16-bit format anywhere); 'fp8' (bf16 with e4m3 links between 3x3 / stride-1 convs on maps of at least
+    fp8_min_px pixels a side -- the 8 x 8 sub-patches of the ping-pong tiles waste a third of a 20-wide map; fp8_scales: link buffer name -> max|activation| from a
+    calibration forward, see engine.calibrate_fp8; a missing entry takes max = 8)."""
     assert precision in PRECISION_FMT, precision
+    fp8 = precision == "fp8"
+    fp8_scales = fp8_scales or {}
+
+    def link_scale(name: str) -> float:
+        return max(float(fp8_scales.get(name, 8.0)), 1e-6) * FP8_HEADROOM / FP8_MAX
+
+    def r64(c: int) -> int:
+        return (c + 63) // 64 * 64
     v = VARIANTS[variant]
     F = fold_state_dict(variant, sd)
     P = Program(variant=variant, image_size=image_size)
@@ -396,12 +422,20 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
         prev = x1_off
         for i in range(n):
             dst = hid * (i + 1) if ci else (0 if i == n - 1 else hid * (3 + i))
-            mid = P.buf(f"{p}.mid{i}", res_px, res_px, hid)
             wa, ba = F[f"{p}.bottlenecks.{i}.cv1"]
             wb, bb = F[f"{p}.bottlenecks.{i}.cv2"]
             alpha = F[f"{p}.bottlenecks.{i}.alpha"][0]
-            P.conv(f"{p}.bottlenecks.{i}.cv1", View(cat, prev, hid), View(mid, 0, hid), _ohwi(wa, hid), ba, 3)
-            P.conv(f"{p}.bottlenecks.{i}.cv2", View(mid, 0, hid), View(cat, dst, hid), _ohwi(wb, hid), bb, 3, res=(View(cat, prev, hid), alpha))
+            if fp8 and res_px >= fp8_min_px:
+                # cv1 -> cv2 is a single-writer / single-reader link: e4m3 bytes, K blocks of 64 channels (a 96-channel tensor sits in a 128-byte pixel whose last 32
+                # bytes are never written: the arena's zero bytes are e4m3 +0 and meet zero weight columns)
+                mid = P.buf(f"{p}.mid{i}", res_px, res_px, r64(hid), fp8_scale=link_scale(f"{p}.mid{i}"))
+                P.bufs[mid]["live"] = hid
+                P.conv(f"{p}.bottlenecks.{i}.cv1", View(cat, prev, hid), View(mid, 0, hid), _ohwi(wa, hid), ba, 3)
+                P.conv(f"{p}.bottlenecks.{i}.cv2", View(mid, 0, r64(hid)), View(cat, dst, hid), _ohwi(wb, r64(hid)), bb, 3, res=(View(cat, prev, hid), alpha), flops_macs=hid * 9 * hid)
+            else:
+                mid = P.buf(f"{p}.mid{i}", res_px, res_px, hid)
+                P.conv(f"{p}.bottlenecks.{i}.cv1", View(cat, prev, hid), View(mid, 0, hid), _ohwi(wa, hid), ba, 3)
+                P.conv(f"{p}.bottlenecks.{i}.cv2", View(mid, 0, hid), View(cat, dst, hid), _ohwi(wb, hid), bb, 3, res=(View(cat, prev, hid), alpha))
             prev = dst
         w3, b3 = F[f"{p}.conv3"]
         P.conv(f"{p}.conv3", View(cat, 0, hid * slots), out, _ohwi(w3, hid * slots), b3, 1)
@@ -523,12 +557,20 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
         cur = P.buf(f"{p}.f0", r, r, width)
         P.conv(f"{p}.flame_*_pred.0", View(hs, 0, fl), View(cur, 0, width), Wf, bf, 3, cout_store=width, flops_macs=sum(inters) * 9 * fl)
         assert offs[3] == offs[2] + trp and offs[5] == offs[2] + 3 * trp
+        cur_q = None  # fp8 mode: the shape | expression part of `cur` as an e4m3 link
         for bi in range(1, nb):
             nxt = P.buf(f"{p}.f{bi}", r, r, width)
+            # layer bi -> layer bi + 1 of the shape / expression branches is a 3x3 -> 3x3 link as long as layer bi + 1 is not the 1x1 prediction conv
+            link_out = fp8 and r >= fp8_min_px and bi + 1 < nb and all(_r32(c) % 64 == 0 for c in inters[:2])
+            nxt_q = None
+            if link_out:
+                nxt_q = P.buf(f"{p}.f{bi}q", r, r, offs[2], fp8_scale=link_scale(f"{p}.f{bi}q"))
+                P.bufs[nxt_q]["live"] = offs[2]
             for n_, inter, off in zip(names[:2], inters[:2], offs[:2]):
                 W, b = F[f"{p}.flame_{n_}_pred.{bi}"]
                 ip = _r32(inter)
-                P.conv(f"{p}.flame_{n_}_pred.{bi}", View(cur, off, ip), View(nxt, off, ip), _ohwi(W, ip), b, 3, cout_store=ip, flops_macs=inter * 9 * inter)
+                P.conv(f"{p}.flame_{n_}_pred.{bi}", View(cur_q if cur_q is not None else cur, off, ip), View(nxt_q if nxt_q is not None else nxt, off, ip), _ohwi(W, ip), b, 3, cout_store=ip,
+                       flops_macs=inter * 9 * inter)
             # the four transform branches (rotation / jaw / translation / scale: 3x3, tr -> tr each) are ONE grouped launch: cout group g
             # reads its own trp-channel window of the previous layer (four launches of a [M,32,288] GEMM could not fill the chip)
             parts = [(_ohwi(F[f"{p}.flame_{n_}_pred.{bi}"][0], trp), F[f"{p}.flame_{n_}_pred.{bi}"][1]) for n_, _ in TR_OUTS]
@@ -539,7 +581,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
                 Wg, bg, _ = _stack(parts, pad_to=trp)
                 P.conv(f"{p}.flame_transform_pred.{bi}", View(cur, offs[2], trp), View(nxt, offs[2], 4 * trp), Wg, bg, 3, cout_store=4 * trp, flops_macs=4 * tr * 9 * tr,
                        groups=(trp, trp))
-            cur = nxt
+            cur, cur_q = nxt, nxt_q
         # final 1x1 predictions -> fp32 prediction buffer [reg68 | cls1 | .. | shape | expr | rot6 | jaw3 | trans3 | scale1].  (r03 measured ONE
         # block-diagonal GEMM over the whole last-layer buffer instead of these three: 324 + 86 + 27 us vs 238 + 67 + 36 us at L b64 -- the zero
         # blocks cost more MFMA time than the two saved launches return; kept as three launches.)
@@ -581,6 +623,11 @@ def is_net_kernel(kernel_name: str) -> bool:
     return any(m in kernel_name for m in NET_KERNEL_MARKERS)
 
 
+def op_touches_fp8(P: "Program", op: dict) -> bool:
+    """The op reads or writes an e4m3 link (it then runs on the ping-pong tile the library picks: no table entry applies)."""
+    return op["kind"] == 1 and (P.bufs[op["in_buf"]]["is_f32"] == FMT_FP8 or P.bufs[op["out_buf"]]["is_f32"] == FMT_FP8)
+
+
 def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]:
     """HBM bytes one op moves when every tensor is read / written exactly once (SURVEY.md 8(d) "algorithmic bytes"): the input view, the
     residual view and the packed weights read, the stored channels written.  What `roofline.traffic` (PMC FETCH_SIZE / WRITE_SIZE) is
@@ -605,7 +652,7 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     wr = out_px * store * eb_out
     if op["res_buf"] >= 0:
         rd += out_px * store * FMT_BYTES[P.bufs[op["res_buf"]]["is_f32"]]
-    rd += op["cout_pad"] * op["ksize"] ** 2 * op["cin"] * (2 if ib["is_f32"] == FMT_BF16 else 4 if ib["is_f32"] == FMT_F32 else 6)
+    rd += op["cout_pad"] * op["ksize"] ** 2 * op["cin"] * (1 if ib["is_f32"] == FMT_FP8 else 2 if ib["is_f32"] == FMT_BF16 else 4 if ib["is_f32"] == FMT_F32 else 6)
     return dict(read=float(rd), write=float(wr))
 
 

@@ -332,6 +332,7 @@ int vgh_conv_cfg_cout_tile(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cf
 static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) return 0;
     if (a.grp_cout && a.grp_cout % g_cfgs[cfg].BC) return 0;
+    if ((a.in_fp8 || a.out_fp8) && g_cfgs[cfg].patch != 5) return 0;  // e4m3 links: g tiles only (conv_pp.hip)
     if ((g_cfgs[cfg].patch == 5 || g_cfgs[cfg].patch == 6) && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || !vgh_conv_pp_fits(a))) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
     if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
     return 1;
@@ -379,6 +380,10 @@ int pick_size_only(const ConvArgs& a) {  // last resort: largest plain implicit-
 }  // namespace
 
 int vgh_conv_pick_cfg(const ConvArgs& a) {
+    if (a.in_fp8 || a.out_fp8) {  // e4m3 links run on the g tiles: the widest cout tile that divides the layer
+        static const int g128 = cfg_by_name("g8x8x128_n8"), g96 = cfg_by_name("g8x8x96_n8"), g64 = cfg_by_name("g8x8x64_n8");
+        return a.cout_pad % 128 == 0 ? g128 : a.cout_pad % 96 == 0 ? g96 : g64;
+    }
     // A measured per-layer table (tuning/*.json) overrides this through force_cfg.
     static int row_cfg[kNumHeur];
     static bool resolved = false;
@@ -407,6 +412,7 @@ int vgh_conv_pick_cfg(const ConvArgs& a) {
 
 int vgh_conv_prepare(ConvArgs& a) {
     VGH_REQUIRE(a.cin % 32 == 0 && a.cin > 0, "conv: cin=%d must be a positive multiple of 32", a.cin);
+    VGH_REQUIRE(!(a.in_fp8 || a.out_fp8) || (a.ksize == 3 && a.stride == 1 && !a.split && !a.out_f32), "conv: e4m3 tensors link 3x3 / stride-1 convs only");
     VGH_REQUIRE(a.cout_pad % 32 == 0 && a.cout_pad > 0, "conv: cout_pad=%d must be a multiple of 32", a.cout_pad);
     VGH_REQUIRE(a.ksize == 1 || a.ksize == 3, "conv: ksize=%d unsupported", a.ksize);
     VGH_REQUIRE(a.in_coff % 8 == 0 && a.in_pitch % 8 == 0, "conv: input channel offset / pitch must keep 16-byte alignment");

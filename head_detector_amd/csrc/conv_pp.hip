@@ -60,6 +60,8 @@
 #define PP_PRIO 1  // s_setprio 1 around: 1 the M phase (MFMAs), 2 the L phase (fragment reads + LDS-DMA issue), 0 nothing (A/B knob)
 #endif
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
 namespace {
 
@@ -90,6 +92,32 @@ __device__ __forceinline__ unsigned max_pk(unsigned d, unsigned bound) {
     typedef __attribute__((ext_vector_type(2))) short s16x2;
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, bound)));
 }
+// ---- fp8 (OCP e4m3fn) variants (r05; SURVEY 8(f) N4, the reference's own exporter offers INT8 / FP16: yolo_head_training/yolo_head/exportable_mesh_model.py:175-178,398-411) ----
+// F8 = 1: the INPUT tensor and the weights are e4m3 bytes.  A 64-byte halo record / weight row then holds 64 channels instead of 32, a "channel block" is 64
+// channels, and one v_mfma_f32_32x32x64_f8f6f4 (16 passes: twice the bf16 FLOPs per cycle) replaces the two 32x32x16 bf16 MFMAs of a (cout group, pixel group)
+// pair -- same LDS geometry, same fragment reads (a lane's two 16-byte chunks of a row are the low and the high half of the instruction's 32-byte operand; the
+// K order inside a block is irrelevant as long as weights and activations use the same one, which the shared chunk -> lane map guarantees), same barrier slots.
+// O8 = 1: the OUTPUT tensor is e4m3 (no residual): 32 couts of a pixel = 32 contiguous bytes = one 16-byte store of each half-wave.
+// Either way the epilogue multiplies by a per-cout factor g[c] staged in LDS beside the bias: F8: g = weight_scale[c] * input_scale (/ output_scale), the bias
+// vector arrives pre-divided by it (host, vgh_net_create / vgh_conv2d); bf16 -> fp8: g = 1 / output_scale.
+__device__ __forceinline__ i32x8_t cat8(bf16x8_t lo, bf16x8_t hi) {
+    return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x16_t mfma_f8(bf16x8_t alo, bf16x8_t ahi, bf16x8_t blo, bf16x8_t bhi, f32x16_t c) {
+    // cbsz = blgp = 0: both operands e4m3; scale operands 0 -> hipcc selects the unscaled v_mfma_f32_32x32x64_f8f6f4
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(alo, ahi), cat8(blo, bhi), c, 0, 0, 0, 0, 0, 0);
+}
+// four floats -> four e4m3 bytes (element 0 in the low byte), clamped to [lo, 448] first: the convert itself does not saturate in every mode
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d, float lo) {
+    a = __builtin_amdgcn_fmed3f(a, lo, 448.0f);
+    b = __builtin_amdgcn_fmed3f(b, lo, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, lo, 448.0f);
+    d = __builtin_amdgcn_fmed3f(d, lo, 448.0f);
+    int r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
 // lanes 32-63 of `a` trade places with lanes 0-31 of `b`
 __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -97,7 +125,7 @@ __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
     b = r[1];
 }
 
-template <int TI, int V = 1>
+template <int TI, int V = 1, int SC = 0>
 struct PPGeo {
     static constexpr int BC = 32 * TI, NW = 8;
     static constexpr int XU = 7;           // 16-pixel LDS-DMA units of a wave's 10 x 10 halo (100 of 112 records used)
@@ -108,7 +136,8 @@ struct PPGeo {
     static constexpr int WOFF = NW * 2 * XST;
     static constexpr int DUMMY = WOFF + NWS * WST;
     static constexpr int BIAS = DUMMY + 1024;  // the layer's bias vector (<= 2048 couts), staged once per workgroup
-    static constexpr int LDS = BIAS + 8192;
+    static constexpr int GS = BIAS + 8192;     // fp8 variants: the per-cout output factors g[c] (same shape as the bias vector)
+    static constexpr int LDS = GS + (SC ? 8192 : 0);
 };
 
 struct PPDiv {  // n / d == (umulhi(n, m) + n) >> s for n < 2^30 (vgh_fastdiv_magic): the three divisions of a tile decode
@@ -126,9 +155,12 @@ struct PPTile {
     int b, y0, x0;
 };
 
-template <int TI, int V>
+template <int TI, int V, int F8 = 0, int O8 = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk, const PPDiv dv) {
-    using G = PPGeo<TI, V>;
+    constexpr int SC = (F8 || O8) ? 1 : 0;  // per-cout output factors in the epilogue
+    constexpr int ES = F8 ? 1 : 2;          // bytes per input element
+    static_assert(!(F8 || O8) || (V == 1 && PP_BAR_TAIL == 0 && PP_RES_PREFETCH == 0), "fp8 variants: g tiles only");
+    using G = PPGeo<TI, V, SC>;
     constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
     // out-of-range marker for buffer offsets (descriptor range 2 GiB): still out of range, and not wrapped past 2^32, after the immediate / scalar
     // offsets the instructions add (channel offsets of the epilogue, weight k-block offsets < 2^30)
@@ -162,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         t.x0 = (rem - sy * nsx) * 8;
         // byte offset of halo record (0, 0) = input pixel (y0 - 1, x0 - 1): wave-uniform (scalar) and possibly "negative" -- only in-range records add up to an
         // offset that is used
-        hb.base = 2 * (((t.b * a.H + t.y0 - 1) * a.W + t.x0 - 1) * in_pitch + a.in_coff);
+        hb.base = ES * (((t.b * a.H + t.y0 - 1) * a.W + t.x0 - 1) * in_pitch + a.in_coff);
         hb.y0m1 = t.spok ? t.y0 - 1 : -64;  // a missing sub-patch: every record out of range
         hb.x0m1 = t.x0 - 1;
         wv = (t.valid && w < WU) ? (unsigned)(lane * 16 + w * 1024) : OOB;
@@ -172,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     // lane geometry would cost registers across the whole K loop; the opaque lane copy stops hipcc from hoisting it -- and, for the NEXT tile, just in time in the
     // L phase that issues the unit (r04 trace: decoding all seven units at the top of the last channel block cost every SIMD ~2 000 cycles per tile with all
     // eight waves in it at once; inside an L phase the other group's MFMAs cover it)
-    const unsigned rowb = 2u * (unsigned)(a.W * in_pitch), pixb = 2u * (unsigned)in_pitch;
+    const unsigned rowb = (unsigned)ES * (unsigned)(a.W * in_pitch), pixb = (unsigned)ES * (unsigned)in_pitch;
     auto unit_off = [&](int u, const PPHalo& hb) -> unsigned {
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
@@ -234,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     dma16(wbase_cur, wv_cur, (unsigned)(1 * ncb) * wkstride, wdst + 1 * wdst_step);
     if constexpr (V == 2) dma16(wbase_cur, wv_cur, (unsigned)(2 * ncb) * wkstride, wdst + 2 * wdst_step);
     dma16(a.bias, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::BIAS + w * 1024);
+    if constexpr (SC) dma16(a.gscale, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::GS + w * 1024);
     wait_vm<0>();
     barrier_raw();
     if constexpr (V == 1) {
@@ -488,7 +521,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     // its epilogue shares a barrier slot with group 0's (which follows group 0's side of this barrier) instead of taking a slot of its own
                     const bool closing = !(PP_EPI_SAME_SLOT && T == 8 && last && grp);
                     constexpr int NM = TI * 4, BAR_AT = NM - (PP_BAR_TAIL < NM ? PP_BAR_TAIL : NM - 1);
-                    if (!VGH_ABLATE(a, 2)) {
+                    if constexpr (F8) {
+                        if (!VGH_ABLATE(a, 2)) {
+#pragma unroll
+                            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f8(a0[i], a1[i], b0[j], b1[j], acc[i][j]);
+                        }
+                    } else if (!VGH_ABLATE(a, 2)) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -546,14 +586,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x80000000, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, 0x80000000, 0x00020000);
             const int cbase = cur.c0;
-            const int dsplit = (a.out_coff2 - a.out_split - a.out_coff) * 2;  // byte shift of the second output segment
+            constexpr int OS = O8 ? 1 : 2;                                     // bytes per output element
+            const int dsplit = (a.out_coff2 - a.out_split - a.out_coff) * OS;  // byte shift of the second output segment
             unsigned ovb[2], rvb[2];  // byte offsets of this lane's pixel + channel (cbase + 8 hi) in the output / residual tensor
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int y = cur.y0 + 4 * j + (n32 >> 3), x = cur.x0 + (n32 & 7);
                 const bool okpx = cur.spok && y < a.Ho && x < a.Wo;
                 const int opix = (cur.b * a.Ho + y) * a.Wo + x;
-                ovb[j] = okpx ? (unsigned)((opix * (int)a.out_pitch + a.out_coff + cbase + 8 * hi) * 2) : OOB;
+                // bf16: a lane ends up with couts cbase + 32 i + 16 m + 8 hi .. + 7; e4m3: with couts cbase + 32 i + 16 hi .. + 15
+                ovb[j] = okpx ? (unsigned)((opix * (int)a.out_pitch + a.out_coff + cbase + (O8 ? 16 : 8) * hi) * OS) : OOB;
                 rvb[j] = okpx ? (unsigned)((opix * (int)a.res_pitch + a.res_coff + cbase + 8 * hi) * 2) : OOB;
             }
             // order: residual loads of pixel group 0 -> arithmetic of group 0 (results held) -> residual loads of group 1 -> stores of group 0 ->
@@ -581,6 +623,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     for (int m = 0; m < 2; ++m) {
                         // after the exchange this lane holds couts cv .. cv + 7; before it, runs q = 2m and q = 2m + 1 (couts 32 i + 8 q + 4 hi + e)
                         unsigned pa0, pa1, pb0, pb1;
+                        if constexpr (SC) {  // fp8 input: accumulator units -> real units, per cout (g > 0: commutes with the ReLU below)
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq) {
+                                const f32x4_t gv = *(const f32x4_t*)(smem + G::GS + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] *= gv[e];
+                            }
+                        }
                         if constexpr (RES) {
                             float va[4], vb[4];
 #pragma unroll
@@ -637,7 +687,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                 else
                     store_out(j, std::false_type{});
             };
-            if (a.res) {
+            // e4m3 output (no residual): runs q = 0 .. 3 of a cout group -> four packed dwords; two half-wave exchanges leave every lane with 16 consecutive couts
+            const float lo8 = a.act == VGH_ACT_RELU ? 0.0f : -448.0f;
+            auto arith8 = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    unsigned R[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t gv = *(const f32x4_t*)(smem + G::GS + (cbase + i * 32 + q * 8 + hi * 4) * 4);
+                        R[q] = pack_fp8x4(acc[i][j][q * 4 + 0] * gv[0], acc[i][j][q * 4 + 1] * gv[1], acc[i][j][q * 4 + 2] * gv[2], acc[i][j][q * 4 + 3] * gv[3], lo8);
+                    }
+                    swap32(R[0], R[2]);  // lower half-wave: couts 0-3, 4-7, 8-11, 12-15 in R0, R2, R1, R3; upper: 16-19, 20-23, 24-27, 28-31
+                    swap32(R[1], R[3]);
+                    ov[i][0] = u32x4_t{R[0], R[2], R[1], R[3]};
+                }
+            };
+            auto stores8 = [&](int j) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    if (VGH_ABLATE(a, 128))
+                        asm volatile("" ::"v"(ov[i][0]));
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(ov[i][0], rs_out, ovb[j] + seg + i * 32, 0, 0);
+                }
+            };
+            if constexpr (O8) {
+                arith8(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                stores8(0);
+                __builtin_amdgcn_sched_barrier(0);
+                arith8(std::integral_constant<int, 1>{});
+            } else if (a.res) {
                 load_res(0);
                 __builtin_amdgcn_sched_barrier(0);
                 arith(std::integral_constant<int, 0>{}, std::true_type{});
@@ -672,7 +754,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             __builtin_amdgcn_sched_barrier(0);                                                                                                    \
         }                                                                                                                                         \
     }
-            if (simple) {  // wave-uniform branch AROUND the loop (no runtime condition per vector)
+            if constexpr (O8) {  // one 16-byte store per cout group, the next tile's bias for that group behind it
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    if (VGH_ABLATE(a, 128))
+                        asm volatile("" ::"v"(ov[i][0]));
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(ov[i][0], rs_out, ovb[1] + seg + i * 32, 0, 0);
+                    if constexpr (PP_INIT_IN_EPILOGUE) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_INIT_ROWS(i, 0, nxt.c0);
+                        PP_INIT_ROWS(i, 1, nxt.c0);
+                        PP_INIT_ROWS(i, 2, nxt.c0);
+                        PP_INIT_ROWS(i, 3, nxt.c0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if (simple) {  // wave-uniform branch AROUND the loop (no runtime condition per vector)
                 PP_TAIL_STORES(true)
             } else {
                 PP_TAIL_STORES(false)
@@ -700,13 +798,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 }
 
 constexpr int kMaxDev = 16;
-template <int TI, int V>
+template <int TI, int V, int F8 = 0, int O8 = 0>
 int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, int chunk, int max_blocks_per_xcd, hipStream_t st) {
+    using G = PPGeo<TI, V, (F8 || O8) ? 1 : 0>;
     static std::atomic<int> done[kMaxDev];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
     if (!done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (PPGeo<TI, V>::LDS)));
+        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V, F8, O8>, hipFuncAttributeMaxDynamicSharedMemorySize, (G::LDS)));
         done[dev].store(1, std::memory_order_release);
     }
     int gpx = 32;  // one workgroup per CU, 32 CUs per XCD
@@ -716,7 +815,7 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
     vgh_fastdiv_magic((unsigned)ntc, &dv.m_ntc, &dv.s_ntc);
     vgh_fastdiv_magic((unsigned)(nsy * nsx), &dv.m_per, &dv.s_per);
     vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
-    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V>), dim3(gpx * 8), dim3(512), (PPGeo<TI, V>::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V, F8, O8>), dim3(gpx * 8), dim3(512), (G::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -726,13 +825,21 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
 // the epilogue addresses the output and residual tensors through buffer descriptors: 32-bit byte offsets
 int vgh_conv_pp_fits(const ConvArgs& a) {
     const int64_t lim = (1ll << 31) - 4096;
-    return (int64_t)a.P * a.out_pitch * 2 < lim && (!a.res || (int64_t)a.P * a.res_pitch * 2 < lim) && a.cout_pad <= 2048 &&
+    return (int64_t)a.P * a.out_pitch * (a.out_fp8 ? 1 : 2) < lim && (!a.res || (int64_t)a.P * a.res_pitch * 2 < lim) && a.cout_pad <= 2048 &&
            (int64_t)a.W * a.in_pitch * 2 < (1 << 24);  // one input row in 24 bits: the halo offsets are 24-bit multiply-adds
 }
 int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4, 2>::LDS : bc == 96 ? PPGeo<3, 2>::LDS : bc == 64 ? PPGeo<2, 2>::LDS : 0; }
+static_assert(PPGeo<4, 1, 1>::LDS <= 160 * 1024, "e4m3 g tiles: bias + factor vectors must fit the 160 KB LDS");
 
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_per_xcd, hipStream_t stream) {
-    VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && !a.split && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 convs only");
+    VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && !a.split && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 / e4m3 convs only");
+    if (a.in_fp8 || a.out_fp8) {
+        VGH_REQUIRE(version == 1, "conv: the e4m3 variants exist for the g tiles only");
+        VGH_REQUIRE(a.gscale, "conv: an e4m3 conv needs its per-cout output factors (gscale)");
+        VGH_REQUIRE(!a.in_fp8 || (a.cin % 64 == 0 && a.in_coff % 16 == 0 && a.in_pitch % 16 == 0), "conv: an e4m3 input view needs cin %% 64 == 0 and 16-byte aligned offset / pitch (cin=%d)", a.cin);
+        VGH_REQUIRE(!a.out_fp8 || (!a.res && a.cout_store == a.cout_pad && (a.out_split >= a.cout_pad || a.out_split % bc == 0) && a.out_coff % 16 == 0 && a.out_coff2 % 16 == 0 && a.out_pitch % 16 == 0),
+                    "conv: an e4m3 output takes whole cout tiles, 16-byte aligned segments and no residual");
+    }
     VGH_REQUIRE(a.cout_pad % bc == 0 && a.cout_pad <= 2048, "conv: cout_pad %d is not a multiple of the %d-cout ping-pong tile (or above 2048)", a.cout_pad, bc);
     VGH_REQUIRE(vgh_conv_pp_fits(a), "conv: output / residual tensor above 2 GiB (32-bit buffer offsets), or an input row above 16 MiB");
     const int nsx = (a.Wo + 7) / 8, nsy = (a.Ho + 7) / 8, ntc = a.cout_pad / bc;
@@ -740,6 +847,20 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
     const int64_t total = (nsp + 7) / 8 * ntc;
     VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
     const int chunk = (int)((total + 7) / 8);
+    if (a.in_fp8 || a.out_fp8) {
+        const int f = a.in_fp8 ? 1 : 0, o = a.out_fp8 ? 1 : 0;
+#define PP_F8_CASE(TI_)                                                                                            \
+    if (bc == 32 * TI_) {                                                                                          \
+        if (f && o) return launch_pp<TI_, 1, 1, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream); \
+        if (f) return launch_pp<TI_, 1, 1, 0>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);      \
+        return launch_pp<TI_, 1, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);             \
+    }
+        PP_F8_CASE(4)
+        PP_F8_CASE(3)
+        PP_F8_CASE(2)
+#undef PP_F8_CASE
+        VGH_REQUIRE(false, "conv: no e4m3 ping-pong tile with %d couts", bc);
+    }
     switch (bc + (version == 2 ? 1 : 0)) {
         case 128: return launch_pp<4, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
         case 96: return launch_pp<3, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
@@ -750,4 +871,65 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
     }
     VGH_REQUIRE(false, "conv: no ping-pong tile with %d couts", bc);
     return VGH_OK;
+}
+
+// ---- e4m3 host side ------------------------------------------------------------------------------------------------------------------------
+// fp32 -> OCP e4m3fn (1-4-3, bias 7, no infinities, 0x7f / 0xff = NaN), round to nearest even, SATURATING at +-448 (what v_cvt_pk_fp8_f32 does to a value
+// the epilogue has clamped; torch.float8_e4m3fn rounds the same way below the clamp)
+uint8_t vgh_f32_to_e4m3_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return sign | 0x7f;
+    float a = f < 0 ? -f : f;
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < 0.015625f) {  // below 2^-6: subnormal grid of 2^-9 (8 * 2^-9 = the smallest normal, whose code is 8 as well)
+        const float q = __builtin_nearbyintf(a * 512.0f);
+        return sign | (uint8_t)q;
+    }
+    int e;
+    const float m = frexpf(a, &e);  // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                  // a = (2m) * 2^E, 2m in [1, 2)
+    int r = (int)__builtin_nearbyintf((2.0f * m - 1.0f) * 8.0f);
+    if (r == 8) {
+        r = 0;
+        ++E;
+    }
+    if (E > 8 || (E == 8 && r == 7)) return sign | 0x7e;
+    return sign | (uint8_t)(((E + 7) << 3) | r);
+}
+
+// dense [cout_pad][ks][ks][cin] f32 -> e4m3 image [tap * (cin / 64) + cb][cout][64 B] (16-byte chunks swizzled like the bf16 image: slot = chunk ^ ((cout >> 2) & 3))
+// with one POWER-OF-TWO scale per cout: stored = rn_e4m3(w / wscale[c]), wscale[c] = 2^ceil(log2(max|w[c]| / 448)) (1 for an all-zero row): the division is exact,
+// every weight is rounded once
+void vgh_pack_conv_weights_fp8_host(const float* w, int cout_pad, int ksize, int cin, uint8_t* dst, float* wscale) {
+    const int cblocks = cin / 64, taps = ksize * ksize;
+    const size_t row = (size_t)taps * cin;
+    for (int co = 0; co < cout_pad; ++co) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < row; ++i) {
+            const float v = fabsf(w[(size_t)co * row + i]);
+            if (v > mx) mx = v;  // (a NaN weight never compares greater: it is converted to the NaN code below)
+        }
+        float sc = 1.0f;
+        if (mx > 0.0f && mx <= 3.0e38f) {
+            int e;
+            frexpf(mx / 448.0f, &e);  // mx / 448 = m * 2^e, m in [0.5, 1): 2^e >= mx / 448
+            sc = ldexpf(1.0f, e);
+            if (mx / 448.0f == ldexpf(1.0f, e - 1)) sc = ldexpf(1.0f, e - 1);  // an exact power of two
+        }
+        wscale[co] = sc;
+    }
+    for (int tap = 0; tap < taps; ++tap)
+        for (int cb = 0; cb < cblocks; ++cb) {
+            const int kb = tap * cblocks + cb;
+            for (int co = 0; co < cout_pad; ++co) {
+                const float* src = w + ((size_t)co * taps + tap) * cin + cb * 64;
+                uint8_t* d = dst + ((size_t)kb * cout_pad + co) * 64;
+                const int sw = (co >> 2) & 3;
+                const float inv = 1.0f / wscale[co];
+                for (int chunk = 0; chunk < 4; ++chunk)
+                    for (int e = 0; e < 16; ++e) d[(chunk ^ sw) * 16 + e] = vgh_f32_to_e4m3_host(src[chunk * 16 + e] * inv);
+            }
+        }
 }

@@ -65,9 +65,9 @@ int vgh_create(const vgh_config* cfg, vgh_ctx** out) {
     std::vector<float> w, b, v_template, shapedirs, posedirs, jreg, lbsw;
     std::vector<int32_t> parents;
     bool ok = read_exact(f, &h, sizeof(h)) && memcmp(h.magic, "VGHPACK", 8) == 0;
-    if (ok && h.version != 2) {
+    if (ok && h.version != 3) {
         fclose(f);
-        VGH_REQUIRE(false, "vgh_create: %s is pack version %u, this library reads version 2", cfg->pack_path, h.version);
+        VGH_REQUIRE(false, "vgh_create: %s is pack version %u, this library reads version 3 (vgh_buf_desc.scale, r05)", cfg->pack_path, h.version);
     }
     ok = ok && h.n_bufs > 0 && h.n_ops > 0 && h.n_levels > 0 && h.n_levels <= VGH_MAX_LEVELS && h.n_weights > 0 && h.n_biases > 0 && h.header_bytes >= sizeof(h) &&
          fseek(f, h.header_bytes, SEEK_SET) == 0;

@@ -31,6 +31,7 @@ struct NetOp {
     // the input view is WIDER than the buffer's pitch (the 48-channel stem tensor read as 64-channel K blocks): channels past the pitch are the next
     // pixel's first ones; vgh_net_create has verified that every weight row is exactly zero there (finite x 0 adds +-0 to the accumulator)
     int overhang_ok = 0;
+    float* gscale = nullptr;  // device [cout_pad]: per-cout output factors of an op that reads or writes a VGH_FMT_FP8 buffer (conv_pp.hip), else nullptr
 };
 
 struct vgh_net {
@@ -105,8 +106,14 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->res = d.res_buf >= 0 ? (const uint16_t*)((const char*)n->buf_ptr[d.res_buf] + at * buf_image_bytes(n->bufs[d.res_buf])) : nullptr;
     a->res_pitch = d.res_buf >= 0 ? (int64_t)n->bufs[d.res_buf].pitch * vgh_fmt_planes(n->bufs[d.res_buf].is_f32) : 0;
     a->res_plane = d.res_buf >= 0 ? n->bufs[d.res_buf].pitch : 0;
-    VGH_REQUIRE(a->out_f32 || ob.is_f32 == ib.is_f32, "net: op writes buffer %d in another 16-bit format than it reads", d.out_buf);
-    VGH_REQUIRE(d.res_buf < 0 || n->bufs[d.res_buf].is_f32 == ib.is_f32, "net: residual buffer %d has another format than the input", d.res_buf);
+    // e4m3 links (r05): bf16 -> e4m3, e4m3 -> bf16 and e4m3 -> e4m3 are legal pairs (3x3 / stride-1 convs on the ping-pong tiles); the residual of such an op is bf16
+    const bool in8 = ib.is_f32 == VGH_FMT_FP8, out8 = ob.is_f32 == VGH_FMT_FP8;
+    a->in_fp8 = in8;
+    a->out_fp8 = out8;
+    a->gscale = op.gscale;
+    VGH_REQUIRE(a->out_f32 || ob.is_f32 == ib.is_f32 || (in8 && ob.is_f32 == VGH_FMT_BF16) || (out8 && ib.is_f32 == VGH_FMT_BF16), "net: op writes buffer %d in another format than it reads", d.out_buf);
+    VGH_REQUIRE(d.res_buf < 0 || n->bufs[d.res_buf].is_f32 == (in8 ? VGH_FMT_BF16 : ib.is_f32), "net: residual buffer %d has another format than the input", d.res_buf);
+    VGH_REQUIRE(!(in8 || out8) || (d.ksize == 3 && d.stride == 1 && !d.grp_cout && !d.shuffle && (!in8 || d.cin % 64 == 0)), "net: an e4m3 buffer can only link plain 3x3 / stride-1 convs (cin %% 64 == 0)");
     a->res_coff = d.res_coff;
     a->alpha = d.alpha;
     a->act = d.act;
@@ -114,7 +121,7 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->shuffle_c = d.shuffle ? d.cout_pad / 4 : 0;
     a->zeros = n->zeros;
     a->P = B * a->Ho * a->Wo;
-    a->cblocks = d.cin / 32;
+    a->cblocks = d.cin / (in8 ? 64 : 32);  // 64-byte channel blocks
     a->nkb = d.ksize * d.ksize * a->cblocks;
     const int eh = d.shuffle ? 2 * a->Ho : a->Ho, ew = d.shuffle ? 2 * a->Wo : a->Wo;
     VGH_REQUIRE(ob.h == eh && ob.w == ew, "net: op output buffer %d is %dx%d, conv produces %dx%d", d.out_buf, ob.h, ob.w, eh, ew);
@@ -269,7 +276,8 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     int64_t off = 0;
     std::vector<int64_t> offs(n_bufs);
     for (int i = 0; i < n_bufs; ++i) {
-        VGH_REQUIRE(bufs[i].is_f32 >= VGH_FMT_BF16 && bufs[i].is_f32 <= VGH_FMT_F16X2, "net_create: buffer %d has unknown format %d", i, bufs[i].is_f32);
+        VGH_REQUIRE(bufs[i].is_f32 >= VGH_FMT_BF16 && bufs[i].is_f32 <= VGH_FMT_FP8, "net_create: buffer %d has unknown format %d", i, bufs[i].is_f32);
+        VGH_REQUIRE(bufs[i].is_f32 != VGH_FMT_FP8 || (bufs[i].scale > 0.0f && bufs[i].scale < 1e30f && bufs[i].pitch % 16 == 0), "net_create: e4m3 buffer %d needs a positive scale and a pitch that is a multiple of 16", i);
         const int64_t bytes = (int64_t)max_batch * bufs[i].h * bufs[i].w * bufs[i].pitch * vgh_fmt_bytes(bufs[i].is_f32);
         offs[i] = off;
         n->buf_bytes.push_back(bytes);
@@ -286,7 +294,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     for (int l = 0; l < vgh_net::kLanes; ++l) VGH_HIP(hipEventCreateWithFlags(&n->ev_lag[l], hipEventDisableTiming));
     // ---- weights: pack on the host, one upload ----
     int64_t wbytes = 0;
-    std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0);
+    std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0), goff(n_ops, -1);
     for (int i = 0; i < n_ops; ++i) {
         const vgh_op_desc& d = ops[i];
         if (d.kind == VGH_OP_CONV) {
@@ -305,9 +313,13 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             }
             woff[i] = wbytes;
             const int wf = bufs[d.in_buf].is_f32;  // weight image: bf16 (2 B), dense fp32 (4 B) or the three 16-bit segments of the split modes (6 B)
-            wbytes += align_up(we * (wf == VGH_FMT_BF16 ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
+            wbytes += align_up(we * (wf == VGH_FMT_FP8 ? 1 : wf == VGH_FMT_BF16 ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
             boff[i] = wbytes;
             wbytes += align_up((int64_t)d.cout_pad * 4, 256);
+            if (wf == VGH_FMT_FP8 || bufs[d.out_buf].is_f32 == VGH_FMT_FP8) {
+                goff[i] = wbytes;
+                wbytes += align_up((int64_t)d.cout_pad * 4, 256);
+            }
         } else if (d.kind == VGH_OP_STEM) {
             VGH_REQUIRE(d.w_off >= 0 && d.w_off + 27 * 48 <= n_weights && d.b_off + 48 <= n_biases, "net_create: stem weight range");
             woff[i] = wbytes;
@@ -344,9 +356,29 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
                 memcpy(host.data() + woff[i], weights_host + d.w_off, (size_t)d.cout_pad * d.ksize * d.ksize * d.cin * 4);
             else if (wf == VGH_FMT_BF16)
                 vgh_pack_conv_weights_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint16_t*)(host.data() + woff[i]));
+            else if (wf == VGH_FMT_FP8)
+                ;  // below: the e4m3 image comes with per-cout scales that also enter the bias
             else
                 vgh_pack_conv_weights_split_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, wf, (uint16_t*)(host.data() + woff[i]), &oscale[i]);
             memcpy(host.data() + boff[i], biases_host + d.b_off, (size_t)d.cout_pad * 4);
+            if (goff[i] >= 0) {
+                // e4m3 links: out = act(acc * g + bias) with g[c] = wscale[c] * scale(in) for an e4m3 input (1 for bf16), divided by scale(out) for an e4m3 output.
+                // The kernel starts its accumulator at the bias, so the bias is stored in accumulator units: bias / (wscale[c] * scale(in)).
+                float* g = (float*)(host.data() + goff[i]);
+                float* bq = (float*)(host.data() + boff[i]);
+                const float s_out = bufs[d.out_buf].is_f32 == VGH_FMT_FP8 ? bufs[d.out_buf].scale : 1.0f;
+                if (wf == VGH_FMT_FP8) {
+                    std::vector<float> ws(d.cout_pad);
+                    vgh_pack_conv_weights_fp8_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint8_t*)(host.data() + woff[i]), ws.data());
+                    for (int c = 0; c < d.cout_pad; ++c) {
+                        const float acc_unit = ws[c] * bufs[d.in_buf].scale;
+                        bq[c] = bq[c] / acc_unit;
+                        g[c] = acc_unit / s_out;
+                    }
+                } else {
+                    for (int c = 0; c < d.cout_pad; ++c) g[c] = 1.0f / s_out;
+                }
+            }
         } else if (d.kind == VGH_OP_STEM) {
             // host gives [48][3(ky)][3(kx)][3(ci)] -> device [27][48]
             float* dst = (float*)(host.data() + woff[i]);
@@ -366,6 +398,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             op.wf32 = (float*)(n->wblob + woff[i]);  // same storage: bf16 image (throughput mode) or dense fp32 (parity mode)
             op.bias = (float*)(n->wblob + boff[i]);
             op.overhang_ok = (!ops[i].grp_cout && ops[i].in_coff + ops[i].cin > bufs[ops[i].in_buf].pitch) ? 1 : 0;  // zero weight columns verified above
+            if (goff[i] >= 0) op.gscale = (float*)(n->wblob + goff[i]);
         } else if (ops[i].kind == VGH_OP_STEM) {
             op.wf32 = (float*)(n->wblob + woff[i]);
             op.bias = (float*)(n->wblob + boff[i]);
@@ -557,7 +590,7 @@ int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {
     const bool split_net = vgh_fmt_planes(n->bufs[n->ops[op_index].d.kind == VGH_OP_CONV ? n->ops[op_index].d.in_buf : 0].is_f32) > 1;
     VGH_REQUIRE(cfg >= -1 && cfg < (split_net ? vgh_conv_split_num_cfgs() : vgh_conv_num_cfgs()), "net_set_cfg: bad cfg");
     NetOp& op = n->ops[op_index];
-    if (cfg >= 0 && op.d.kind == VGH_OP_CONV && !split_net && n->bufs[op.d.in_buf].is_f32 == VGH_FMT_BF16) {
+    if (cfg >= 0 && op.d.kind == VGH_OP_CONV && !split_net && (n->bufs[op.d.in_buf].is_f32 == VGH_FMT_BF16 || n->bufs[op.d.in_buf].is_f32 == VGH_FMT_FP8)) {
         // eligibility is decided ONCE, for the arena batch: a tile that fits a small chunk but not max_batch (the ping-pong tiles' 2 GiB rule depends on the
         // pixel count) would otherwise run some batch sizes and silently fall back on others -- two summation orders for one op, against the "same bits for
         // any chunk" invariant of NetOp::auto_cfg.  Such a tile is replaced by the automatic one for every batch, and the replacement is logged.
@@ -589,7 +622,11 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     const int planes = vgh_fmt_planes(c->fmt);
-    VGH_REQUIRE(c->fmt == VGH_FMT_BF16 || c->fmt == VGH_FMT_BF16X2 || c->fmt == VGH_FMT_F16X2, "conv2d: fmt %d", c->fmt);
+    VGH_REQUIRE(c->fmt == VGH_FMT_BF16 || c->fmt == VGH_FMT_BF16X2 || c->fmt == VGH_FMT_F16X2 || c->fmt == VGH_FMT_FP8, "conv2d: fmt %d", c->fmt);
+    a.in_fp8 = c->fmt == VGH_FMT_FP8;
+    a.out_fp8 = c->out_fp8 ? 1 : 0;
+    a.gscale = c->gscale_dev;
+    VGH_REQUIRE(!(a.in_fp8 || a.out_fp8) || (c->gscale_dev && (c->fmt == VGH_FMT_FP8 || c->fmt == VGH_FMT_BF16) && !c->out_f32), "conv2d: an e4m3 conv needs gscale_dev, a bf16 or e4m3 input and no fp32 output");
     a.split = planes > 1 ? c->fmt : 0;
     a.in_plane = (int)c->in_pitch;
     a.out_plane = (int)c->out_pitch;
@@ -628,7 +665,7 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream) {
     a.shuffle_c = c->shuffle ? c->cout_pad / 4 : 0;
     a.zeros = g_zeros[dev];
     a.P = c->B * a.Ho * a.Wo;
-    a.cblocks = c->cin / 32;
+    a.cblocks = c->cin / (a.in_fp8 ? 64 : 32);
     a.nkb = c->ksize * c->ksize * a.cblocks;
     return vgh_launch_conv(a, c->force_cfg, (hipStream_t)stream);
 }
@@ -637,6 +674,13 @@ int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin,
     VGH_REQUIRE(w_host && wpack_host, "pack: null argument");
     VGH_REQUIRE(cin % 32 == 0 && cout_pad % 32 == 0 && (ksize == 1 || ksize == 3), "pack: cin/cout_pad must be multiples of 32, ksize 1 or 3");
     vgh_pack_conv_weights_host(w_host, cout_pad, ksize, cin, wpack_host);
+    return VGH_OK;
+}
+
+int vgh_pack_conv_weights_fp8(const float* w_host, int cout_pad, int ksize, int cin, uint8_t* wpack_host, float* wscale_host) {
+    VGH_REQUIRE(w_host && wpack_host && wscale_host, "pack_fp8: null argument");
+    VGH_REQUIRE(cin % 64 == 0 && cout_pad % 32 == 0 && ksize == 3, "pack_fp8: cin must be a multiple of 64, cout_pad of 32, ksize 3");
+    vgh_pack_conv_weights_fp8_host(w_host, cout_pad, ksize, cin, wpack_host, wscale_host);
     return VGH_OK;
 }
 

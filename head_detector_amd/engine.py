@@ -80,7 +80,12 @@ def _alias(ptr: int, shape, typestr: str, device: torch.device) -> torch.Tensor:
 class VGHeadsEngine:
     def __init__(self, variant: str = "vgg_heads_l", state_dict: Optional[Dict[str, np.ndarray]] = None, image_size: int = 640, max_batch: int = 1,
                  device: Optional[int] = None, seed: int = 1, pre_nms_top_k: int = 1000, keep_top_k: int = 100, use_tuning: bool = True,
-                 arena_batch: Optional[int] = None, precision: str = "bf16"):
+                 arena_batch: Optional[int] = None, precision: str = "bf16", fp8_scales: Optional[Dict[str, float]] = None, calib_images: Optional[torch.Tensor] = None,
+                 fp8_min_px: int = 40):
+        """``precision="fp8"`` (r05): the bf16 network with OCP-e4m3 links between 3x3 / stride-1 convs (arch.build_program).  Every link needs the largest
+        activation it will carry: ``fp8_scales`` {link name: max|x|} from an earlier ``calibrate_fp8``, or ``calib_images`` (u8 NHWC / f32 NCHW GPU batch of
+        representative inputs) to run that calibration now; with neither, two seeded random images are used -- adequate for the synthetic benchmark, NOT for
+        real weights and real photographs."""
         if variant not in arch.VARIANTS:
             raise ValueError(f"unknown model variant {variant!r}; known: {sorted(arch.VARIANTS)}")
         if not torch.cuda.is_available():
@@ -92,14 +97,21 @@ class VGHeadsEngine:
         if state_dict is None:
             state_dict = arch.random_state_dict(variant, seed)  # synthetic weights of the exact architecture
         self.precision = precision
-        self.program = arch.build_program(variant, state_dict, image_size, precision)
+        self.fp8_scales = None
+        if precision == "fp8":
+            if fp8_scales is None:
+                if calib_images is None:
+                    calib_images = torch.randint(0, 256, (2, image_size, image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(12345)).to(torch.device("cuda", self.device_index))
+                fp8_scales = calibrate_fp8(variant, state_dict, image_size, calib_images, self.device_index, fp8_min_px)
+            self.fp8_scales = dict(fp8_scales)
+        self.program = arch.build_program(variant, state_dict, image_size, precision, fp8_scales=self.fp8_scales, fp8_min_px=fp8_min_px)
         P = self.program
         # the conv loader addresses an input tensor with 32-bit byte offsets: keep every arena tensor below 2 GiB by running
         # large batches through the network in chunks (post-network stages always see the whole batch)
         per_image = max(bf["h"] * bf["w"] * bf["pitch"] * arch.FMT_BYTES[bf["is_f32"]] for bf in P.bufs)
         self.arena_batch = max(1, min(max_batch, ((1 << 31) - 1) // per_image, arena_batch or max_batch))
         w, b = P.arrays()
-        bufs = (_lib.BufDesc * len(P.bufs))(*[_lib.BufDesc(bf["h"], bf["w"], bf["pitch"], bf["is_f32"]) for bf in P.bufs])
+        bufs = (_lib.BufDesc * len(P.bufs))(*[_lib.BufDesc(bf["h"], bf["w"], bf["pitch"], bf["is_f32"], float(bf.get("scale", 0.0))) for bf in P.bufs])
         fields = [f for f, _ in _lib.OpDesc._fields_]
         ops = (_lib.OpDesc * len(P.ops))(*[_lib.OpDesc(**{f: (op.get(f, 0) if f != "in_buf" else max(op[f], 0)) for f in fields}) for op in P.ops])
         h = C.c_void_p()
@@ -141,7 +153,7 @@ class VGHeadsEngine:
         self._head_out = None  # (capacity, head_image, proj, rpy) allocated on first FLAME use
         self._levels = None
         self._graph_key = None
-        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp16x3", "bf16x3"))  # the split modes have their own keys (precision prefix) and tile set
+        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp8", "fp16x3", "bf16x3"))  # the split modes have their own keys (precision prefix) and tile set
         self.nsplit = 1
         if self._use_tuning:
             self.load_tuning()
@@ -184,6 +196,9 @@ class VGHeadsEngine:
         fmt = bf["is_f32"]
         n = B * bf["h"] * bf["w"] * bf["pitch"]
         self.stream.synchronize()
+        if fmt == arch.FMT_FP8:  # e4m3 link: decoded to fp32 (stored * scale)
+            t = _alias(self.lib.vgh_net_buffer(self._net, bid), (n,), "|u1", self.device).clone().view(torch.float8_e4m3fn).float() * bf["scale"]
+            return t.view(B, bf["h"], bf["w"], bf["pitch"])
         if fmt in (arch.FMT_BF16X2, arch.FMT_F16X2):
             t = _alias(self.lib.vgh_net_buffer(self._net, bid), (2 * n,), "<i2", self.device).clone().view(B, bf["h"], bf["w"], 2, bf["pitch"])
             t = t.view(torch.bfloat16 if fmt == arch.FMT_BF16X2 else torch.float16).float()
@@ -443,14 +458,30 @@ class VGHeadsEngine:
         names = {n: i for i, n in enumerate(self.cfg_names())}
         applied = 0
         for i, op in enumerate(self.program.ops):
-            if op["kind"] != 1:
+            if op["kind"] != 1 or arch.op_touches_fp8(self.program, op):  # e4m3 links run on the g tile the library picks
                 continue
-            pre = "" if self.precision == "bf16" else self.precision + ":"
+            pre = "" if self.precision in ("bf16", "fp8") else self.precision + ":"
             name = tuning_lookup(table, op, self.max_batch, getattr(self, "nsplit", 1), pre)
             if name in names and self.cfg_ok(names[name], op):  # a stale entry (a tile that cannot run this op) is skipped here, not replaced -- and logged -- by the library
                 self.set_cfg(i, names[name])
                 applied += 1
         return applied
+
+
+def calibrate_fp8(variant: str, state_dict: Optional[Dict[str, np.ndarray]], image_size: int, images: torch.Tensor, device: Optional[int] = None, fp8_min_px: int = 40) -> Dict[str, float]:
+    """{e4m3 link name: max|activation|} of the "fp8" program, measured on ``images`` with the bf16 engine (every tensor of a forward stays in the arena: single
+    assignment), for ``VGHeadsEngine(precision="fp8", fp8_scales=...)`` / ``arch.build_program(..., fp8_scales=...)``.  Pass images like the ones the detector will see."""
+    B = int(images.shape[0])
+    eng = VGHeadsEngine(variant, state_dict, image_size, max_batch=B, device=device, precision="bf16", use_tuning=False)
+    try:
+        eng.forward_net(images)
+        eng.stream.synchronize()
+        out = {}
+        for link, (src, live) in arch.fp8_link_names(variant, image_size, fp8_min_px).items():
+            out[link] = float(eng.buffer(src, B)[..., :live].float().abs().max())
+        return out
+    finally:
+        eng.close()
 
 
 def tuning_key(op: dict, batch: int, nsplit: int = 1, bucket: Optional[int] = None, res: Optional[bool] = None) -> str:

@@ -9,7 +9,7 @@ seeded synthetic weights of the exact architecture (what the benchmarks use: the
 `--batch/--split` select the tile-table bucket (head_detector_amd/tuning/conv_cfg.json) the per-op choices are resolved for.
 Pure host code: packing needs neither a GPU nor libvgh.so.
 
-Layout (little-endian):  header (128 B: magic "VGHPACK\\0", version 2, header_bytes, variant[32], image_size, precision,
+Layout (little-endian):  header (128 B: magic "VGHPACK\\0", version 3, header_bytes, variant[32], image_size, precision,
 n_bufs, n_ops, n_levels, shape_c, expr_c, has_flame, tune_batch, reserved, flops_per_image f64, n_weights i64, n_biases i64,
 V, NB, NJ, F) | vgh_buf_desc[n_bufs] | vgh_op_desc[n_ops] | char tile_name[n_ops][32] | level[n_levels]{buf,h,w,pitch,stride} |
 f32 weights | f32 biases | FLAME: v_template[V,3] shapedirs[V,3,NB] posedirs[(NJ-1)*9,3V] J_regressor[NJ,V] parents[NJ] i32
@@ -30,7 +30,7 @@ import numpy as np
 from . import _lib, arch
 
 MAGIC = b"VGHPACK\0"
-VERSION = 2  # 2: vgh_op_desc grew grp_cout / grp_in_stride; precision = VGH_FMT_* of the activation buffers
+VERSION = 3  # 2: vgh_op_desc grew grp_cout / grp_in_stride; precision = VGH_FMT_* of the activation buffers; 3 (r05): vgh_buf_desc grew `scale` (VGH_FMT_FP8 links)
 HEADER_BYTES = 128
 _HDR = "<8sII32s8i2idqq4i"
 assert struct.calcsize(_HDR) == HEADER_BYTES
@@ -57,7 +57,7 @@ def write_pack(path: str, program: "arch.Program", flame_model: Optional[Dict[st
     w, b = P.arrays()
     fields = [f for f, _ in _lib.OpDesc._fields_]
     ops = (_lib.OpDesc * len(P.ops))(*[_lib.OpDesc(**{f: (op.get(f, 0) if f != "in_buf" else max(op[f], 0)) for f in fields}) for op in P.ops])
-    bufs = (_lib.BufDesc * len(P.bufs))(*[_lib.BufDesc(bf["h"], bf["w"], bf["pitch"], bf["is_f32"]) for bf in P.bufs])
+    bufs = (_lib.BufDesc * len(P.bufs))(*[_lib.BufDesc(bf["h"], bf["w"], bf["pitch"], bf["is_f32"], float(bf.get("scale", 0.0))) for bf in P.bufs])
     names = np.zeros((len(P.ops), 32), dtype=np.uint8)
     for i, nm in (tile_names or {}).items():
         raw = nm.encode()[:31]
@@ -107,10 +107,10 @@ def tile_names_for(program: "arch.Program", batch: int, nsplit: int = 1, table_p
     if not os.path.exists(path):
         return {}
     table = json.load(open(path))
-    pre = "" if program.precision == "bf16" else program.precision + ":"  # the split-precision modes have their own keys and tile names
+    pre = "" if program.precision in ("bf16", "fp8") else program.precision + ":"  # the split-precision modes have their own keys and tile names
     out = {}
     for i, op in enumerate(program.ops):
-        if op["kind"] != 1:
+        if op["kind"] != 1 or arch.op_touches_fp8(program, op):  # e4m3 links run on the g tile the library picks
             continue
         name = tuning_lookup(table, op, batch, nsplit, pre)
         if name:

@@ -38,9 +38,9 @@ const char* vgh_last_error(void);
 
 /* ABI revision of this header: bumped whenever a struct below grows or a function changes meaning (r03 -> 3: vgh_conv_call / vgh_op_desc gained
  * grp_cout, grp_in_stride, fmt, out_scale and vgh_flame_set_matrix_path became a 0..4 mode; r04 -> 4: this call; -> 5: modes 0..7 of
- * vgh_flame_set_matrix_path).  A client built against another
+ * vgh_flame_set_matrix_path; r05 -> 6: VGH_FMT_FP8, vgh_buf_desc.scale, vgh_conv_call.out_fp8 / gscale_dev, vgh_pack_conv_weights_fp8).  A client built against another
  * revision passes structs of another size: compare before the first call that takes one (head_detector_amd/_lib.py and tests/c_abi_smoke.c do). */
-#define VGH_ABI_VERSION 5
+#define VGH_ABI_VERSION 6
 int vgh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -60,11 +60,14 @@ int vgh_abi_version(void);
 #define VGH_FMT_F32 1    /* fp32 NHWC: head prediction outputs in every mode; every buffer in the fp32 (VALU) parity mode */
 #define VGH_FMT_BF16X2 2 /* split parity mode: per pixel [hi C | lo C] bf16, value = hi + lo (16 significand bits) */
 #define VGH_FMT_F16X2 3  /* split parity mode: per pixel [hi C | lo C] fp16, value = hi + lo / 2048 (22 significand bits) */
+#define VGH_FMT_FP8 4    /* r05, "fp8" throughput mode: OCP e4m3fn bytes, value = stored * vgh_buf_desc.scale.  Only on links between two 3x3 / stride-1  */
+                         /*   convs that run on the ping-pong tiles (csrc/conv_pp.hip): written by one, read by one; every other tensor stays bf16     */
 
 typedef struct vgh_buf_desc {
     int32_t h, w;   /* spatial size per image */
     int32_t pitch;  /* LOGICAL channels per pixel (concat width); 16-bit formats: multiple of 8; the two-plane formats occupy 2*pitch */
     int32_t is_f32; /* VGH_FMT_* */
+    float scale;    /* VGH_FMT_FP8: value = stored * scale (> 0; from a calibration forward: max|activation| / 448 with head-room); other formats: ignored */
 } vgh_buf_desc;
 
 typedef struct vgh_op_desc {
@@ -143,11 +146,20 @@ typedef struct vgh_conv_call {
     int32_t fmt;                         /* VGH_FMT_BF16 (0) or a split format: then in/out/res pitches are the LOGICAL pitches, the lo planes   */
                                          /*   sit `pitch` elements behind the hi planes, wpack_dev comes from vgh_pack_conv_weights_split        */
     float out_scale;                     /*   and out_scale is what that call returned                                                           */
+                                         /* fmt = VGH_FMT_FP8 (3x3 / stride 1, ping-pong tiles only): in_dev holds e4m3 bytes (in_pitch / in_coff count   */
+                                         /*   bytes, cin % 64 == 0), wpack_dev comes from vgh_pack_conv_weights_fp8, res_dev stays bf16, and bias_dev     */
+                                         /*   holds bias[c] / gscale[c] (the accumulator starts there and is multiplied by gscale[c] at the end)          */
+    int32_t out_fp8;                     /* 1: out_dev receives e4m3 bytes (out_pitch / offsets count bytes; whole cout tiles, no residual)               */
+    const float* gscale_dev;             /* [cout_pad] per-cout output factor: e4m3 in: wscale[c] * input scale (/ output scale when out_fp8);           */
+                                         /*   bf16 in, e4m3 out: 1 / output scale.  NULL otherwise                                                       */
 } vgh_conv_call;
 int vgh_conv2d(const vgh_conv_call* c, void* stream);
 /* Split-precision weight image (parity modes): dense [cout_pad][k][k][cin] f32 -> 3*cout_pad*k*k*cin u16 ([w_lo | w_hi | w_hi] segments);
  * *out_scale receives the accumulator scale of the op (see vgh_conv_call.out_scale). */
 int vgh_pack_conv_weights_split(const float* w_host, int cout_pad, int ksize, int cin, int fmt, uint16_t* wpack_host, float* out_scale);
+/* e4m3 weight image of the ping-pong tiles: dense [cout_pad][k][k][cin] f32 -> cout_pad*k*k*cin bytes + one power-of-two scale per cout
+ * (stored = rn_e4m3(w / wscale[c])); cin % 64 == 0, k = 3. */
+int vgh_pack_conv_weights_fp8(const float* w_host, int cout_pad, int ksize, int cin, uint8_t* wpack_host, float* wscale_host);
 /* dense [cout_pad][k][k][cin] f32 (host) -> kernel-private bf16 image (host, cout_pad*k*k*cin u16) */
 int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin, uint16_t* wpack_host);
 int vgh_conv_num_cfgs(void);

@@ -348,12 +348,12 @@ def test_pack_file_round_trip(tmp_path):
     assert (h["variant"], h["image_size"], h["n_ops"], h["n_bufs"], h["n_levels"], h["shape_c"], h["expr_c"], h["has_flame"], h["tune_batch"]) == \
         ("vgg_heads_m", 128, len(P.ops), len(P.bufs), 3, 64, 32, 1, 32)
     assert (h["V"], h["NB"], h["NJ"]) == (5023, 400, 5) and abs(h["flops_per_image"] - P.flops) < 1
-    assert C.sizeof(_lib.OpDesc) == 104 and C.sizeof(_lib.BufDesc) == 16
+    assert C.sizeof(_lib.OpDesc) == 104 and C.sizeof(_lib.BufDesc) == 20
     w, b = P.arrays()
     flame_bytes = 4 * (5023 * 3 + 5023 * 3 * 400 + 36 * 3 * 5023 + 5 * 5023 + 5 + 5023 * 5) + 4 * 3 * h["F"]
-    assert n == 128 + 16 * len(P.bufs) + (104 + 32) * len(P.ops) + 20 * 3 + 4 * (w.size + b.size) + flame_bytes
+    assert n == 128 + 20 * len(P.bufs) + (104 + 32) * len(P.ops) + 20 * 3 + 4 * (w.size + b.size) + flame_bytes
     raw = open(path, "rb").read()
-    off = 128 + 16 * len(P.bufs)
+    off = 128 + 20 * len(P.bufs)
     ops = (_lib.OpDesc * len(P.ops)).from_buffer_copy(raw[off : off + 104 * len(P.ops)])
     assert [o.cout_pad for o in ops] == [op["cout_pad"] for op in P.ops] and [o.w_off for o in ops] == [op["w_off"] for op in P.ops]
     tn = np.frombuffer(raw[off + 104 * len(P.ops) : off + 136 * len(P.ops)], dtype="S32")
