@@ -41,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+MFMA_FP8_DENSE_PEAK_TFLOPS = 5000.0  # same guide: ~5 PFLOP/s dense fp8 (v_mfma_f32_32x32x64_f8f6f4)
 NORTH_STAR_IMG_PER_S_PER_GPU = 1250.0  # BASELINE.json north_star: >= 10k images/sec on 8 GPUs
 
 
@@ -620,7 +621,8 @@ def main():
             eng.set_split(1)  # per-op events make sense on one stream only: the table is the single-stream view of every op
             json.dump(eng.profile_ops(images), open(per_layer_path, "w"), indent=0)
         alg = arch.program_algorithmic_bytes(eng.program, B)
-        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,
+        fp8_flops = 2.0 * sum(op["macs"] for op in eng.program.ops if arch.op_touches_fp8(eng.program, op) and eng.program.bufs[op["in_buf"]]["is_f32"] == arch.FMT_FP8)
+        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, fp8_flops_per_image=fp8_flops, fp8_links=sum(bf["is_f32"] == arch.FMT_FP8 for bf in eng.program.bufs), heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,
                    value=B * world * nfw / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,
                    alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch, power=power.summary(), exchange_dropped_rows=dropped, per_rank=per_rank)
         thr = throttle.summary()
@@ -731,6 +733,18 @@ def main():
                 "fp32_valu_mode": {"workload": f"{args.variant} fp32 (v_fma_f32, csrc/conv_f32.hip) batch 8 @ {S}", **brief(pv)}}
             print(f"[bench] parity mode fp16x3 {args.variant} batch 32 @ {S}: {pm['value']:.1f} img/s (target {NORTH_STAR_IMG_PER_S_PER_GPU:.0f}/GPU), net {pm['net_ms']:.3f} ms; "
                   f"fp32 VALU mode batch 8: {pv['value']:.1f} img/s", file=sys.stderr)
+            # N4 (r05): the "fp8" mode -- bf16 with OCP-e4m3 links between 3x3 / stride-1 convs (csrc/conv_pp.hip) -- timed by the same loop.  Its roof is MIXED: the
+            # convs that read an e4m3 link are priced at the 5 PFLOP/s fp8 peak, everything else at the bf16 peak
+            f8 = run_workload(args.variant, B, max(20, sec_steps // 2), max(3, args.warmup // 2), precision="fp8", inner=max(1, args.inner))
+            f8_fl, all_fl = f8["fp8_flops_per_image"] * B, f8["flops_per_image"] * B
+            ideal_ms = (f8_fl / (MFMA_FP8_DENSE_PEAK_TFLOPS * 1e12) + (all_fl - f8_fl) / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12)) * 1e3
+            config["secondary_fp8_links"] = dict(
+                brief(f8), workload=f"{args.variant} fp8 links batch {B} @ {S}", e4m3_link_tensors=f8["fp8_links"], share_of_flops_on_fp8_mfma=round(f8_fl / all_fl, 4),
+                roofline_frac_vs_mixed_roof=round(ideal_ms / f8["net_ms"], 4), mixed_roof_ms_per_forward=round(ideal_ms, 3), speedup_vs_bf16_headline=round(f8["value"] / main_run["value"], 4),
+                note="roofline_frac above is against the bf16 peak (algorithmic FLOPs / time / 2.5 PF), roofline_frac_vs_mixed_roof prices the e4m3-input convs at 5 PF; "
+                     "activation scales calibrated on two seeded random images; deviation from the oracle: modes_vs_oracle_one_image.fp8")
+            print(f"[bench] fp8 links {args.variant} batch {B} @ {S}: {f8['value']:.1f} img/s ({f8['value'] / main_run['value']:.3f} x the bf16 headline), net {f8['net_ms']:.3f} ms, "
+                  f"{100 * f8_fl / all_fl:.1f} % of the FLOPs on the fp8 MFMA, {ideal_ms / f8['net_ms']:.3f} of the mixed roof", file=sys.stderr)
             # BASELINE configs[0]'s shape on the GPU: ONE 640 x 640 image per call, the caller waits for the result (the reference's own API is single-image)
             config["latency_one_image_synchronous"] = {v: one_image_latency(v) for v in ("vgg_heads_l", "vgg_heads_m")}
         # roofline.traffic: HBM bytes of one forward of the main workload
@@ -765,7 +779,7 @@ def main():
             line["cpu_baseline"], ref = cpu_baseline(args.variant, S, flame_model)
             if not args.no_accuracy and S == 640:
                 # checker role of the oracle: every precision mode on the oracle's image (parity_mode.vs_oracle is what north_star's bar reads)
-                dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16")}
+                dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16", "fp8")}
                 config.setdefault("parity_mode", {})["vs_oracle"] = dev_tab["fp16x3"]
                 config["modes_vs_oracle_one_image"] = dev_tab
         print(json.dumps(line))
