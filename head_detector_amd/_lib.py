@@ -110,6 +110,7 @@ SYMBOLS = {
     "vgh_net_set_lane_lag": (_I, [_I]),
     "vgh_net_set_fuse_stem": (_I, [_P, _I]),
     "vgh_net_set_pred_guard": (_I, [_P, _P]),
+    "vgh_stem_set_mfma": (_I, [_I]),
     "vgh_net_max_batch": (_I, [_P]),
     "vgh_net_image_size": (_I, [_P]),
     "vgh_conv2d": (_I, [C.POINTER(ConvCall), _P]),

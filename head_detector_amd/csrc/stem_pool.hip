@@ -186,6 +186,140 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ i
     }
 }
 
+// ---- stem on the matrix cores (r05, bf16 throughput mode, u8 images) ----------------------------------------------------------------------
+// The VALU kernel above is exact fp32 and VALU-bound: 27 x 48 FMAs per output pixel = 17 GFLOP per 64 images at ~35 % of the vector rate is 0.31 ms, 2.6 x the
+// time its 0.7 GB of traffic needs.  In the bf16 mode the stem's OUTPUT is rounded to bf16 anyway, so here the layer is a K = 27 (padded
+// to 32) bf16 GEMM: a u8 pixel value is exact in bf16 (8 significant bits), the /255 of detector.py:51 is folded into the weights (w / 255 rounded to bf16 --
+// the one new rounding, 2^-9 relative on a weight, below the bf16 rounding of the output), fp32 accumulate from the bias.  Per 32-pixel group and wave:
+// 4 x v_mfma_f32_32x32x16_bf16 (two cout groups x two k slices) instead of 648 v_pk_fma_f32 per lane.  Same 16 x 16 tile, same LDS-transposed full-line stores.
+// The parity modes (and float images) keep the exact kernel.
+__device__ __forceinline__ unsigned stem_pack_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf2));
+}
+template <int NCH>
+__global__ __launch_bounds__(256, 4) void stem_mfma_kernel(const uint8_t* __restrict__ image, int H, int W, const float* __restrict__ wgt /*[27][48]*/, const float* __restrict__ bias /*[48]*/,
+                                                        uint16_t* __restrict__ out, int64_t out_pitch, int out_coff) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr int PR = 100;  // bf16 values per patch row: 33 pixels x 3 channels (+1)
+    __shared__ __attribute__((aligned(16))) char smem_raw[256 * 8 * 16];  // the 32 KiB output staging aliases the 6.6 KB patch (dead once the fragments are in registers)
+    uint16_t* patch = (uint16_t*)smem_raw;                               // [33][PR]: bf16(u8 value) of image pixel (2 ty - 1 + r, 2 tx - 1 + c), channel ci at [r][3 c + ci]
+    bf16x8_t* stage = (bf16x8_t*)smem_raw;
+    const int Ho = H / 2, Wo = W / 2;
+    const int b = blockIdx.z, ty = blockIdx.y * ST, tx = blockIdx.x * ST;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n32 = lane & 31, hi = lane >> 5;
+    const int iy_base = ty * 2 - 1, ix_base = tx * 2 - 1;
+    // ---- weights: this lane's A fragments.  Lane (n32, hi) of cout group i, k slice s holds w[k = 16 s + 8 hi + e][cout = 32 i + n32] / 255, e = 0 .. 7 ----
+    float wf[2][2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * sl + 8 * hi + e, co = 32 * i + n32;
+                wf[i][sl][e] = (k < 27 && co < STEM_CO) ? wgt[k * STEM_CO + co] : 0.0f;
+            }
+    // ---- image patch: 33 x 99 bytes, one byte per load, all of a lane's loads in flight together ----
+    constexpr int NLD = (3 * SIN * SIN + 255) / 256;
+    int pq[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int e = tid + it * 256;
+        const int r = e / (SIN * 3), rem = e - r * SIN * 3, c = rem / 3;
+        const int iy = iy_base + r, ix = ix_base + c;
+        int q = 0;
+        if (e < 3 * SIN * SIN && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) q = image[(((int64_t)b * H + iy) * W) * 3 + (int64_t)ix_base * 3 + rem];
+        pq[it] = q;
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int e = tid + it * 256;
+        if (e >= 3 * SIN * SIN) break;
+        const int r = e / (SIN * 3), rem = e - r * SIN * 3;
+        patch[r * PR + rem] = (uint16_t)(__float_as_uint((float)pq[it]) >> 16);  // 0 .. 255 is exact in bf16
+    }
+    bf16x8_t afr[2][2];
+    const float inv255 = 1.0f / 255.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const u32x4 v = {stem_pack_bf16(wf[i][sl][0] * inv255, wf[i][sl][1] * inv255), stem_pack_bf16(wf[i][sl][2] * inv255, wf[i][sl][3] * inv255),
+                             stem_pack_bf16(wf[i][sl][4] * inv255, wf[i][sl][5] * inv255), stem_pack_bf16(wf[i][sl][6] * inv255, wf[i][sl][7] * inv255)};
+            afr[i][sl] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    __syncthreads();
+    // ---- B fragments: pixel p = 64 wv + 32 g + n32 of the tile, k = 16 s + 8 hi + e -> patch[(2 ly + k / 9) * PR + 6 lx + k % 9] ----
+    bf16x8_t bfr[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int pidx = 64 * wv + 32 * g + n32, ly = pidx / ST, lx = pidx % ST;
+        const uint16_t* pb = patch + (2 * ly) * PR + 6 * lx;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            unsigned hv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k0 = 16 * sl + e, k1 = k0 + 8;  // this element's k for hi = 0 / hi = 1 (k1 < 27 unless sl = 1 and e >= 3)
+                const int o0 = (k0 / 9) * PR + k0 % 9, o1 = k1 < 27 ? (k1 / 9) * PR + k1 % 9 : 0;
+                const unsigned v = pb[hi ? o1 : o0];
+                hv[e] = (hi && k1 >= 27) ? 0u : v;
+            }
+            const u32x4 v = {hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
+            bfr[g][sl] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    __syncthreads();  // the patch is dead: its memory becomes the staging buffer
+    // ---- accumulate from the bias: register 4 q + e of lane (n32, hi) is cout 32 i + 8 q + 4 hi + e of pixel n32 ----
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = 32 * i + 8 * q + 4 * hi + e;
+                const float bv = co < STEM_CO ? bias[co] : 0.0f;
+                acc[0][i][4 * q + e] = bv;
+                acc[1][i][4 * q + e] = bv;
+            }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) acc[g][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[i][sl], bfr[g][sl], acc[g][i], 0, 0, 0);
+    // ---- ReLU, bf16, half-wave exchange: lane (n32, hi) ends with couts 32 i + 16 m + 8 hi .. + 7 of its pixel = 16-byte chunk 4 i + 2 m + hi ----
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int pidx = 64 * wv + 32 * g + n32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (4 * i + 2 * m >= NCH) continue;
+                unsigned pa0 = stem_pack_bf16(fmaxf(acc[g][i][8 * m + 0], 0.0f), fmaxf(acc[g][i][8 * m + 1], 0.0f)), pa1 = stem_pack_bf16(fmaxf(acc[g][i][8 * m + 2], 0.0f), fmaxf(acc[g][i][8 * m + 3], 0.0f));
+                unsigned pb0 = stem_pack_bf16(fmaxf(acc[g][i][8 * m + 4], 0.0f), fmaxf(acc[g][i][8 * m + 5], 0.0f)), pb1 = stem_pack_bf16(fmaxf(acc[g][i][8 * m + 6], 0.0f), fmaxf(acc[g][i][8 * m + 7], 0.0f));
+                auto r0 = __builtin_amdgcn_permlane32_swap(pa0, pb0, false, false);  // lanes 32-63 of pa trade places with lanes 0-31 of pb
+                auto r1 = __builtin_amdgcn_permlane32_swap(pa1, pb1, false, false);
+                const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+                const int ch = 4 * i + 2 * m + hi;
+                stage[pidx * 8 + (ch ^ (pidx & 7))] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+        const int e = it * 256 + tid;
+        const int p = e / NCH, ch = e - p * NCH;  // consecutive lanes write consecutive 16-byte chunks: whole lines also across the 96-byte pixels of NCH = 6
+        const int oy = ty + (p / ST), ox = tx + (p % ST);
+        if (oy < Ho && ox < Wo)
+            *(bf16x8_t*)(out + (((int64_t)b * Ho + oy) * Wo + ox) * out_pitch + out_coff + ch * 8) = stage[p * 8 + (ch ^ (p & 7))];
+    }
+}
+
 // ---- SPP ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8_t max8(bf16x8_t a, bf16x8_t b) {
     bf16x8_t r;
@@ -298,6 +432,13 @@ __global__ __launch_bounds__(256) void spp_pool_split_kernel(uint16_t* __restric
 
 }  // namespace
 
+#include <atomic>
+static std::atomic<int> g_stem_mfma{1};
+extern "C" int vgh_stem_set_mfma(int on) {
+    g_stem_mfma.store(on ? 1 : 0, std::memory_order_relaxed);
+    return VGH_OK;
+}
+
 int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w, const float* bias, uint16_t* out, int64_t out_pitch,
                     int out_coff, int store_ch, int fmt, int plane, hipStream_t stream) {
     VGH_REQUIRE(store_ch == 64 || (store_ch == 48 && fmt == VGH_FMT_BF16), "stem: stores 64 channels (48 + 16 zeros), or 48 in the bf16 mode; got %d", store_ch);
@@ -319,6 +460,14 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
         else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, VGH_FMT_BF16X2, 1.0f);
     } else {
         VGH_REQUIRE(fmt == VGH_FMT_BF16, "stem: output format %d", fmt);
+        if (u8 && g_stem_mfma.load(std::memory_order_relaxed)) {  // bf16 mode, u8 image: the layer on the matrix cores (stem_mfma_kernel)
+            if (store_ch == 48)
+                hipLaunchKernelGGL((stem_mfma_kernel<6>), grid, dim3(256), 0, stream, (const uint8_t*)image, H, W, w, bias, out, out_pitch, out_coff);
+            else
+                hipLaunchKernelGGL((stem_mfma_kernel<8>), grid, dim3(256), 0, stream, (const uint8_t*)image, H, W, w, bias, out, out_pitch, out_coff);
+            VGH_HIP(hipGetLastError());
+            return VGH_OK;
+        }
         if (store_ch == 48) {
             if (u8) VGH_STEM_LAUNCH48(VGH_IMG_U8_NHWC);
             else VGH_STEM_LAUNCH48(VGH_IMG_F32_NCHW);

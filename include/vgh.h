@@ -118,6 +118,10 @@ int vgh_net_set_lane_lag(int ops);
  * pair in bf16: the 48-channel stem activation then never goes to HBM and its arena buffer is not written.  Results are bit-identical either way.
  * Default off: measured (r03) it removes 1.5 GB of traffic per 64-image forward but is no faster than the two launches (latency-bound small tiles). */
 int vgh_net_set_fuse_stem(vgh_net* net, int enable);
+/* Process-wide (default 1): in the bf16 mode the stem of a u8 image runs as a K = 27 bf16 GEMM on the matrix cores (csrc/stem_pool.hip::stem_mfma_kernel: pixel values
+ * are exact in bf16, /255 folded into bf16-rounded weights, fp32 accumulate) instead of the exact-fp32 VALU kernel: 2^-9 relative on a weight, below the bf16
+ * rounding of the stem's output.  0 restores the exact kernel (what float images and the parity modes always use). */
+int vgh_stem_set_mfma(int on);
 /* Borrowed HIP event (or NULL): the first op of the next forwards that writes a prediction buffer waits for it on its stream.
  * Lets a consumer of the previous forward's predictions run on another stream underneath this forward's backbone / neck. */
 int vgh_net_set_pred_guard(vgh_net* net, void* event);

@@ -649,10 +649,14 @@ def test_fused_stem_downsample_is_bit_identical(gpu_lib, variant, S, B, fmt):
     x = (torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g) if fmt == "u8" else torch.rand(B, 3, S, S, generator=g)).to(_dev())
     eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=3, use_tuning=False)
     outs = {}
-    for fuse in (True, False):
-        eng.set_fuse_stem(fuse)
-        eng.forward_net(x)
-        outs[fuse] = (eng.buffer("backbone.stage1.ds", B), [t.clone() for t in eng.model(x)])
+    try:
+        gpu_lib.vgh_stem_set_mfma(0)  # the fused kernel computes the EXACT fp32 stem: its two-launch twin is the exact stem kernel, not the (r05) matrix-core one
+        for fuse in (True, False):
+            eng.set_fuse_stem(fuse)
+            eng.forward_net(x)
+            outs[fuse] = (eng.buffer("backbone.stage1.ds", B), [t.clone() for t in eng.model(x)])
+    finally:
+        gpu_lib.vgh_stem_set_mfma(1)
     assert float(outs[True][0].float().abs().max()) > 0
     assert torch.equal(outs[True][0], outs[False][0]), "stage-1 downsample output differs"
     for a, b in zip(outs[True][1], outs[False][1]):
@@ -676,8 +680,12 @@ def test_stem_tensor_at_its_48_channel_pitch(gpu_lib, monkeypatch):
     g = torch.Generator().manual_seed(11)
     big = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g)
     x = torch.randint(0, 256, (2, S, S, 3), dtype=torch.uint8, generator=g)
-    eng.forward_net(big.to(_dev()))  # image 2's stem pixels stay in the arena behind the 2-image batch
-    eng.forward_net(x.to(_dev()))
+    try:
+        gpu_lib.vgh_stem_set_mfma(0)  # (i) compares with the exact fp32 reference bit for bit: the exact stem kernel (the matrix-core one has its own test below)
+        eng.forward_net(big.to(_dev()))  # image 2's stem pixels stay in the arena behind the 2-image batch
+        eng.forward_net(x.to(_dev()))
+    finally:
+        gpu_lib.vgh_stem_set_mfma(1)
     stem = eng.buffer("stem", 2).float().cpu()
     assert stem.shape == (2, S // 2, S // 2, 48)
     bufs = pr.alloc(P, 2)
@@ -709,13 +717,56 @@ def test_u8_nhwc_input_equals_f32_nchw(gpu_lib):
     eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=1, seed=3, use_tuning=False)
     u8 = torch.randint(0, 256, (1, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
     f = (u8.permute(0, 3, 1, 2).float() / 255.0).contiguous()
-    for fuse, name in ((False, "stem"), (True, "backbone.stage1.ds")):  # the stem kernel's own output; the fused stem + downsample kernel's output
-        eng.set_fuse_stem(fuse)
-        eng.forward_net(u8.to(_dev()))
-        a = eng.buffer(name, 1).float().cpu()
-        eng.forward_net(f.to(_dev()))
-        b = eng.buffer(name, 1).float().cpu()
-        assert float(a.abs().max()) > 0 and torch.equal(a, b), name
+    try:
+        gpu_lib.vgh_stem_set_mfma(0)  # the exact kernels: u8 and float images give the same bits (the matrix-core stem of u8 images: next test)
+        for fuse, name in ((False, "stem"), (True, "backbone.stage1.ds")):  # the stem kernel's own output; the fused stem + downsample kernel's output
+            eng.set_fuse_stem(fuse)
+            eng.forward_net(u8.to(_dev()))
+            a = eng.buffer(name, 1).float().cpu()
+            eng.forward_net(f.to(_dev()))
+            b = eng.buffer(name, 1).float().cpu()
+            assert float(a.abs().max()) > 0 and torch.equal(a, b), name
+    finally:
+        gpu_lib.vgh_stem_set_mfma(1)
+    eng.close()
+
+
+@pytest.mark.parametrize("variant,S,B,pitch", [("vgg_heads_l", 160, 3, 48), ("vgg_heads_m", 672, 1, 48), ("vgg_heads_m", 104, 2, 48), ("vgg_heads_l", 96, 2, 64)])
+def test_stem_on_the_matrix_cores_vs_exact_operand_reference(gpu_lib, monkeypatch, variant, S, B, pitch):
+    """r05 (VERDICT r04 item 1b): in the bf16 mode the stem of a u8 image is a K = 27 bf16 GEMM (csrc/stem_pool.hip::stem_mfma_kernel).  Its operands are exact --
+    pixel values 0 .. 255 in bf16, weights bf16(w / 255) -- so the reference is an fp64 conv of exactly those operands and what is left is fp32 accumulation
+    order + the bf16 rounding of the output (one ulp); against the exact-fp32 kernel it replaces it stays within two bf16 ulps (2^-9 per weight); image borders
+    on every side, maps that are not a multiple of the 16 x 16 tile (104 -> 52, 672 -> 336 = 21 tiles), the 64-channel pitch variant (stored zeros in 48 .. 63)."""
+    from head_detector_amd import arch
+    from head_detector_amd.engine import VGHeadsEngine
+
+    monkeypatch.setattr(arch, "STEM_PITCH_BF16", pitch)
+    sd = arch.random_state_dict(variant, 13)
+    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, use_tuning=False)
+    P = eng.program
+    assert P.bufs[0]["pitch"] == pitch
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(S))
+    x[0, :3] = 255  # saturated rows at the top border
+    eng.forward_net(x.to(_dev()))
+    got = eng.buffer("stem", B).float().cpu()
+    w_all, b_all = P.arrays()
+    op = P.ops[0]
+    W = torch.from_numpy(w_all[op["w_off"] : op["w_off"] + 48 * 27].reshape(48, 3, 3, 3).copy()).permute(0, 3, 1, 2).contiguous()
+    bias = torch.from_numpy(b_all[op["b_off"] : op["b_off"] + 48].copy())
+    Wq = (W * np.float32(1.0 / 255.0)).to(torch.bfloat16).double()
+    ref = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), Wq, bias.double(), stride=2, padding=1)).permute(0, 2, 3, 1).float()
+    assert got.shape == (B, S // 2, S // 2, pitch) and float(got.abs().max()) > 0
+    assert not ((got[..., :48] - ref).abs() > 2e-3 + 1.0 / 128 * ref.abs()).any(), float((got[..., :48] - ref).abs().max())
+    if pitch == 64:
+        assert float(got[..., 48:].abs().max()) == 0.0
+    try:
+        gpu_lib.vgh_stem_set_mfma(0)
+        eng.forward_net(x.to(_dev()))
+        exact = eng.buffer("stem", B).float().cpu()
+    finally:
+        gpu_lib.vgh_stem_set_mfma(1)
+    assert not ((got - exact).abs() > 4e-3 + 1.0 / 64 * exact.abs()).any(), float((got - exact).abs().max())
+    assert float((got != exact).float().mean()) > 0.001, "the knob did not switch kernels"
     eng.close()
 
 
