@@ -745,6 +745,11 @@ def main():
                      "activation scales calibrated on two seeded random images; deviation from the oracle: modes_vs_oracle_one_image.fp8")
             print(f"[bench] fp8 links {args.variant} batch {B} @ {S}: {f8['value']:.1f} img/s ({f8['value'] / main_run['value']:.3f} x the bf16 headline), net {f8['net_ms']:.3f} ms, "
                   f"{100 * f8_fl / all_fl:.1f} % of the FLOPs on the fp8 MFMA, {ideal_ms / f8['net_ms']:.3f} of the mixed roof", file=sys.stderr)
+            # r05: the single-plane fp16 mode (the reference's own FP16 export format: exportable_mesh_model.py:177,299,409) -- same bytes and MFMA count as bf16
+            fh = run_workload(args.variant, B, max(20, sec_steps // 2), max(3, args.warmup // 2), precision="fp16", inner=max(1, args.inner))
+            config["secondary_fp16"] = dict(brief(fh), workload=f"{args.variant} fp16 (one fp16 plane per value, v_mfma_f32_32x32x16_f16) batch {B} @ {S}", speed_vs_bf16_headline=round(fh["value"] / main_run["value"], 4),
+                                            note="untuned: the split modes' size rule + the fp16 ping-pong tiles (no per-layer table); deviation from the oracle: modes_vs_oracle_one_image.fp16")
+            print(f"[bench] fp16 {args.variant} batch {B} @ {S}: {fh['value']:.1f} img/s ({fh['value'] / main_run['value']:.3f} x the bf16 headline), net {fh['net_ms']:.3f} ms", file=sys.stderr)
             # BASELINE configs[0]'s shape on the GPU: ONE 640 x 640 image per call, the caller waits for the result (the reference's own API is single-image)
             config["latency_one_image_synchronous"] = {v: one_image_latency(v) for v in ("vgg_heads_l", "vgg_heads_m")}
         # roofline.traffic: HBM bytes of one forward of the main workload
@@ -779,7 +784,7 @@ def main():
             line["cpu_baseline"], ref = cpu_baseline(args.variant, S, flame_model)
             if not args.no_accuracy and S == 640:
                 # checker role of the oracle: every precision mode on the oracle's image (parity_mode.vs_oracle is what north_star's bar reads)
-                dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16", "fp8")}
+                dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16", "fp16", "fp8")}
                 config.setdefault("parity_mode", {})["vs_oracle"] = dev_tab["fp16x3"]
                 config["modes_vs_oracle_one_image"] = dev_tab
         print(json.dumps(line))

@@ -14,7 +14,7 @@ ABI_VERSION = 6  # = VGH_ABI_VERSION of include/vgh.h
 VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
 VGH_IMG_F32_NCHW, VGH_IMG_U8_NHWC = 0, 1
-VGH_FMT_BF16, VGH_FMT_F32, VGH_FMT_BF16X2, VGH_FMT_F16X2, VGH_FMT_FP8 = 0, 1, 2, 3, 4
+VGH_FMT_BF16, VGH_FMT_F32, VGH_FMT_BF16X2, VGH_FMT_F16X2, VGH_FMT_FP8, VGH_FMT_F16 = 0, 1, 2, 3, 4, 5
 NUM_FLAME_PARAMS = 413
 
 

@@ -42,11 +42,12 @@ VARIANTS: Dict[str, dict] = {
     ),
 }
 # activation storage formats (VGH_FMT_* of include/vgh.h; the buffer field keeps its historical name is_f32) per precision mode
-FMT_BF16, FMT_F32, FMT_BF16X2, FMT_F16X2, FMT_FP8 = 0, 1, 2, 3, 4
+FMT_BF16, FMT_F32, FMT_BF16X2, FMT_F16X2, FMT_FP8, FMT_F16 = 0, 1, 2, 3, 4, 5
 # "fp8" (r05) is the bf16 program with OCP-e4m3 LINKS: a tensor written by one 3x3 / stride-1 conv and read by one (bottleneck cv1 -> cv2, the middle layers of the
 # FLAME shape / expression branches) is stored as e4m3 bytes with a calibrated per-tensor scale, and its consumer runs v_mfma_f32_32x32x64_f8f6f4 (csrc/conv_pp.hip)
-PRECISION_FMT = {"bf16": FMT_BF16, "fp32": FMT_F32, "bf16x3": FMT_BF16X2, "fp16x3": FMT_F16X2, "fp8": FMT_BF16}
-FMT_BYTES = {FMT_BF16: 2, FMT_F32: 4, FMT_BF16X2: 4, FMT_F16X2: 4, FMT_FP8: 1}  # bytes per logical element
+# "fp16" (r05): ONE fp16 plane per value -- the reference's own FP16 export (exportable_mesh_model.py:177,299,409) -- same bytes and MFMA count as bf16, 11 significand bits
+PRECISION_FMT = {"bf16": FMT_BF16, "fp32": FMT_F32, "bf16x3": FMT_BF16X2, "fp16x3": FMT_F16X2, "fp8": FMT_BF16, "fp16": FMT_F16}
+FMT_BYTES = {FMT_BF16: 2, FMT_F32: 4, FMT_BF16X2: 4, FMT_F16X2: 4, FMT_FP8: 1, FMT_F16: 2}  # bytes per logical element
 FP8_MAX, FP8_HEADROOM = 448.0, 2.0  # scale of an e4m3 link = calibrated max|activation| * headroom / 448
 TR_OUTS = (("rotation", 6), ("jaw", 3), ("translation", 3), ("scale", 1))  # order of the transform branches in the prediction buffer
 STRIDES = (8, 16, 32)
@@ -399,7 +400,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     # bf16 throughput mode: the stem tensor is stored at its own 48-channel pitch (96-byte pixels); the stage-1 downsample still reads 64-channel K
     # windows, whose last 16 channels (the next pixel's first 16) meet the 16 zero weight columns _ohwi pads in below -- the executor verifies that at
     # vgh_net_create.  The parity modes keep the 64-channel pitch with stored zeros (a split pixel is [hi | lo] planes: no such window).
-    stem_pitch = STEM_PITCH_BF16 if precision == "bf16" else 64
+    stem_pitch = STEM_PITCH_BF16 if precision in ("bf16", "fp8") else 64
     stem_buf = P.buf("stem", S // 2, S // 2, stem_pitch)
     P.ops.append(dict(name="backbone.stem.conv", kind=0, in_buf=-1, in_coff=0, cin=3, out_buf=stem_buf, out_coff=0, cout_pad=64, cout_store=stem_pitch, out_split=64,
                       out_coff2=0, res_buf=-1, res_coff=0, alpha=0.0, ksize=3, stride=2, act=1, shuffle=0, w_off=wo, b_off=bo, force_cfg=-1,
@@ -652,7 +653,7 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     wr = out_px * store * eb_out
     if op["res_buf"] >= 0:
         rd += out_px * store * FMT_BYTES[P.bufs[op["res_buf"]]["is_f32"]]
-    rd += op["cout_pad"] * op["ksize"] ** 2 * op["cin"] * (1 if ib["is_f32"] == FMT_FP8 else 2 if ib["is_f32"] == FMT_BF16 else 4 if ib["is_f32"] == FMT_F32 else 6)
+    rd += op["cout_pad"] * op["ksize"] ** 2 * op["cin"] * (1 if ib["is_f32"] == FMT_FP8 else 2 if ib["is_f32"] in (FMT_BF16, FMT_F16) else 4 if ib["is_f32"] == FMT_F32 else 6)
     return dict(read=float(rd), write=float(wr))
 
 

@@ -312,6 +312,7 @@ int vgh_conv_set_nt_store(int on) {
     return VGH_OK;
 }
 
+int vgh_conv_max_blocks_per_xcd() { return g_max_blocks_per_xcd.load(std::memory_order_relaxed); }
 int vgh_conv_set_max_blocks_per_xcd(int blocks) {
     VGH_REQUIRE(blocks >= 0, "conv_set_max_blocks_per_xcd: negative");
     g_max_blocks_per_xcd.store(blocks, std::memory_order_relaxed);

@@ -118,6 +118,45 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
     return (unsigned)r;
 }
+// ---- single-plane fp16 variant (H16 = 1; VGH_FMT_F16, r05: the reference's own FP16 export, exportable_mesh_model.py:177,299,409): same tile, same bytes, same MFMA
+//      count as bf16 with v_mfma_f32_32x32x16_f16; the weights carry a per-op power-of-two prescale, so the accumulator starts at bias / out_scale and is multiplied by
+//      out_scale at the end; stores saturate at +-65504 ----
+template <int H16>
+__device__ __forceinline__ f32x16_t mfma16pp(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    if constexpr (H16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int H16>
+__device__ __forceinline__ unsigned pack16(float lo, float hi) {
+    if constexpr (H16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const f32x2_t f = {__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h2));
+    } else {
+        return pack_bf16(lo, hi);
+    }
+}
+template <int H16>
+__device__ __forceinline__ float unpack_lo(unsigned d) {
+    if constexpr (H16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        return (float)__builtin_bit_cast(h2, d)[0];
+    } else {
+        return bf_lo(d);
+    }
+}
+template <int H16>
+__device__ __forceinline__ float unpack_hi(unsigned d) {
+    if constexpr (H16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        return (float)__builtin_bit_cast(h2, d)[1];
+    } else {
+        return bf_hi(d);
+    }
+}
 // lanes 32-63 of `a` trade places with lanes 0-31 of `b`
 __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -155,11 +194,13 @@ struct PPTile {
     int b, y0, x0;
 };
 
-template <int TI, int V, int F8 = 0, int O8 = 0>
+template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk, const PPDiv dv) {
     constexpr int SC = (F8 || O8) ? 1 : 0;  // per-cout output factors in the epilogue
     constexpr int ES = F8 ? 1 : 2;          // bytes per input element
-    static_assert(!(F8 || O8) || (V == 1 && PP_BAR_TAIL == 0 && PP_RES_PREFETCH == 0), "fp8 variants: g tiles only");
+    static_assert(!(F8 || O8 || H16) || (V == 1 && PP_BAR_TAIL == 0 && PP_RES_PREFETCH == 0), "fp8 / fp16 variants: g tiles only");
+    static_assert(!(H16 && (F8 || O8)), "one storage format per variant");
+    // fp16: the accumulator runs in prescaled-weight units: it starts at bias * a.bias_scale (= 1 / out_scale, host-computed: a kernel argument, no register)
     using G = PPGeo<TI, V, SC>;
     constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
     // out-of-range marker for buffer offsets (descriptor range 2 GiB): still out of range, and not wrapped past 2^32, after the immediate / scalar
@@ -332,8 +373,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     do {                                                                                                            \
         const f32x4_t bv_ = *(const f32x4_t*)(smem + G::BIAS + ((c0n) + (i) * 32 + (q) * 8 + hi * 4) * 4);         \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                          \
-            acc[i][0][(q) * 4 + e_] = bv_[e_];                                                                      \
-            acc[i][1][(q) * 4 + e_] = bv_[e_];                                                                      \
+            const float b0_ = H16 ? bv_[e_] * a.bias_scale : bv_[e_];                                               \
+            acc[i][0][(q) * 4 + e_] = b0_;                                                                          \
+            acc[i][1][(q) * 4 + e_] = b0_;                                                                          \
         }                                                                                                           \
     } while (0)
 #pragma unroll
@@ -535,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                             for (int i = 0; i < TI; ++i)
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? a1[i] : a0[i], h ? b1[j] : b0[j], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = mfma16pp<H16>(h ? a1[i] : a0[i], h ? b1[j] : b0[j], acc[i][j]);
                                     if (PP_BAR_TAIL > 0 && (h * TI + i) * 2 + j + 1 == BAR_AT) {
                                         __builtin_amdgcn_sched_barrier(0);
                                         if (closing && !VGH_ABLATE(a, 64)) barrier_raw();
@@ -631,6 +673,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                                 for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] *= gv[e];
                             }
                         }
+                        if constexpr (H16) {  // prescaled-weight units -> real units (one factor per op)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[i][j][8 * m + e] *= a.out_scale;
+                        }
                         if constexpr (RES) {
                             float va[4], vb[4];
 #pragma unroll
@@ -641,20 +687,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                             unsigned d0 = rv[i][m][0], d1 = rv[i][m][1], d2 = rv[i][m][2], d3 = rv[i][m][3];
                             swap32(d0, d2);  // back to the accumulator layout: (d0, d1) = run 2m, (d2, d3) = run 2m + 1 of this lane
                             swap32(d1, d3);
-                            va[0] += a.alpha * bf_lo(d0);
-                            va[1] += a.alpha * bf_hi(d0);
-                            va[2] += a.alpha * bf_lo(d1);
-                            va[3] += a.alpha * bf_hi(d1);
-                            vb[0] += a.alpha * bf_lo(d2);
-                            vb[1] += a.alpha * bf_hi(d2);
-                            vb[2] += a.alpha * bf_lo(d3);
-                            vb[3] += a.alpha * bf_hi(d3);
-                            pa0 = pack_bf16(va[0], va[1]), pa1 = pack_bf16(va[2], va[3]);
-                            pb0 = pack_bf16(vb[0], vb[1]), pb1 = pack_bf16(vb[2], vb[3]);
+                            va[0] += a.alpha * unpack_lo<H16>(d0);
+                            va[1] += a.alpha * unpack_hi<H16>(d0);
+                            va[2] += a.alpha * unpack_lo<H16>(d1);
+                            va[3] += a.alpha * unpack_hi<H16>(d1);
+                            vb[0] += a.alpha * unpack_lo<H16>(d2);
+                            vb[1] += a.alpha * unpack_hi<H16>(d2);
+                            vb[2] += a.alpha * unpack_lo<H16>(d3);
+                            vb[3] += a.alpha * unpack_hi<H16>(d3);
+                            pa0 = pack16<H16>(va[0], va[1]), pa1 = pack16<H16>(va[2], va[3]);
+                            pb0 = pack16<H16>(vb[0], vb[1]), pb1 = pack16<H16>(vb[2], vb[3]);
                         } else {
                             // round first, ReLU on the packed pairs: bf16 as int16 is negative exactly when the float is (rounding keeps the sign)
-                            pa0 = max_pk(pack_bf16(acc[i][j][8 * m + 0], acc[i][j][8 * m + 1]), relu_lo), pa1 = max_pk(pack_bf16(acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]), relu_lo);
-                            pb0 = max_pk(pack_bf16(acc[i][j][8 * m + 4], acc[i][j][8 * m + 5]), relu_lo), pb1 = max_pk(pack_bf16(acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]), relu_lo);
+                            pa0 = max_pk(pack16<H16>(acc[i][j][8 * m + 0], acc[i][j][8 * m + 1]), relu_lo), pa1 = max_pk(pack16<H16>(acc[i][j][8 * m + 2], acc[i][j][8 * m + 3]), relu_lo);
+                            pb0 = max_pk(pack16<H16>(acc[i][j][8 * m + 4], acc[i][j][8 * m + 5]), relu_lo), pb1 = max_pk(pack16<H16>(acc[i][j][8 * m + 6], acc[i][j][8 * m + 7]), relu_lo);
                         }
                         swap32(pa0, pb0);
                         swap32(pa1, pb1);
@@ -798,14 +844,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 }
 
 constexpr int kMaxDev = 16;
-template <int TI, int V, int F8 = 0, int O8 = 0>
+template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0>
 int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, int chunk, int max_blocks_per_xcd, hipStream_t st) {
     using G = PPGeo<TI, V, (F8 || O8) ? 1 : 0>;
     static std::atomic<int> done[kMaxDev];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
     if (!done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V, F8, O8>, hipFuncAttributeMaxDynamicSharedMemorySize, (G::LDS)));
+        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V, F8, O8, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (G::LDS)));
         done[dev].store(1, std::memory_order_release);
     }
     int gpx = 32;  // one workgroup per CU, 32 CUs per XCD
@@ -815,7 +861,7 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
     vgh_fastdiv_magic((unsigned)ntc, &dv.m_ntc, &dv.s_ntc);
     vgh_fastdiv_magic((unsigned)(nsy * nsx), &dv.m_per, &dv.s_per);
     vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
-    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V, F8, O8>), dim3(gpx * 8), dim3(512), (G::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V, F8, O8, H16>), dim3(gpx * 8), dim3(512), (G::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -832,7 +878,9 @@ int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4, 2>::LDS : bc == 96 ? P
 static_assert(PPGeo<4, 1, 1>::LDS <= 160 * 1024, "e4m3 g tiles: bias + factor vectors must fit the 160 KB LDS");
 
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_per_xcd, hipStream_t stream) {
-    VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && !a.split && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 / e4m3 convs only");
+    const bool h16 = a.split == VGH_FMT_F16X2 && a.nseg == 1;  // single-plane fp16 (VGH_FMT_F16) through conv_split.hip's pseudo-tiles
+    VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && (!a.split || h16) && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 / fp16 / e4m3 convs only");
+    VGH_REQUIRE(!h16 || (version == 1 && !a.in_fp8 && !a.out_fp8 && a.out_scale > 0.0f && a.cout_store == a.cout_pad), "conv: the fp16 ping-pong variant takes whole cout tiles and the op's weight prescale");
     if (a.in_fp8 || a.out_fp8) {
         VGH_REQUIRE(version == 1, "conv: the e4m3 variants exist for the g tiles only");
         VGH_REQUIRE(a.gscale, "conv: an e4m3 conv needs its per-cout output factors (gscale)");
@@ -860,6 +908,16 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
         PP_F8_CASE(2)
 #undef PP_F8_CASE
         VGH_REQUIRE(false, "conv: no e4m3 ping-pong tile with %d couts", bc);
+    }
+    if (h16) {
+        ConvArgs ah = a;
+        ah.bias_scale = 1.0f / a.out_scale;
+        switch (bc) {
+            case 128: return launch_pp<4, 1, 0, 0, 1>(ah, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+            case 96: return launch_pp<3, 1, 0, 0, 1>(ah, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+            case 64: return launch_pp<2, 1, 0, 0, 1>(ah, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        }
+        VGH_REQUIRE(false, "conv: no fp16 ping-pong tile with %d couts", bc);
     }
     switch (bc + (version == 2 ? 1 : 0)) {
         case 128: return launch_pp<4, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);

@@ -131,7 +131,18 @@ const SplitCfg g_scfgs[] = {
 };
 constexpr int kNumSplitCfgs = sizeof(g_scfgs) / sizeof(g_scfgs[0]);
 
+// single-plane fp16 (VGH_FMT_F16, r05): besides the tiles above, the 8-wave ping-pong 3x3 tiles of conv_pp.hip in their fp16 variant, addressed as the three
+// pseudo-indices kNumSplitCfgs + {0, 1, 2} = 128 / 96 / 64 couts per workgroup
+constexpr int kPPBC[3] = {128, 96, 64};
+const char* const kPPNames[3] = {"g8x8x128_n8", "g8x8x96_n8", "g8x8x64_n8"};
+bool pp16_ok(int cfg, const ConvArgs& a) {
+    const int i = cfg - kNumSplitCfgs;
+    return i >= 0 && i < 3 && a.nseg == 1 && a.split == VGH_FMT_F16X2 && a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && a.act != VGH_ACT_SILU &&
+           a.cout_pad % kPPBC[i] == 0 && a.cout_store == a.cout_pad && vgh_conv_pp_fits(a);
+}
+
 bool scfg_ok(int cfg, const ConvArgs& a) {
+    if (cfg >= kNumSplitCfgs) return pp16_ok(cfg, a);
     if (cfg < 0 || cfg >= kNumSplitCfgs) return false;
     const SplitCfg& e = g_scfgs[cfg];
     if (a.cout_pad % e.BC) return false;
@@ -146,6 +157,12 @@ bool scfg_ok(int cfg, const ConvArgs& a) {
 int pick_split_cfg(const ConvArgs& a) {
     const int n = a.grp_cout ? a.grp_cout : a.cout_pad;
     const int bc = n % 128 == 0 ? 128 : n % 96 == 0 ? 96 : n % 64 == 0 ? 64 : 32;
+    // single-plane fp16: the ping-pong tiles where the bf16 table runs them -- 3x3 / stride-1 layers of the maps at least 40 pixels a side (8 x 8 sub-patches tile
+    // a 20-wide map badly)
+    if (a.nseg == 1 && bc >= 64 && a.W >= 40 && a.H >= 40) {
+        const int c = kNumSplitCfgs + (bc == 128 ? 0 : bc == 96 ? 1 : 2);
+        if (pp16_ok(c, a)) return c;
+    }
     const bool patch_ok = a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle;
     if (patch_ok && a.W % 16 == 0 && a.H % 16 == 0) return bc == 128 ? 8 : bc == 96 ? 9 : bc == 64 ? 10 : 11;
     if (patch_ok && a.W % 40 == 0 && a.H % 8 == 0 && bc >= 64) return bc == 128 ? 12 : bc == 96 ? 13 : 14;
@@ -214,8 +231,8 @@ void pack_image16(const uint16_t* w16, int cout_pad, int ksize, int cin, uint16_
 
 int vgh_conv_split_pick(const ConvArgs& a) { return pick_split_cfg(a); }
 
-extern "C" int vgh_conv_split_num_cfgs(void) { return kNumSplitCfgs; }
-extern "C" const char* vgh_conv_split_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumSplitCfgs) ? g_scfgs[cfg].name : "?"; }
+extern "C" int vgh_conv_split_num_cfgs(void) { return kNumSplitCfgs + 3; }
+extern "C" const char* vgh_conv_split_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumSplitCfgs) ? g_scfgs[cfg].name : (cfg >= kNumSplitCfgs && cfg < kNumSplitCfgs + 3) ? kPPNames[cfg - kNumSplitCfgs] : "?"; }
 extern "C" int vgh_conv_split_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle, int grp_cout) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -225,6 +242,13 @@ extern "C" int vgh_conv_split_cfg_ok(int cfg, int ksize, int stride, int cout_pa
     a.fast_epi = fast_epilogue;
     a.shuffle = shuffle;
     a.grp_cout = grp_cout;
+    if (cfg >= kNumSplitCfgs) {  // the fp16 ping-pong tiles: single-plane fp16 nets only (the ABI-level query has no tensor sizes: P = 0 passes the 2 GiB rule)
+        a.nseg = 1;
+        a.split = VGH_FMT_F16X2;
+        a.cout_store = cout_pad;
+        a.W = 1;
+        a.in_pitch = 8;
+    }
     return scfg_ok(cfg, a) ? 1 : 0;
 }
 
@@ -232,7 +256,7 @@ void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, i
     const size_t n = (size_t)cout_pad * ksize * ksize * cin;
     std::vector<uint16_t> hi(n), lo(n);
     float scale = 1.0f;
-    if (fmt == VGH_FMT_F16X2) {
+    if (fmt == VGH_FMT_F16X2 || fmt == VGH_FMT_F16) {
         float mx = 0.0f;
         for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
         if (mx > 0.0f && isfinite(mx)) {
@@ -255,6 +279,12 @@ void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, i
             lo[i] = vgh_f32_to_bf16_host(w[i] - bf16_to_f32_host(h));
         }
     }
+    if (fmt == VGH_FMT_F16) {  // single-plane fp16: one segment, the rounded (and prescaled) weights themselves
+        for (size_t i = 0; i < n; ++i) hi[i] = f32_to_f16_host(w[i] * scale);  // (no flush of the sub-normal range here: there is no lo plane to carry it)
+        pack_image16(hi.data(), cout_pad, ksize, cin, dst);
+        if (out_scale) *out_scale = 1.0f / scale;
+        return;
+    }
     // K segments in the order the kernels walk them: x_hi * w_lo, x_lo * w_hi, x_hi * w_hi
     pack_image16(lo.data(), cout_pad, ksize, cin, dst);
     pack_image16(hi.data(), cout_pad, ksize, cin, dst + n);
@@ -265,9 +295,12 @@ void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, i
 int vgh_launch_conv_split(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
     VGH_REQUIRE(a0.split == VGH_FMT_BF16X2 || a0.split == VGH_FMT_F16X2, "conv_split: format %d is not a split format", a0.split);
     ConvArgs a = a0;
+    const bool single = a.nseg == 1;  // VGH_FMT_F16: the caller has set split = F16X2 and the plane strides to 0
+    VGH_REQUIRE(!single || (a.split == VGH_FMT_F16X2 && a.in_plane == 0 && a.out_plane == 0 && a.res_plane == 0), "conv_split: a single-plane launch rides the fp16 kernels with plane strides 0");
+    if (!single) a.nseg = 3;
     a.seg_kb = a.ksize * a.ksize * a.cblocks;
-    a.nkb = 3 * a.seg_kb;
-    a.acc_scale = a.split == VGH_FMT_F16X2 ? 1.0f / 2048.0f : 1.0f;
+    a.nkb = a.nseg * a.seg_kb;
+    a.acc_scale = single ? 0.0f : a.split == VGH_FMT_F16X2 ? 1.0f / 2048.0f : 1.0f;  // single plane: the residual's "lo" term (a second read of its hi plane) is multiplied away
     a.lo_scale = a.split == VGH_FMT_F16X2 ? 2048.0f : 1.0f;
     if (a.split != VGH_FMT_F16X2) a.out_scale = 1.0f;
     VGH_REQUIRE(a.out_scale > 0.0f, "conv_split: out_scale must come from vgh_pack_conv_weights_split");
@@ -275,6 +308,7 @@ int vgh_launch_conv_split(const ConvArgs& a0, int force_cfg, hipStream_t stream)
     VGH_REQUIRE((int64_t)a.B * a.H * a.W * a.in_pitch * 2 < (1ll << 31), "conv_split: input tensor (both planes) must stay below 2 GiB; run the batch in chunks");
     int cfg = (force_cfg >= 0 && scfg_ok(force_cfg, a)) ? force_cfg : (a.fallback_cfg1 > 0 && scfg_ok(a.fallback_cfg1 - 1, a)) ? a.fallback_cfg1 - 1 : pick_split_cfg(a);
     VGH_REQUIRE(scfg_ok(cfg, a), "conv_split: no tile for cout_pad=%d k=%d s=%d grp=%d", a.cout_pad, a.ksize, a.stride, a.grp_cout);
+    if (cfg >= kNumSplitCfgs) return vgh_launch_conv_pp(a, kPPBC[cfg - kNumSplitCfgs], 1, vgh_conv_max_blocks_per_xcd(), stream);  // fp16 ping-pong tiles (conv_pp.hip)
     const SplitCfg& e = g_scfgs[cfg];
     const int ntc = a.cout_pad / e.BC;
     if (e.patch) {
@@ -294,7 +328,7 @@ int vgh_launch_conv_split(const ConvArgs& a0, int force_cfg, hipStream_t stream)
 extern "C" int vgh_pack_conv_weights_split(const float* w_host, int cout_pad, int ksize, int cin, int fmt, uint16_t* wpack_host, float* out_scale) {
     VGH_REQUIRE(w_host && wpack_host && out_scale, "pack_split: null argument");
     VGH_REQUIRE(cin % 32 == 0 && cout_pad % 32 == 0 && (ksize == 1 || ksize == 3), "pack_split: cin/cout_pad must be multiples of 32, ksize 1 or 3");
-    VGH_REQUIRE(fmt == VGH_FMT_BF16X2 || fmt == VGH_FMT_F16X2, "pack_split: fmt must be VGH_FMT_BF16X2 or VGH_FMT_F16X2");
+    VGH_REQUIRE(fmt == VGH_FMT_BF16X2 || fmt == VGH_FMT_F16X2 || fmt == VGH_FMT_F16, "pack_split: fmt must be VGH_FMT_BF16X2, VGH_FMT_F16X2 or VGH_FMT_F16 (one segment: cout_pad*k*k*cin u16)");
     vgh_pack_conv_weights_split_host(w_host, cout_pad, ksize, cin, fmt, wpack_host, out_scale);
     return VGH_OK;
 }

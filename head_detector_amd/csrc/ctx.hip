@@ -130,7 +130,7 @@ int vgh_create(const vgh_config* cfg, vgh_ctx** out) {
     for (int i = 0; rc == VGH_OK && i < h.n_ops; ++i) {
         const char* nm = names.data() + (size_t)i * 32;
         if (ops[i].kind != VGH_OP_CONV || !nm[0]) continue;
-        const bool split = h.precision == VGH_FMT_BF16X2 || h.precision == VGH_FMT_F16X2;  // the parity modes index their own tile table
+        const bool split = h.precision == VGH_FMT_BF16X2 || h.precision == VGH_FMT_F16X2 || h.precision == VGH_FMT_F16;  // the parity modes (and single-plane fp16) index their own tile table
         const int ncfg = split ? vgh_conv_split_num_cfgs() : vgh_conv_num_cfgs();
         for (int k = 0; k < ncfg; ++k)
             if (strncmp(split ? vgh_conv_split_cfg_name(k) : vgh_conv_cfg_name(k), nm, 31) == 0) {

@@ -76,9 +76,11 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->in = (const uint16_t*)((const char*)n->buf_ptr[d.in_buf] + at * buf_image_bytes(ib));
     // split parity modes: a pixel is [hi plane | lo plane]; the kernels address it with the physical pitch and the plane stride
     const int ipl = vgh_fmt_planes(ib.is_f32), opl = vgh_fmt_planes(ob.is_f32);
-    a->split = ipl > 1 ? ib.is_f32 : 0;
-    a->in_plane = ib.pitch;
-    a->out_plane = ob.pitch;
+    const bool h16 = ib.is_f32 == VGH_FMT_F16;  // single-plane fp16 (r05): the fp16 split kernels with ONE K segment and no lo plane (ConvArgs::nseg)
+    a->split = h16 ? VGH_FMT_F16X2 : ipl > 1 ? ib.is_f32 : 0;
+    a->nseg = h16 ? 1 : 3;
+    a->in_plane = h16 ? 0 : ib.pitch;
+    a->out_plane = h16 ? 0 : ob.pitch;
     a->out_scale = op.out_scale;
     a->grp_cout = d.grp_cout;
     a->grp_in_stride = d.grp_in_stride;
@@ -105,7 +107,7 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->out_f32 = ob.is_f32 == VGH_FMT_F32;
     a->res = d.res_buf >= 0 ? (const uint16_t*)((const char*)n->buf_ptr[d.res_buf] + at * buf_image_bytes(n->bufs[d.res_buf])) : nullptr;
     a->res_pitch = d.res_buf >= 0 ? (int64_t)n->bufs[d.res_buf].pitch * vgh_fmt_planes(n->bufs[d.res_buf].is_f32) : 0;
-    a->res_plane = d.res_buf >= 0 ? n->bufs[d.res_buf].pitch : 0;
+    a->res_plane = (d.res_buf >= 0 && !h16) ? n->bufs[d.res_buf].pitch : 0;
     // e4m3 links (r05): bf16 -> e4m3, e4m3 -> bf16 and e4m3 -> e4m3 are legal pairs (3x3 / stride-1 convs on the ping-pong tiles); the residual of such an op is bf16
     const bool in8 = ib.is_f32 == VGH_FMT_FP8, out8 = ob.is_f32 == VGH_FMT_FP8;
     a->in_fp8 = in8;
@@ -146,6 +148,8 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
             const vgh_buf_desc& ob = n->bufs[d.out_buf];
             if (ob.is_f32 == VGH_FMT_F32)  // fp32 parity mode
                 return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)bp(d.out_buf), ob.pitch, d.out_coff, st);
+            if (ob.is_f32 == VGH_FMT_F16)  // single-plane fp16: the fp16 split stem with plane stride 0 (split_store then writes the hi plane only)
+                return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)bp(d.out_buf), ob.pitch, d.out_coff, d.cout_store, VGH_FMT_F16X2, 0, st);
             return vgh_launch_stem(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (uint16_t*)bp(d.out_buf), (int64_t)ob.pitch * vgh_fmt_planes(ob.is_f32), d.out_coff,
                                    d.cout_store, ob.is_f32, ob.pitch, st);
         }
@@ -168,6 +172,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
         case VGH_OP_SPP_POOL: {
             const vgh_buf_desc& ib = n->bufs[d.in_buf];
             if (ib.is_f32 == VGH_FMT_F32) return vgh_launch_spp_pool_f32((float*)bp(d.in_buf), ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, st);
+            if (ib.is_f32 == VGH_FMT_F16) return vgh_launch_spp_pool((uint16_t*)bp(d.in_buf), ib.pitch, d.in_coff, d.cin, B, ib.h, ib.w, VGH_FMT_F16X2, 0, st);  // plane stride 0: single plane
             return vgh_launch_spp_pool((uint16_t*)bp(d.in_buf), (int64_t)ib.pitch * vgh_fmt_planes(ib.is_f32), d.in_coff, d.cin, B, ib.h, ib.w, ib.is_f32, ib.pitch, st);
         }
         case VGH_OP_FORK:
@@ -276,7 +281,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     int64_t off = 0;
     std::vector<int64_t> offs(n_bufs);
     for (int i = 0; i < n_bufs; ++i) {
-        VGH_REQUIRE(bufs[i].is_f32 >= VGH_FMT_BF16 && bufs[i].is_f32 <= VGH_FMT_FP8, "net_create: buffer %d has unknown format %d", i, bufs[i].is_f32);
+        VGH_REQUIRE(bufs[i].is_f32 >= VGH_FMT_BF16 && bufs[i].is_f32 <= VGH_FMT_F16, "net_create: buffer %d has unknown format %d", i, bufs[i].is_f32);
         VGH_REQUIRE(bufs[i].is_f32 != VGH_FMT_FP8 || (bufs[i].scale > 0.0f && bufs[i].scale < 1e30f && bufs[i].pitch % 16 == 0), "net_create: e4m3 buffer %d needs a positive scale and a pitch that is a multiple of 16", i);
         const int64_t bytes = (int64_t)max_batch * bufs[i].h * bufs[i].w * bufs[i].pitch * vgh_fmt_bytes(bufs[i].is_f32);
         offs[i] = off;
@@ -313,7 +318,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             }
             woff[i] = wbytes;
             const int wf = bufs[d.in_buf].is_f32;  // weight image: bf16 (2 B), dense fp32 (4 B) or the three 16-bit segments of the split modes (6 B)
-            wbytes += align_up(we * (wf == VGH_FMT_FP8 ? 1 : wf == VGH_FMT_BF16 ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
+            wbytes += align_up(we * (wf == VGH_FMT_FP8 ? 1 : (wf == VGH_FMT_BF16 || wf == VGH_FMT_F16) ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
             boff[i] = wbytes;
             wbytes += align_up((int64_t)d.cout_pad * 4, 256);
             if (wf == VGH_FMT_FP8 || bufs[d.out_buf].is_f32 == VGH_FMT_FP8) {
@@ -587,7 +592,8 @@ int vgh_net_image_size(vgh_net* n) { return n ? n->image_size : 0; }
 
 int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {
     VGH_REQUIRE(n && op_index >= 0 && op_index < (int)n->ops.size(), "net_set_cfg: bad op index");
-    const bool split_net = vgh_fmt_planes(n->bufs[n->ops[op_index].d.kind == VGH_OP_CONV ? n->ops[op_index].d.in_buf : 0].is_f32) > 1;
+    const int fmt0 = n->bufs[n->ops[op_index].d.kind == VGH_OP_CONV ? n->ops[op_index].d.in_buf : 0].is_f32;
+    const bool split_net = vgh_fmt_planes(fmt0) > 1 || fmt0 == VGH_FMT_F16;  // the single-plane fp16 nets index the split modes' tile table too
     VGH_REQUIRE(cfg >= -1 && cfg < (split_net ? vgh_conv_split_num_cfgs() : vgh_conv_num_cfgs()), "net_set_cfg: bad cfg");
     NetOp& op = n->ops[op_index];
     if (cfg >= 0 && op.d.kind == VGH_OP_CONV && !split_net && (n->bufs[op.d.in_buf].is_f32 == VGH_FMT_BF16 || n->bufs[op.d.in_buf].is_f32 == VGH_FMT_FP8)) {
@@ -622,15 +628,17 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     const int planes = vgh_fmt_planes(c->fmt);
-    VGH_REQUIRE(c->fmt == VGH_FMT_BF16 || c->fmt == VGH_FMT_BF16X2 || c->fmt == VGH_FMT_F16X2 || c->fmt == VGH_FMT_FP8, "conv2d: fmt %d", c->fmt);
+    VGH_REQUIRE(c->fmt == VGH_FMT_BF16 || c->fmt == VGH_FMT_BF16X2 || c->fmt == VGH_FMT_F16X2 || c->fmt == VGH_FMT_FP8 || c->fmt == VGH_FMT_F16, "conv2d: fmt %d", c->fmt);
     a.in_fp8 = c->fmt == VGH_FMT_FP8;
     a.out_fp8 = c->out_fp8 ? 1 : 0;
     a.gscale = c->gscale_dev;
     VGH_REQUIRE(!(a.in_fp8 || a.out_fp8) || (c->gscale_dev && (c->fmt == VGH_FMT_FP8 || c->fmt == VGH_FMT_BF16) && !c->out_f32), "conv2d: an e4m3 conv needs gscale_dev, a bf16 or e4m3 input and no fp32 output");
-    a.split = planes > 1 ? c->fmt : 0;
-    a.in_plane = (int)c->in_pitch;
-    a.out_plane = (int)c->out_pitch;
-    a.res_plane = (int)c->res_pitch;
+    const bool h16 = c->fmt == VGH_FMT_F16;  // single-plane fp16: the fp16 split kernels with one K segment and plane strides 0
+    a.split = h16 ? VGH_FMT_F16X2 : planes > 1 ? c->fmt : 0;
+    a.nseg = h16 ? 1 : 3;
+    a.in_plane = h16 ? 0 : (int)c->in_pitch;
+    a.out_plane = h16 ? 0 : (int)c->out_pitch;
+    a.res_plane = h16 ? 0 : (int)c->res_pitch;
     a.out_scale = c->out_scale;
     a.grp_cout = c->grp_cout;
     a.grp_in_stride = c->grp_in_stride;

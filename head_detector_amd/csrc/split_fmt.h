@@ -50,12 +50,18 @@ __device__ __forceinline__ void split_store(const float (&v)[N], float lo_scale,
         l[e] = le;
     }
     *(V*)p = h;
-    *(V*)(p + plane) = l;
+    if (plane) *(V*)(p + plane) = l;  // plane == 0: the single-plane fp16 format (VGH_FMT_F16, r05) -- the value is its hi plane alone
 }
 template <int SP, int N>
 __device__ __forceinline__ void join_load(const uint16_t* p, int plane, float lo_inv, float (&v)[N]) {
     using V = std::conditional_t<N == 8, typename SplitT<SP>::v8, typename SplitT<SP>::v4>;
-    const V h = *(const V*)p, l = *(const V*)(p + plane);
+    const V h = *(const V*)p;
+    if (!plane) {  // single-plane fp16 (VGH_FMT_F16)
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = (float)h[e];
+        return;
+    }
+    const V l = *(const V*)(p + plane);
 #pragma unroll
     for (int e = 0; e < N; ++e) v[e] = (float)h[e] + (float)l[e] * lo_inv;
 }

@@ -433,7 +433,10 @@ __global__ __launch_bounds__(256) void spp_pool_split_kernel(uint16_t* __restric
 }  // namespace
 
 #include <atomic>
-static std::atomic<int> g_stem_mfma{1};
+// default OFF: measured r05 (tools/ab_knob.py vgh_stem_set_mfma, one box, alternating) the matrix-core stem is correct but SLOWER -- 442 vs 306 us per 64 images
+// (M b32: 232 vs 168 us; two-lane forward L b64 12.47 vs 12.25 ms): with 25 600 blocks of 256 pixels the kernel is a chain of latencies per block (image bytes ->
+// LDS -> 32 scattered 2-byte LDS gathers per lane -> 8 MFMAs -> LDS transpose -> stores), not the VALU-bound loop the FMA count suggested (EXPERIMENTS.md 8e)
+static std::atomic<int> g_stem_mfma{0};
 extern "C" int vgh_stem_set_mfma(int on) {
     g_stem_mfma.store(on ? 1 : 0, std::memory_order_relaxed);
     return VGH_OK;

@@ -67,7 +67,9 @@ struct ConvArgs {
     //      three segments x_hi*w_lo, x_lo*w_hi (corrections), then -- after one multiply of the accumulators by acc_scale -- x_hi*w_hi ----
     int split;        // VGH_FMT_BF16 (0): plain; VGH_FMT_BF16X2 / VGH_FMT_F16X2: hi|lo planes
     int in_plane, out_plane, res_plane;  // elements from a pixel's hi plane to its lo plane (the buffer's logical pitch)
-    int seg_kb;       // k-blocks per segment = ksize^2 * cblocks (nkb = 3 * seg_kb)
+    int seg_kb;       // k-blocks per segment = ksize^2 * cblocks (nkb = nseg * seg_kb)
+    int nseg;         // 3: the split modes' x_hi*w_lo, x_lo*w_hi, x_hi*w_hi; 1: the single-plane fp16 format (VGH_FMT_F16, r05) rides the F16X2 kernels with its one
+                      //    plane as "hi" (split = VGH_FMT_F16X2, in/out/res_plane = 0, acc_scale = 0: no lo plane is read or written) and the [w_hi] weight image
     float acc_scale;  // 1/2048 (fp16: lo planes are stored scaled by 2^11) or 1 (bf16)
     float lo_scale;   // lo = (v - hi) * lo_scale
     float out_scale;  // undoes the per-op power-of-two weight prescale (fp16), applied to the accumulator before the bias
@@ -75,6 +77,7 @@ struct ConvArgs {
     //      bf16.  gscale[cout_pad]: per-cout output factor applied to the accumulator (which starts at bias / gscale when the input is e4m3) ----
     int in_fp8, out_fp8;
     const float* gscale;
+    float bias_scale;  // fp16 ping-pong variant: 1 / out_scale (set by vgh_launch_conv_pp)
     int fallback_cfg1;  // 0: a forced tile that cannot run this conv is an error; k + 1: it falls back to tile k (network executor: a table may be stale)
     int nt_out;          // bf16 output stores carry the non-temporal hint (set by vgh_conv_prepare from vgh_conv_set_nt_store)
     int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
@@ -104,7 +107,7 @@ int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);
 // vgh_pack_conv_weights_host); fmt = VGH_FMT_BF16X2 / VGH_FMT_F16X2.  Returns through *out_scale the factor the kernel multiplies the
 // accumulators by (fp16: 2^-s with 2^s the power-of-two prescale that brings max|w| to ~2^9; bf16: 1).
 void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, int cin, int fmt, uint16_t* dst, float* out_scale);
-static inline int vgh_fmt_bytes(int fmt) { return fmt == VGH_FMT_FP8 ? 1 : fmt == 0 ? 2 : 4; }  // bytes per logical element of an activation buffer
+static inline int vgh_fmt_bytes(int fmt) { return fmt == VGH_FMT_FP8 ? 1 : (fmt == 0 || fmt == VGH_FMT_F16) ? 2 : 4; }  // bytes per logical element of an activation buffer
 static inline int vgh_fmt_planes(int fmt) { return (fmt == VGH_FMT_BF16X2 || fmt == VGH_FMT_F16X2) ? 2 : 1; }
 // conv_pp.hip (host): OCP e4m3fn conversion and the e4m3 weight image of the ping-pong tiles
 uint8_t vgh_f32_to_e4m3_host(float f);
@@ -112,6 +115,7 @@ void vgh_pack_conv_weights_fp8_host(const float* w, int cout_pad, int ksize, int
 // conv_pp.hip: the 8-wave ping-pong 3x3 / stride-1 tiles ("g" tiles; bc = 128 / 96 / 64 couts per workgroup); `a` must be prepared
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version /* 1: "g" (two barriers per tap), 2: "h" (one) */, int max_blocks_per_xcd, hipStream_t stream);
 int vgh_conv_pp_lds(int bc);
+int vgh_conv_max_blocks_per_xcd();  // the process-wide cap of vgh_conv_set_max_blocks_per_xcd (0 = none)
 int vgh_conv_pp_fits(const ConvArgs& a);
 int vgh_conv_persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int blocks_per_cu);
 int vgh_conv_pick_cfg(const ConvArgs& a);

@@ -153,7 +153,7 @@ class VGHeadsEngine:
         self._head_out = None  # (capacity, head_image, proj, rpy) allocated on first FLAME use
         self._levels = None
         self._graph_key = None
-        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp8", "fp16x3", "bf16x3"))  # the split modes have their own keys (precision prefix) and tile set
+        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp8", "fp16x3", "bf16x3"))  # "fp16" has no measured table: the library's size rule + the fp16 ping-pong tiles  # the split modes have their own keys (precision prefix) and tile set
         self.nsplit = 1
         if self._use_tuning:
             self.load_tuning()
@@ -206,6 +206,8 @@ class VGHeadsEngine:
         t = _alias(self.lib.vgh_net_buffer(self._net, bid), (n,), "<f4" if fmt == arch.FMT_F32 else "<i2", self.device)
         if fmt == arch.FMT_BF16:
             t = t.view(torch.bfloat16)
+        elif fmt == arch.FMT_F16:
+            t = t.view(torch.float16)
         return t.clone().view(B, bf["h"], bf["w"], bf["pitch"])
 
     # ---------------------------------------------------------------------------------------------------
@@ -428,7 +430,7 @@ class VGHeadsEngine:
 
     def cfg_names(self) -> List[str]:
         """Tile names ``set_cfg`` indexes: the bf16 table, or the split-precision table for the fp16x3 / bf16x3 modes."""
-        if self.precision in ("fp16x3", "bf16x3"):
+        if self.precision in ("fp16x3", "bf16x3", "fp16"):
             return [self.lib.vgh_conv_split_cfg_name(i).decode() for i in range(self.lib.vgh_conv_split_num_cfgs())]
         return [self.lib.vgh_conv_cfg_name(i).decode() for i in range(self.lib.vgh_conv_num_cfgs())]
 
@@ -437,7 +439,7 @@ class VGHeadsEngine:
         ob = self.program.bufs[op["out_buf"]]
         al = all(op[k] % 8 == 0 for k in ("out_coff", "out_coff2", "out_split", "cout_store", "res_coff")) and ob["pitch"] % 8 == 0
         fast = int(ob["is_f32"] != arch.FMT_F32 and al)
-        if self.precision in ("fp16x3", "bf16x3"):
+        if self.precision in ("fp16x3", "bf16x3", "fp16"):
             return bool(self.lib.vgh_conv_split_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"], op.get("grp_cout", 0)))
         if not self.lib.vgh_conv_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"]):
             return False

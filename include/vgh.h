@@ -60,6 +60,9 @@ int vgh_abi_version(void);
 #define VGH_FMT_F32 1    /* fp32 NHWC: head prediction outputs in every mode; every buffer in the fp32 (VALU) parity mode */
 #define VGH_FMT_BF16X2 2 /* split parity mode: per pixel [hi C | lo C] bf16, value = hi + lo (16 significand bits) */
 #define VGH_FMT_F16X2 3  /* split parity mode: per pixel [hi C | lo C] fp16, value = hi + lo / 2048 (22 significand bits) */
+#define VGH_FMT_F16 5    /* r05, "fp16" throughput mode: ONE fp16 plane per value (the reference's own FP16 export: exportable_mesh_model.py:177,299,409); same bytes and MFMA */
+                         /*   count as bf16, 11 instead of 8 significand bits; weights carry a per-op power-of-two prescale (undone on the accumulator), values beyond       */
+                         /*   +-65504 saturate                                                                                                                              */
 #define VGH_FMT_FP8 4    /* r05, "fp8" throughput mode: OCP e4m3fn bytes, value = stored * vgh_buf_desc.scale.  Only on links between two 3x3 / stride-1  */
                          /*   convs that run on the ping-pong tiles (csrc/conv_pp.hip): written by one, read by one; every other tensor stays bf16     */
 
@@ -118,9 +121,10 @@ int vgh_net_set_lane_lag(int ops);
  * pair in bf16: the 48-channel stem activation then never goes to HBM and its arena buffer is not written.  Results are bit-identical either way.
  * Default off: measured (r03) it removes 1.5 GB of traffic per 64-image forward but is no faster than the two launches (latency-bound small tiles). */
 int vgh_net_set_fuse_stem(vgh_net* net, int enable);
-/* Process-wide (default 1): in the bf16 mode the stem of a u8 image runs as a K = 27 bf16 GEMM on the matrix cores (csrc/stem_pool.hip::stem_mfma_kernel: pixel values
- * are exact in bf16, /255 folded into bf16-rounded weights, fp32 accumulate) instead of the exact-fp32 VALU kernel: 2^-9 relative on a weight, below the bf16
- * rounding of the stem's output.  0 restores the exact kernel (what float images and the parity modes always use). */
+/* Process-wide opt-in (default 0): in the bf16 mode the stem of a u8 image runs as a K = 27 bf16 GEMM on the matrix cores (csrc/stem_pool.hip::stem_mfma_kernel: pixel
+ * values are exact in bf16, /255 folded into bf16-rounded weights, fp32 accumulate) instead of the exact-fp32 VALU kernel.  Correct (2^-9 relative on a weight, below
+ * the bf16 rounding of the stem's output) but measured SLOWER in r05 (442 vs 306 us per 64 images: per-block latency chain), hence off; float images and the parity
+ * modes always use the exact kernel. */
 int vgh_stem_set_mfma(int on);
 /* Borrowed HIP event (or NULL): the first op of the next forwards that writes a prediction buffer waits for it on its stream.
  * Lets a consumer of the previous forward's predictions run on another stream underneath this forward's backbone / neck. */

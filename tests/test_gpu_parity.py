@@ -656,7 +656,7 @@ def test_fused_stem_downsample_is_bit_identical(gpu_lib, variant, S, B, fmt):
             eng.forward_net(x)
             outs[fuse] = (eng.buffer("backbone.stage1.ds", B), [t.clone() for t in eng.model(x)])
     finally:
-        gpu_lib.vgh_stem_set_mfma(1)
+        gpu_lib.vgh_stem_set_mfma(0)  # the default
     assert float(outs[True][0].float().abs().max()) > 0
     assert torch.equal(outs[True][0], outs[False][0]), "stage-1 downsample output differs"
     for a, b in zip(outs[True][1], outs[False][1]):
@@ -685,7 +685,7 @@ def test_stem_tensor_at_its_48_channel_pitch(gpu_lib, monkeypatch):
         eng.forward_net(big.to(_dev()))  # image 2's stem pixels stay in the arena behind the 2-image batch
         eng.forward_net(x.to(_dev()))
     finally:
-        gpu_lib.vgh_stem_set_mfma(1)
+        gpu_lib.vgh_stem_set_mfma(0)  # the default
     stem = eng.buffer("stem", 2).float().cpu()
     assert stem.shape == (2, S // 2, S // 2, 48)
     bufs = pr.alloc(P, 2)
@@ -727,16 +727,17 @@ def test_u8_nhwc_input_equals_f32_nchw(gpu_lib):
             b = eng.buffer(name, 1).float().cpu()
             assert float(a.abs().max()) > 0 and torch.equal(a, b), name
     finally:
-        gpu_lib.vgh_stem_set_mfma(1)
+        gpu_lib.vgh_stem_set_mfma(0)  # the default
     eng.close()
 
 
 @pytest.mark.parametrize("variant,S,B,pitch", [("vgg_heads_l", 160, 3, 48), ("vgg_heads_m", 672, 1, 48), ("vgg_heads_m", 104, 2, 48), ("vgg_heads_l", 96, 2, 64)])
 def test_stem_on_the_matrix_cores_vs_exact_operand_reference(gpu_lib, monkeypatch, variant, S, B, pitch):
-    """r05 (VERDICT r04 item 1b): in the bf16 mode the stem of a u8 image is a K = 27 bf16 GEMM (csrc/stem_pool.hip::stem_mfma_kernel).  Its operands are exact --
+    """r05 (VERDICT r04 item 1b): in the bf16 mode the stem of a u8 image CAN run as a K = 27 bf16 GEMM (csrc/stem_pool.hip::stem_mfma_kernel).  Its operands are exact --
     pixel values 0 .. 255 in bf16, weights bf16(w / 255) -- so the reference is an fp64 conv of exactly those operands and what is left is fp32 accumulation
     order + the bf16 rounding of the output (one ulp); against the exact-fp32 kernel it replaces it stays within two bf16 ulps (2^-9 per weight); image borders
-    on every side, maps that are not a multiple of the 16 x 16 tile (104 -> 52, 672 -> 336 = 21 tiles), the 64-channel pitch variant (stored zeros in 48 .. 63)."""
+    on every side, maps that are not a multiple of the 16 x 16 tile (104 -> 52, 672 -> 336 = 21 tiles), the 64-channel pitch variant (stored zeros in 48 .. 63).
+    The kernel is an OPT-IN (vgh_stem_set_mfma): measured slower than the exact kernel (a per-block latency chain, EXPERIMENTS.md 8e); kept, with this test, as the record."""
     from head_detector_amd import arch
     from head_detector_amd.engine import VGHeadsEngine
 
@@ -747,8 +748,12 @@ def test_stem_on_the_matrix_cores_vs_exact_operand_reference(gpu_lib, monkeypatc
     assert P.bufs[0]["pitch"] == pitch
     x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(S))
     x[0, :3] = 255  # saturated rows at the top border
-    eng.forward_net(x.to(_dev()))
-    got = eng.buffer("stem", B).float().cpu()
+    try:
+        gpu_lib.vgh_stem_set_mfma(1)  # opt-in (default off: correct but measured slower than the exact kernel, EXPERIMENTS.md 8e)
+        eng.forward_net(x.to(_dev()))
+        got = eng.buffer("stem", B).float().cpu()
+    finally:
+        gpu_lib.vgh_stem_set_mfma(0)
     w_all, b_all = P.arrays()
     op = P.ops[0]
     W = torch.from_numpy(w_all[op["w_off"] : op["w_off"] + 48 * 27].reshape(48, 3, 3, 3).copy()).permute(0, 3, 1, 2).contiguous()
@@ -759,13 +764,11 @@ def test_stem_on_the_matrix_cores_vs_exact_operand_reference(gpu_lib, monkeypatc
     assert not ((got[..., :48] - ref).abs() > 2e-3 + 1.0 / 128 * ref.abs()).any(), float((got[..., :48] - ref).abs().max())
     if pitch == 64:
         assert float(got[..., 48:].abs().max()) == 0.0
-    try:
-        gpu_lib.vgh_stem_set_mfma(0)
-        eng.forward_net(x.to(_dev()))
-        exact = eng.buffer("stem", B).float().cpu()
-    finally:
-        gpu_lib.vgh_stem_set_mfma(1)
-    assert not ((got - exact).abs() > 4e-3 + 1.0 / 64 * exact.abs()).any(), float((got - exact).abs().max())
+    eng.forward_net(x.to(_dev()))
+    exact = eng.buffer("stem", B).float().cpu()
+    # against the exact-fp32 kernel: the weights differ by 2^-9 relative each, i.e. the output by up to sum|w x| * 2^-9 -- an absolute bound (terms cancel), plus the output's own bf16 ulp
+    bound = F.conv2d(x.permute(0, 3, 1, 2).double(), Wq.abs(), None, stride=2, padding=1).permute(0, 2, 3, 1).float() * 2.0 ** -9
+    assert not ((got[..., :48] - exact[..., :48]).abs() > 2e-3 + bound + 1.0 / 128 * exact[..., :48].abs()).any(), float((got - exact).abs().max())
     assert float((got != exact).float().mean()) > 0.001, "the knob did not switch kernels"
     eng.close()
 
