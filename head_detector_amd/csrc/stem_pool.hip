@@ -20,7 +20,8 @@ constexpr int STEM_CO = 48, STEM_CP = 64;
 // NCH (STAGE = 1): 16-byte chunks stored per pixel -- 8: the 48 channels + 16 zero channels of a 64-channel pitch (the K padding of the next conv);
 // 6: the 48 channels alone at a 48-channel pitch (r04: 96-byte pixels, the next conv reads a 64-channel window whose last 16 channels are the
 // neighbouring pixel's first 16 and meet all-zero weight rows -- net.hip checks that -- so the 210 MB of zeros per 64 images are neither written nor read)
-template <int FMT, int STAGE, int SP = 0, int NCH = 8>
+// H16 (STAGE = 1, SP = 0): the staged path storing ONE fp16 plane (VGH_FMT_F16, r05) instead of bf16 -- same LDS transpose, same full-line stores
+template <int FMT, int STAGE, int SP = 0, int NCH = 8, int H16 = 0>
 __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ image, int H, int W, const float* __restrict__ wgt /*[27][48]*/,
                                                    const float* __restrict__ bias /*[48]*/, uint16_t* __restrict__ out, int64_t out_pitch,
                                                    int out_coff, int plane, float lo_scale) {
@@ -140,14 +141,19 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ i
         auto act = [](float v) {
             v = fmaxf(v, 0.0f);
             if constexpr (FMT == VGH_IMG_F32_NCHW && NCH == 6) v = fminf(v, 3.3895313892515355e38f);
-            return v;
+            if constexpr (H16) {  // the 16 bits of the fp16 value travel in the bf16-typed staging vector; values beyond fp16's range saturate
+                const _Float16 h = (_Float16)fminf(v, 65504.0f);
+                return __builtin_bit_cast(__bf16, h);
+            } else {
+                return (__bf16)v;
+            }
         };
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            o0[2 * c] = (__bf16)act(acc[c][0] + bias[cg * 16 + 2 * c]);
-            o0[2 * c + 1] = (__bf16)act(acc[c][1] + bias[cg * 16 + 2 * c + 1]);
-            o1[2 * c] = (__bf16)act(acc[4 + c][0] + bias[cg * 16 + 8 + 2 * c]);
-            o1[2 * c + 1] = (__bf16)act(acc[4 + c][1] + bias[cg * 16 + 8 + 2 * c + 1]);
+            o0[2 * c] = act(acc[c][0] + bias[cg * 16 + 2 * c]);
+            o0[2 * c + 1] = act(acc[c][1] + bias[cg * 16 + 2 * c + 1]);
+            o1[2 * c] = act(acc[4 + c][0] + bias[cg * 16 + 8 + 2 * c]);
+            o1[2 * c + 1] = act(acc[4 + c][1] + bias[cg * 16 + 8 + 2 * c + 1]);
         }
         if (STAGE) {
             stage[tid * 8 + ((2 * cg) ^ (tid & 7))] = o0;
@@ -455,7 +461,12 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
     hipLaunchKernelGGL((stem_kernel<FMT, STAGE, SP>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff, plane, LO)
 #define VGH_STEM_LAUNCH48(FMT) \
     hipLaunchKernelGGL((stem_kernel<FMT, 1, 0, 6>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff, plane, 1.0f)
-    if (fmt == VGH_FMT_F16X2) {
+    if (fmt == VGH_FMT_F16X2 && plane == 0 && store_ch == 64) {  // single-plane fp16 (VGH_FMT_F16): the staged kernel with fp16 stores (zero bits are zero in both formats)
+        if (u8)
+            hipLaunchKernelGGL((stem_kernel<VGH_IMG_U8_NHWC, 1, 0, 8, 1>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff, plane, 1.0f);
+        else
+            hipLaunchKernelGGL((stem_kernel<VGH_IMG_F32_NCHW, 1, 0, 8, 1>), grid, dim3(256), 0, stream, image, H, W, w, bias, out, out_pitch, out_coff, plane, 1.0f);
+    } else if (fmt == VGH_FMT_F16X2) {
         if (u8) VGH_STEM_LAUNCH(VGH_IMG_U8_NHWC, 0, VGH_FMT_F16X2, 2048.0f);
         else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, VGH_FMT_F16X2, 2048.0f);
     } else if (fmt == VGH_FMT_BF16X2) {

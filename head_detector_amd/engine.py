@@ -153,7 +153,7 @@ class VGHeadsEngine:
         self._head_out = None  # (capacity, head_image, proj, rpy) allocated on first FLAME use
         self._levels = None
         self._graph_key = None
-        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp8", "fp16x3", "bf16x3"))  # "fp16" has no measured table: the library's size rule + the fp16 ping-pong tiles  # the split modes have their own keys (precision prefix) and tile set
+        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp8", "fp16", "fp16x3", "bf16x3"))  # the split modes have their own keys (precision prefix) and tile set
         self.nsplit = 1
         if self._use_tuning:
             self.load_tuning()

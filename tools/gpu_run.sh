@@ -100,6 +100,11 @@ for step in "$@"; do
     py)
       # any tools/ script:  PY_CMD="tools/ab_stem_pitch.py --rounds 4"  (log named by PY_TAG)
       timeout ${PY_TIMEOUT:-900} python ${PY_CMD} > $O/py${PY_TAG:-}.log 2>&1; echo "py rc=$?" >> $O/py${PY_TAG:-}.log; grep -v amdgpu $O/py${PY_TAG:-}.log | tail -${TAILN:-40} ;;
+    tune16)
+      # tile table of the single-plane fp16 mode (keys "fp16:..."), two lanes, both benchmark buckets; the merged table comes back as $O/conv_cfg.json
+      timeout 1200 python tools/tune_conv.py --variant vgg_heads_l --batch 64 --precision fp16 --split 2 --reps 3 --report $O/${TAG}_tune_fp16_l64x2.json > $O/tune16.log 2>&1
+      timeout 900 python tools/tune_conv.py --variant vgg_heads_m --batch 32 --precision fp16 --split 2 --reps 3 --report $O/${TAG}_tune_fp16_m32x2.json >> $O/tune16.log 2>&1
+      grep -v amdgpu $O/tune16.log | tail -4; cp head_detector_amd/tuning/conv_cfg.json $O/conv_cfg.json ;;
     benchm)
       # BASELINE configs[1] (VGGHeads_M b32) as the MAIN workload of bench.py: its own line, per-layer table and (PROF_ARGS / PMC_VARIANT) kernel stats / PMC passes
       timeout 900 python bench.py --variant vgg_heads_m --batch 32 --no-secondary --no-cpu-baseline --no-accuracy --per-layer $O/${TAG}_per_layer_m32.json ${BENCH_ARGS:-} > $O/bench_m32.json 2> $O/bench_m32.err; echo "benchm rc=$?"; tail -3 $O/bench_m32.err; cut -c1-700 $O/bench_m32.json ;;
