@@ -748,7 +748,8 @@ def main():
             # r05: the single-plane fp16 mode (the reference's own FP16 export format: exportable_mesh_model.py:177,299,409) -- same bytes and MFMA count as bf16
             fh = run_workload(args.variant, B, max(20, sec_steps // 2), max(3, args.warmup // 2), precision="fp16", inner=max(1, args.inner))
             config["secondary_fp16"] = dict(brief(fh), workload=f"{args.variant} fp16 (one fp16 plane per value, v_mfma_f32_32x32x16_f16) batch {B} @ {S}", speed_vs_bf16_headline=round(fh["value"] / main_run["value"], 4),
-                                            note="untuned: the split modes' size rule + the fp16 ping-pong tiles (no per-layer table); deviation from the oracle: modes_vs_oracle_one_image.fp16")
+                                            note="the fp16 split kernels with one K segment + the fp16 ping-pong tiles, per-op tile table tuned once (profiles/r05_tune_fp16_*.json); no streaming 1x1 / pipelined patch tiles in this "
+                                                 "format yet, hence the gap to bf16; deviation from the oracle: modes_vs_oracle_one_image.fp16")
             print(f"[bench] fp16 {args.variant} batch {B} @ {S}: {fh['value']:.1f} img/s ({fh['value'] / main_run['value']:.3f} x the bf16 headline), net {fh['net_ms']:.3f} ms", file=sys.stderr)
             # BASELINE configs[0]'s shape on the GPU: ONE 640 x 640 image per call, the caller waits for the result (the reference's own API is single-image)
             config["latency_one_image_synchronous"] = {v: one_image_latency(v) for v in ("vgg_heads_l", "vgg_heads_m")}

@@ -148,8 +148,14 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="batch the per-op tile choices are resolved for")
     ap.add_argument("--split", type=int, default=1, help="lane count the tile choices are resolved for")
     ap.add_argument("--precision", default="bf16", choices=sorted(arch.PRECISION_FMT))
+    ap.add_argument("--fp8-scales", default=None, help="--precision fp8: json {e4m3 link name: max|activation|} from head_detector_amd.engine.calibrate_fp8")
     args = ap.parse_args(argv)
-    P = arch.build_program(args.variant, _weights_arg(args.weights, args.variant), args.image_size, args.precision)
+    scales = None
+    if args.precision == "fp8":  # the e4m3 links need calibrated activation maxima (engine.calibrate_fp8 on a GPU box, saved as {link name: max|x|}); packing itself needs no GPU
+        if not args.fp8_scales:
+            sys.exit("pack: --precision fp8 needs --fp8-scales <json from head_detector_amd.engine.calibrate_fp8>")
+        scales = json.load(open(args.fp8_scales))
+    P = arch.build_program(args.variant, _weights_arg(args.weights, args.variant), args.image_size, args.precision, fp8_scales=scales)
     names = tile_names_for(P, args.batch, args.split) if args.precision != "fp32" else {}
     n = write_pack(args.out, P, _flame_arg(args.flame), names, args.batch)
     print(f"{args.out}: {n / 2 ** 20:.1f} MiB, {len(P.ops)} ops, {len(P.bufs)} buffers, {len(names)} tuned tile choices, {P.flops / 1e9:.2f} GFLOP/image")

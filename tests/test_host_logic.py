@@ -543,6 +543,41 @@ def test_onnx_initializer_ingest_without_the_onnx_package(tmp_path):
         load_weights(str(tmp_path / "short.onnx"))
 
 
+def test_fp8_and_fp16_programs_are_the_bf16_program_with_other_storage():
+    """r05 (CPU): precision="fp8" is the bf16 op program with OCP-e4m3 LINKS -- a buffer written by one 3x3 / stride-1 conv and read by one: every bottleneck's cv1 -> cv2
+    tensor on maps of at least fp8_min_px pixels a side, and the shape | expression part of the FLAME branches' middle layer (a buffer of its own beside the bf16 transform
+    channels) -- with 64-byte K blocks (a 96-channel link sits in a 128-byte pixel over zero weight columns); precision="fp16" is the same program with every 16-bit buffer
+    as ONE fp16 plane.  Same ops, same FLOPs, same weights; the algorithmic byte count follows the storage."""
+    for variant, n_links, min20 in (("vgg_heads_l", 24, 31), ("vgg_heads_m", 17, 22)):
+        sd = arch.random_state_dict(variant, 2)
+        Pb = arch.build_program(variant, sd, 640, "bf16")
+        P8 = arch.build_program(variant, sd, 640, "fp8", fp8_scales={"backbone.stage2.blocks.mid0": 10.0})
+        Ph = arch.build_program(variant, sd, 640, "fp16")
+        assert [o["name"] for o in P8.ops] == [o["name"] for o in Pb.ops] == [o["name"] for o in Ph.ops] and P8.flops == Pb.flops == Ph.flops
+        links = [i for i, bf in enumerate(P8.bufs) if bf["is_f32"] == arch.FMT_FP8]
+        assert len(links) == n_links and set(arch.fp8_link_names(variant)) == {P8.bufs[i]["name"] for i in links}
+        assert len([bf for bf in arch.build_program(variant, sd, 640, "fp8", fp8_min_px=20).bufs if bf["is_f32"] == arch.FMT_FP8]) == min20
+        for i in links:
+            bf = P8.bufs[i]
+            wr = [o for o in P8.ops if o["kind"] == 1 and o["out_buf"] == i]
+            rd = [o for o in P8.ops if o["kind"] == 1 and o["in_buf"] == i]
+            assert bf["pitch"] % 64 == 0 and bf["scale"] > 0 and min(bf["h"], bf["w"]) >= 40 and not any(o["res_buf"] == i for o in P8.ops)
+            assert wr and rd and all(o["ksize"] == 3 and o["stride"] == 1 and not o.get("grp_cout") for o in wr + rd) and all(o["cin"] % 64 == 0 and o["in_coff"] % 16 == 0 for o in rd)
+            assert len(wr) == len(rd) and all(o["res_buf"] < 0 and o["cout_store"] == o["cout_pad"] for o in wr)  # an e4m3 output takes whole cout tiles and no residual
+            if bf["name"].split(".")[-1].startswith("mid"):
+                assert len(wr) == 1 and bf["live"] == wr[0]["cout_store"] and rd[0]["cin"] == bf["pitch"]
+        sc = {bf["name"]: bf["scale"] for bf in P8.bufs if bf["is_f32"] == arch.FMT_FP8}
+        assert abs(sc["backbone.stage2.blocks.mid0"] - 10.0 * arch.FP8_HEADROOM / arch.FP8_MAX) < 1e-9 and abs(sc["backbone.stage2.blocks.mid1"] - 8.0 * arch.FP8_HEADROOM / arch.FP8_MAX) < 1e-9
+        if variant == "vgg_heads_l":  # the 96-channel links of stage 1: zero weight columns over the 32 bytes nobody writes
+            op = next(o for o in P8.ops if o["name"] == "backbone.stage1.blocks.bottlenecks.0.cv2")
+            w = P8.arrays()[0][op["w_off"] : op["w_off"] + op["cout_pad"] * 9 * op["cin"]].reshape(op["cout_pad"], 9, op["cin"])
+            assert op["cin"] == 128 and float(np.abs(w[..., 96:]).max()) == 0.0 and float(np.abs(w[..., :96]).max()) > 0
+        assert all(bf["is_f32"] in (arch.FMT_F16, arch.FMT_F32) for bf in Ph.bufs) and sum(bf["is_f32"] == arch.FMT_F32 for bf in Ph.bufs) == 3
+        ab, a8, ah = (arch.program_algorithmic_bytes(P, 64) for P in (Pb, P8, Ph))
+        assert a8["write"] < ab["write"] and a8["read"] < ab["read"] and ah["read"] > 0.98 * ab["read"]  # fp16 keeps the padded 64-channel stem pitch: a little more than bf16
+        assert arch.op_touches_fp8(P8, next(o for o in P8.ops if o["name"].endswith("bottlenecks.0.cv1") and "stage2" in o["name"])) and not any(arch.op_touches_fp8(Pb, o) for o in Pb.ops)
+
+
 def test_flame_prologue_joint_reduction_tree_is_the_xor_butterfly():
     """CPU spec of the cross-lane reduction in csrc/flame.hip::prep_head (J = J0 + JS beta: 24 sums over 64 lanes): on the first three levels the xor partners split
     the outputs between them (keep half, send half), then three outputs per lane go through a plain butterfly -- 30 cross-lane moves instead of 144.  Every output's
