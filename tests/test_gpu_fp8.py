@@ -270,3 +270,54 @@ def test_fp8_mode_deviation_from_the_oracle_is_pinned_next_to_bf16(gpu_lib, flam
     # a 3-bit significand on 17 - 24 tensors of a random-weight network costs 5 - 10 x the bf16 mode's deviation.  Pinned with margin so that a regression cannot hide.
     assert r8["kept_iou_min"] >= 0.65 and r8["kept_param_max_rel_err"] < 1.2 and r8["vertex_l2_metric_max"] < 6e-2 and r8["dense_score_max_abs_err"] < 6e-3, (r8, r1)
     assert r8["kept_param_max_rel_err"] > r1["kept_param_max_rel_err"], "the e4m3 links cannot be more exact than the bf16 mode they replace: the comparison is broken"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp8", "fp16"])
+def test_r05_modes_through_the_pack_and_the_c_context(gpu_lib, flame_model, tmp_path, precision):
+    """`pack --precision fp8 | fp16` -> vgh_create -> vgh_ctx_detect (a C client's path to the two r05 throughput modes) equals the Python engine of the same mode bit for
+    bit: the pack (version 3) carries the e4m3 buffers with their calibrated scales / the fp16 buffers, the library quantises the weights itself, and the per-op tiles
+    of the linked ops are the library's choice on both sides."""
+    from head_detector_amd import _lib, arch, pack
+    from head_detector_amd.engine import VGHeadsEngine, calibrate_fp8
+    from head_detector_amd.flame import FLAMELayer
+
+    variant, S, B = "vgg_heads_m", 320, 2
+    sd = arch.random_state_dict(variant, 11)
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).to(_dev())
+    scales = calibrate_fp8(variant, sd, S, x) if precision == "fp8" else None
+    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, use_tuning=False, precision=precision, fp8_scales=scales)
+    P = eng.program
+    if precision == "fp8":
+        assert sum(bf["is_f32"] == arch.FMT_FP8 for bf in P.bufs) >= 5  # 80- and 40-wide maps at 320
+    pk = str(tmp_path / f"m_{precision}.vghpack")
+    pack.write_pack(pk, P, flame_model, {}, B)
+    hdr = pack.read_header(pk)
+    assert hdr["version"] == 3 and hdr["precision"] == arch.PRECISION_FMT[precision]
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=B * 100)
+    _, sc, _ = eng.model(x)
+    conf = float(sc[:, 5, 0].min())
+    ref = eng.detect(x, confidence_threshold=conf, flame=fl)
+    n_ref = ref.num_heads
+    assert n_ref >= B
+    h = C.c_void_p()
+    cfg = _lib.Config(device=torch.cuda.current_device(), pack_path=pk.encode(), max_batch=B)
+    _lib.check(gpu_lib.vgh_create(C.byref(cfg), C.byref(h)))
+    kk, V = 100, fl.num_vertices
+    f32 = dict(dtype=torch.float32, device=_dev())
+    ob, os_, of = torch.zeros(B, kk, 4, **f32), torch.zeros(B, kk, **f32), torch.zeros(B, kk, 413, **f32)
+    oc, nh, hi = torch.zeros(B, dtype=torch.int32, device=_dev()), torch.zeros(1, dtype=torch.int32, device=_dev()), torch.zeros(B * kk, dtype=torch.int32, device=_dev())
+    proj = torch.zeros(B * kk, V, 3, **f32)
+    o = _lib.DetectOut(boxes_dev=ob.data_ptr(), scores_dev=os_.data_ptr(), flame_dev=of.data_ptr(), counts_dev=oc.data_ptr(), n_heads_dev=nh.data_ptr(), head_image_dev=hi.data_ptr(),
+                       head_capacity=B * kk, unpad_dev=None, verts_dev=None, rot_dev=None, rpy_dev=None, proj_dev=proj.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_lib.vgh_ctx_detect(h, x.data_ptr(), _lib.VGH_IMG_U8_NHWC, B, conf, 0.5, C.byref(o), st) == 0, gpu_lib.vgh_ctx_last_error(h)
+    _lib.check(gpu_lib.vgh_ctx_join(h, st))
+    torch.cuda.synchronize()
+    assert torch.equal(oc, ref.counts) and int(nh) == n_ref
+    for b in range(B):
+        n = int(oc[b])
+        assert torch.equal(ob[b, :n], ref.boxes[b, :n]) and torch.equal(of[b, :n], ref.flame_params[b, :n])
+    assert torch.equal(proj[:n_ref], ref.vertices_3d)
+    gpu_lib.vgh_destroy(h)
+    eng.close()
