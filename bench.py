@@ -207,11 +207,14 @@ def deviation_from_oracle(variant: str, precision: str, ref: dict, dev) -> dict:
 
 def make_step(eng, flame, images, unpad, conf, B, slots, gat, overlap, use_graph, n_heads_all, ev0=None, ev1=None, ready=None):
     """One step of the benchmark loop as a closure (also driven by tests/test_dist_cpu.py with a stand-in engine on gloo, so that the
-    N>1 control flow -- two output slots, the gatherer's slot hand-shake, the join -- runs on every CPU test pass)."""
+    N>1 control flow -- the output slots, the gatherer's slot hand-shake, the join -- runs on every CPU test pass).  The slot count is len(slots): with THREE
+    (r05) a forward waits for the exchange of three batches ago; with two it waited for the exchange of the batch whose low-priority select had only just finished
+    under the previous forward, i.e. for pack + collectives at every forward boundary (measured with one RCCL rank: 13.65 vs 12.66 ms per forward)."""
     nstep = [0]
+    nslots = len(slots) if slots else 2
 
     def step(i=None):
-        s = nstep[0] & 1
+        s = nstep[0] % nslots
         nstep[0] += 1
         if gat is not None:
             gat.wait_slot_free(s, eng.stream)  # the exchange that last read this output slot (two batches ago) is over
@@ -565,10 +568,11 @@ def main():
         # nothing in the steady-state loop waits on the host (head_detector_amd/dist.py::DetectionGatherer)
         slots = gat = ready = None
         if world > 1 or args.exchange:
-            slots = [eng.new_output_slot(flame) for _ in range(2)]
+            NSLOTS = 3
+            slots = [eng.new_output_slot(flame) for _ in range(NSLOTS)]
             gat = DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=B * int(1.5 * heads_per_image + 1), device=dev, dst=0, stream=eng.acquire_stream(),
-                                    always_collective=args.exchange, compact_rows=B * int(1.5 * heads_per_image + 1) if args.compact_gather else 0)
-            ready = [torch.cuda.Event() for _ in range(2)]
+                                    always_collective=args.exchange, compact_rows=B * int(1.5 * heads_per_image + 1) if args.compact_gather else 0, slots=NSLOTS)
+            ready = [torch.cuda.Event() for _ in range(NSLOTS)]
             if gat.collective and not steered[0]:
                 # RCCL launches its kernels on a stream of torch's pool; on the hardware queue of the engine stream or of a lane they would
                 # hold up the next batch's network (a queue is in-order).  Steer the pool before the first collective, then measure.
@@ -591,8 +595,8 @@ def main():
             eng.join()
             last_exchanges = []
             if gat is not None:
-                for s in range(2):
-                    last_exchanges.append(gat.result(s))  # the last two exchanges
+                for s in range(len(slots)):
+                    last_exchanges.append(gat.result(s))  # the exchanges still in flight
             torch.cuda.synchronize()
             if dist.is_initialized():
                 dist.barrier()
@@ -788,9 +792,20 @@ def main():
                 dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16", "fp16", "fp8")}
                 config.setdefault("parity_mode", {})["vs_oracle"] = dev_tab["fp16x3"]
                 config["modes_vs_oracle_one_image"] = dev_tab
-        print(json.dumps(line))
+    # the line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which (redirected to a file or a pipe) is block-buffered and would
+    # otherwise be flushed at process exit, i.e. AFTER a line python has already written.  Every rank flushes its C and python buffers, then a barrier, then rank 0 prints
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 """First-contact kit for the N > 1 path (BASELINE configs[3]) that needs NO GPU: `bench.py`'s own step closure (`bench.make_step`) and
 `DetectionGatherer` driven on the gloo backend by a STAND-IN engine -- no kernel runs, `select` writes synthetic detections that are a function of the
 global image index only, so rank 0 can check the gathered batches against the unsharded expectation bit for bit.  What it exercises is the control flow
-an 8-GPU lease would otherwise see first: two output slots, `wait_slot_free` before a slot is rewritten, `join_into` + `submit` after every select, the
+an 8-GPU lease would otherwise see first: the output slots (three, as in bench.py), `wait_slot_free` before a slot is rewritten, `join_into` + `submit` after every select, the
 late read of the previous batch, uneven shards, and the capacity-slab vs compact-rows exchange.
 
     python tools/dryrun_dist.py --gpus 2 --steps 5 [--compact]        (also:  python bench.py --gpus 2 --dry-run-cpu)
@@ -91,8 +91,9 @@ def step_worker(rank, world, port, q, total, steps, compact=False):
     eng = StandInEngine(rank, world, total, keep, V)
     mk = lambda: dict(boxes=torch.zeros(B, keep, 4), scores=torch.zeros(B, keep), flame=torch.zeros(B, keep, 413), counts=torch.zeros(B, dtype=torch.int32),  # noqa: E731
                       n_heads=torch.zeros(1, dtype=torch.int32), proj=torch.zeros(B * keep, V, 3))
-    slots = [mk(), mk()]
-    gat = DetectionGatherer(B, keep, V, vertex_rows=B * keep, device="cpu", dst=0, compact_rows=B * keep if compact else 0)
+    NSLOTS = 3  # as bench.py: a forward waits for the exchange of three batches ago
+    slots = [mk() for _ in range(NSLOTS)]
+    gat = DetectionGatherer(B, keep, V, vertex_rows=B * keep, device="cpu", dst=0, compact_rows=B * keep if compact else 0, slots=NSLOTS)
     n_heads_all = torch.zeros(steps, dtype=torch.int32)
     step = bench.make_step(eng, None, None, None, 0.5, B, slots, gat, True, False, n_heads_all)
     got = []
@@ -108,8 +109,8 @@ def step_worker(rank, world, port, q, total, steps, compact=False):
     for i in range(steps):
         step(i)
         if i >= 1:
-            collect((i - 1) & 1)
-    collect((steps - 1) & 1)
+            collect((i - 1) % NSLOTS)
+    collect((steps - 1) % NSLOTS)
     dt = time.perf_counter() - t0
     assert eng.calls == ["net", "cand", "select", "join_into"] * steps
     if rank == 0:
