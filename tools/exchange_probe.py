@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""What the N>1 exchange costs a rank, piece by piece, on ONE GPU (single-rank RCCL group): bench.make_step with
+   (0) no gatherer, (1) gatherer with local copies instead of collectives, (2) collectives without the vertex slab, (3) the full exchange, (4) the compact exchange.
+ms per forward (wall) and per network part (HIP events), alternating rounds.     python tools/exchange_probe.py [variant] [batch]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bench  # noqa: E402
+from head_detector_amd.dist import DetectionGatherer, init_from_env, steer_collective_stream  # noqa: E402
+from head_detector_amd.engine import VGHeadsEngine  # noqa: E402
+from head_detector_amd.flame import FLAMELayer  # noqa: E402
+from head_detector_amd.synthetic import synthetic_flame_model  # noqa: E402
+
+
+def main():
+    variant = sys.argv[1] if len(sys.argv) > 1 else "vgg_heads_l"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    init_from_env(single_rank_group=True)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    flame = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=B * 100)
+    eng = VGHeadsEngine(variant, image_size=640, max_batch=B, seed=1)
+    images = torch.randint(0, 256, (B, 640, 640, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+    unpad = torch.tensor([[0.0, 0.0, 1.0]], device=dev).expand(B, 3).contiguous()
+    _, scores, _ = eng.model(images)
+    conf = float(torch.sort(scores.flatten(), descending=True).values[3 * B])
+    eng.set_overlap(True)
+    eng.set_split(2)
+    NS, K = 3, 48
+    slots = [eng.new_output_slot(flame) for _ in range(NS)]
+    n_heads_all = torch.zeros(K, dtype=torch.int32, device=dev)
+    comm = eng.acquire_stream()
+    steered = steer_collective_stream(eng.streams_in_use())
+    print(f"collective stream {'clear of' if steered else 'SHARES a queue with'} the engine's streams")
+    rows = B * 5
+
+    def variant_gat(kind):
+        if kind == 0:
+            return None
+        return DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=0 if kind == 2 else rows, device=dev, dst=0, stream=comm, always_collective=kind >= 2,
+                                 compact_rows=rows if kind == 4 else 0, slots=NS)
+
+    names = ["no gatherer", "gatherer, local copies (no collectives)", "collectives, no vertex slab", "full exchange (capacity slab + vertex slab)", "compact exchange"]
+    res = {k: [] for k in range(5)}
+    for rnd in range(3):
+        for kind in range(5):
+            gat = variant_gat(kind)
+            ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+            ready = [torch.cuda.Event() for _ in range(NS)]
+            step = bench.make_step(eng, flame, images, unpad, conf, B, slots if gat is not None else None, gat, True, False, n_heads_all, ev0, ev1, ready)
+            for _ in range(12):
+                step()
+            eng.join()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(K):
+                step(i)
+            eng.join()
+            if gat is not None:
+                for s in range(NS):
+                    gat.result(s)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / K * 1e3
+            net = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / K
+            res[kind].append((dt, net))
+    for kind in range(5):
+        best = min(res[kind])
+        print(f"{variant} B={B} {names[kind]:48s}: {best[0]:7.3f} ms per forward (network part {best[1]:7.3f})   all: {', '.join(f'{a:.3f}' for a, _ in res[kind])}")
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
