@@ -46,15 +46,24 @@ def main():
         return DetectionGatherer(B, eng.keep_k, flame.num_vertices, vertex_rows=0 if kind == 2 else rows, device=dev, dst=0, stream=comm, always_collective=kind >= 2,
                                  compact_rows=rows if kind == 4 else 0, slots=NS)
 
-    names = ["no gatherer", "gatherer, local copies (no collectives)", "collectives, no vertex slab", "full exchange (capacity slab + vertex slab)", "compact exchange"]
-    res = {k: [] for k in range(5)}
+    names = ["no gatherer", "gatherer, local copies (no collectives)", "collectives, no vertex slab", "full exchange (capacity slab + vertex slab)", "compact exchange",
+             "local copies, wait_slot_free disabled", "local copies, submit = record the done event only", "local copies, no join_into (ready event instead)"]
+    NV = len(names)
+    res = {k: [] for k in range(NV)}
     for rnd in range(3):
-        for kind in range(5):
-            gat = variant_gat(kind)
+        for kind in range(NV):
+            gat = variant_gat(min(kind, 1) if kind >= 5 else kind)
+            if kind == 5:
+                gat.wait_slot_free = lambda slot, stream=None: None
+            if kind == 6:
+                def only_done(slot, *a, _g=gat, **k):
+                    _g.slots[slot]["done"].record(_g.stream)
+                    _g.slots[slot]["busy"] = True
+                gat.submit = only_done
             ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
             ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
             ready = [torch.cuda.Event() for _ in range(NS)]
-            step = bench.make_step(eng, flame, images, unpad, conf, B, slots if gat is not None else None, gat, True, False, n_heads_all, ev0, ev1, ready)
+            step = bench.make_step(eng, flame, images, unpad, conf, B, slots if gat is not None else None, gat, kind != 7, False, n_heads_all, ev0, ev1, ready)
             for _ in range(12):
                 step()
             eng.join()
@@ -70,7 +79,7 @@ def main():
             dt = (time.perf_counter() - t0) / K * 1e3
             net = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / K
             res[kind].append((dt, net))
-    for kind in range(5):
+    for kind in range(NV):
         best = min(res[kind])
         print(f"{variant} B={B} {names[kind]:48s}: {best[0]:7.3f} ms per forward (network part {best[1]:7.3f})   all: {', '.join(f'{a:.3f}' for a, _ in res[kind])}")
     eng.close()
