@@ -313,6 +313,17 @@ int vgh_detector_join(vgh_detector* d, void* stream) {
     return VGH_OK;
 }
 
+int vgh_detector_record(vgh_detector* d, void* event, void* stream) {
+    VGH_REQUIRE(d && event, "detector_record: null argument");
+    // the caller's event behind everything queued so far for the post-network stages: on the side stream in overlap mode (nothing is made to WAIT for it on the
+    // device -- a host that polls / synchronises on it can queue dependent work later without parking a hardware queue behind a low-priority stream), else on `stream`
+    if (d->overlap && d->side && d->side_pending)
+        VGH_HIP(hipEventRecord((hipEvent_t)event, d->side));
+    else
+        VGH_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return VGH_OK;
+}
+
 int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, float conf_thr, float iou_thr, vgh_detect_out* o, void* stream) {
     int rc = vgh_detector_candidates(d, images_dev, image_fmt, B, stream);
     if (rc) return rc;

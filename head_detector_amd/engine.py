@@ -404,6 +404,15 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_stream_acquire(self.device.index or 0, avoid, len(order), C.byref(got)))
         return torch.cuda.ExternalStream(got.value, device=self.device)
 
+    def record_select_done(self, event: "torch.cuda.Event"):
+        """Record ``event`` behind the post-network stages queued so far (vgh_detector_record: on the side stream in overlap mode), with no stream waiting on it:
+        the host can synchronise on an earlier batch's event and then queue that batch's consumers without a device-side wait."""
+        seen = self.__dict__.setdefault("_materialised_events", set())
+        if id(event) not in seen:  # torch creates the HIP event lazily on its first record: once per event object (the library re-records it where it belongs)
+            event.record(self.stream)
+            seen.add(id(event))
+        _lib.check(self.lib.vgh_detector_record(self._det, event.cuda_event, self._sp()))
+
     def join_into(self, stream: "torch.cuda.Stream"):
         """Make ``stream`` (not the engine stream) wait for the last queued select: a consumer on its own stream -- e.g. the
         communication stream of dist.DetectionGatherer -- picks the results up without stalling the next batch's network."""

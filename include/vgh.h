@@ -358,6 +358,10 @@ int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, fl
  * not read them). */
 int vgh_detector_set_overlap(vgh_detector* d, int enable);
 int vgh_detector_join(vgh_detector* d, void* stream);
+/* Records the caller's HIP event behind everything queued so far for the post-network stages (overlap mode: on the detector's side stream; else on `stream`)
+ * WITHOUT making any stream wait for it: a host that synchronises on the event of an EARLIER batch can queue that batch's consumers (e.g. the N>1 exchange) with no
+ * device-side wait -- a hardware queue parked behind the low-priority side stream costs the network ~7 % (r05, tools/exchange_probe.py). */
+int vgh_detector_record(vgh_detector* d, void* event, void* stream);
 int vgh_detector_streams(vgh_detector* d, void* main_stream, void** out /*[4]*/);
 
 /* ------------------------------------------------------------------------------------------------

@@ -18,6 +18,37 @@ from head_detector_amd.flame import FLAMELayer  # noqa: E402
 from head_detector_amd.synthetic import synthetic_flame_model  # noqa: E402
 
 
+def lazy_step(eng, flame, images, unpad, conf, B, slots, gat, n_heads_all, ev0, ev1, NS):
+    """The N>1 step with a LAZY exchange: batch k's detections are submitted at step k+2, after the HOST has seen select(k)'s event complete -- the communication stream never
+    waits on the low-priority side stream."""
+    sel_done = [torch.cuda.Event() for _ in range(NS)]
+    dets = [None] * NS
+    n = [0]
+
+    def step(i=None):
+        k = n[0]
+        n[0] += 1
+        s = k % NS
+        gat.wait_slot_free(s, eng.stream)
+        if i is not None:
+            ev0[i].record(eng.stream)
+        eng.forward_net(images)
+        if i is not None:
+            ev1[i].record(eng.stream)
+        eng.candidates(B)
+        kk = i if i is not None else 0
+        dets[s] = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[kk : kk + 1], slot=slots[s])
+        eng.record_select_done(sel_done[s])
+        j = k - 2
+        if j >= 0:
+            sj = j % NS
+            sel_done[sj].synchronize()  # host: select(j) is over (two batches ago: the host stays ahead of the GPU)
+            d = dets[sj]
+            gat.submit(sj, d.boxes, d.scores, d.flame_params, d.counts, d.n_heads, d.vertices_cap, None)
+
+    return step
+
+
 def main():
     variant = sys.argv[1] if len(sys.argv) > 1 else "vgg_heads_l"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -47,12 +78,13 @@ def main():
                                  compact_rows=rows if kind == 4 else 0, slots=NS)
 
     names = ["no gatherer", "gatherer, local copies (no collectives)", "collectives, no vertex slab", "full exchange (capacity slab + vertex slab)", "compact exchange",
-             "local copies, wait_slot_free disabled", "local copies, submit = record the done event only", "local copies, no join_into (ready event instead)"]
+             "local copies, wait_slot_free disabled", "local copies, submit = record the done event only", "local copies, no join_into (ready event instead)",
+             "LAZY: host waits for select(k-2), then queues exchange(k-2) with no device-side wait; local copies", "LAZY, full collectives"]
     NV = len(names)
     res = {k: [] for k in range(NV)}
     for rnd in range(3):
         for kind in range(NV):
-            gat = variant_gat(min(kind, 1) if kind >= 5 else kind)
+            gat = variant_gat(3 if kind == 9 else min(kind, 1) if kind >= 5 else kind)
             if kind == 5:
                 gat.wait_slot_free = lambda slot, stream=None: None
             if kind == 6:
@@ -63,7 +95,10 @@ def main():
             ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
             ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
             ready = [torch.cuda.Event() for _ in range(NS)]
-            step = bench.make_step(eng, flame, images, unpad, conf, B, slots if gat is not None else None, gat, kind != 7, False, n_heads_all, ev0, ev1, ready)
+            if kind >= 8:
+                step = lazy_step(eng, flame, images, unpad, conf, B, slots, gat, n_heads_all, ev0, ev1, NS)
+            else:
+                step = bench.make_step(eng, flame, images, unpad, conf, B, slots if gat is not None else None, gat, kind != 7, False, n_heads_all, ev0, ev1, ready)
             for _ in range(12):
                 step()
             eng.join()
