@@ -407,10 +407,8 @@ class VGHeadsEngine:
     def record_select_done(self, event: "torch.cuda.Event"):
         """Record ``event`` behind the post-network stages queued so far (vgh_detector_record: on the side stream in overlap mode), with no stream waiting on it:
         the host can synchronise on an earlier batch's event and then queue that batch's consumers without a device-side wait."""
-        seen = self.__dict__.setdefault("_materialised_events", set())
-        if id(event) not in seen:  # torch creates the HIP event lazily on its first record: once per event object (the library re-records it where it belongs)
+        if not event.cuda_event:  # torch creates the HIP event lazily on its first record (the library re-records it where it belongs)
             event.record(self.stream)
-            seen.add(id(event))
         _lib.check(self.lib.vgh_detector_record(self._det, event.cuda_event, self._sp()))
 
     def join_into(self, stream: "torch.cuda.Stream"):
