@@ -207,17 +207,31 @@ def deviation_from_oracle(variant: str, precision: str, ref: dict, dev) -> dict:
 
 def make_step(eng, flame, images, unpad, conf, B, slots, gat, overlap, use_graph, n_heads_all, ev0=None, ev1=None, ready=None):
     """One step of the benchmark loop as a closure (also driven by tests/test_dist_cpu.py with a stand-in engine on gloo, so that the
-    N>1 control flow -- the output slots, the gatherer's slot hand-shake, the join -- runs on every CPU test pass).  The slot count is len(slots): with THREE
-    (r05) a forward waits for the exchange of three batches ago; with two it waited for the exchange of the batch whose low-priority select had only just finished
-    under the previous forward, i.e. for pack + collectives at every forward boundary (measured with one RCCL rank: 13.65 vs 12.66 ms per forward)."""
+    N>1 control flow -- the output slots, the gatherer's slot hand-shake, the lazy hand-over -- runs on every CPU test pass).
+
+    r05: the exchange is LAZY.  Queuing batch k's pack + collectives right after its select (r02 - r04) parks the communication stream's hardware queue behind the
+    detector's LOW-PRIORITY side stream, and a parked fourth queue cost the network 7 - 8 % (tools/exchange_probe.py, one RCCL rank: 13.63 vs 12.60 ms per forward, the
+    same with plain copies instead of collectives).  Now select(k) only gets an event recorded behind it (vgh_detector_record: nothing waits for it on the device); at
+    step k + EXCHANGE_LAG the HOST synchronises on that event -- two batches old, so the host still runs ahead of the GPU -- and then queues exchange(k) with no
+    device-side wait: 12.72 ms.  len(slots) >= EXCHANGE_LAG + 1 output slots keep batch k's results intact until then; `step.flush()` queues what is still pending."""
     nstep = [0]
     nslots = len(slots) if slots else 2
+    EXCHANGE_LAG = 2
+    assert gat is None or nslots > EXCHANGE_LAG, "the lazy exchange needs at least three output slots"
+    sel_done = [eng.make_event() for _ in range(nslots)] if gat is not None else None
+    pending = []  # (slot, detections) of the batches whose exchange has not been queued yet, oldest first
+
+    def hand_over(n_keep):
+        while len(pending) > n_keep:
+            s0, d0 = pending.pop(0)
+            sel_done[s0].synchronize()  # host: that batch's select is over
+            gat.submit(s0, d0.boxes, d0.scores, d0.flame_params, d0.counts, d0.n_heads, d0.vertices_cap, None)
 
     def step(i=None):
         s = nstep[0] % nslots
         nstep[0] += 1
         if gat is not None:
-            gat.wait_slot_free(s, eng.stream)  # the exchange that last read this output slot (two batches ago) is over
+            gat.wait_slot_free(s, eng.stream)  # the exchange that last read this output slot (nslots batches ago) is over
         if i is not None and ev0 is not None:
             ev0[i].record(eng.stream)  # HIP events on the stream the kernels are launched on
         eng.forward_net(images, use_graph=use_graph)
@@ -230,15 +244,12 @@ def make_step(eng, flame, images, unpad, conf, B, slots, gat, overlap, use_graph
         det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1],
                          slot=slots[s] if slots else None)
         if gat is not None:
-            if overlap:
-                eng.join_into(gat.stream)  # the communication stream (not the engine stream) waits for this batch's select
-                ev = None
-            else:
-                ev = ready[s]
-                ev.record(eng.stream)
-            gat.submit(s, det.boxes, det.scores, det.flame_params, det.counts, det.n_heads, det.vertices_cap, ev)
+            eng.record_select_done(sel_done[s])  # behind this batch's select, on whichever stream runs it; nothing waits for it on the device
+            pending.append((s, det))
+            hand_over(EXCHANGE_LAG)
         return det
 
+    step.flush = lambda: hand_over(0) if gat is not None else None
     return step
 
 
@@ -592,6 +603,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(nfw):  # K steps of `inner` forwards each
                 step(i)
+            step.flush()  # the exchanges of the last two batches
             eng.join()
             last_exchanges = []
             if gat is not None:

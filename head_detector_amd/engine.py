@@ -404,6 +404,9 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_stream_acquire(self.device.index or 0, avoid, len(order), C.byref(got)))
         return torch.cuda.ExternalStream(got.value, device=self.device)
 
+    def make_event(self) -> "torch.cuda.Event":
+        return torch.cuda.Event()
+
     def record_select_done(self, event: "torch.cuda.Event"):
         """Record ``event`` behind the post-network stages queued so far (vgh_detector_record: on the side stream in overlap mode), with no stream waiting on it:
         the host can synchronise on an earlier batch's event and then queue that batch's consumers without a device-side wait."""

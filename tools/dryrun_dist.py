@@ -69,8 +69,11 @@ class StandInEngine:
         self.calls.append("select")
         return types.SimpleNamespace(boxes=slot["boxes"], scores=slot["scores"], flame_params=slot["flame"], counts=slot["counts"], n_heads=slot["n_heads"], vertices_cap=slot["proj"])
 
-    def join_into(self, stream):
-        self.calls.append("join_into")
+    def make_event(self):
+        return types.SimpleNamespace(synchronize=lambda: self.calls.append("host_wait"))
+
+    def record_select_done(self, event):
+        self.calls.append("record")
 
 
 def free_port():
@@ -106,13 +109,18 @@ def step_worker(rank, world, port, q, total, steps, compact=False):
             got.append({k: getattr(c, k).clone().numpy() for k in ("boxes", "scores", "flame_params", "counts", "vertices_3d")})
 
     t0 = time.perf_counter()
+    LAG = 2  # bench.make_step hands batch k's exchange over at step k + 2 (after a host wait on its select): batch k can be collected from step k + 2 on
     for i in range(steps):
         step(i)
-        if i >= 1:
-            collect((i - 1) % NSLOTS)
-    collect((steps - 1) % NSLOTS)
+        if i >= LAG:
+            collect((i - LAG) % NSLOTS)
+    step.flush()
+    for j in range(max(steps - LAG, 0), steps):
+        collect(j % NSLOTS)
     dt = time.perf_counter() - t0
-    assert eng.calls == ["net", "cand", "select", "join_into"] * steps
+    per_step = ["net", "cand", "select", "record"]
+    assert [c for c in eng.calls if c != "host_wait"] == per_step * steps and eng.calls.count("host_wait") == steps
+    assert eng.calls[: 4 * LAG] == per_step * LAG and eng.calls[4 * LAG : 4 * LAG + 5] == per_step + ["host_wait"], "the first exchange is handed over at step LAG, behind a host wait"
     if rank == 0:
         q.put((got, n_heads_all.tolist(), dt))
     dist.barrier()

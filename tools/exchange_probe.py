@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What the N>1 exchange costs a rank, piece by piece, on ONE GPU (single-rank RCCL group): bench.make_step with
-   (0) no gatherer, (1) gatherer with local copies instead of collectives, (2) collectives without the vertex slab, (3) the full exchange, (4) the compact exchange.
+   (0) no gatherer; the EAGER step of r02 - r04 with (1) local copies instead of collectives, (2) collectives without the vertex slab, (3) the full exchange, (4) the compact
+exchange, (5 - 7) parts of it switched off; (8, 9) the LAZY hand-over of bench.make_step (host waits for select(k - 2), no device-side wait).
 ms per forward (wall) and per network part (HIP events), alternating rounds.     python tools/exchange_probe.py [variant] [batch]"""
 import os
 import sys
@@ -18,34 +19,35 @@ from head_detector_amd.flame import FLAMELayer  # noqa: E402
 from head_detector_amd.synthetic import synthetic_flame_model  # noqa: E402
 
 
-def lazy_step(eng, flame, images, unpad, conf, B, slots, gat, n_heads_all, ev0, ev1, NS):
-    """The N>1 step with a LAZY exchange: batch k's detections are submitted at step k+2, after the HOST has seen select(k)'s event complete -- the communication stream never
-    waits on the low-priority side stream."""
-    sel_done = [torch.cuda.Event() for _ in range(NS)]
-    dets = [None] * NS
+def eager_step(eng, flame, images, unpad, conf, B, slots, gat, join, n_heads_all, ev0, ev1, ready):
+    """The r02 - r04 step: batch k's exchange is queued right after its select; the communication stream waits for it ON THE DEVICE (join = True: on the detector's
+    low-priority side stream through vgh_detector_join; False: on an event recorded on the engine stream)."""
     n = [0]
+    ns = len(slots) if slots else 2
 
     def step(i=None):
-        k = n[0]
+        s = n[0] % ns
         n[0] += 1
-        s = k % NS
-        gat.wait_slot_free(s, eng.stream)
+        if gat is not None:
+            gat.wait_slot_free(s, eng.stream)
         if i is not None:
             ev0[i].record(eng.stream)
         eng.forward_net(images)
         if i is not None:
             ev1[i].record(eng.stream)
         eng.candidates(B)
-        kk = i if i is not None else 0
-        dets[s] = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[kk : kk + 1], slot=slots[s])
-        eng.record_select_done(sel_done[s])
-        j = k - 2
-        if j >= 0:
-            sj = j % NS
-            sel_done[sj].synchronize()  # host: select(j) is over (two batches ago: the host stays ahead of the GPU)
-            d = dets[sj]
-            gat.submit(sj, d.boxes, d.scores, d.flame_params, d.counts, d.n_heads, d.vertices_cap, None)
+        k = i if i is not None else 0
+        det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1], slot=slots[s] if slots else None)
+        if gat is not None:
+            ev = None
+            if join:
+                eng.join_into(gat.stream)
+            else:
+                ev = ready[s]
+                ev.record(eng.stream)
+            gat.submit(s, det.boxes, det.scores, det.flame_params, det.counts, det.n_heads, det.vertices_cap, ev)
 
+    step.flush = lambda: None
     return step
 
 
@@ -79,7 +81,7 @@ def main():
 
     names = ["no gatherer", "gatherer, local copies (no collectives)", "collectives, no vertex slab", "full exchange (capacity slab + vertex slab)", "compact exchange",
              "local copies, wait_slot_free disabled", "local copies, submit = record the done event only", "local copies, no join_into (ready event instead)",
-             "LAZY: host waits for select(k-2), then queues exchange(k-2) with no device-side wait; local copies", "LAZY, full collectives"]
+             "LAZY (bench.make_step): host waits for select(k-2), no device-side wait; local copies", "LAZY (bench.make_step), full collectives"]
     NV = len(names)
     res = {k: [] for k in range(NV)}
     for rnd in range(3):
@@ -95,10 +97,10 @@ def main():
             ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
             ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
             ready = [torch.cuda.Event() for _ in range(NS)]
-            if kind >= 8:
-                step = lazy_step(eng, flame, images, unpad, conf, B, slots, gat, n_heads_all, ev0, ev1, NS)
+            if kind >= 8:  # what bench.py does since r05
+                step = bench.make_step(eng, flame, images, unpad, conf, B, slots, gat, True, False, n_heads_all, ev0, ev1, ready)
             else:
-                step = bench.make_step(eng, flame, images, unpad, conf, B, slots if gat is not None else None, gat, kind != 7, False, n_heads_all, ev0, ev1, ready)
+                step = eager_step(eng, flame, images, unpad, conf, B, slots if gat is not None else None, gat, kind != 7, n_heads_all, ev0, ev1, ready)
             for _ in range(12):
                 step()
             eng.join()
@@ -106,6 +108,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(K):
                 step(i)
+            step.flush()
             eng.join()
             if gat is not None:
                 for s in range(NS):
