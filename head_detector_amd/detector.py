@@ -107,8 +107,11 @@ def weight_manifest_diff(variant: str, sd: Dict[str, np.ndarray]) -> Dict[str, l
 class HeadDetector:
     def __init__(self, model: str = "vgg_heads_l", image_size: int = 640, *, weights: Optional[str] = None, flame_path: Optional[str] = None,
                  flame_model: Optional[Dict[str, Any]] = None, seed: int = 1, max_batch: int = 1,
-                 assets_dir: Optional[str] = None, mesh_assets=None, precision: str = "bf16"):
-        """``precision``: "bf16" (throughput mode, the default) or "fp16x3" -- the matrix-core parity mode whose outputs match the reference's
+                 assets_dir: Optional[str] = None, mesh_assets=None, precision: str = "bf16", calibration_images: Optional[Sequence] = None):
+        """``precision``: "bf16" (throughput mode, the default); "fp16" (r05: one fp16 plane per value -- the reference exporter's own FP16 format -- 8 x closer to the fp32 network at
+        0.92 x the speed); "fp8" (r05: bf16 with OCP-e4m3 links between 3x3 convs, 1.12 x the speed at 5 - 10 x the bf16 deviation; its activation scales are calibrated on
+        ``calibration_images`` -- a list of images like the ones this detector will see (paths, PIL or HWC uint8 arrays), letterboxed here -- and WITHOUT them on two seeded random images, which is
+        adequate for plumbing only: a warning says so); "fp16x3" -- the matrix-core parity mode whose outputs match the reference's
         fp32 CPU network to IoU >= 0.999 / 1e-4 (csrc/conv_split.hip; ~1/3 of the bf16 throughput); "fp32" = the VALU parity mode."""
         if not torch.cuda.is_available():
             raise _lib.VghError("HeadDetector: no GPU visible. This package is the MI355X HIP path only; it does not fall back to the CPU.")
@@ -116,6 +119,7 @@ class HeadDetector:
         self._device = torch.device("cuda", torch.cuda.current_device())
         self._max_batch = max_batch
         self._precision = precision
+        self._calibration_images = calibration_images
         self._flame = FLAMELayer(flame_path=flame_path, model=flame_model, device=self._device, max_heads=max(1024, 100 * max_batch))
         self.model = self._read_model(model, weights, seed)
         # mesh assets of the reference (head_detector/assets) for PredictionResult.get_pncc(); user-supplied, optional
@@ -145,7 +149,15 @@ class HeadDetector:
             diff = weight_manifest_diff(model, sd)
             if any(diff.values()):
                 raise ValueError(f"{weights} does not match the {model} architecture this engine lowers:\n" + "\n".join(f"  {k}: {v[:12]}{' ...' if len(v) > 12 else ''}" for k, v in diff.items() if v))
-        return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=self._max_batch, seed=seed, precision=self._precision)
+        calib = None
+        if self._precision == "fp8":
+            if self._calibration_images:
+                # the letterboxed u8 canvases the network will see (detector.py:40-52), as one batch
+                calib = torch.cat([self._transform_image(self._convert_image(im))[0] for im in self._calibration_images]).contiguous()
+            else:
+                warnings.warn("HeadDetector(precision='fp8') without calibration_images: the e4m3 links are scaled for two seeded RANDOM images -- pass images like the ones you will detect on",
+                              stacklevel=3)
+        return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=self._max_batch, seed=seed, precision=self._precision, calib_images=calib)
 
     # ---- host-side image handling (detector.py:32-56) ----------------------------------------------------
     def _convert_image(self, image) -> np.ndarray:

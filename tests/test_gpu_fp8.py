@@ -321,3 +321,37 @@ def test_r05_modes_through_the_pack_and_the_c_context(gpu_lib, flame_model, tmp_
     assert torch.equal(proj[:n_ref], ref.vertices_3d)
     gpu_lib.vgh_destroy(h)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_head_detector_facade_in_the_fp8_and_fp16_modes(gpu_lib, flame_model):
+    """The drop-in facade (head_detector/detector.py:97-102 contract) with precision="fp16" / "fp8": same call, same result types; the fp8 detector calibrates its e4m3 links on the
+    images it is given (letterboxed like any other input) and warns when it has to fall back to random ones."""
+    import warnings
+
+    from head_detector_amd import HeadDetector
+
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (300, 420, 3), dtype=np.uint8), rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, precision="fp16x3")
+        out = ref(imgs[0], confidence_threshold=0.0)
+        sc = sorted((h.score for h in out.heads), reverse=True)
+        conf = float(sc[min(5, len(sc) - 1)]) - 1e-3
+        base = ref(imgs[0], confidence_threshold=conf)
+        dets = {}
+        for prec in ("fp16", "fp8"):
+            det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, precision=prec, calibration_images=imgs if prec == "fp8" else None)
+            if prec == "fp8":
+                assert len(det.model.fp8_scales) >= 5 and all(v > 0 for v in det.model.fp8_scales.values())
+            dets[prec] = det(imgs[0], confidence_threshold=conf)
+    with pytest.warns(UserWarning, match="calibration_images"):
+        HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, precision="fp8")
+    a = base.heads
+    assert len(a) >= 3
+    h16 = dets["fp16"].heads
+    assert abs(len(h16) - len(a)) <= 1
+    for ha, hb in zip(a[:3], h16[:3]):  # the strongest detections agree closely in fp16
+        assert abs(ha.bbox.x - hb.bbox.x) <= 2 and abs(ha.bbox.w - hb.bbox.w) <= 3 and abs(ha.score - hb.score) < 1e-3
+    assert len(dets["fp8"].heads) >= 1 and all(np.isfinite(np.asarray(h.vertices_3d)).all() for h in dets["fp8"].heads)
