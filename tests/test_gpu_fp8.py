@@ -355,3 +355,35 @@ def test_head_detector_facade_in_the_fp8_and_fp16_modes(gpu_lib, flame_model):
     for ha, hb in zip(a[:3], h16[:3]):  # the strongest detections agree closely in fp16
         assert abs(ha.bbox.x - hb.bbox.x) <= 2 and abs(ha.bbox.w - hb.bbox.w) <= 3 and abs(ha.score - hb.score) < 1e-3
     assert len(dets["fp8"].heads) >= 1 and all(np.isfinite(np.asarray(h.vertices_3d)).all() for h in dets["fp8"].heads)
+
+
+@pytest.mark.gpu
+def test_r05_modes_at_1280(gpu_lib):
+    """BASELINE configs[4]'s geometry (1280 x 1280: 320- / 160- / 80- / 40-wide maps, 33 600 anchors) in the fp16 and fp8 modes: the e4m3 links and the fp16 ping-pong tiles on
+    the 320-wide maps, outputs finite and close to the bf16 mode's on the same image (mean dense IoU; the modes differ by their storage rounding only)."""
+    from head_detector_amd.engine import VGHeadsEngine
+
+    x = torch.randint(0, 256, (1, 1280, 1280, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(4)).to(_dev())
+    out = {}
+    for prec in ("bf16", "fp16", "fp8"):
+        eng = VGHeadsEngine("vgg_heads_l", image_size=1280, max_batch=1, seed=1, precision=prec, calib_images=x if prec == "fp8" else None)
+        if prec == "fp8":
+            assert sum(bf["is_f32"] == 4 for bf in eng.program.bufs) == 31  # the 40-wide maps of the /32 level qualify at 1280
+        eng.model(x)
+        torch.cuda.synchronize()
+        out[prec] = (eng.boxes_all[:1].cpu().clone(), eng.scores_all[:1].cpu().clone())
+        eng.close()
+
+    def iou(a, b):
+        lt, rb = torch.maximum(a[..., :2], b[..., :2]), torch.minimum(a[..., 2:], b[..., 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        return inter / ((a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter)
+
+    assert out["bf16"][0].shape == (1, 33600, 4)
+    for prec, lo in (("fp16", 0.95), ("fp8", 0.75)):
+        b, s = out[prec]
+        assert bool(torch.isfinite(b).all()) and bool(torch.isfinite(s).all())
+        m = float(iou(b, out["bf16"][0]).mean())
+        assert m > lo, (prec, m)
+        assert float((s - out["bf16"][1]).abs().max()) < (2e-3 if prec == "fp16" else 2e-2), prec
