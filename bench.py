@@ -637,8 +637,8 @@ def main():
             eng.set_split(1)  # per-op events make sense on one stream only: the table is the single-stream view of every op
             json.dump(eng.profile_ops(images), open(per_layer_path, "w"), indent=0)
         alg = arch.program_algorithmic_bytes(eng.program, B)
-        fp8_flops = 2.0 * sum(op["macs"] for op in eng.program.ops if arch.op_touches_fp8(eng.program, op) and eng.program.bufs[op["in_buf"]]["is_f32"] == arch.FMT_FP8)
-        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, fp8_flops_per_image=fp8_flops, fp8_links=sum(bf["is_f32"] == arch.FMT_FP8 for bf in eng.program.bufs), heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,
+        fp8_flops = 2.0 * sum(op["macs"] for op in eng.program.ops if arch.op_touches_fp8(eng.program, op) and eng.program.bufs[op["in_buf"]]["is_f32"] in arch.Q8_FMTS)
+        out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, fp8_flops_per_image=fp8_flops, fp8_links=sum(bf["is_f32"] in arch.Q8_FMTS for bf in eng.program.bufs), heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,
                    value=B * world * nfw / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,
                    alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch, power=power.summary(), exchange_dropped_rows=dropped, per_rank=per_rank)
         thr = throttle.summary()
@@ -761,6 +761,19 @@ def main():
                      "activation scales calibrated on two seeded random images; deviation from the oracle: modes_vs_oracle_one_image.fp8")
             print(f"[bench] fp8 links {args.variant} batch {B} @ {S}: {f8['value']:.1f} img/s ({f8['value'] / main_run['value']:.3f} x the bf16 headline), net {f8['net_ms']:.3f} ms, "
                   f"{100 * f8_fl / all_fl:.1f} % of the FLOPs on the fp8 MFMA, {ideal_ms / f8['net_ms']:.3f} of the mixed roof", file=sys.stderr)
+            # r05: the "int8" mode -- the same links as signed bytes (the reference exporter's QuantizationMode.INT8: exportable_mesh_model.py:175-178,398-411), v_mfma_i32_32x32x32_i8,
+            # with the folded identity branch of the RepVGG convs applied in fp32 (diagonal bypass, csrc/conv_pp.hip DG).  No spec peak for int8 in the guide ("2 x the bf16 rate"):
+            # the mixed roof prices the int8-input convs at 5 POP/s like the fp8 ones
+            i8 = run_workload(args.variant, B, max(20, sec_steps // 2), max(3, args.warmup // 2), precision="int8", inner=max(1, args.inner))
+            i8_fl = i8["fp8_flops_per_image"] * B
+            ideal8 = (i8_fl / (MFMA_FP8_DENSE_PEAK_TFLOPS * 1e12) + (all_fl - i8_fl) / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12)) * 1e3
+            config["secondary_int8_links"] = dict(
+                brief(i8), workload=f"{args.variant} int8 links batch {B} @ {S}", int8_link_tensors=i8["fp8_links"], share_of_flops_on_int8_mfma=round(i8_fl / all_fl, 4),
+                roofline_frac_vs_mixed_roof=round(ideal8 / i8["net_ms"], 4), mixed_roof_ms_per_forward=round(ideal8, 3), speedup_vs_bf16_headline=round(i8["value"] / main_run["value"], 4),
+                note="as secondary_fp8_links with int8 codes (scale = calibrated max * 1.25 / 127) and the diagonal bypass on the RepVGG cv2 convs; deviation from the oracle: "
+                     "modes_vs_oracle_one_image.int8 (about 2.5 x the bf16 mode's, less than half of the e4m3 links')")
+            print(f"[bench] int8 links {args.variant} batch {B} @ {S}: {i8['value']:.1f} img/s ({i8['value'] / main_run['value']:.3f} x the bf16 headline), net {i8['net_ms']:.3f} ms, "
+                  f"{ideal8 / i8['net_ms']:.3f} of the mixed roof", file=sys.stderr)
             # r05: the single-plane fp16 mode (the reference's own FP16 export format: exportable_mesh_model.py:177,299,409) -- same bytes and MFMA count as bf16
             fh = run_workload(args.variant, B, max(20, sec_steps // 2), max(3, args.warmup // 2), precision="fp16", inner=max(1, args.inner))
             config["secondary_fp16"] = dict(brief(fh), workload=f"{args.variant} fp16 (one fp16 plane per value, v_mfma_f32_32x32x16_f16) batch {B} @ {S}", speed_vs_bf16_headline=round(fh["value"] / main_run["value"], 4),
@@ -801,7 +814,7 @@ def main():
             line["cpu_baseline"], ref = cpu_baseline(args.variant, S, flame_model)
             if not args.no_accuracy and S == 640:
                 # checker role of the oracle: every precision mode on the oracle's image (parity_mode.vs_oracle is what north_star's bar reads)
-                dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16", "fp16", "fp8")}
+                dev_tab = {p: deviation_from_oracle(args.variant, p, ref, dev) for p in ("fp16x3", "fp32", "bf16x3", "bf16", "fp16", "fp8", "int8")}
                 config.setdefault("parity_mode", {})["vs_oracle"] = dev_tab["fp16x3"]
                 config["modes_vs_oracle_one_image"] = dev_tab
     # the line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which (redirected to a file or a pipe) is block-buffered and would

@@ -9,12 +9,12 @@ from typing import Optional
 HERE = os.path.dirname(os.path.abspath(__file__))
 # VGH_LIB_PATH: load another build of the library (tools/ use it for the -DVGH_EXPERIMENTS build, which is never shipped)
 LIB_PATH = os.environ.get("VGH_LIB_PATH") or os.path.join(HERE, "libvgh.so")
-ABI_VERSION = 6  # = VGH_ABI_VERSION of include/vgh.h
+ABI_VERSION = 7  # = VGH_ABI_VERSION of include/vgh.h
 
 VGH_OP_STEM, VGH_OP_CONV, VGH_OP_SPP_POOL, VGH_OP_FORK = 0, 1, 2, 3
 VGH_ACT_NONE, VGH_ACT_RELU, VGH_ACT_SILU = 0, 1, 2
 VGH_IMG_F32_NCHW, VGH_IMG_U8_NHWC = 0, 1
-VGH_FMT_BF16, VGH_FMT_F32, VGH_FMT_BF16X2, VGH_FMT_F16X2, VGH_FMT_FP8, VGH_FMT_F16 = 0, 1, 2, 3, 4, 5
+VGH_FMT_BF16, VGH_FMT_F32, VGH_FMT_BF16X2, VGH_FMT_F16X2, VGH_FMT_FP8, VGH_FMT_F16, VGH_FMT_I8 = 0, 1, 2, 3, 4, 5, 6
 NUM_FLAME_PARAMS = 413
 
 
@@ -55,7 +55,7 @@ class ConvCall(C.Structure):
         ("force_cfg", C.c_int32),
         ("grp_cout", C.c_int32), ("grp_in_stride", C.c_int32),
         ("fmt", C.c_int32), ("out_scale", C.c_float),
-        ("out_fp8", C.c_int32), ("gscale_dev", C.c_void_p),
+        ("out_fp8", C.c_int32), ("gscale_dev", C.c_void_p), ("diag_dev", C.c_void_p),
     ]
 
 
@@ -117,6 +117,7 @@ SYMBOLS = {
     "vgh_pack_conv_weights": (_I, [_P, _I, _I, _I, _P]),
     "vgh_pack_conv_weights_split": (_I, [_P, _I, _I, _I, _I, _P, C.POINTER(_F)]),
     "vgh_pack_conv_weights_fp8": (_I, [_P, _I, _I, _I, _P, _P]),
+    "vgh_pack_conv_weights_i8": (_I, [_P, _I, _I, _I, _P, _P]),
     "vgh_conv_num_cfgs": (_I, []),
     "vgh_conv_cfg_name": (C.c_char_p, [_I]),
     "vgh_conv_cfg_cout_tile": (_I, [_I]),
@@ -126,6 +127,8 @@ SYMBOLS = {
     "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "vgh_conv_set_max_blocks_per_xcd": (_I, [_I]),
     "vgh_conv_set_nt_store": (_I, [_I]),
+    "vgh_net_set_i8_diag": (_I, [_I]),
+    "vgh_net_op_has_diag": (_I, [_P, _I]),
     "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),
     "vgh_topk": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "vgh_gather_candidates": (_I, [C.POINTER(HeadLevel), _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),

@@ -42,13 +42,18 @@ VARIANTS: Dict[str, dict] = {
     ),
 }
 # activation storage formats (VGH_FMT_* of include/vgh.h; the buffer field keeps its historical name is_f32) per precision mode
-FMT_BF16, FMT_F32, FMT_BF16X2, FMT_F16X2, FMT_FP8, FMT_F16 = 0, 1, 2, 3, 4, 5
+FMT_BF16, FMT_F32, FMT_BF16X2, FMT_F16X2, FMT_FP8, FMT_F16, FMT_I8 = 0, 1, 2, 3, 4, 5, 6
 # "fp8" (r05) is the bf16 program with OCP-e4m3 LINKS: a tensor written by one 3x3 / stride-1 conv and read by one (bottleneck cv1 -> cv2, the middle layers of the
 # FLAME shape / expression branches) is stored as e4m3 bytes with a calibrated per-tensor scale, and its consumer runs v_mfma_f32_32x32x64_f8f6f4 (csrc/conv_pp.hip)
 # "fp16" (r05): ONE fp16 plane per value -- the reference's own FP16 export (exportable_mesh_model.py:177,299,409) -- same bytes and MFMA count as bf16, 11 significand bits
-PRECISION_FMT = {"bf16": FMT_BF16, "fp32": FMT_F32, "bf16x3": FMT_BF16X2, "fp16x3": FMT_F16X2, "fp8": FMT_BF16, "fp16": FMT_F16}
-FMT_BYTES = {FMT_BF16: 2, FMT_F32: 4, FMT_BF16X2: 4, FMT_F16X2: 4, FMT_FP8: 1, FMT_F16: 2}  # bytes per logical element
+# "int8" (r05): the same links as signed bytes in [-127, 127] -- the reference exporter's QuantizationMode.INT8 (exportable_mesh_model.py:175-178,398-411) -- through
+# v_mfma_i32_32x32x32_i8: a uniform grid (relative step 1 / 127 of the tensor's range instead of e4m3's 1 / 16 of the value) and an exact int32 accumulator
+PRECISION_FMT = {"bf16": FMT_BF16, "fp32": FMT_F32, "bf16x3": FMT_BF16X2, "fp16x3": FMT_F16X2, "fp8": FMT_BF16, "fp16": FMT_F16, "int8": FMT_BF16}
+FMT_BYTES = {FMT_BF16: 2, FMT_F32: 4, FMT_BF16X2: 4, FMT_F16X2: 4, FMT_FP8: 1, FMT_F16: 2, FMT_I8: 1}  # bytes per logical element
 FP8_MAX, FP8_HEADROOM = 448.0, 2.0  # scale of an e4m3 link = calibrated max|activation| * headroom / 448
+I8_MAX, I8_HEADROOM = 127.0, 1.25   # scale of an int8 link = calibrated max|activation| * headroom / 127 (a uniform grid pays for head-room linearly: less of it)
+Q8_FMTS = (FMT_FP8, FMT_I8)
+Q8_PRECISIONS = {"fp8": FMT_FP8, "int8": FMT_I8}  # the bf16 program with 8-bit links
 TR_OUTS = (("rotation", 6), ("jaw", 3), ("translation", 3), ("scale", 1))  # order of the transform branches in the prediction buffer
 STRIDES = (8, 16, 32)
 
@@ -287,9 +292,9 @@ class Program:
     flops: float = 0.0  # algorithmic 2*MACs per image (fused-conv accounting)
     precision: str = "bf16"
 
-    def buf(self, name: str, h: int, w: int, pitch: int, f32: bool = False, fp8_scale: Optional[float] = None) -> int:
-        """fp8_scale: the buffer is an e4m3 link (FMT_FP8), value = stored * fp8_scale."""
-        self.bufs.append(dict(name=name, h=h, w=w, pitch=pitch, is_f32=int(f32)) if fp8_scale is None else dict(name=name, h=h, w=w, pitch=pitch, is_f32=FMT_FP8, scale=float(fp8_scale)))
+    def buf(self, name: str, h: int, w: int, pitch: int, f32: bool = False, fp8_scale: Optional[float] = None, q8_fmt: int = FMT_FP8) -> int:
+        """fp8_scale: the buffer is an 8-bit link (q8_fmt: FMT_FP8 e4m3 / FMT_I8 int8), value = stored * fp8_scale."""
+        self.bufs.append(dict(name=name, h=h, w=w, pitch=pitch, is_f32=int(f32)) if fp8_scale is None else dict(name=name, h=h, w=w, pitch=pitch, is_f32=q8_fmt, scale=float(fp8_scale)))
         return len(self.bufs) - 1
 
     def _push_w(self, W: np.ndarray, b: np.ndarray) -> Tuple[int, int]:
@@ -361,12 +366,12 @@ STEM_PITCH_BF16 = 48  # 64 restores the zero-padded stem tensor of r01 - r03 (to
 
 
 def fp8_link_names(variant: str, image_size: int = 640, fp8_min_px: int = 40) -> Dict[str, Tuple[str, int]]:
-    """e4m3 link buffer of the "fp8" program -> (buffer of the bf16 program that holds the same tensor, its leading channels): what a calibration forward of the
+    """8-bit link buffer of the "fp8" (and "int8": same links) program -> (buffer of the bf16 program that holds the same tensor, its leading channels): what a calibration forward of the
     bf16 engine has to look at (engine.calibrate_fp8)."""
     P = build_program(variant, random_state_dict(variant, 0), image_size, "fp8", fp8_scales={}, fp8_min_px=fp8_min_px)
     out = {}
     for bf in P.bufs:
-        if bf["is_f32"] == FMT_FP8:
+        if bf["is_f32"] in Q8_FMTS:
             out[bf["name"]] = (bf["name"][:-1], bf["live"]) if bf["name"].endswith("q") else (bf["name"], bf["live"])
     return out
 
@@ -379,11 +384,13 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     fp8_min_px pixels a side -- the 8 x 8 sub-patches of the ping-pong tiles waste a third of a 20-wide map; fp8_scales: link buffer name -> max|activation| from a
     calibration forward, see engine.calibrate_fp8; a missing entry takes max = 8)."""
     assert precision in PRECISION_FMT, precision
-    fp8 = precision == "fp8"
+    fp8 = precision in Q8_PRECISIONS  # 8-bit links (e4m3 or int8)
+    q8_fmt = Q8_PRECISIONS.get(precision, FMT_FP8)
     fp8_scales = fp8_scales or {}
 
     def link_scale(name: str) -> float:
-        return max(float(fp8_scales.get(name, 8.0)), 1e-6) * FP8_HEADROOM / FP8_MAX
+        amax = max(float(fp8_scales.get(name, 8.0)), 1e-6)
+        return amax * I8_HEADROOM / I8_MAX if q8_fmt == FMT_I8 else amax * FP8_HEADROOM / FP8_MAX
 
     def r64(c: int) -> int:
         return (c + 63) // 64 * 64
@@ -400,7 +407,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
     # bf16 throughput mode: the stem tensor is stored at its own 48-channel pitch (96-byte pixels); the stage-1 downsample still reads 64-channel K
     # windows, whose last 16 channels (the next pixel's first 16) meet the 16 zero weight columns _ohwi pads in below -- the executor verifies that at
     # vgh_net_create.  The parity modes keep the 64-channel pitch with stored zeros (a split pixel is [hi | lo] planes: no such window).
-    stem_pitch = STEM_PITCH_BF16 if precision in ("bf16", "fp8") else 64
+    stem_pitch = STEM_PITCH_BF16 if precision in ("bf16", "fp8", "int8") else 64
     stem_buf = P.buf("stem", S // 2, S // 2, stem_pitch)
     P.ops.append(dict(name="backbone.stem.conv", kind=0, in_buf=-1, in_coff=0, cin=3, out_buf=stem_buf, out_coff=0, cout_pad=64, cout_store=stem_pitch, out_split=64,
                       out_coff2=0, res_buf=-1, res_coff=0, alpha=0.0, ksize=3, stride=2, act=1, shuffle=0, w_off=wo, b_off=bo, force_cfg=-1,
@@ -429,7 +436,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
             if fp8 and res_px >= fp8_min_px:
                 # cv1 -> cv2 is a single-writer / single-reader link: e4m3 bytes, K blocks of 64 channels (a 96-channel tensor sits in a 128-byte pixel whose last 32
                 # bytes are never written: the arena's zero bytes are e4m3 +0 and meet zero weight columns)
-                mid = P.buf(f"{p}.mid{i}", res_px, res_px, r64(hid), fp8_scale=link_scale(f"{p}.mid{i}"))
+                mid = P.buf(f"{p}.mid{i}", res_px, res_px, r64(hid), fp8_scale=link_scale(f"{p}.mid{i}"), q8_fmt=q8_fmt)
                 P.bufs[mid]["live"] = hid
                 P.conv(f"{p}.bottlenecks.{i}.cv1", View(cat, prev, hid), View(mid, 0, hid), _ohwi(wa, hid), ba, 3)
                 P.conv(f"{p}.bottlenecks.{i}.cv2", View(mid, 0, r64(hid)), View(cat, dst, hid), _ohwi(wb, r64(hid)), bb, 3, res=(View(cat, prev, hid), alpha), flops_macs=hid * 9 * hid)
@@ -565,7 +572,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
             link_out = fp8 and r >= fp8_min_px and bi + 1 < nb and all(_r32(c) % 64 == 0 for c in inters[:2])
             nxt_q = None
             if link_out:
-                nxt_q = P.buf(f"{p}.f{bi}q", r, r, offs[2], fp8_scale=link_scale(f"{p}.f{bi}q"))
+                nxt_q = P.buf(f"{p}.f{bi}q", r, r, offs[2], fp8_scale=link_scale(f"{p}.f{bi}q"), q8_fmt=q8_fmt)
                 P.bufs[nxt_q]["live"] = offs[2]
             for n_, inter, off in zip(names[:2], inters[:2], offs[:2]):
                 W, b = F[f"{p}.flame_{n_}_pred.{bi}"]
@@ -626,7 +633,7 @@ def is_net_kernel(kernel_name: str) -> bool:
 
 def op_touches_fp8(P: "Program", op: dict) -> bool:
     """The op reads or writes an e4m3 link (it then runs on the ping-pong tile the library picks: no table entry applies)."""
-    return op["kind"] == 1 and (P.bufs[op["in_buf"]]["is_f32"] == FMT_FP8 or P.bufs[op["out_buf"]]["is_f32"] == FMT_FP8)
+    return op["kind"] == 1 and (P.bufs[op["in_buf"]]["is_f32"] in Q8_FMTS or P.bufs[op["out_buf"]]["is_f32"] in Q8_FMTS)
 
 
 def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]:
@@ -653,7 +660,7 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     wr = out_px * store * eb_out
     if op["res_buf"] >= 0:
         rd += out_px * store * FMT_BYTES[P.bufs[op["res_buf"]]["is_f32"]]
-    rd += op["cout_pad"] * op["ksize"] ** 2 * op["cin"] * (1 if ib["is_f32"] == FMT_FP8 else 2 if ib["is_f32"] in (FMT_BF16, FMT_F16) else 4 if ib["is_f32"] == FMT_F32 else 6)
+    rd += op["cout_pad"] * op["ksize"] ** 2 * op["cin"] * (1 if ib["is_f32"] in Q8_FMTS else 2 if ib["is_f32"] in (FMT_BF16, FMT_F16) else 4 if ib["is_f32"] == FMT_F32 else 6)
     return dict(read=float(rd), write=float(wr))
 
 

@@ -334,6 +334,7 @@ static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (!vgh_conv_cfg_ok(cfg, a.ksize, a.stride, a.cout_pad, a.fast_epi && !a.out_f32, a.shuffle)) return 0;
     if (a.grp_cout && a.grp_cout % g_cfgs[cfg].BC) return 0;
     if ((a.in_fp8 || a.out_fp8) && g_cfgs[cfg].patch != 5) return 0;  // e4m3 links: g tiles only (conv_pp.hip)
+    if (a.dvec && g_cfgs[cfg].BC == 128) return 0;
     if ((g_cfgs[cfg].patch == 5 || g_cfgs[cfg].patch == 6) && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || !vgh_conv_pp_fits(a))) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
     if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
     return 1;
@@ -383,7 +384,8 @@ int pick_size_only(const ConvArgs& a) {  // last resort: largest plain implicit-
 int vgh_conv_pick_cfg(const ConvArgs& a) {
     if (a.in_fp8 || a.out_fp8) {  // e4m3 links run on the g tiles: the widest cout tile that divides the layer
         static const int g128 = cfg_by_name("g8x8x128_n8"), g96 = cfg_by_name("g8x8x96_n8"), g64 = cfg_by_name("g8x8x64_n8");
-        return a.cout_pad % 128 == 0 ? g128 : a.cout_pad % 96 == 0 ? g96 : g64;
+        // (the 128-cout variant of the diagonal bypass spills ~100 registers: 96 or 64 couts per workgroup there)
+        return (a.cout_pad % 128 == 0 && !a.dvec) ? g128 : a.cout_pad % 96 == 0 ? g96 : g64;
     }
     // A measured per-layer table (tuning/*.json) overrides this through force_cfg.
     static int row_cfg[kNumHeur];

@@ -118,6 +118,19 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
     return (unsigned)r;
 }
+// ---- int8 variants (F8 = 2 / O8 = 2; VGH_FMT_I8, the reference exporter's QuantizationMode.INT8): the same geometry as e4m3 -- 64 channels per 64-byte record -- with two
+//      v_mfma_i32_32x32x32_i8 per (cout group, pixel group) pair, one per 16-byte chunk of a lane, exactly where the bf16 tile issues its two MFMAs.  The accumulator
+//      registers hold int32 bit patterns (exact sums), start at 0, and the epilogue computes act(float(acc) * g[c] + bias[c]) ----
+__device__ __forceinline__ f32x16_t mfma_i8(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    typedef __attribute__((ext_vector_type(16))) int i32x16;
+    return __builtin_bit_cast(f32x16_t, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), __builtin_bit_cast(i32x16, c), 0, 0, 0));
+}
+// four floats -> four int8 bytes (element 0 in the low byte): clamp to [lo, 127], round to nearest even
+__device__ __forceinline__ unsigned pack_i8x4(float a, float b, float c, float d, float lo) {
+    const int ia = (int)__builtin_rintf(__builtin_amdgcn_fmed3f(a, lo, 127.0f)), ib = (int)__builtin_rintf(__builtin_amdgcn_fmed3f(b, lo, 127.0f));
+    const int ic = (int)__builtin_rintf(__builtin_amdgcn_fmed3f(c, lo, 127.0f)), id = (int)__builtin_rintf(__builtin_amdgcn_fmed3f(d, lo, 127.0f));
+    return ((unsigned)ia & 255u) | (((unsigned)ib & 255u) << 8) | (((unsigned)ic & 255u) << 16) | ((unsigned)id << 24);
+}
 // ---- single-plane fp16 variant (H16 = 1; VGH_FMT_F16, r05: the reference's own FP16 export, exportable_mesh_model.py:177,299,409): same tile, same bytes, same MFMA
 //      count as bf16 with v_mfma_f32_32x32x16_f16; the weights carry a per-op power-of-two prescale, so the accumulator starts at bias / out_scale and is multiplied by
 //      out_scale at the end; stores saturate at +-65504 ----
@@ -194,12 +207,18 @@ struct PPTile {
     int b, y0, x0;
 };
 
-template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0>
+// DG = 1 (int8 input, bf16 output): the DIAGONAL BYPASS.  A re-parameterised RepVGG block folds its identity branch into the centre tap, so row c of the folded kernel
+// holds one weight w[c][centre][c] 15 - 30 x its rms -- a per-cout int8 grid sized for it leaves ~23 dB for everything else (e4m3: 32 dB).  The host takes that one
+// element out of the int8 image (which then reaches ~41 dB) and the epilogue adds it back exactly: + dvec[c] * code(input pixel, channel c), dvec = w[c][centre][c] * scale(in),
+// from one dword load per four couts (the pixel's own input bytes: L2 hits, the halo has just been read).  dvec sits in the upper half of the factor region: cout_pad <= 1024.
+template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0, int DG = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk, const PPDiv dv) {
     constexpr int SC = (F8 || O8) ? 1 : 0;  // per-cout output factors in the epilogue
     constexpr int ES = F8 ? 1 : 2;          // bytes per input element
     static_assert(!(F8 || O8 || H16) || (V == 1 && PP_BAR_TAIL == 0 && PP_RES_PREFETCH == 0), "fp8 / fp16 variants: g tiles only");
     static_assert(!(H16 && (F8 || O8)), "one storage format per variant");
+    static_assert(!(F8 && O8) || F8 == O8, "an 8-bit input and an 8-bit output share one format");
+    static_assert(!DG || (F8 == 2 && O8 == 0), "the diagonal bypass belongs to the int8 -> bf16 variant");
     // fp16: the accumulator runs in prescaled-weight units: it starts at bias * a.bias_scale (= 1 / out_scale, host-computed: a kernel argument, no register)
     using G = PPGeo<TI, V, SC>;
     constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
@@ -307,7 +326,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     dma16(wbase_cur, wv_cur, (unsigned)(1 * ncb) * wkstride, wdst + 1 * wdst_step);
     if constexpr (V == 2) dma16(wbase_cur, wv_cur, (unsigned)(2 * ncb) * wkstride, wdst + 2 * wdst_step);
     dma16(a.bias, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::BIAS + w * 1024);
-    if constexpr (SC) dma16(a.gscale, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::GS + w * 1024);
+    if constexpr (SC) {
+        if (!DG || w < 4) dma16(a.gscale, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::GS + w * 1024);
+    }
+    if constexpr (DG) {  // waves 4 .. 7 stage dvec behind the (<= 4 KB: cout_pad <= 1024) factor vector
+        if (w >= 4) dma16(a.dvec, (lane * 16 + (w - 4) * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + (w - 4) * 1024) : OOB, 0, smem + G::GS + w * 1024);
+    }
     wait_vm<0>();
     barrier_raw();
     if constexpr (V == 1) {
@@ -373,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     do {                                                                                                            \
         const f32x4_t bv_ = *(const f32x4_t*)(smem + G::BIAS + ((c0n) + (i) * 32 + (q) * 8 + hi * 4) * 4);         \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                          \
-            const float b0_ = H16 ? bv_[e_] * a.bias_scale : bv_[e_];                                               \
+            const float b0_ = F8 == 2 ? 0.0f /* int32 zero */ : H16 ? bv_[e_] * a.bias_scale : bv_[e_];             \
             acc[i][0][(q) * 4 + e_] = b0_;                                                                          \
             acc[i][1][(q) * 4 + e_] = b0_;                                                                          \
         }                                                                                                           \
@@ -563,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     // its epilogue shares a barrier slot with group 0's (which follows group 0's side of this barrier) instead of taking a slot of its own
                     const bool closing = !(PP_EPI_SAME_SLOT && T == 8 && last && grp);
                     constexpr int NM = TI * 4, BAR_AT = NM - (PP_BAR_TAIL < NM ? PP_BAR_TAIL : NM - 1);
-                    if constexpr (F8) {
+                    if constexpr (F8 == 1) {
                         if (!VGH_ABLATE(a, 2)) {
 #pragma unroll
                             for (int i = 0; i < TI; ++i)
@@ -577,7 +601,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                             for (int i = 0; i < TI; ++i)
 #pragma unroll
                                 for (int j = 0; j < 2; ++j) {
-                                    acc[i][j] = mfma16pp<H16>(h ? a1[i] : a0[i], h ? b1[j] : b0[j], acc[i][j]);
+                                    if constexpr (F8 == 2)
+                                        acc[i][j] = mfma_i8(h ? a1[i] : a0[i], h ? b1[j] : b0[j], acc[i][j]);
+                                    else
+                                        acc[i][j] = mfma16pp<H16>(h ? a1[i] : a0[i], h ? b1[j] : b0[j], acc[i][j]);
                                     if (PP_BAR_TAIL > 0 && (h * TI + i) * 2 + j + 1 == BAR_AT) {
                                         __builtin_amdgcn_sched_barrier(0);
                                         if (closing && !VGH_ABLATE(a, 64)) barrier_raw();
@@ -626,11 +653,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
         //      one in-order counter, so a residual load issued behind a store could only be awaited together with that store's write acknowledgement ----
         if (!VGH_ABLATE(a, 8)) {
             const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x80000000, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, 0x80000000, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, 0x80000000, 0x00020000);
             const int cbase = cur.c0;
             constexpr int OS = O8 ? 1 : 2;                                     // bytes per output element
             const int dsplit = (a.out_coff2 - a.out_split - a.out_coff) * OS;  // byte shift of the second output segment
             unsigned ovb[2], rvb[2];  // byte offsets of this lane's pixel + channel (cbase + 8 hi) in the output / residual tensor
+            unsigned ivb[2];          // DG: byte offset of the pixel's own int8 input, channel cbase + 16 hi
+            // DG: one 16-byte load per cout group = the pixel's codes of channels cbase + 32 i + 16 hi .. + 15; two half-wave exchanges (diag_run) turn them into the
+            // accumulator's runs q = 0 .. 3 (channels 32 i + 8 q + 4 hi .. + 3) -- the same trade the bf16 residual makes
+            u32x4_t dq[TI];
+            auto load_diag = [&](int j) {
+                if constexpr (DG) {
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) dq[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ivb[j] + i * 32, 0, 0);
+                }
+            };
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int y = cur.y0 + 4 * j + (n32 >> 3), x = cur.x0 + (n32 & 7);
@@ -639,6 +677,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                 // bf16: a lane ends up with couts cbase + 32 i + 16 m + 8 hi .. + 7; e4m3: with couts cbase + 32 i + 16 hi .. + 15
                 ovb[j] = okpx ? (unsigned)((opix * (int)a.out_pitch + a.out_coff + cbase + (O8 ? 16 : 8) * hi) * OS) : OOB;
                 rvb[j] = okpx ? (unsigned)((opix * (int)a.res_pitch + a.res_coff + cbase + 8 * hi) * 2) : OOB;
+                if constexpr (DG) ivb[j] = okpx ? (unsigned)(opix * in_pitch + a.in_coff + cbase + 16 * hi) : OOB;  // 3x3 / stride 1: input pixel = output pixel
             }
             // order: residual loads of pixel group 0 -> arithmetic of group 0 (results held) -> residual loads of group 1 -> stores of group 0 ->
             // arithmetic + stores of group 1: every load is issued ahead of every store, and group 1's vectors land in group 0's dead accumulators
@@ -660,7 +699,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                 constexpr int j = decltype(jc)::value;
                 constexpr bool RES = decltype(rc)::value;
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i) {
+                    unsigned dr[4] = {0u, 0u, 0u, 0u};  // DG: input codes of run q (see load_diag)
+                    if constexpr (DG) {
+                        unsigned x0 = dq[i][0], x1 = dq[i][1], x2 = dq[i][2], x3 = dq[i][3];
+                        swap32(x0, x1);  // lower half-wave: own channels 0-3 | the partner's 16-19; upper: the partner's 4-7 | own 20-23
+                        swap32(x2, x3);  //                  own 8-11 | 24-27;                              12-15 | 28-31
+                        dr[0] = x0, dr[1] = x2, dr[2] = x1, dr[3] = x3;
+                    }
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         // after the exchange this lane holds couts cv .. cv + 7; before it, runs q = 2m and q = 2m + 1 (couts 32 i + 8 q + 4 hi + e)
@@ -669,8 +715,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 #pragma unroll
                             for (int qq = 0; qq < 2; ++qq) {
                                 const f32x4_t gv = *(const f32x4_t*)(smem + G::GS + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
+                                if constexpr (F8 == 2) {  // exact int32 sum -> real units, then the bias
+                                    const f32x4_t bv = *(const f32x4_t*)(smem + G::BIAS + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] *= gv[e];
+                                    for (int e = 0; e < 4; ++e) {
+                                        // (through a scalar: __builtin_bit_cast applied to a vector-element lvalue reads element 0 -- hipcc 7.2, seen in the ISA)
+                                        const float raw = acc[i][j][(2 * m + qq) * 4 + e];
+                                        acc[i][j][(2 * m + qq) * 4 + e] = (float)__builtin_bit_cast(int, raw) * gv[e] + bv[e];
+                                    }
+                                    if constexpr (DG) {
+                                        const f32x4_t dv = *(const f32x4_t*)(smem + G::GS + 4096 + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
+                                        const unsigned xw = dr[2 * m + qq];
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] += dv[e] * (float)(int)(signed char)(xw >> (8 * e));
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] *= gv[e];
+                                }
                             }
                         }
                         if constexpr (H16) {  // prescaled-weight units -> real units (one factor per op)
@@ -706,6 +768,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         swap32(pa1, pb1);
                         ov[i][m] = u32x4_t{pa0, pa1, pb0, pb1};
                     }
+                }
             };
             // the whole cout tile stored, into ONE output segment: the offset of a vector is this lane's base + an immediate
             const bool simple = cbase + BC <= a.cout_store && (a.out_split >= cbase + BC || a.out_split <= cbase);
@@ -734,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     store_out(j, std::false_type{});
             };
             // e4m3 output (no residual): runs q = 0 .. 3 of a cout group -> four packed dwords; two half-wave exchanges leave every lane with 16 consecutive couts
-            const float lo8 = a.act == VGH_ACT_RELU ? 0.0f : -448.0f;
+            const float lo8 = a.act == VGH_ACT_RELU ? 0.0f : O8 == 2 ? -127.0f : -448.0f;
             auto arith8 = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
 #pragma unroll
@@ -743,7 +806,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4_t gv = *(const f32x4_t*)(smem + G::GS + (cbase + i * 32 + q * 8 + hi * 4) * 4);
-                        R[q] = pack_fp8x4(acc[i][j][q * 4 + 0] * gv[0], acc[i][j][q * 4 + 1] * gv[1], acc[i][j][q * 4 + 2] * gv[2], acc[i][j][q * 4 + 3] * gv[3], lo8);
+                        float v[4];
+                        if constexpr (F8 == 2) {
+                            const f32x4_t bv = *(const f32x4_t*)(smem + G::BIAS + (cbase + i * 32 + q * 8 + hi * 4) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float raw = acc[i][j][q * 4 + e];  // (scalar first: see arith)
+                                v[e] = (float)__builtin_bit_cast(int, raw) * gv[e] + bv[e];
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * gv[e];
+                        }
+                        R[q] = O8 == 2 ? pack_i8x4(v[0], v[1], v[2], v[3], lo8) : pack_fp8x4(v[0], v[1], v[2], v[3], lo8);
                     }
                     swap32(R[0], R[2]);  // lower half-wave: couts 0-3, 4-7, 8-11, 12-15 in R0, R2, R1, R3; upper: 16-19, 20-23, 24-27, 28-31
                     swap32(R[1], R[3]);
@@ -767,16 +842,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                 arith8(std::integral_constant<int, 1>{});
             } else if (a.res) {
                 load_res(0);
+                load_diag(0);
                 __builtin_amdgcn_sched_barrier(0);
                 arith(std::integral_constant<int, 0>{}, std::true_type{});
                 __builtin_amdgcn_sched_barrier(0);
                 load_res(1);
+                load_diag(1);
                 __builtin_amdgcn_sched_barrier(0);
                 stores(0);
                 __builtin_amdgcn_sched_barrier(0);
                 arith(std::integral_constant<int, 1>{}, std::true_type{});
             } else {
+                load_diag(0);
                 arith(std::integral_constant<int, 0>{}, std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                load_diag(1);
                 __builtin_amdgcn_sched_barrier(0);
                 stores(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -844,14 +924,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 }
 
 constexpr int kMaxDev = 16;
-template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0>
+template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0, int DG = 0>
 int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, int chunk, int max_blocks_per_xcd, hipStream_t st) {
     using G = PPGeo<TI, V, (F8 || O8) ? 1 : 0>;
     static std::atomic<int> done[kMaxDev];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
     if (!done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V, F8, O8, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (G::LDS)));
+        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V, F8, O8, H16, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (G::LDS)));
         done[dev].store(1, std::memory_order_release);
     }
     int gpx = 32;  // one workgroup per CU, 32 CUs per XCD
@@ -861,7 +941,7 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
     vgh_fastdiv_magic((unsigned)ntc, &dv.m_ntc, &dv.s_ntc);
     vgh_fastdiv_magic((unsigned)(nsy * nsx), &dv.m_per, &dv.s_per);
     vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
-    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V, F8, O8, H16>), dim3(gpx * 8), dim3(512), (G::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V, F8, O8, H16, DG>), dim3(gpx * 8), dim3(512), (G::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -882,7 +962,8 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
     VGH_REQUIRE(a.ksize == 3 && a.stride == 1 && a.fast_epi && !a.out_f32 && !a.shuffle && !a.grp_cout && (!a.split || h16) && a.act != VGH_ACT_SILU, "conv: the ping-pong tiles run plain 3x3 / stride-1 bf16 / fp16 / e4m3 convs only");
     VGH_REQUIRE(!h16 || (version == 1 && !a.in_fp8 && !a.out_fp8 && a.out_scale > 0.0f && a.cout_store == a.cout_pad), "conv: the fp16 ping-pong variant takes whole cout tiles and the op's weight prescale");
     if (a.in_fp8 || a.out_fp8) {
-        VGH_REQUIRE(version == 1, "conv: the e4m3 variants exist for the g tiles only");
+        VGH_REQUIRE(version == 1, "conv: the e4m3 / int8 variants exist for the g tiles only");
+        VGH_REQUIRE(a.in_fp8 >= 0 && a.in_fp8 <= 2 && a.out_fp8 >= 0 && a.out_fp8 <= 2 && (!a.in_fp8 || !a.out_fp8 || a.in_fp8 == a.out_fp8), "conv: 8-bit formats are 1 (e4m3) or 2 (int8), the same on both sides");
         VGH_REQUIRE(a.gscale, "conv: an e4m3 conv needs its per-cout output factors (gscale)");
         VGH_REQUIRE(!a.in_fp8 || (a.cin % 64 == 0 && a.in_coff % 16 == 0 && a.in_pitch % 16 == 0), "conv: an e4m3 input view needs cin %% 64 == 0 and 16-byte aligned offset / pitch (cin=%d)", a.cin);
         VGH_REQUIRE(!a.out_fp8 || (!a.res && a.cout_store == a.cout_pad && (a.out_split >= a.cout_pad || a.out_split % bc == 0) && a.out_coff % 16 == 0 && a.out_coff2 % 16 == 0 && a.out_pitch % 16 == 0),
@@ -897,15 +978,30 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
     const int chunk = (int)((total + 7) / 8);
     if (a.in_fp8 || a.out_fp8) {
         const int f = a.in_fp8 ? 1 : 0, o = a.out_fp8 ? 1 : 0;
-#define PP_F8_CASE(TI_)                                                                                            \
-    if (bc == 32 * TI_) {                                                                                          \
-        if (f && o) return launch_pp<TI_, 1, 1, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream); \
-        if (f) return launch_pp<TI_, 1, 1, 0>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);      \
-        return launch_pp<TI_, 1, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);             \
+        const bool i8 = a.in_fp8 == 2 || a.out_fp8 == 2;
+#define PP_F8_CASE(TI_, Q_)                                                                                            \
+    if (bc == 32 * TI_) {                                                                                              \
+        if (f && o) return launch_pp<TI_, 1, Q_, Q_>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream); \
+        if (f) return launch_pp<TI_, 1, Q_, 0>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);       \
+        return launch_pp<TI_, 1, 0, Q_>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);              \
     }
-        PP_F8_CASE(4)
-        PP_F8_CASE(3)
-        PP_F8_CASE(2)
+        if (a.dvec) {
+            VGH_REQUIRE(a.in_fp8 == 2 && !a.out_fp8 && a.cout_pad <= 1024 && a.cin >= a.cout_pad && a.Ho == a.H && a.Wo == a.W,
+                        "conv: the diagonal bypass (dvec) belongs to an int8 -> bf16 conv with cout_pad <= min(cin, 1024)");
+            switch (bc) {  // (no 128-cout variant: it spills; vgh_conv_pick_cfg / cfg_ok_for keep such ops on 96 / 64)
+                case 96: return launch_pp<3, 1, 2, 0, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+                case 64: return launch_pp<2, 1, 2, 0, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+            }
+        }
+        if (i8) {
+            PP_F8_CASE(4, 2)
+            PP_F8_CASE(3, 2)
+            PP_F8_CASE(2, 2)
+        } else {
+            PP_F8_CASE(4, 1)
+            PP_F8_CASE(3, 1)
+            PP_F8_CASE(2, 1)
+        }
 #undef PP_F8_CASE
         VGH_REQUIRE(false, "conv: no e4m3 ping-pong tile with %d couts", bc);
     }
@@ -988,6 +1084,36 @@ void vgh_pack_conv_weights_fp8_host(const float* w, int cout_pad, int ksize, int
                 const float inv = 1.0f / wscale[co];
                 for (int chunk = 0; chunk < 4; ++chunk)
                     for (int e = 0; e < 16; ++e) d[(chunk ^ sw) * 16 + e] = vgh_f32_to_e4m3_host(src[chunk * 16 + e] * inv);
+            }
+        }
+}
+
+// dense [cout_pad][ks][ks][cin] f32 -> int8 image, same layout as the e4m3 one; one scale per cout: wscale[c] = max|w[c]| / 127 (1 for an all-zero or non-finite row),
+// stored = clamp(rn(w / wscale[c]), -127, 127) (-128 is never produced: the grid is symmetric)
+void vgh_pack_conv_weights_i8_host(const float* w, int cout_pad, int ksize, int cin, uint8_t* dst, float* wscale) {
+    const int cblocks = cin / 64, taps = ksize * ksize;
+    const size_t row = (size_t)taps * cin;
+    for (int co = 0; co < cout_pad; ++co) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < row; ++i) {
+            const float v = fabsf(w[(size_t)co * row + i]);
+            if (v > mx) mx = v;
+        }
+        wscale[co] = (mx > 0.0f && mx <= 3.0e38f) ? mx / 127.0f : 1.0f;
+    }
+    for (int tap = 0; tap < taps; ++tap)
+        for (int cb = 0; cb < cblocks; ++cb) {
+            const int kb = tap * cblocks + cb;
+            for (int co = 0; co < cout_pad; ++co) {
+                const float* src = w + ((size_t)co * taps + tap) * cin + cb * 64;
+                uint8_t* d = dst + ((size_t)kb * cout_pad + co) * 64;
+                const int sw = (co >> 2) & 3;
+                for (int chunk = 0; chunk < 4; ++chunk)
+                    for (int e = 0; e < 16; ++e) {
+                        float q = __builtin_nearbyintf(src[chunk * 16 + e] / wscale[co]);
+                        q = q != q ? 0.0f : q > 127.0f ? 127.0f : q < -127.0f ? -127.0f : q;
+                        d[(chunk ^ sw) * 16 + e] = (uint8_t)(int8_t)(int)q;
+                    }
             }
         }
 }

@@ -32,7 +32,27 @@ struct NetOp {
     // pixel's first ones; vgh_net_create has verified that every weight row is exactly zero there (finite x 0 adds +-0 to the accumulator)
     int overhang_ok = 0;
     float* gscale = nullptr;  // device [cout_pad]: per-cout output factors of an op that reads or writes a VGH_FMT_FP8 buffer (conv_pp.hip), else nullptr
+    float* dvec = nullptr;    // device [cout_pad]: the diagonal bypass of an int8 -> bf16 conv whose rows are dominated by w[c][centre][c] (i8_peel_diag), else nullptr
 };
+
+static std::atomic<int> g_i8_diag{1};
+// An int8 -> bf16 3x3 conv takes the diagonal bypass (conv_pp.hip DG) when at least half of its live rows have w[c][centre][c] as their largest weight -- the folded
+// identity branch of a RepVGG block.  Exact either way (one element of the sum is evaluated in fp32 instead of through the int8 image); what it buys is the int8 grid
+// of the remaining weights.
+static bool i8_peel_diag(const float* w, const vgh_op_desc& d) {
+    if (!g_i8_diag.load(std::memory_order_relaxed) || d.ksize != 3 || d.stride != 1 || d.grp_cout || d.cin < d.cout_pad || d.cout_pad > 1024) return false;
+    const size_t row = (size_t)9 * d.cin;
+    int live = 0, dom = 0;
+    for (int c = 0; c < d.cout_pad; ++c) {
+        float mx = 0.0f;
+        for (size_t i = 0; i < row; ++i) mx = fmaxf(mx, fabsf(w[(size_t)c * row + i]));
+        if (mx > 0.0f) {
+            ++live;
+            if (fabsf(w[(size_t)c * row + (size_t)4 * d.cin + c]) >= mx) ++dom;
+        }
+    }
+    return live > 0 && 2 * dom >= live;
+}
 
 struct vgh_net {
     int device = 0, image_size = 0, max_batch = 0;
@@ -109,10 +129,11 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     a->res_pitch = d.res_buf >= 0 ? (int64_t)n->bufs[d.res_buf].pitch * vgh_fmt_planes(n->bufs[d.res_buf].is_f32) : 0;
     a->res_plane = (d.res_buf >= 0 && !h16) ? n->bufs[d.res_buf].pitch : 0;
     // e4m3 links (r05): bf16 -> e4m3, e4m3 -> bf16 and e4m3 -> e4m3 are legal pairs (3x3 / stride-1 convs on the ping-pong tiles); the residual of such an op is bf16
-    const bool in8 = ib.is_f32 == VGH_FMT_FP8, out8 = ob.is_f32 == VGH_FMT_FP8;
-    a->in_fp8 = in8;
-    a->out_fp8 = out8;
+    const bool in8 = vgh_fmt_is_q8(ib.is_f32), out8 = vgh_fmt_is_q8(ob.is_f32);
+    a->in_fp8 = vgh_fmt_q8_kind(ib.is_f32);
+    a->out_fp8 = vgh_fmt_q8_kind(ob.is_f32);
     a->gscale = op.gscale;
+    a->dvec = op.dvec;
     VGH_REQUIRE(a->out_f32 || ob.is_f32 == ib.is_f32 || (in8 && ob.is_f32 == VGH_FMT_BF16) || (out8 && ib.is_f32 == VGH_FMT_BF16), "net: op writes buffer %d in another format than it reads", d.out_buf);
     VGH_REQUIRE(d.res_buf < 0 || n->bufs[d.res_buf].is_f32 == (in8 ? VGH_FMT_BF16 : ib.is_f32), "net: residual buffer %d has another format than the input", d.res_buf);
     VGH_REQUIRE(!(in8 || out8) || (d.ksize == 3 && d.stride == 1 && !d.grp_cout && !d.shuffle && (!in8 || d.cin % 64 == 0)), "net: an e4m3 buffer can only link plain 3x3 / stride-1 convs (cin %% 64 == 0)");
@@ -281,8 +302,8 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     int64_t off = 0;
     std::vector<int64_t> offs(n_bufs);
     for (int i = 0; i < n_bufs; ++i) {
-        VGH_REQUIRE(bufs[i].is_f32 >= VGH_FMT_BF16 && bufs[i].is_f32 <= VGH_FMT_F16, "net_create: buffer %d has unknown format %d", i, bufs[i].is_f32);
-        VGH_REQUIRE(bufs[i].is_f32 != VGH_FMT_FP8 || (bufs[i].scale > 0.0f && bufs[i].scale < 1e30f && bufs[i].pitch % 16 == 0), "net_create: e4m3 buffer %d needs a positive scale and a pitch that is a multiple of 16", i);
+        VGH_REQUIRE(bufs[i].is_f32 >= VGH_FMT_BF16 && bufs[i].is_f32 <= VGH_FMT_I8, "net_create: buffer %d has unknown format %d", i, bufs[i].is_f32);
+        VGH_REQUIRE(!vgh_fmt_is_q8(bufs[i].is_f32) || (bufs[i].scale > 0.0f && bufs[i].scale < 1e30f && bufs[i].pitch % 16 == 0), "net_create: 8-bit buffer %d needs a positive scale and a pitch that is a multiple of 16", i);
         const int64_t bytes = (int64_t)max_batch * bufs[i].h * bufs[i].w * bufs[i].pitch * vgh_fmt_bytes(bufs[i].is_f32);
         offs[i] = off;
         n->buf_bytes.push_back(bytes);
@@ -299,7 +320,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     for (int l = 0; l < vgh_net::kLanes; ++l) VGH_HIP(hipEventCreateWithFlags(&n->ev_lag[l], hipEventDisableTiming));
     // ---- weights: pack on the host, one upload ----
     int64_t wbytes = 0;
-    std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0), goff(n_ops, -1);
+    std::vector<int64_t> woff(n_ops, 0), boff(n_ops, 0), goff(n_ops, -1), doff(n_ops, -1);
     for (int i = 0; i < n_ops; ++i) {
         const vgh_op_desc& d = ops[i];
         if (d.kind == VGH_OP_CONV) {
@@ -318,12 +339,16 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             }
             woff[i] = wbytes;
             const int wf = bufs[d.in_buf].is_f32;  // weight image: bf16 (2 B), dense fp32 (4 B) or the three 16-bit segments of the split modes (6 B)
-            wbytes += align_up(we * (wf == VGH_FMT_FP8 ? 1 : (wf == VGH_FMT_BF16 || wf == VGH_FMT_F16) ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
+            wbytes += align_up(we * (vgh_fmt_is_q8(wf) ? 1 : (wf == VGH_FMT_BF16 || wf == VGH_FMT_F16) ? 2 : wf == VGH_FMT_F32 ? 4 : 6), 256);
             boff[i] = wbytes;
             wbytes += align_up((int64_t)d.cout_pad * 4, 256);
-            if (wf == VGH_FMT_FP8 || bufs[d.out_buf].is_f32 == VGH_FMT_FP8) {
+            if (vgh_fmt_is_q8(wf) || vgh_fmt_is_q8(bufs[d.out_buf].is_f32)) {
                 goff[i] = wbytes;
                 wbytes += align_up((int64_t)d.cout_pad * 4, 256);
+                if (wf == VGH_FMT_I8 && bufs[d.out_buf].is_f32 == VGH_FMT_BF16 && i8_peel_diag(weights_host + d.w_off, d)) {
+                    doff[i] = wbytes;
+                    wbytes += align_up((int64_t)d.cout_pad * 4, 256);
+                }
             }
         } else if (d.kind == VGH_OP_STEM) {
             VGH_REQUIRE(d.w_off >= 0 && d.w_off + 27 * 48 <= n_weights && d.b_off + 48 <= n_biases, "net_create: stem weight range");
@@ -361,8 +386,8 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
                 memcpy(host.data() + woff[i], weights_host + d.w_off, (size_t)d.cout_pad * d.ksize * d.ksize * d.cin * 4);
             else if (wf == VGH_FMT_BF16)
                 vgh_pack_conv_weights_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint16_t*)(host.data() + woff[i]));
-            else if (wf == VGH_FMT_FP8)
-                ;  // below: the e4m3 image comes with per-cout scales that also enter the bias
+            else if (vgh_fmt_is_q8(wf))
+                ;  // below: the 8-bit image comes with per-cout scales that also enter the bias
             else
                 vgh_pack_conv_weights_split_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, wf, (uint16_t*)(host.data() + woff[i]), &oscale[i]);
             memcpy(host.data() + boff[i], biases_host + d.b_off, (size_t)d.cout_pad * 4);
@@ -371,8 +396,28 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
                 // The kernel starts its accumulator at the bias, so the bias is stored in accumulator units: bias / (wscale[c] * scale(in)).
                 float* g = (float*)(host.data() + goff[i]);
                 float* bq = (float*)(host.data() + boff[i]);
-                const float s_out = bufs[d.out_buf].is_f32 == VGH_FMT_FP8 ? bufs[d.out_buf].scale : 1.0f;
-                if (wf == VGH_FMT_FP8) {
+                const float s_out = vgh_fmt_is_q8(bufs[d.out_buf].is_f32) ? bufs[d.out_buf].scale : 1.0f;
+                if (wf == VGH_FMT_I8) {
+                    // int8: exact int32 accumulator from 0; out = act(acc * g + b) with g = wscale[c] * scale(in) / scale(out) and the bias in output units
+                    std::vector<float> ws(d.cout_pad);
+                    const float* wsrc = weights_host + d.w_off;
+                    std::vector<float> peeled;
+                    if (doff[i] >= 0) {  // diagonal bypass: w[c][centre][c] leaves the int8 image and is applied in fp32 by the epilogue (s_out = 1: bf16 output)
+                        peeled.assign(wsrc, wsrc + (size_t)d.cout_pad * 9 * d.cin);
+                        float* dv = (float*)(host.data() + doff[i]);
+                        for (int c = 0; c < d.cout_pad; ++c) {
+                            float& wd = peeled[(size_t)c * 9 * d.cin + (size_t)4 * d.cin + c];
+                            dv[c] = wd * bufs[d.in_buf].scale;
+                            wd = 0.0f;
+                        }
+                        wsrc = peeled.data();
+                    }
+                    vgh_pack_conv_weights_i8_host(wsrc, d.cout_pad, d.ksize, d.cin, (uint8_t*)(host.data() + woff[i]), ws.data());
+                    for (int c = 0; c < d.cout_pad; ++c) {
+                        g[c] = ws[c] * bufs[d.in_buf].scale / s_out;
+                        bq[c] = bq[c] / s_out;
+                    }
+                } else if (wf == VGH_FMT_FP8) {
                     std::vector<float> ws(d.cout_pad);
                     vgh_pack_conv_weights_fp8_host(weights_host + d.w_off, d.cout_pad, d.ksize, d.cin, (uint8_t*)(host.data() + woff[i]), ws.data());
                     for (int c = 0; c < d.cout_pad; ++c) {
@@ -404,6 +449,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             op.bias = (float*)(n->wblob + boff[i]);
             op.overhang_ok = (!ops[i].grp_cout && ops[i].in_coff + ops[i].cin > bufs[ops[i].in_buf].pitch) ? 1 : 0;  // zero weight columns verified above
             if (goff[i] >= 0) op.gscale = (float*)(n->wblob + goff[i]);
+            if (doff[i] >= 0) op.dvec = (float*)(n->wblob + doff[i]);
         } else if (ops[i].kind == VGH_OP_STEM) {
             op.wf32 = (float*)(n->wblob + woff[i]);
             op.bias = (float*)(n->wblob + boff[i]);
@@ -596,7 +642,7 @@ int vgh_net_set_cfg(vgh_net* n, int op_index, int cfg) {
     const bool split_net = vgh_fmt_planes(fmt0) > 1 || fmt0 == VGH_FMT_F16;  // the single-plane fp16 nets index the split modes' tile table too
     VGH_REQUIRE(cfg >= -1 && cfg < (split_net ? vgh_conv_split_num_cfgs() : vgh_conv_num_cfgs()), "net_set_cfg: bad cfg");
     NetOp& op = n->ops[op_index];
-    if (cfg >= 0 && op.d.kind == VGH_OP_CONV && !split_net && (n->bufs[op.d.in_buf].is_f32 == VGH_FMT_BF16 || n->bufs[op.d.in_buf].is_f32 == VGH_FMT_FP8)) {
+    if (cfg >= 0 && op.d.kind == VGH_OP_CONV && !split_net && (n->bufs[op.d.in_buf].is_f32 == VGH_FMT_BF16 || vgh_fmt_is_q8(n->bufs[op.d.in_buf].is_f32))) {
         // eligibility is decided ONCE, for the arena batch: a tile that fits a small chunk but not max_batch (the ping-pong tiles' 2 GiB rule depends on the
         // pixel count) would otherwise run some batch sizes and silently fall back on others -- two summation orders for one op, against the "same bits for
         // any chunk" invariant of NetOp::auto_cfg.  Such a tile is replaced by the automatic one for every batch, and the replacement is logged.
@@ -628,11 +674,14 @@ int vgh_conv2d(const vgh_conv_call* c, void* stream) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     const int planes = vgh_fmt_planes(c->fmt);
-    VGH_REQUIRE(c->fmt == VGH_FMT_BF16 || c->fmt == VGH_FMT_BF16X2 || c->fmt == VGH_FMT_F16X2 || c->fmt == VGH_FMT_FP8 || c->fmt == VGH_FMT_F16, "conv2d: fmt %d", c->fmt);
-    a.in_fp8 = c->fmt == VGH_FMT_FP8;
-    a.out_fp8 = c->out_fp8 ? 1 : 0;
+    VGH_REQUIRE(c->fmt == VGH_FMT_BF16 || c->fmt == VGH_FMT_BF16X2 || c->fmt == VGH_FMT_F16X2 || c->fmt == VGH_FMT_FP8 || c->fmt == VGH_FMT_F16 || c->fmt == VGH_FMT_I8, "conv2d: fmt %d", c->fmt);
+    a.in_fp8 = vgh_fmt_q8_kind(c->fmt);
+    a.out_fp8 = c->out_fp8;
+    VGH_REQUIRE(c->out_fp8 >= 0 && c->out_fp8 <= 2 && (!a.in_fp8 || !a.out_fp8 || a.in_fp8 == a.out_fp8), "conv2d: out_fp8 is 0, 1 (e4m3) or 2 (int8), and an 8-bit input keeps its format");
     a.gscale = c->gscale_dev;
-    VGH_REQUIRE(!(a.in_fp8 || a.out_fp8) || (c->gscale_dev && (c->fmt == VGH_FMT_FP8 || c->fmt == VGH_FMT_BF16) && !c->out_f32), "conv2d: an e4m3 conv needs gscale_dev, a bf16 or e4m3 input and no fp32 output");
+    a.dvec = c->diag_dev;
+    VGH_REQUIRE(!c->diag_dev || (c->fmt == VGH_FMT_I8 && !c->out_fp8 && c->cin >= c->cout_pad && c->cout_pad <= 1024), "conv2d: diag_dev belongs to an int8 -> bf16 conv with cout_pad <= min(cin, 1024)");
+    VGH_REQUIRE(!(a.in_fp8 || a.out_fp8) || (c->gscale_dev && (vgh_fmt_is_q8(c->fmt) || c->fmt == VGH_FMT_BF16) && !c->out_f32), "conv2d: an e4m3 / int8 conv needs gscale_dev, a bf16 or e4m3 input and no fp32 output");
     const bool h16 = c->fmt == VGH_FMT_F16;  // single-plane fp16: the fp16 split kernels with one K segment and plane strides 0
     a.split = h16 ? VGH_FMT_F16X2 : planes > 1 ? c->fmt : 0;
     a.nseg = h16 ? 1 : 3;
@@ -689,6 +738,17 @@ int vgh_pack_conv_weights_fp8(const float* w_host, int cout_pad, int ksize, int 
     VGH_REQUIRE(w_host && wpack_host && wscale_host, "pack_fp8: null argument");
     VGH_REQUIRE(cin % 64 == 0 && cout_pad % 32 == 0 && ksize == 3, "pack_fp8: cin must be a multiple of 64, cout_pad of 32, ksize 3");
     vgh_pack_conv_weights_fp8_host(w_host, cout_pad, ksize, cin, wpack_host, wscale_host);
+    return VGH_OK;
+}
+int vgh_net_set_i8_diag(int on) {
+    g_i8_diag.store(on ? 1 : 0, std::memory_order_relaxed);
+    return VGH_OK;
+}
+int vgh_net_op_has_diag(vgh_net* n, int op_index) { return (n && op_index >= 0 && op_index < (int)n->ops.size() && n->ops[op_index].dvec) ? 1 : 0; }
+int vgh_pack_conv_weights_i8(const float* w_host, int cout_pad, int ksize, int cin, uint8_t* wpack_host, float* wscale_host) {
+    VGH_REQUIRE(w_host && wpack_host && wscale_host, "pack_i8: null argument");
+    VGH_REQUIRE(cin % 64 == 0 && cout_pad % 32 == 0 && ksize == 3, "pack_i8: cin must be a multiple of 64, cout_pad of 32, ksize 3");
+    vgh_pack_conv_weights_i8_host(w_host, cout_pad, ksize, cin, wpack_host, wscale_host);
     return VGH_OK;
 }
 

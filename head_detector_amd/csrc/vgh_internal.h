@@ -75,8 +75,10 @@ struct ConvArgs {
     float out_scale;  // undoes the per-op power-of-two weight prescale (fp16), applied to the accumulator before the bias
     // ---- e4m3 links (conv_pp.hip, r05): the input view / the output tensor hold OCP e4m3 bytes (pitches and channel offsets then count bytes); the residual stays
     //      bf16.  gscale[cout_pad]: per-cout output factor applied to the accumulator (which starts at bias / gscale when the input is e4m3) ----
+    //      in_fp8 / out_fp8: 0 = 16-bit, 1 = e4m3, 2 = int8 (VGH_FMT_I8: int32 accumulator from 0, out = act(acc * gscale + bias), bias in output units) ----
     int in_fp8, out_fp8;
     const float* gscale;
+    const float* dvec;  // int8 -> bf16 only (or nullptr): the diagonal bypass, out[c] += dvec[c] * code(input pixel, channel c) before the activation (conv_pp.hip DG)
     float bias_scale;  // fp16 ping-pong variant: 1 / out_scale (set by vgh_launch_conv_pp)
     int fallback_cfg1;  // 0: a forced tile that cannot run this conv is an error; k + 1: it falls back to tile k (network executor: a table may be stale)
     int nt_out;          // bf16 output stores carry the non-temporal hint (set by vgh_conv_prepare from vgh_conv_set_nt_store)
@@ -107,11 +109,14 @@ int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);
 // vgh_pack_conv_weights_host); fmt = VGH_FMT_BF16X2 / VGH_FMT_F16X2.  Returns through *out_scale the factor the kernel multiplies the
 // accumulators by (fp16: 2^-s with 2^s the power-of-two prescale that brings max|w| to ~2^9; bf16: 1).
 void vgh_pack_conv_weights_split_host(const float* w, int cout_pad, int ksize, int cin, int fmt, uint16_t* dst, float* out_scale);
-static inline int vgh_fmt_bytes(int fmt) { return fmt == VGH_FMT_FP8 ? 1 : (fmt == 0 || fmt == VGH_FMT_F16) ? 2 : 4; }  // bytes per logical element of an activation buffer
+static inline int vgh_fmt_bytes(int fmt) { return (fmt == VGH_FMT_FP8 || fmt == VGH_FMT_I8) ? 1 : (fmt == 0 || fmt == VGH_FMT_F16) ? 2 : 4; }  // bytes per logical element of an activation buffer
 static inline int vgh_fmt_planes(int fmt) { return (fmt == VGH_FMT_BF16X2 || fmt == VGH_FMT_F16X2) ? 2 : 1; }
 // conv_pp.hip (host): OCP e4m3fn conversion and the e4m3 weight image of the ping-pong tiles
 uint8_t vgh_f32_to_e4m3_host(float f);
 void vgh_pack_conv_weights_fp8_host(const float* w, int cout_pad, int ksize, int cin, uint8_t* dst, float* wscale);
+void vgh_pack_conv_weights_i8_host(const float* w, int cout_pad, int ksize, int cin, uint8_t* dst, float* wscale);
+static inline int vgh_fmt_is_q8(int fmt) { return fmt == VGH_FMT_FP8 || fmt == VGH_FMT_I8; }    // an 8-bit link format
+static inline int vgh_fmt_q8_kind(int fmt) { return fmt == VGH_FMT_FP8 ? 1 : fmt == VGH_FMT_I8 ? 2 : 0; }  // ConvArgs::in_fp8 / out_fp8 code
 // conv_pp.hip: the 8-wave ping-pong 3x3 / stride-1 tiles ("g" tiles; bc = 128 / 96 / 64 couts per workgroup); `a` must be prepared
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version /* 1: "g" (two barriers per tap), 2: "h" (one) */, int max_blocks_per_xcd, hipStream_t stream);
 int vgh_conv_pp_lds(int bc);

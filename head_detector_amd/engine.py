@@ -85,7 +85,8 @@ class VGHeadsEngine:
         """``precision="fp8"`` (r05): the bf16 network with OCP-e4m3 links between 3x3 / stride-1 convs (arch.build_program).  Every link needs the largest
         activation it will carry: ``fp8_scales`` {link name: max|x|} from an earlier ``calibrate_fp8``, or ``calib_images`` (u8 NHWC / f32 NCHW GPU batch of
         representative inputs) to run that calibration now; with neither, two seeded random images are used -- adequate for the synthetic benchmark, NOT for
-        real weights and real photographs."""
+        real weights and real photographs.  ``precision="int8"``: the same links as signed bytes (VGH_FMT_I8, the reference exporter's QuantizationMode.INT8), same
+        calibration, same arguments."""
         if variant not in arch.VARIANTS:
             raise ValueError(f"unknown model variant {variant!r}; known: {sorted(arch.VARIANTS)}")
         if not torch.cuda.is_available():
@@ -98,7 +99,7 @@ class VGHeadsEngine:
             state_dict = arch.random_state_dict(variant, seed)  # synthetic weights of the exact architecture
         self.precision = precision
         self.fp8_scales = None
-        if precision == "fp8":
+        if precision in arch.Q8_PRECISIONS:
             if fp8_scales is None:
                 if calib_images is None:
                     calib_images = torch.randint(0, 256, (2, image_size, image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(12345)).to(torch.device("cuda", self.device_index))
@@ -153,7 +154,7 @@ class VGHeadsEngine:
         self._head_out = None  # (capacity, head_image, proj, rpy) allocated on first FLAME use
         self._levels = None
         self._graph_key = None
-        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp8", "fp16", "fp16x3", "bf16x3"))  # the split modes have their own keys (precision prefix) and tile set
+        self._use_tuning = bool(use_tuning and precision in ("bf16", "fp8", "int8", "fp16", "fp16x3", "bf16x3"))  # the split modes have their own keys (precision prefix) and tile set
         self.nsplit = 1
         if self._use_tuning:
             self.load_tuning()
@@ -198,6 +199,9 @@ class VGHeadsEngine:
         self.stream.synchronize()
         if fmt == arch.FMT_FP8:  # e4m3 link: decoded to fp32 (stored * scale)
             t = _alias(self.lib.vgh_net_buffer(self._net, bid), (n,), "|u1", self.device).clone().view(torch.float8_e4m3fn).float() * bf["scale"]
+            return t.view(B, bf["h"], bf["w"], bf["pitch"])
+        if fmt == arch.FMT_I8:  # int8 link
+            t = _alias(self.lib.vgh_net_buffer(self._net, bid), (n,), "|i1", self.device).clone().float() * bf["scale"]
             return t.view(B, bf["h"], bf["w"], bf["pitch"])
         if fmt in (arch.FMT_BF16X2, arch.FMT_F16X2):
             t = _alias(self.lib.vgh_net_buffer(self._net, bid), (2 * n,), "<i2", self.device).clone().view(B, bf["h"], bf["w"], 2, bf["pitch"])
@@ -472,7 +476,7 @@ class VGHeadsEngine:
         for i, op in enumerate(self.program.ops):
             if op["kind"] != 1 or arch.op_touches_fp8(self.program, op):  # e4m3 links run on the g tile the library picks
                 continue
-            pre = "" if self.precision in ("bf16", "fp8") else self.precision + ":"
+            pre = "" if self.precision in ("bf16", "fp8", "int8") else self.precision + ":"
             name = tuning_lookup(table, op, self.max_batch, getattr(self, "nsplit", 1), pre)
             if name in names and self.cfg_ok(names[name], op):  # a stale entry (a tile that cannot run this op) is skipped here, not replaced -- and logged -- by the library
                 self.set_cfg(i, names[name])

@@ -107,7 +107,7 @@ def tile_names_for(program: "arch.Program", batch: int, nsplit: int = 1, table_p
     if not os.path.exists(path):
         return {}
     table = json.load(open(path))
-    pre = "" if program.precision in ("bf16", "fp8") else program.precision + ":"  # the split-precision modes have their own keys and tile names
+    pre = "" if program.precision in ("bf16", "fp8", "int8") else program.precision + ":"  # the split-precision modes have their own keys and tile names
     out = {}
     for i, op in enumerate(program.ops):
         if op["kind"] != 1 or arch.op_touches_fp8(program, op):  # e4m3 links run on the g tile the library picks
@@ -151,9 +151,9 @@ def main(argv=None):
     ap.add_argument("--fp8-scales", default=None, help="--precision fp8: json {e4m3 link name: max|activation|} from head_detector_amd.engine.calibrate_fp8")
     args = ap.parse_args(argv)
     scales = None
-    if args.precision == "fp8":  # the e4m3 links need calibrated activation maxima (engine.calibrate_fp8 on a GPU box, saved as {link name: max|x|}); packing itself needs no GPU
+    if args.precision in arch.Q8_PRECISIONS:  # the e4m3 links need calibrated activation maxima (engine.calibrate_fp8 on a GPU box, saved as {link name: max|x|}); packing itself needs no GPU
         if not args.fp8_scales:
-            sys.exit("pack: --precision fp8 needs --fp8-scales <json from head_detector_amd.engine.calibrate_fp8>")
+            sys.exit(f"pack: --precision {args.precision} needs --fp8-scales <json from head_detector_amd.engine.calibrate_fp8>")
         scales = json.load(open(args.fp8_scales))
     P = arch.build_program(args.variant, _weights_arg(args.weights, args.variant), args.image_size, args.precision, fp8_scales=scales)
     names = tile_names_for(P, args.batch, args.split) if args.precision != "fp32" else {}

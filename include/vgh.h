@@ -38,9 +38,10 @@ const char* vgh_last_error(void);
 
 /* ABI revision of this header: bumped whenever a struct below grows or a function changes meaning (r03 -> 3: vgh_conv_call / vgh_op_desc gained
  * grp_cout, grp_in_stride, fmt, out_scale and vgh_flame_set_matrix_path became a 0..4 mode; r04 -> 4: this call; -> 5: modes 0..7 of
- * vgh_flame_set_matrix_path; r05 -> 6: VGH_FMT_FP8, vgh_buf_desc.scale, vgh_conv_call.out_fp8 / gscale_dev, vgh_pack_conv_weights_fp8).  A client built against another
+ * vgh_flame_set_matrix_path; r05 -> 6: VGH_FMT_FP8, vgh_buf_desc.scale, vgh_conv_call.out_fp8 / gscale_dev, vgh_pack_conv_weights_fp8;
+ * -> 7: VGH_FMT_I8, vgh_conv_call.out_fp8 = 2 / diag_dev, vgh_pack_conv_weights_i8, vgh_net_set_i8_diag).  A client built against another
  * revision passes structs of another size: compare before the first call that takes one (head_detector_amd/_lib.py and tests/c_abi_smoke.c do). */
-#define VGH_ABI_VERSION 6
+#define VGH_ABI_VERSION 7
 int vgh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -65,12 +66,14 @@ int vgh_abi_version(void);
                          /*   +-65504 saturate                                                                                                                              */
 #define VGH_FMT_FP8 4    /* r05, "fp8" throughput mode: OCP e4m3fn bytes, value = stored * vgh_buf_desc.scale.  Only on links between two 3x3 / stride-1  */
                          /*   convs that run on the ping-pong tiles (csrc/conv_pp.hip): written by one, read by one; every other tensor stays bf16     */
+#define VGH_FMT_I8 6     /* r05, "int8" throughput mode (the reference exporter's QuantizationMode.INT8: exportable_mesh_model.py:175-178,398-411): signed bytes */
+                         /*   in [-127, 127], value = stored * vgh_buf_desc.scale, on the same links as VGH_FMT_FP8; v_mfma_i32_32x32x32_i8, exact int32 accumulation */
 
 typedef struct vgh_buf_desc {
     int32_t h, w;   /* spatial size per image */
     int32_t pitch;  /* LOGICAL channels per pixel (concat width); 16-bit formats: multiple of 8; the two-plane formats occupy 2*pitch */
     int32_t is_f32; /* VGH_FMT_* */
-    float scale;    /* VGH_FMT_FP8: value = stored * scale (> 0; from a calibration forward: max|activation| / 448 with head-room); other formats: ignored */
+    float scale;    /* VGH_FMT_FP8 / VGH_FMT_I8: value = stored * scale (> 0; from a calibration forward: max|activation| / 448 resp. / 127 with head-room); other formats: ignored */
 } vgh_buf_desc;
 
 typedef struct vgh_op_desc {
@@ -157,9 +160,16 @@ typedef struct vgh_conv_call {
                                          /* fmt = VGH_FMT_FP8 (3x3 / stride 1, ping-pong tiles only): in_dev holds e4m3 bytes (in_pitch / in_coff count   */
                                          /*   bytes, cin % 64 == 0), wpack_dev comes from vgh_pack_conv_weights_fp8, res_dev stays bf16, and bias_dev     */
                                          /*   holds bias[c] / gscale[c] (the accumulator starts there and is multiplied by gscale[c] at the end)          */
-    int32_t out_fp8;                     /* 1: out_dev receives e4m3 bytes (out_pitch / offsets count bytes; whole cout tiles, no residual)               */
+                                         /* fmt = VGH_FMT_I8: the same with int8 bytes and vgh_pack_conv_weights_i8, except that the accumulator is an      */
+                                         /*   exact int32 sum that starts at 0: out = act(acc * gscale[c] + bias_dev[c]), bias_dev in OUTPUT units           */
+                                         /*   (bias[c] / output scale when out_fp8 = 2, bias[c] for a bf16 output)                                           */
+    int32_t out_fp8;                     /* 1: out_dev receives e4m3 bytes, 2: int8 bytes (out_pitch / offsets count bytes; whole cout tiles, no residual; */
+                                         /*   an 8-bit input and an 8-bit output must be the same format)                                                   */
     const float* gscale_dev;             /* [cout_pad] per-cout output factor: e4m3 in: wscale[c] * input scale (/ output scale when out_fp8);           */
                                          /*   bf16 in, e4m3 out: 1 / output scale.  NULL otherwise                                                       */
+    const float* diag_dev;               /* fmt = VGH_FMT_I8, bf16 output, cout_pad <= min(cin, 1024) (or NULL): the diagonal bypass -- before the         */
+                                         /*   activation, out[c] += diag_dev[c] * code(input pixel, channel c): the caller has taken w[c][centre][c]         */
+                                         /*   (the folded identity branch of a RepVGG block) out of the int8 image, diag_dev[c] = that weight * input scale  */
 } vgh_conv_call;
 int vgh_conv2d(const vgh_conv_call* c, void* stream);
 /* Split-precision weight image (parity modes): dense [cout_pad][k][k][cin] f32 -> 3*cout_pad*k*k*cin u16 ([w_lo | w_hi | w_hi] segments);
@@ -168,6 +178,8 @@ int vgh_pack_conv_weights_split(const float* w_host, int cout_pad, int ksize, in
 /* e4m3 weight image of the ping-pong tiles: dense [cout_pad][k][k][cin] f32 -> cout_pad*k*k*cin bytes + one power-of-two scale per cout
  * (stored = rn_e4m3(w / wscale[c])); cin % 64 == 0, k = 3. */
 int vgh_pack_conv_weights_fp8(const float* w_host, int cout_pad, int ksize, int cin, uint8_t* wpack_host, float* wscale_host);
+/* int8 weight image of the ping-pong tiles (same layout): stored = clamp(rn(w / wscale[c]), -127, 127) with wscale[c] = max|w[c]| / 127 (1 for an all-zero row) */
+int vgh_pack_conv_weights_i8(const float* w_host, int cout_pad, int ksize, int cin, uint8_t* wpack_host, float* wscale_host);
 /* dense [cout_pad][k][k][cin] f32 (host) -> kernel-private bf16 image (host, cout_pad*k*k*cin u16) */
 int vgh_pack_conv_weights(const float* w_host, int cout_pad, int ksize, int cin, uint16_t* wpack_host);
 int vgh_conv_num_cfgs(void);
@@ -186,6 +198,11 @@ int vgh_conv_set_max_blocks_per_xcd(int blocks);
 /* Process-wide: bf16 conv outputs are stored with the non-temporal hint (evict-first in L2, so the input lines neighbouring tiles re-read survive).
  * Results do not change. */
 int vgh_conv_set_nt_store(int on);
+/* Process-wide, read by vgh_net_create (default on): an int8 -> bf16 3x3 conv whose rows are dominated by w[c][centre][c] -- at least half of the live rows have it as
+ * their largest weight: the identity branch a RepVGG block folds into its kernel -- keeps that element out of the int8 image and applies it in fp32 in the epilogue
+ * (vgh_conv_call.diag_dev).  Off: the plain per-cout int8 grid (for the comparison; ~17 dB less weight precision on such rows). */
+int vgh_net_set_i8_diag(int on);
+int vgh_net_op_has_diag(vgh_net* net, int op_index); /* 1: the op of a created network runs with the diagonal bypass */
 
 /* ------------------------------------------------------------------------------------------------
  * Head decode: replaces YoloHeadsNDFLHeads.forward's tail (yolo_head_ndfl_heads.py:143-172) and the

@@ -273,7 +273,7 @@ def test_fp8_mode_deviation_from_the_oracle_is_pinned_next_to_bf16(gpu_lib, flam
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp8", "fp16"])
+@pytest.mark.parametrize("precision", ["fp8", "fp16", "int8"])
 def test_r05_modes_through_the_pack_and_the_c_context(gpu_lib, flame_model, tmp_path, precision):
     """`pack --precision fp8 | fp16` -> vgh_create -> vgh_ctx_detect (a C client's path to the two r05 throughput modes) equals the Python engine of the same mode bit for
     bit: the pack (version 3) carries the e4m3 buffers with their calibrated scales / the fp16 buffers, the library quantises the weights itself, and the per-op tiles
@@ -285,11 +285,11 @@ def test_r05_modes_through_the_pack_and_the_c_context(gpu_lib, flame_model, tmp_
     variant, S, B = "vgg_heads_m", 320, 2
     sd = arch.random_state_dict(variant, 11)
     x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).to(_dev())
-    scales = calibrate_fp8(variant, sd, S, x) if precision == "fp8" else None
+    scales = calibrate_fp8(variant, sd, S, x) if precision in ("fp8", "int8") else None
     eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, use_tuning=False, precision=precision, fp8_scales=scales)
     P = eng.program
-    if precision == "fp8":
-        assert sum(bf["is_f32"] == arch.FMT_FP8 for bf in P.bufs) >= 5  # 80- and 40-wide maps at 320
+    if precision in ("fp8", "int8"):
+        assert sum(bf["is_f32"] == arch.Q8_PRECISIONS[precision] for bf in P.bufs) >= 5  # 80- and 40-wide maps at 320
     pk = str(tmp_path / f"m_{precision}.vghpack")
     pack.write_pack(pk, P, flame_model, {}, B)
     hdr = pack.read_header(pk)
@@ -341,9 +341,9 @@ def test_head_detector_facade_in_the_fp8_and_fp16_modes(gpu_lib, flame_model):
         conf = float(sc[min(5, len(sc) - 1)]) - 1e-3
         base = ref(imgs[0], confidence_threshold=conf)
         dets = {}
-        for prec in ("fp16", "fp8"):
-            det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, precision=prec, calibration_images=imgs if prec == "fp8" else None)
-            if prec == "fp8":
+        for prec in ("fp16", "fp8", "int8"):
+            det = HeadDetector("vgg_heads_m", 320, flame_model=flame_model, weights="synthetic", seed=4, precision=prec, calibration_images=imgs if prec != "fp16" else None)
+            if prec != "fp16":
                 assert len(det.model.fp8_scales) >= 5 and all(v > 0 for v in det.model.fp8_scales.values())
             dets[prec] = det(imgs[0], confidence_threshold=conf)
     with pytest.warns(UserWarning, match="calibration_images"):
@@ -354,7 +354,8 @@ def test_head_detector_facade_in_the_fp8_and_fp16_modes(gpu_lib, flame_model):
     assert abs(len(h16) - len(a)) <= 1
     for ha, hb in zip(a[:3], h16[:3]):  # the strongest detections agree closely in fp16
         assert abs(ha.bbox.x - hb.bbox.x) <= 2 and abs(ha.bbox.w - hb.bbox.w) <= 3 and abs(ha.score - hb.score) < 1e-3
-    assert len(dets["fp8"].heads) >= 1 and all(np.isfinite(np.asarray(h.vertices_3d)).all() for h in dets["fp8"].heads)
+    for prec in ("fp8", "int8"):
+        assert len(dets[prec].heads) >= 1 and all(np.isfinite(np.asarray(h.vertices_3d)).all() for h in dets[prec].heads)
 
 
 @pytest.mark.gpu
@@ -365,10 +366,10 @@ def test_r05_modes_at_1280(gpu_lib):
 
     x = torch.randint(0, 256, (1, 1280, 1280, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(4)).to(_dev())
     out = {}
-    for prec in ("bf16", "fp16", "fp8"):
-        eng = VGHeadsEngine("vgg_heads_l", image_size=1280, max_batch=1, seed=1, precision=prec, calib_images=x if prec == "fp8" else None)
-        if prec == "fp8":
-            assert sum(bf["is_f32"] == 4 for bf in eng.program.bufs) == 31  # the 40-wide maps of the /32 level qualify at 1280
+    for prec in ("bf16", "fp16", "fp8", "int8"):
+        eng = VGHeadsEngine("vgg_heads_l", image_size=1280, max_batch=1, seed=1, precision=prec, calib_images=x if prec in ("fp8", "int8") else None)
+        if prec in ("fp8", "int8"):
+            assert sum(bf["is_f32"] == (4 if prec == "fp8" else 6) for bf in eng.program.bufs) == 31  # the 40-wide maps of the /32 level qualify at 1280
         eng.model(x)
         torch.cuda.synchronize()
         out[prec] = (eng.boxes_all[:1].cpu().clone(), eng.scores_all[:1].cpu().clone())
@@ -381,7 +382,7 @@ def test_r05_modes_at_1280(gpu_lib):
         return inter / ((a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter)
 
     assert out["bf16"][0].shape == (1, 33600, 4)
-    for prec, lo in (("fp16", 0.95), ("fp8", 0.75)):
+    for prec, lo in (("fp16", 0.95), ("fp8", 0.75), ("int8", 0.75)):
         b, s = out[prec]
         assert bool(torch.isfinite(b).all()) and bool(torch.isfinite(s).all())
         m = float(iou(b, out["bf16"][0]).mean())

@@ -253,7 +253,7 @@ def _box_iou(a, b):
     return inter / ua
 
 
-def network_vs_oracle(variant, okey, precision, S, B, flame_model, per_op_tol=None, weight_seed=21, image_seed=5, heads_per_image=8.0):
+def network_vs_oracle(variant, okey, precision, S, B, flame_model, per_op_tol=None, weight_seed=21, image_seed=5, heads_per_image=8.0, calibrate_on_inputs=False):
     """Runs the engine in `precision` on seeded images and measures it against the unfused fp32 oracle (torch CPU) on the same images:
     dense boxes / scores, the top-k candidates (matched by anchor: anchors whose scores differ by less than round-off may swap places), and
     the detections the ORACLE keeps after NMS (~heads_per_image per image): IoU, parameter error, FLAME vertex error in metric space.
@@ -266,9 +266,10 @@ def network_vs_oracle(variant, okey, precision, S, B, flame_model, per_op_tol=No
     from oracle import postproc_oracle as po
 
     sd = arch.random_state_dict(variant, weight_seed)
-    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, precision=precision)
-    P = eng.program
     x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(image_seed))
+    # calibrate_on_inputs (8-bit link modes): the link scales come from the measured images themselves instead of the engine's two seeded random ones
+    eng = VGHeadsEngine(variant, state_dict=sd, image_size=S, max_batch=B, precision=precision, calib_images=x.to(_dev()) if calibrate_on_inputs else None)
+    P = eng.program
     boxes, scores, flame = eng.model(x.to(_dev()))
     out = {"variant": variant, "precision": precision, "image_size": S, "batch": B}
     if per_op_tol is not None:

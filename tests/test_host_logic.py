@@ -578,6 +578,26 @@ def test_fp8_and_fp16_programs_are_the_bf16_program_with_other_storage():
         assert arch.op_touches_fp8(P8, next(o for o in P8.ops if o["name"].endswith("bottlenecks.0.cv1") and "stage2" in o["name"])) and not any(arch.op_touches_fp8(Pb, o) for o in Pb.ops)
 
 
+def test_int8_program_is_the_fp8_program_with_signed_byte_links():
+    """r05 (CPU): precision="int8" (the reference exporter's QuantizationMode.INT8: exportable_mesh_model.py:175-178,398-411) places VGH_FMT_I8 buffers exactly where "fp8"
+    places e4m3 ones -- same ops, same pitches, same byte counts -- with scale = calibrated max * 1.25 / 127; the pack header keeps the bf16 precision code."""
+    from head_detector_amd import _lib
+
+    assert arch.FMT_I8 == _lib.VGH_FMT_I8 == 6 and arch.Q8_PRECISIONS == {"fp8": arch.FMT_FP8, "int8": arch.FMT_I8}
+    for variant in ("vgg_heads_l", "vgg_heads_m"):
+        sd = arch.random_state_dict(variant, 2)
+        sc = {"backbone.stage2.blocks.mid0": 10.0}
+        P8, Pi = arch.build_program(variant, sd, 640, "fp8", fp8_scales=sc), arch.build_program(variant, sd, 640, "int8", fp8_scales=sc)
+        assert [o["name"] for o in P8.ops] == [o["name"] for o in Pi.ops] and len(P8.bufs) == len(Pi.bufs)
+        for b8, bi in zip(P8.bufs, Pi.bufs):
+            assert (b8["is_f32"] == arch.FMT_FP8) == (bi["is_f32"] == arch.FMT_I8) and {k: b8[k] for k in ("name", "h", "w", "pitch")} == {k: bi[k] for k in ("name", "h", "w", "pitch")}
+            if bi["is_f32"] == arch.FMT_I8:
+                amax = sc.get(bi["name"], 8.0)
+                assert abs(bi["scale"] - amax * arch.I8_HEADROOM / 127.0) < 1e-9 and abs(b8["scale"] - amax * arch.FP8_HEADROOM / 448.0) < 1e-9
+        assert arch.program_algorithmic_bytes(P8, 64) == arch.program_algorithmic_bytes(Pi, 64)
+        assert arch.PRECISION_FMT["int8"] == arch.FMT_BF16 and sum(arch.op_touches_fp8(Pi, o) for o in Pi.ops) == sum(arch.op_touches_fp8(P8, o) for o in P8.ops) > 0
+
+
 def test_flame_prologue_joint_reduction_tree_is_the_xor_butterfly():
     """CPU spec of the cross-lane reduction in csrc/flame.hip::prep_head (J = J0 + JS beta: 24 sums over 64 lanes): on the first three levels the xor partners split
     the outputs between them (keep half, send half), then three outputs per lane go through a plain butterfly -- 30 cross-lane moves instead of 144.  Every output's
