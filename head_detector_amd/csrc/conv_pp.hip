@@ -120,7 +120,9 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 }
 // ---- int8 variants (F8 = 2 / O8 = 2; VGH_FMT_I8, the reference exporter's QuantizationMode.INT8): the same geometry as e4m3 -- 64 channels per 64-byte record -- with two
 //      v_mfma_i32_32x32x32_i8 per (cout group, pixel group) pair, one per 16-byte chunk of a lane, exactly where the bf16 tile issues its two MFMAs.  The accumulator
-//      registers hold int32 bit patterns (exact sums), start at 0, and the epilogue computes act(float(acc) * g[c] + bias[c]) ----
+//      registers hold int32 bit patterns (exact sums) that START AT THE BIAS in accumulator units -- the bias vector of such an op holds int32 bit patterns,
+//      rn(bias[c] / (wscale[c] * scale(in))): half a unit is ~1e-5 of a typical output -- and the epilogue computes act(float(acc) * g[c]): the e4m3 epilogue plus one
+//      conversion (a separate bias vector in the epilogue cost the 128-cout variant 170 - 1700 bytes of scratch per lane, r05_int8_links.txt) ----
 __device__ __forceinline__ f32x16_t mfma_i8(bf16x8_t a, bf16x8_t b, f32x16_t c) {
     typedef __attribute__((ext_vector_type(16))) int i32x16;
     return __builtin_bit_cast(f32x16_t, __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, a), __builtin_bit_cast(i32x4_t, b), __builtin_bit_cast(i32x16, c), 0, 0, 0));
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     do {                                                                                                            \
         const f32x4_t bv_ = *(const f32x4_t*)(smem + G::BIAS + ((c0n) + (i) * 32 + (q) * 8 + hi * 4) * 4);         \
         _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                          \
-            const float b0_ = F8 == 2 ? 0.0f /* int32 zero */ : H16 ? bv_[e_] * a.bias_scale : bv_[e_];             \
+            const float b0_ = H16 ? bv_[e_] * a.bias_scale : bv_[e_]; /* int8: the vector holds int32 bit patterns */ \
             acc[i][0][(q) * 4 + e_] = b0_;                                                                          \
             acc[i][1][(q) * 4 + e_] = b0_;                                                                          \
         }                                                                                                           \
@@ -711,28 +713,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     for (int m = 0; m < 2; ++m) {
                         // after the exchange this lane holds couts cv .. cv + 7; before it, runs q = 2m and q = 2m + 1 (couts 32 i + 8 q + 4 hi + e)
                         unsigned pa0, pa1, pb0, pb1;
-                        if constexpr (SC) {  // fp8 input: accumulator units -> real units, per cout (g > 0: commutes with the ReLU below)
+                        if constexpr (SC) {  // 8-bit input: accumulator units -> real units, per cout (g > 0: commutes with the ReLU below)
 #pragma unroll
                             for (int qq = 0; qq < 2; ++qq) {
                                 const f32x4_t gv = *(const f32x4_t*)(smem + G::GS + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
-                                if constexpr (F8 == 2) {  // exact int32 sum -> real units, then the bias
-                                    const f32x4_t bv = *(const f32x4_t*)(smem + G::BIAS + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
+                                for (int e = 0; e < 4; ++e) {
+                                    if constexpr (F8 == 2) {  // the exact int32 sum (it started at the bias in the same units)
                                         // (through a scalar: __builtin_bit_cast applied to a vector-element lvalue reads element 0 -- hipcc 7.2, seen in the ISA)
                                         const float raw = acc[i][j][(2 * m + qq) * 4 + e];
-                                        acc[i][j][(2 * m + qq) * 4 + e] = (float)__builtin_bit_cast(int, raw) * gv[e] + bv[e];
+                                        acc[i][j][(2 * m + qq) * 4 + e] = (float)__builtin_bit_cast(int, raw) * gv[e];
+                                    } else {
+                                        acc[i][j][(2 * m + qq) * 4 + e] *= gv[e];
                                     }
-                                    if constexpr (DG) {
-                                        const f32x4_t dv = *(const f32x4_t*)(smem + G::GS + 4096 + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
-                                        const unsigned xw = dr[2 * m + qq];
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] += dv[e] * (float)(int)(signed char)(xw >> (8 * e));
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] *= gv[e];
                                 }
+                            }
+                        }
+                        if constexpr (DG) {  // the diagonal bypass
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq) {
+                                const f32x4_t dv = *(const f32x4_t*)(smem + G::GS + 4096 + (cbase + i * 32 + (2 * m + qq) * 8 + hi * 4) * 4);
+                                const unsigned xw = dr[2 * m + qq];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[i][j][(2 * m + qq) * 4 + e] += dv[e] * (float)(int)(signed char)(xw >> (8 * e));
                             }
                         }
                         if constexpr (H16) {  // prescaled-weight units -> real units (one factor per op)
@@ -807,16 +810,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     for (int q = 0; q < 4; ++q) {
                         const f32x4_t gv = *(const f32x4_t*)(smem + G::GS + (cbase + i * 32 + q * 8 + hi * 4) * 4);
                         float v[4];
-                        if constexpr (F8 == 2) {
-                            const f32x4_t bv = *(const f32x4_t*)(smem + G::BIAS + (cbase + i * 32 + q * 8 + hi * 4) * 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float raw = acc[i][j][q * 4 + e];  // (scalar first: see arith)
-                                v[e] = (float)__builtin_bit_cast(int, raw) * gv[e] + bv[e];
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e] * gv[e];
+                        for (int e = 0; e < 4; ++e) {
+                            const float raw = acc[i][j][q * 4 + e];  // (scalar first: see arith)
+                            v[e] = (F8 == 2 ? (float)__builtin_bit_cast(int, raw) : raw) * gv[e];
                         }
                         R[q] = O8 == 2 ? pack_i8x4(v[0], v[1], v[2], v[3], lo8) : pack_fp8x4(v[0], v[1], v[2], v[3], lo8);
                     }
@@ -988,7 +985,7 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
         if (a.dvec) {
             VGH_REQUIRE(a.in_fp8 == 2 && !a.out_fp8 && a.cout_pad <= 1024 && a.cin >= a.cout_pad && a.Ho == a.H && a.Wo == a.W,
                         "conv: the diagonal bypass (dvec) belongs to an int8 -> bf16 conv with cout_pad <= min(cin, 1024)");
-            switch (bc) {  // (no 128-cout variant: it spills; vgh_conv_pick_cfg / cfg_ok_for keep such ops on 96 / 64)
+            switch (bc) {  // (no 128-cout variant: it spills ~90 registers; vgh_conv_pick_cfg / cfg_ok_for keep such ops on 96 / 64)
                 case 96: return launch_pp<3, 1, 2, 0, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
                 case 64: return launch_pp<2, 1, 2, 0, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
             }

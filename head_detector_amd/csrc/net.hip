@@ -398,7 +398,8 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
                 float* bq = (float*)(host.data() + boff[i]);
                 const float s_out = vgh_fmt_is_q8(bufs[d.out_buf].is_f32) ? bufs[d.out_buf].scale : 1.0f;
                 if (wf == VGH_FMT_I8) {
-                    // int8: exact int32 accumulator from 0; out = act(acc * g + b) with g = wscale[c] * scale(in) / scale(out) and the bias in output units
+                    // int8: exact int32 accumulator that starts at the bias in accumulator units (int32 bit patterns in the bias vector); out = act(acc * g) with
+                    // g = wscale[c] * scale(in) / scale(out)
                     std::vector<float> ws(d.cout_pad);
                     const float* wsrc = weights_host + d.w_off;
                     std::vector<float> peeled;
@@ -414,8 +415,11 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
                     }
                     vgh_pack_conv_weights_i8_host(wsrc, d.cout_pad, d.ksize, d.cin, (uint8_t*)(host.data() + woff[i]), ws.data());
                     for (int c = 0; c < d.cout_pad; ++c) {
-                        g[c] = ws[c] * bufs[d.in_buf].scale / s_out;
-                        bq[c] = bq[c] / s_out;
+                        const float acc_unit = ws[c] * bufs[d.in_buf].scale;
+                        g[c] = acc_unit / s_out;
+                        const float bi = __builtin_nearbyintf(bq[c] / acc_unit);
+                        const int32_t b32 = bi != bi ? 0 : bi > 2.0e9f ? 2000000000 : bi < -2.0e9f ? -2000000000 : (int32_t)bi;  // (|bias| / unit is ~1e4 - 1e6 in practice)
+                        memcpy(&bq[c], &b32, 4);
                     }
                 } else if (wf == VGH_FMT_FP8) {
                     std::vector<float> ws(d.cout_pad);

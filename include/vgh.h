@@ -161,8 +161,8 @@ typedef struct vgh_conv_call {
                                          /*   bytes, cin % 64 == 0), wpack_dev comes from vgh_pack_conv_weights_fp8, res_dev stays bf16, and bias_dev     */
                                          /*   holds bias[c] / gscale[c] (the accumulator starts there and is multiplied by gscale[c] at the end)          */
                                          /* fmt = VGH_FMT_I8: the same with int8 bytes and vgh_pack_conv_weights_i8, except that the accumulator is an      */
-                                         /*   exact int32 sum that starts at 0: out = act(acc * gscale[c] + bias_dev[c]), bias_dev in OUTPUT units           */
-                                         /*   (bias[c] / output scale when out_fp8 = 2, bias[c] for a bf16 output)                                           */
+                                         /*   exact int32 sum: bias_dev holds INT32 values (bit patterns in the float array), rn(bias[c] / (wscale[c] *      */
+                                         /*   input scale)); out = act(float(acc) * gscale[c])                                                               */
     int32_t out_fp8;                     /* 1: out_dev receives e4m3 bytes, 2: int8 bytes (out_pitch / offsets count bytes; whole cout tiles, no residual; */
                                          /*   an 8-bit input and an 8-bit output must be the same format)                                                   */
     const float* gscale_dev;             /* [cout_pad] per-cout output factor: e4m3 in: wscale[c] * input scale (/ output scale when out_fp8);           */

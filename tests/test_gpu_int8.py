@@ -111,7 +111,8 @@ def test_conv_int8_links_vs_integer_reference(gpu_lib, case):
                 # the exact integer sum (|sum| < 2^31: 9 * 256 * 127 * 127), then real units
                 acc = F.conv2d(xq.double().permute(0, 3, 1, 2), wq.double().permute(0, 3, 1, 2), None, padding=1)
                 assert float(acc.abs().max()) < 2.0 ** 31
-                y = acc * (ws.double() * s_in)[None, :, None, None] + b.double()[None, :, None, None]
+                b_int = torch.round(b / (ws * s_in))  # the accumulator starts at the bias in its own (integer) units
+                y = (acc + b_int.double()[None, :, None, None]) * (ws.double() * s_in)[None, :, None, None]
                 if diag:  # + w[c][centre][c] * x[pixel][c], evaluated on the codes in fp32 by the kernel
                     y = y + (dvals.double() * s_in)[None, :, None, None] * xq[..., :Cout].double().permute(0, 3, 1, 2)
                     d_diag = (dvals * s_in).to(_dev())
@@ -133,8 +134,8 @@ def test_conv_int8_links_vs_integer_reference(gpu_lib, case):
                 y = y + alpha * res.double()
             s_out = float(y.abs().max()) / 140.0 if out8 else 1.0  # some outputs beyond +-127 codes: the clamp is exercised
             gscale = (unit / s_out).to(_dev())
-            # int8 input: the accumulator starts at 0 and the bias is added in OUTPUT units; bf16 input: the accumulator starts at the bias (include/vgh.h)
-            d_bias = (b / s_out if in8 else b).to(_dev())
+            # int8 input: the bias vector holds int32 values in accumulator units (include/vgh.h); bf16 input: the fp32 bias
+            d_bias = (b_int.to(torch.int32).view(torch.float32) if in8 else b).to(_dev())
             out_pitch = Cout + out_coff + 16
             if out8:
                 d_out = torch.full((B, H, Wd, out_pitch), 0x5A, dtype=torch.int8, device=_dev())
@@ -264,6 +265,9 @@ def test_int8_network_every_linked_op(gpu_lib, variant, S, B):
             assert float((codes - codes.round()).abs().max()) < 1e-3 and float(codes.abs().max()) <= 127.0, op["name"]
         else:
             Wv = W.to(torch.bfloat16).double()
+        if ib["is_f32"] == arch.FMT_I8:  # the bias enters the int32 accumulator: rounded to its units
+            unit = ws.double() * ib["scale"]
+            bias = (torch.round(bias / (ws * np.float32(ib["scale"]))).double() * unit).float()
         y = F.conv2d(xin.double().permute(0, 3, 1, 2), Wv.permute(0, 3, 1, 2), None, padding=1) + bias.double()[None, :, None, None]
         if op["act"] == 1:
             y = torch.relu(y)

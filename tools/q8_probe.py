@@ -4,6 +4,7 @@
     python tools/q8_probe.py snr      per link tensor of the bf16 network: quantisation SNR of e4m3 / int8 codes with the engine's per-tensor scale (and a per-channel one)
     python tools/q8_probe.py weights  (no GPU) per int8-input conv: SNR of the per-cout int8 weight image with and without the diagonal bypass, and of the e4m3 image
     python tools/q8_probe.py speed    network time of L b64 in bf16 / fp8 / int8 without / with the diagonal bypass (two lanes, alternating)
+    python tools/q8_probe.py ops      single-stream time of every linked op of L b64 in bf16 / fp8 / int8 (which tile family pays what)
     python tools/q8_probe.py dev      deviation from the fp32 oracle (tests/test_gpu_split.py::network_vs_oracle) of the same modes, M b2 and L b1
 
 `dev` imports the oracle through the test helper: this is a measurement script of the test infrastructure, not a product path."""
@@ -114,6 +115,34 @@ def cmd_speed():
     lib.vgh_net_set_i8_diag(1)
 
 
+def cmd_ops():
+    from head_detector_amd.engine import VGHeadsEngine
+
+    lib = _lib.load()
+    B = 64
+    x = torch.randint(0, 256, (B, 640, 640, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).cuda()
+    tabs = {}
+    for prec in ("bf16", "fp8", "int8"):
+        eng = VGHeadsEngine("vgg_heads_l", image_size=640, max_batch=B, seed=1, precision=prec, calib_images=x[:2])
+        for _ in range(3):
+            eng.forward_net(x)
+        eng.join()
+        rows, rows2 = eng.profile_ops(x), eng.profile_ops(x)
+        tabs[prec] = {r["name"]: min(r["ms"], r2["ms"]) for r, r2 in zip(rows, rows2)}
+        if prec == "int8":
+            P = eng.program
+            diag = {op["name"]: lib.vgh_net_op_has_diag(eng._net, i) for i, op in enumerate(P.ops)}
+            q8 = {op["name"]: (P.bufs[op["in_buf"]]["is_f32"], P.bufs[op["out_buf"]]["is_f32"], op["cin"], op["cout_pad"], P.bufs[op["out_buf"]]["h"]) for op in P.ops if arch.op_touches_fp8(P, op)}
+        eng.close()
+    tot = {k: 0.0 for k in tabs}
+    print(f"{'op':52s} in out  cin cout  map diag   bf16    fp8   int8  (ms, single stream; in / out: VGH_FMT_* of the int8 program)")
+    for name, (fi, fo, ci, co, h) in q8.items():
+        print(f"{name:52s} {fi:2d} {fo:3d} {ci:4d} {co:4d} {h:4d} {diag[name]:4d} {tabs['bf16'][name]:7.4f} {tabs['fp8'][name]:7.4f} {tabs['int8'][name]:7.4f}")
+        for k in tabs:
+            tot[k] += tabs[k][name]
+    print("linked ops total:", {k: round(v, 4) for k, v in tot.items()}, " whole net:", {k: round(sum(t.values()), 4) for k, t in tabs.items()})
+
+
 def cmd_dev():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_split import network_vs_oracle
@@ -132,4 +161,4 @@ def cmd_dev():
 
 
 if __name__ == "__main__":
-    {"snr": cmd_snr, "weights": cmd_weights, "speed": cmd_speed, "dev": cmd_dev}[sys.argv[1] if len(sys.argv) > 1 else "weights"]()
+    {"snr": cmd_snr, "weights": cmd_weights, "speed": cmd_speed, "ops": cmd_ops, "dev": cmd_dev}[sys.argv[1] if len(sys.argv) > 1 else "weights"]()
