@@ -486,6 +486,7 @@ def main():
     ap.add_argument("--heads-per-image", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the (untimed) deviation reports of the bf16 / parity modes")
+    ap.add_argument("--no-overlap-check", action="store_true", help="skip the untimed overlapped-vs-serial post-stage check before the timed steps (N = 1 only)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the separately timed secondary workloads (M b32, L @1280 crowd, parity modes)")
     ap.add_argument("--per-layer", default=None, help="write a per-op timing table (json) to this path")
     ap.add_argument("--split", type=int, default=2, help="independent sub-batches per forward on the net's lane streams (1 = off)")
@@ -596,6 +597,32 @@ def main():
             step()
         for _ in range(warmup * inner):
             step()
+        # Overlap check (untimed, r05): running the post stages on the low-priority side stream under the next forward normally buys 0.2 - 0.3 ms per forward, but an engine can
+        # come up in a state where the side stream is starved and every forward stalls at the prediction guard for 2.5 - 3 ms (seen on int8-link engines created late in a
+        # process: 14.1 vs 11.5 ms, persistent for the engine's life, gone with the overlap off; DESIGN 3.7 "starved side stream").  Measure both, keep the faster.
+        overlap_check = None
+        if overlap and world == 1 and not args.no_overlap_check:
+            def probe(n=4 * max(inner, 2)):
+                eng.join()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    step()
+                eng.join()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e3
+            on_ms = probe()
+            eng.set_overlap(False)
+            off_ms = probe()
+            keep_off = off_ms < 0.97 * on_ms
+            if not keep_off:
+                eng.set_overlap(True)
+                for _ in range(2):
+                    step()
+            overlap_check = dict(ms_per_forward_overlapped=round(on_ms, 3), ms_per_forward_serial_post_stages=round(off_ms, 3), chosen="serial" if keep_off else "overlapped")
+            if keep_off:
+                overlap = False
+                print(f"[bench] {variant} {precision} b{B}: post stages NOT overlapped for this engine ({off_ms:.3f} vs {on_ms:.3f} ms per forward overlapped: starved side stream)", file=sys.stderr)
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
@@ -640,7 +667,7 @@ def main():
         fp8_flops = 2.0 * sum(op["macs"] for op in eng.program.ops if arch.op_touches_fp8(eng.program, op) and eng.program.bufs[op["in_buf"]]["is_f32"] in arch.Q8_FMTS)
         out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, fp8_flops_per_image=fp8_flops, fp8_links=sum(bf["is_f32"] in arch.Q8_FMTS for bf in eng.program.bufs), heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,
                    value=B * world * nfw / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,
-                   alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch, power=power.summary(), exchange_dropped_rows=dropped, per_rank=per_rank)
+                   alg_bytes=alg["read"] + alg["write"], arena_batch=eng.arena_batch, power=power.summary(), exchange_dropped_rows=dropped, per_rank=per_rank, overlap_check=overlap_check)
         thr = throttle.summary()
         if thr and out["power"] is not None:
             out["power"]["throttle"] = thr
@@ -682,7 +709,7 @@ def main():
     def brief(m: dict) -> dict:
         return {"images_per_sec": round(m["value"], 2), "ms_per_step": round(m["dt"] / m["steps"] * 1e3, 3), "net_ms_per_step": round(m["net_ms"] * m.get("inner", 1), 3),
                 "conv_tflops": round(m["conv_tflops"], 2), "roofline_frac": round(m["conv_tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "steps": m["steps"],
-                "heads_per_image_decoded": round(m["heads_per_img"], 2)}
+                "heads_per_image_decoded": round(m["heads_per_img"], 2), **({"overlap_check": m["overlap_check"]} if m.get("overlap_check") else {})}
 
     main_run = run_workload(args.variant, args.batch, args.steps, args.warmup, args.per_layer, precision=args.precision, inner=max(1, args.inner))
     B = args.batch
@@ -719,6 +746,8 @@ def main():
                   "ms_per_forward": round(main_run["dt"] / (args.steps * inner) * 1e3, 3), "net_ms_per_forward": round(main_run["net_ms"], 3), "image_size": S, "parallelism": f"dp{world}", "gflop_per_image": round(main_run["flops_per_image"] / 1e9, 2),
                   "graph": bool(args.graph), "exchange_to_rank0": bool(world > 1 or args.exchange), "overlap_post": main_run["overlap"], "batch_split": nsplit,
                   "flame_decode_us_per_head_n96": round(decode_us_per_head, 3), "flame_decode_us_per_call_all400": decode_sweep, "net_ms_per_step": round(main_run["net_ms"] * inner, 3), "ramp_steps": args.ramp_steps}
+        if main_run["overlap_check"]:
+            config["overlap_check"] = main_run["overlap_check"]  # untimed: overlapped vs serial post stages measured on this engine before the timed steps, the faster kept
         if main_run["power"]:
             config["power_during_timed_steps"] = main_run["power"]
         if main_run["per_rank"]:

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdio>
 #include <mutex>
 #include <vector>
 
@@ -115,6 +116,9 @@ int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoi
         if (s > best_score) best = (int)park.size() - 1, best_score = s;
     }
     VGH_REQUIRE(best >= 0, "stream_acquire: no candidate stream");
+    if (best_score < perfect)  // not silent: a lane or side stream that shares a hardware queue with the stream it should run beside costs 10 - 25 % of a forward
+        fprintf(stderr, "[vgh] stream_acquire (%s priority): no candidate overlaps with all %d streams to avoid (best mask 0x%x of 0x%x, %zu parked candidates)\n",
+                low_priority ? "low" : "normal", n_avoid, best_score, perfect, park.size());
     *out = park[best];
     park.erase(park.begin() + best);
     return VGH_OK;

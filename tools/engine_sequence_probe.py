@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Engines created one after another in ONE process, in bench.py's order (r05; profiles/r05_engine_sequence.txt): per engine the pipelined step (network + post stages on the
+low-priority side stream), the same again, the pairwise overlap of its streams, and -- for the 8-bit link modes -- the step with the post stages serial, with one lane, the
+network alone and the single-stream per-op sum.  Found with it: an int8-link engine can come up in a state where the side stream is STARVED (every forward stalls 2.5 - 3 ms at
+the prediction guard: 14.1 vs 11.5 ms; persistent for the engine's life, deterministic in the creation history, per-op times and the measured stream overlaps unchanged, gone
+with set_overlap(False)); bench.py therefore measures both before its timed steps (overlap_check)."""
+import sys, time, torch
+sys.path.insert(0, ".")
+from head_detector_amd.engine import VGHeadsEngine
+from head_detector_amd.flame import FLAMELayer
+from head_detector_amd.synthetic import synthetic_flame_model
+dev = torch.device("cuda", 0)
+flame = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=6400)
+def run(variant, B, prec, S=640, nf=40):
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=1, precision=prec)
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+    unpad = torch.tensor([[0.0, 0.0, 1.0]], device=dev).expand(B, 3).contiguous()
+    eng.detect(x, confidence_threshold=0.5)
+    eng.set_overlap(B >= 8); eng.set_split(2 if B >= 16 else 1)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(nf)]; ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(nf)]
+    def step(i=None):
+        if i is not None: ev0[i].record(eng.stream)
+        eng.forward_net(x)
+        if i is not None: ev1[i].record(eng.stream)
+        eng.candidates(B)
+        eng.select(B, confidence_threshold=0.6, iou_threshold=0.5, flame=flame, unpad=unpad)
+    for _ in range(5): step()
+    eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
+    for i in range(nf): step(i)
+    eng.join(); torch.cuda.synchronize(); dt = (time.perf_counter() - t) / nf * 1e3
+    net = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nf
+    st = eng.streams_in_use()
+    ov = [[int(eng.lib.vgh_streams_overlap(a.cuda_stream, b.cuda_stream)) if a is not b else 1 for b in st] for a in st]
+    eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
+    for i in range(nf): step(i)
+    eng.join(); torch.cuda.synchronize(); dt2 = (time.perf_counter() - t) / nf * 1e3
+    print(f"SEQ {variant} b{B} @{S} {prec:6s}: {dt:7.3f} ms per forward, network part {net:7.3f}; again {dt2:7.3f}; stream overlap matrix {ov}; arena {eng.lib.vgh_net_buffer(eng._net, 0):#x}", flush=True)
+    if prec in ("int8", "fp8"):
+        def timed(label):
+            for _ in range(3): step()
+            eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
+            for i in range(nf): step(i)
+            eng.join(); torch.cuda.synchronize()
+            print(f"   {label}: {(time.perf_counter() - t) / nf * 1e3:7.3f} ms per forward, network part {sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nf:7.3f}", flush=True)
+        eng.join(); eng.set_overlap(False); timed("split 2, post stages NOT overlapped")
+        eng.join(); eng.set_overlap(True); eng.set_split(1); timed("split 1, overlapped")
+        eng.join(); eng.set_split(2); timed("split 2, overlapped (back)")
+        def net_only(label):
+            for _ in range(3): eng.forward_net(x)
+            eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
+            for i in range(nf): eng.forward_net(x)
+            eng.join(); torch.cuda.synchronize()
+            print(f"   {label}: {(time.perf_counter() - t) / nf * 1e3:7.3f} ms per forward", flush=True)
+        net_only("split 2, network only (no candidates / select)")
+        eng.join(); eng.set_split(1)
+        rows = eng.profile_ops(x); rows = eng.profile_ops(x)
+        tab = {r["name"]: r["ms"] for r in rows}
+        PROF.setdefault(prec, []).append(tab)
+        print(f"   single-stream sum {sum(tab.values()):.3f} ms", flush=True)
+    eng.close()
+PROF = {}
+seq = [("vgg_heads_l", 64, "bf16", 640), ("vgg_heads_m", 32, "bf16", 640), ("vgg_heads_l", 16, "bf16", 1280), ("vgg_heads_l", 32, "fp16x3", 640), ("vgg_heads_l", 8, "fp32", 640),
+       ("vgg_heads_l", 64, "fp8", 640), ("vgg_heads_l", 64, "fp16", 640), ("vgg_heads_l", 64, "int8", 640), ("vgg_heads_l", 64, "bf16", 640), ("vgg_heads_l", 64, "int8", 640), ("vgg_heads_l", 64, "fp8", 640), ("vgg_heads_l", 64, "int8", 640)]
+for v, B, p, S in seq:
+    run(v, B, p, S, nf=10 if p in ("fp32",) else 40)
+
+for prec, tabs in PROF.items():
+    base = tabs[0]
+    for k, t in enumerate(tabs[1:], 1):
+        diffs = [(t[n] - base[n], n, base[n], t[n]) for n in base if abs(t[n] - base[n]) > 0.15 * base[n] and abs(t[n] - base[n]) > 0.005]
+        print(f"PROF {prec} engine {k} vs engine 0: {len(diffs)} ops differ by > 15 %:", [(n, round(a, 4), round(b, 4)) for _, n, a, b in sorted(diffs, reverse=True)[:12]], flush=True)

@@ -93,6 +93,7 @@ def cmd_speed():
 
     lib = _lib.load()
     B = 64
+    NF = int(os.environ.get("Q8_FORWARDS", "20"))  # 20 = a quarter of a second per burst; 300 = long enough for the PPT power controller to settle
     x = torch.randint(0, 256, (B, 640, 640, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).cuda()
     for rnd in range(3):
         for prec, diag in (("bf16", 1), ("fp8", 1), ("int8", 0), ("int8", 1)):
@@ -106,11 +107,11 @@ def cmd_speed():
             eng.join()
             torch.cuda.synchronize()
             t = time.perf_counter()
-            for _ in range(20):
+            for _ in range(NF):
                 eng.forward_net(x)
             eng.join()
             torch.cuda.synchronize()
-            print(f"round {rnd} vgg_heads_l b64 {prec:5s} ops with the diagonal bypass {nd:2d}: {(time.perf_counter() - t) / 20 * 1e3:7.3f} ms per forward (network only, two lanes)", flush=True)
+            print(f"round {rnd} vgg_heads_l b64 {prec:5s} ops with the diagonal bypass {nd:2d}: {(time.perf_counter() - t) / NF * 1e3:7.3f} ms per forward (network only, two lanes, {NF} forwards back to back)", flush=True)
             eng.close()
     lib.vgh_net_set_i8_diag(1)
 
