@@ -3,7 +3,9 @@
 low-priority side stream), the same again, the pairwise overlap of its streams, and -- for the 8-bit link modes -- the step with the post stages serial, with one lane, the
 network alone and the single-stream per-op sum.  Found with it: an int8-link engine can come up in a state where the side stream is STARVED (every forward stalls 2.5 - 3 ms at
 the prediction guard: 14.1 vs 11.5 ms; persistent for the engine's life, deterministic in the creation history, per-op times and the measured stream overlaps unchanged, gone
-with set_overlap(False)); bench.py therefore measures both before its timed steps (overlap_check)."""
+with set_overlap(False)); bench.py therefore measures both before its timed steps (overlap_check).  The "tiny kernel under a never-empty queue" probe it also prints (one
+workgroup spinning on stream i, a tiny kernel on stream j, the chip otherwise idle) finishes in 0.15 ms on starved and healthy engines alike: the queues themselves are not
+the problem, the starvation needs the chip full."""
 import sys, time, torch
 sys.path.insert(0, ".")
 from head_detector_amd.engine import VGHeadsEngine
@@ -30,11 +32,25 @@ def run(variant, B, prec, S=640, nf=40):
     eng.join(); torch.cuda.synchronize(); dt = (time.perf_counter() - t) / nf * 1e3
     net = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / nf
     st = eng.streams_in_use()
+    # starvation probe: a never-empty queue of 1-workgroup spin kernels on one engine stream (the chip is idle otherwise), ONE tiny kernel on another: when does it finish?
+    def lat(busy, probe_s, n=40, cyc=200000):
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(busy):
+            e0.record()
+            for _ in range(n): torch.cuda._sleep(cyc)
+            e2.record()
+        with torch.cuda.stream(probe_s):
+            torch.cuda._sleep(1000)
+            e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1), 3), round(e0.elapsed_time(e2), 3)
+    starv = {f"{i}->{j}": lat(st[i], st[j]) for i in range(len(st)) for j in range(len(st)) if i != j}
     ov = [[int(eng.lib.vgh_streams_overlap(a.cuda_stream, b.cuda_stream)) if a is not b else 1 for b in st] for a in st]
     eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
     for i in range(nf): step(i)
     eng.join(); torch.cuda.synchronize(); dt2 = (time.perf_counter() - t) / nf * 1e3
-    print(f"SEQ {variant} b{B} @{S} {prec:6s}: {dt:7.3f} ms per forward, network part {net:7.3f}; again {dt2:7.3f}; stream overlap matrix {ov}; arena {eng.lib.vgh_net_buffer(eng._net, 0):#x}", flush=True)
+    print(f"SEQ {variant} b{B} @{S} {prec:6s}: {dt:7.3f} ms per forward, network part {net:7.3f}; again {dt2:7.3f}; stream overlap matrix {ov}; tiny kernel on stream j done at / busy chain on stream i done at (ms) {starv}; arena {eng.lib.vgh_net_buffer(eng._net, 0):#x}", flush=True)
     if prec in ("int8", "fp8"):
         def timed(label):
             for _ in range(3): step()
