@@ -111,7 +111,8 @@ class HeadDetector:
         """``precision``: "bf16" (throughput mode, the default); "fp16" (r05: one fp16 plane per value -- the reference exporter's own FP16 format -- 8 x closer to the fp32 network at
         0.92 x the speed); "fp8" (r05: bf16 with OCP-e4m3 links between 3x3 convs, 1.12 x the speed at 5 - 10 x the bf16 deviation; its activation scales are calibrated on
         ``calibration_images`` -- a list of images like the ones this detector will see (paths, PIL or HWC uint8 arrays), letterboxed here -- and WITHOUT them on two seeded random images, which is
-        adequate for plumbing only: a warning says so); "fp16x3" -- the matrix-core parity mode whose outputs match the reference's
+        adequate for plumbing only: a warning says so); "int8" (r05: the same links as int8 codes -- the reference exporter's QuantizationMode.INT8 -- with the folded identity branch of the RepVGG
+        convs kept in fp32; 1.07 x the speed at 2 - 3 x the bf16 deviation; calibrated like "fp8"); "fp16x3" -- the matrix-core parity mode whose outputs match the reference's
         fp32 CPU network to IoU >= 0.999 / 1e-4 (csrc/conv_split.hip; ~1/3 of the bf16 throughput); "fp32" = the VALU parity mode."""
         if not torch.cuda.is_available():
             raise _lib.VghError("HeadDetector: no GPU visible. This package is the MI355X HIP path only; it does not fall back to the CPU.")

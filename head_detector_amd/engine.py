@@ -269,6 +269,34 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_detector_set_overlap(self._det, int(bool(enable))))
         self._overlap = bool(enable)
 
+    def tune_overlap(self, images: torch.Tensor, flame=None, forwards: int = 8, confidence_threshold: float = 0.5) -> Dict[str, float]:
+        """Keep the post-stage overlap only if it pays on THIS engine: times ``forwards`` pipelined forward + detect steps with the post stages on the side stream and with
+        them serial, leaves the faster setting on, returns both times (ms per forward).  Normally the overlap wins by ~0.1 ms; an engine whose side stream is starved loses
+        2.5 - 5 ms per forward with it (profiles/r05_engine_sequence.txt) -- bench.py makes the same comparison before its timed steps."""
+        import time
+
+        B = int(images.shape[0])
+        unpad = torch.tensor([[0.0, 0.0, 1.0]], device=self.device).expand(B, 3).contiguous()
+
+        def run(n):
+            for _ in range(n):
+                self.forward_net(images)
+                self.candidates(B)
+                self.select(B, confidence_threshold=confidence_threshold, iou_threshold=0.5, flame=flame, unpad=unpad)
+            self.join()
+            torch.cuda.synchronize(self.device)
+
+        out = {}
+        for on in (True, False):
+            self.join()
+            self.set_overlap(on)
+            run(2)
+            t = time.perf_counter()
+            run(forwards)
+            out["overlapped" if on else "serial"] = (time.perf_counter() - t) / forwards * 1e3
+        self.set_overlap(out["overlapped"] <= out["serial"])
+        return out
+
     def join(self):
         """Make the engine stream (and the caller's current stream) wait for the last queued select."""
         _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))

@@ -1157,6 +1157,11 @@ def test_overlap_mode_is_race_free_and_identical(gpu_lib, flame_model):
     # detect() keeps its stream-ordered contract in overlap mode
     for r, q in zip(ref_a, snap(eng.detect(xa, confidence_threshold=conf, flame=fl))):
         assert torch.equal(r, q)
+    # tune_overlap: both settings timed on this engine, the faster left on, results unchanged
+    t = eng.tune_overlap(xa, flame=fl, forwards=3, confidence_threshold=conf)
+    assert set(t) == {"overlapped", "serial"} and all(v > 0 for v in t.values()) and eng._overlap == (t["overlapped"] <= t["serial"])
+    for r, q in zip(ref_b, snap(eng.detect(xb, confidence_threshold=conf, flame=fl))):
+        assert torch.equal(r, q)
     eng.set_overlap(False)
     eng.close()
 
