@@ -30,6 +30,8 @@ struct vgh_detector {
     // concurrently with the network of the NEXT batch on the caller's stream
     bool overlap = false, side_pending = false;
     hipStream_t side = nullptr, side_main = nullptr;  // side: picked by ensure_side for work entering on side_main
+    bool side_low = true;   // priority class of `side` (vgh_detector_set_side_priority)
+    bool side_own = false;  // `side` was created for this detector alone (vgh_detector_renew_side): destroyed, not parked, on release
     hipEvent_t ev_net = nullptr, ev_cand = nullptr, ev_side = nullptr;
 };
 
@@ -74,16 +76,23 @@ __global__ __launch_bounds__(1024) void head_list_kernel(const int32_t* __restri
 // side stream; M b32 5.32 vs 5.42)
 constexpr bool kSideLowPriority = true;
 
+void release_side(vgh_detector* d) {
+    if (!d->side) return;
+    (void)hipStreamSynchronize(d->side);
+    if (d->side_own)
+        (void)hipStreamDestroy(d->side);
+    else
+        vgh_stream_release_internal(d->device, d->side, d->side_low);
+    d->side = nullptr;
+    d->side_own = false;
+}
+
 int ensure_side(vgh_detector* d, hipStream_t main) {
     if (d->side && d->side_main == main) return VGH_OK;
     hipStream_t avoid[4] = {main};
     if (int rc = vgh_net_lane_streams(d->net, main, avoid + 1)) return rc;
-    if (d->side) {
-        VGH_HIP(hipStreamSynchronize(d->side));
-        vgh_stream_release_internal(d->device, d->side, kSideLowPriority);
-        d->side = nullptr;
-    }
-    if (int rc = vgh_stream_acquire_internal(d->device, avoid, 4, &d->side, kSideLowPriority)) return rc;
+    release_side(d);
+    if (int rc = vgh_stream_acquire_internal(d->device, avoid, 4, &d->side, d->side_low)) return rc;
     d->side_main = main;
     return VGH_OK;
 }
@@ -154,10 +163,7 @@ void vgh_detector_destroy(vgh_detector* d) {
     hipFree(d->keep_idx);
     hipFree(d->head_row);
     hipFree(d->head_image);
-    if (d->side) {
-        hipStreamSynchronize(d->side);
-        vgh_stream_release_internal(d->device, d->side, kSideLowPriority);
-    }
+    release_side(d);
     if (d->net) vgh_net_set_pred_guard(d->net, nullptr);
     if (d->ev_net) hipEventDestroy(d->ev_net);
     if (d->ev_cand) hipEventDestroy(d->ev_cand);
@@ -273,6 +279,35 @@ int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, v
     const int rc = select_on(d, B, conf_thr, iou_thr, o, d->side);
     d->side_pending = true;
     return rc;
+}
+
+// The side stream's priority class (default: lowest) -- takes effect at the next overlapped call, which picks a new side stream.  Call between batches (after vgh_detector_join).
+int vgh_detector_set_side_priority(vgh_detector* d, int low) {
+    VGH_REQUIRE(d, "detector_set_side_priority: null handle");
+    if ((low != 0) == d->side_low) return VGH_OK;
+    release_side(d);
+    vgh_net_set_pred_guard(d->net, nullptr);
+    d->side_pending = false;
+    d->side_low = low != 0;
+    return VGH_OK;
+}
+// Replaces the side stream by one created now, for this detector alone (same priority class; no overlap measurement, not from the park): the way out for an engine whose
+// parked side stream turns out to be starved under the network.  Call between batches.
+int vgh_detector_renew_side(vgh_detector* d, void* main_stream) {
+    VGH_REQUIRE(d, "detector_renew_side: null handle");
+    release_side(d);
+    vgh_net_set_pred_guard(d->net, nullptr);
+    d->side_pending = false;
+    int least = 0, greatest = 0;
+    if (d->side_low) {
+        VGH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        VGH_HIP(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, least));
+    } else {
+        VGH_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+    }
+    d->side_own = true;
+    d->side_main = (hipStream_t)main_stream;
+    return VGH_OK;
 }
 
 int vgh_detector_set_overlap(vgh_detector* d, int enable) {

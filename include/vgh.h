@@ -374,6 +374,11 @@ int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, fl
  * stream); the caller must not reuse the vgh_detect_out buffers of call s for call s+1 unless it joined in between (or does
  * not read them). */
 int vgh_detector_set_overlap(vgh_detector* d, int enable);
+/* r05, both between batches (after vgh_detector_join).  set_side_priority: the priority class of the side stream the overlapped post stages run on (1 = lowest, the default; 0 = the
+ * caller's); renew_side: replace the side stream by one created now for this detector alone (work entering on main_stream).  For an engine whose side stream is starved under
+ * the network (the forward then stalls at the prediction guard for milliseconds): measure, as head_detector_amd.engine.VGHeadsEngine.tune_overlap does. */
+int vgh_detector_set_side_priority(vgh_detector* d, int low);
+int vgh_detector_renew_side(vgh_detector* d, void* main_stream);
 int vgh_detector_join(vgh_detector* d, void* stream);
 /* Records the caller's HIP event behind everything queued so far for the post-network stages (overlap mode: on the detector's side stream; else on `stream`)
  * WITHOUT making any stream wait for it: a host that synchronises on the event of an EARLIER batch can queue that batch's consumers (e.g. the N>1 exchange) with no

@@ -6,9 +6,10 @@ the prediction guard: 14.1 vs 11.5 ms; persistent for the engine's life, determi
 with set_overlap(False)); bench.py therefore measures both before its timed steps (overlap_check).  The "tiny kernel under a never-empty queue" probe it also prints (one
 workgroup spinning on stream i, a tiny kernel on stream j, the chip otherwise idle) finishes in 0.15 ms on starved and healthy engines alike: the queues themselves are not
 the problem, the starvation needs the chip full."""
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, ".")
 from head_detector_amd.engine import VGHeadsEngine
+from head_detector_amd._lib import check as _lib_check
 from head_detector_amd.flame import FLAMELayer
 from head_detector_amd.synthetic import synthetic_flame_model
 dev = torch.device("cuda", 0)
@@ -45,7 +46,7 @@ def run(variant, B, prec, S=640, nf=40):
             e1.record()
         torch.cuda.synchronize()
         return round(e0.elapsed_time(e1), 3), round(e0.elapsed_time(e2), 3)
-    starv = {f"{i}->{j}": lat(st[i], st[j]) for i in range(len(st)) for j in range(len(st)) if i != j}
+    starv = {f"{i}->{j}": lat(st[i], st[j]) for i in range(len(st)) for j in range(len(st)) if i != j} if os.environ.get("SEQ_STARV") else {}
     ov = [[int(eng.lib.vgh_streams_overlap(a.cuda_stream, b.cuda_stream)) if a is not b else 1 for b in st] for a in st]
     eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
     for i in range(nf): step(i)
@@ -61,6 +62,10 @@ def run(variant, B, prec, S=640, nf=40):
         eng.join(); eng.set_overlap(False); timed("split 2, post stages NOT overlapped")
         eng.join(); eng.set_overlap(True); eng.set_split(1); timed("split 1, overlapped")
         eng.join(); eng.set_split(2); timed("split 2, overlapped (back)")
+        if os.environ.get("SEQ_RENEW"):
+            eng.join(); _lib_check(eng.lib.vgh_detector_renew_side(eng._det, eng._sp())); timed("split 2, overlapped, side stream RENEWED (fresh low-priority stream)")
+        eng.join(); _lib_check(eng.lib.vgh_detector_set_side_priority(eng._det, 0)); timed("split 2, overlapped, side stream at NORMAL priority")
+        eng.join(); _lib_check(eng.lib.vgh_detector_set_side_priority(eng._det, 1)); timed("split 2, overlapped, low priority again (from the park)")
         def net_only(label):
             for _ in range(3): eng.forward_net(x)
             eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
