@@ -24,7 +24,7 @@ struct CfgEntry {
     const char* name;
     int BP, BC, threads, lds;
     void (*launch)(const ConvArgs&, int, int, int, int, hipStream_t);
-    int patch, TW, TH;  // 5: conv3x3_pp_kernel (conv_pp.hip: 8-wave ping-pong, 8 x 8 sub-patch per wave); 1 / 2: conv3x3_patch_kernel / conv3x3_patch3_kernel (3x3, stride 1, tile TH x TW); 3: conv1x1_stream_kernel; 4: conv3x3_patch_kernel stride 2 (output tile TH x TW); fast epilogue only
+    int patch, TW, TH;  // 7: conv3x3_pp_kernel with two 4 x 8 sub-patches per wave; 5: conv3x3_pp_kernel (conv_pp.hip: 8-wave ping-pong, 8 x 8 sub-patch per wave); 1 / 2: conv3x3_patch_kernel / conv3x3_patch3_kernel (3x3, stride 1, tile TH x TW); 3: conv1x1_stream_kernel; 4: conv3x3_patch_kernel stride 2 (output tile TH x TW); fast epilogue only
     void (*launch_patch)(const ConvArgs&, int, int, int, int, int, int, hipStream_t);
 };
 
@@ -151,6 +151,8 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
     { "g8x8x" #BC "_n8", 512, BC, 512, 0, nullptr, 5, 8, 8, nullptr }
 #define HCFG(BC) \
     { "h8x8x" #BC "_n8", 512, BC, 512, 0, nullptr, 6, 8, 8, nullptr }
+#define SCFG(BC) \
+    { "s4x8x" #BC "_n8", 512, BC, 512, 0, nullptr, 7, 8, 4, nullptr }
 
 const CfgEntry g_cfgs[] = {
     CFG(128, 128, 64, 64, 1),  // 0
@@ -292,6 +294,11 @@ const CfgEntry g_cfgs[] = {
     HCFG(128),  // 125
     HCFG(96),   // 126
     HCFG(64),   // 127
+    // the g tiles with TWO 4 x 8 sub-patches per wave (conv3x3_pp_kernel<TI, 1, ..., GEO = 1>, r06): 20-wide maps tile as 8 + 8 + 8 (the last one overlapping four
+    // columns) x five 4-row bands -- 1.2 x the pixels where the 8 x 8 patches cover 1.44 x -- and small maps split into twice as many independent sub-patches
+    SCFG(128),  // 128
+    SCFG(96),   // 129
+    SCFG(64),   // 130
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
@@ -322,7 +329,8 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     if (cfg < 0 || cfg >= kNumCfgs) return 0;
     const CfgEntry& e = g_cfgs[cfg];
     if (cout_pad % e.BC) return 0;
-    if ((e.patch == 1 || e.patch == 2 || e.patch == 5 || e.patch == 6) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    if ((e.patch == 1 || e.patch == 2 || e.patch == 5 || e.patch == 6 || e.patch == 7) && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle)) return 0;
+    if (e.patch == 7 && cout_pad > 1024) return 0;
     if (e.patch == 3 && !(ksize == 1 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 4 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle)) return 0;
     return 1;
@@ -335,7 +343,8 @@ static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (a.grp_cout && a.grp_cout % g_cfgs[cfg].BC) return 0;
     if ((a.in_fp8 || a.out_fp8) && g_cfgs[cfg].patch != 5) return 0;  // e4m3 links: g tiles only (conv_pp.hip)
     if (a.dvec && g_cfgs[cfg].BC == 128) return 0;
-    if ((g_cfgs[cfg].patch == 5 || g_cfgs[cfg].patch == 6) && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || !vgh_conv_pp_fits(a))) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
+    if ((g_cfgs[cfg].patch == 5 || g_cfgs[cfg].patch == 6 || g_cfgs[cfg].patch == 7) && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || !vgh_conv_pp_fits(a))) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
+    if (g_cfgs[cfg].patch == 7 && (a.Wo < 8 || a.Ho < 4)) return 0;  // 4 x 8 sub-patches are moved back inside the map, never cut
     if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
     return 1;
 }
@@ -473,7 +482,7 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
         cfg = t;
     }
     const CfgEntry& e = g_cfgs[cfg];
-    if (e.patch == 5 || e.patch == 6) return vgh_launch_conv_pp(a, e.BC, e.patch == 6 ? 2 : 1, g_max_blocks_per_xcd.load(std::memory_order_relaxed), stream);
+    if (e.patch == 5 || e.patch == 6 || e.patch == 7) return vgh_launch_conv_pp(a, e.BC, e.patch == 7 ? 3 : e.patch == 6 ? 2 : 1, g_max_blocks_per_xcd.load(std::memory_order_relaxed), stream);
     if (e.patch == 1 || e.patch == 2 || e.patch == 4) {
         const int ntc = a.cout_pad / e.BC, ntx = (a.Wo + e.TW - 1) / e.TW, nty = (a.Ho + e.TH - 1) / e.TH;  // (Ho, Wo) = (H, W) for the stride-1 tiles
         const int64_t total = (int64_t)a.B * nty * ntx * ntc;

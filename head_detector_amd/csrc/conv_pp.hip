@@ -179,18 +179,25 @@ __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
     b = r[1];
 }
 
-template <int TI, int V = 1, int SC = 0>
+// GEO = 1 ("s" tiles, r06): the wave's 64 pixels are TWO 4-row x 8-column sub-patches with origins of their own (any image, any position) instead of one 8 x 8 patch:
+// pixel group j of the MFMAs = sub-patch j, its 6 x 10 halo = records 60 j .. 60 j + 59 of the wave's stage (120 of 128 records = 8 LDS-DMA units).  20-wide maps
+// tile as 8 + 8 + (8 overlapping the previous four columns) x five 4-row bands: 1.2 x the pixels where the 8 x 8 patches cover 24 x 24 = 1.44 x, and twice as many
+// independent sub-patches for the small maps (20^2 at batch 32 per lane: 480 instead of 288 -> 30 workgroup tiles per cout tile instead of 36 half-empty ones).
+// The overlap columns / rows are computed twice with the same summation order and stored twice with the same bits.
+template <int TI, int V = 1, int SC = 0, int GEO = 0>
 struct PPGeo {
     static constexpr int BC = 32 * TI, NW = 8;
-    static constexpr int XU = 7;           // 16-pixel LDS-DMA units of a wave's 10 x 10 halo (100 of 112 records used)
+    static constexpr int XU = GEO ? 8 : 7;  // 16-pixel LDS-DMA units of a wave's halo: 10 x 10 (100 of 112 records used) / two 6 x 10 (120 of 128)
+    static constexpr int JOFF = GEO ? 60 * 64 : 4 * 10 * 64;  // bytes from pixel group 0's records to pixel group 1's
     static constexpr int XST = XU * 1024;  // bytes of one halo stage of one wave
     static constexpr int WST = BC * 64;    // bytes of one weight stage (one tap, one 32-channel block, BC couts)
     static constexpr int WU = BC / 16;     // 1-KiB units per weight stage (waves >= WU stage into the dummy unit)
     static constexpr int NWS = V == 2 ? 4 : 3;  // weight ring (v2: prefetch distance 3 taps, one barrier per tap)
     static constexpr int WOFF = NW * 2 * XST;
     static constexpr int DUMMY = WOFF + NWS * WST;
-    static constexpr int BIAS = DUMMY + 1024;  // the layer's bias vector (<= 2048 couts), staged once per workgroup
-    static constexpr int GS = BIAS + 8192;     // fp8 variants: the per-cout output factors g[c] (same shape as the bias vector)
+    static constexpr int BIAS = DUMMY + 1024;  // the layer's bias vector (<= 2048 couts; GEO = 1: <= 1024, its halo stages take 16 KB more), staged once per workgroup
+    static constexpr int BIASB = GEO ? 4096 : 8192;
+    static constexpr int GS = BIAS + BIASB;    // fp8 variants: the per-cout output factors g[c] (same shape as the bias vector)
     static constexpr int LDS = GS + (SC ? 8192 : 0);
 };
 
@@ -207,23 +214,25 @@ struct PPTile {
     int c0;     // first cout of the tile
     int spok;   // this wave's sub-patch exists
     int b, y0, x0;
+    int spok1, b1, y01, x01;  // GEO = 1: the wave's second 4 x 8 sub-patch (pixel group 1); (spok, b, y0, x0) is the first
 };
 
 // DG = 1 (int8 input, bf16 output): the DIAGONAL BYPASS.  A re-parameterised RepVGG block folds its identity branch into the centre tap, so row c of the folded kernel
 // holds one weight w[c][centre][c] 15 - 30 x its rms -- a per-cout int8 grid sized for it leaves ~23 dB for everything else (e4m3: 32 dB).  The host takes that one
 // element out of the int8 image (which then reaches ~41 dB) and the epilogue adds it back exactly: + dvec[c] * code(input pixel, channel c), dvec = w[c][centre][c] * scale(in),
 // from one dword load per four couts (the pixel's own input bytes: L2 hits, the halo has just been read).  dvec sits in the upper half of the factor region: cout_pad <= 1024.
-template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0, int DG = 0>
+template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0, int DG = 0, int GEO = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, const int ntc, const int nsx, const int nsy, const int nsp, const int total_tiles, const int chunk, const PPDiv dv) {
     constexpr int SC = (F8 || O8) ? 1 : 0;  // per-cout output factors in the epilogue
     constexpr int ES = F8 ? 1 : 2;          // bytes per input element
+    static_assert(!GEO || (V == 1 && !F8 && !O8 && !DG && PP_RES_PREFETCH == 0 && PP_XFRONT == 1), "4 x 8 sub-patches: 16-bit g tiles only");
     static_assert(!(F8 || O8 || H16) || (V == 1 && PP_BAR_TAIL == 0 && PP_RES_PREFETCH == 0), "fp8 / fp16 variants: g tiles only");
     static_assert(!(H16 && (F8 || O8)), "one storage format per variant");
     static_assert(!(F8 && O8) || F8 == O8, "an 8-bit input and an 8-bit output share one format");
     static_assert(!DG || (F8 == 2 && O8 == 0), "the diagonal bypass belongs to the int8 -> bf16 variant");
     // fp16: the accumulator runs in prescaled-weight units: it starts at bias * a.bias_scale (= 1 / out_scale, host-computed: a kernel argument, no register)
-    using G = PPGeo<TI, V, SC>;
-    constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU;
+    using G = PPGeo<TI, V, SC, GEO>;
+    constexpr int BC = G::BC, XST = G::XST, WST = G::WST, WU = G::WU, XU = G::XU, JOFF = G::JOFF;
     // out-of-range marker for buffer offsets (descriptor range 2 GiB): still out of range, and not wrapped past 2^32, after the immediate / scalar
     // offsets the instructions add (channel offsets of the epilogue, weight k-block offsets < 2^30)
     constexpr unsigned OOB = 0xC0000000u;
@@ -239,26 +248,49 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     const int in_pitch = (int)a.in_pitch;
 
     // a tile's wave-uniform part: cout tile, this wave's sub-patch, and what the per-lane halo offsets are built from (PPHalo)
-    auto decode_tile = [&](int local, PPTile& t, PPHalo& hb, unsigned& wv) {
+    auto decode_tile = [&](int local, PPTile& t, PPHalo& hb, PPHalo& hb1, unsigned& wv) {
         const int tile = xcd * chunk + local;
         t.valid = (local < chunk && tile < total_tiles) ? 1 : 0;
         const int tl = t.valid ? tile : 0;
         const int g8 = pp_div(tl, dv.m_ntc, dv.s_ntc);  // tl / ntc
         t.c0 = (tl - g8 * ntc) * BC;
-        const int sp = g8 * 8 + w;
-        t.spok = (t.valid && sp < nsp) ? 1 : 0;
-        const int spc = t.spok ? sp : 0;
         const int per = nsy * nsx;
-        t.b = pp_div(spc, dv.m_per, dv.s_per);  // spc / per
-        const int rem = spc - t.b * per;
-        const int sy = pp_div(rem, dv.m_nsx, dv.s_nsx);  // rem / nsx
-        t.y0 = sy * 8;
-        t.x0 = (rem - sy * nsx) * 8;
-        // byte offset of halo record (0, 0) = input pixel (y0 - 1, x0 - 1): wave-uniform (scalar) and possibly "negative" -- only in-range records add up to an
-        // offset that is used
-        hb.base = ES * (((t.b * a.H + t.y0 - 1) * a.W + t.x0 - 1) * in_pitch + a.in_coff);
-        hb.y0m1 = t.spok ? t.y0 - 1 : -64;  // a missing sub-patch: every record out of range
-        hb.x0m1 = t.x0 - 1;
+        if constexpr (GEO) {  // two 4 x 8 sub-patches per wave: 2 (8 g8 + w) and the next one; the last sub-patch of a row / the last band is moved back inside the map
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int sp = (g8 * 8 + w) * 2 + j;
+                const int ok = (t.valid && sp < nsp) ? 1 : 0;
+                const int spc = ok ? sp : 0;
+                const int b = pp_div(spc, dv.m_per, dv.s_per);
+                const int rem = spc - b * per;
+                const int sy = pp_div(rem, dv.m_nsx, dv.s_nsx);
+                int y0 = sy * 4, x0 = (rem - sy * nsx) * 8;
+                y0 = y0 + 4 > a.H ? a.H - 4 : y0;
+                x0 = x0 + 8 > a.W ? a.W - 8 : x0;
+                PPHalo& h = j ? hb1 : hb;
+                h.base = ES * (((b * a.H + y0 - 1) * a.W + x0 - 1) * in_pitch + a.in_coff);
+                h.y0m1 = ok ? y0 - 1 : -64;
+                h.x0m1 = x0 - 1;
+                if (j == 0)
+                    t.spok = ok, t.b = b, t.y0 = y0, t.x0 = x0;
+                else
+                    t.spok1 = ok, t.b1 = b, t.y01 = y0, t.x01 = x0;
+            }
+        } else {
+            const int sp = g8 * 8 + w;
+            t.spok = (t.valid && sp < nsp) ? 1 : 0;
+            const int spc = t.spok ? sp : 0;
+            t.b = pp_div(spc, dv.m_per, dv.s_per);  // spc / per
+            const int rem = spc - t.b * per;
+            const int sy = pp_div(rem, dv.m_nsx, dv.s_nsx);  // rem / nsx
+            t.y0 = sy * 8;
+            t.x0 = (rem - sy * nsx) * 8;
+            // byte offset of halo record (0, 0) = input pixel (y0 - 1, x0 - 1): wave-uniform (scalar) and possibly "negative" -- only in-range records add up to an
+            // offset that is used
+            hb.base = ES * (((t.b * a.H + t.y0 - 1) * a.W + t.x0 - 1) * in_pitch + a.in_coff);
+            hb.y0m1 = t.spok ? t.y0 - 1 : -64;  // a missing sub-patch: every record out of range
+            hb.x0m1 = t.x0 - 1;
+        }
         wv = (t.valid && w < WU) ? (unsigned)(lane * 16 + w * 1024) : OOB;
     };
     // source offset of this lane's 16 bytes of LDS-DMA unit u of the halo: record hp = 16 u + lane / 4 = halo pixel (hp / 10, hp % 10), two 24-bit multiply-adds
@@ -267,9 +299,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     // L phase that issues the unit (r04 trace: decoding all seven units at the top of the last channel block cost every SIMD ~2 000 cycles per tile with all
     // eight waves in it at once; inside an L phase the other group's MFMAs cover it)
     const unsigned rowb = (unsigned)ES * (unsigned)(a.W * in_pitch), pixb = (unsigned)ES * (unsigned)in_pitch;
-    auto unit_off = [&](int u, const PPHalo& hb) -> unsigned {
+    auto unit_off = [&](int u, const PPHalo& hb, const PPHalo& hb1) -> unsigned {
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
+        if constexpr (GEO) {  // record hp = 16 u + lane / 4 < 120: sub-patch hp / 60, halo pixel ((hp % 60) / 10, hp % 10) of its 6 x 10 halo
+            const unsigned hp = (unsigned)(u * 16) + ((unsigned)lane_t >> 2);
+            const bool j1 = hp >= 60u;
+            const unsigned hl = j1 ? hp - 60u : hp;
+            const unsigned hy = __umul24(hl, 205u) >> 11;
+            const unsigned hx = hl - hy * 10u;
+            const int y0m1 = j1 ? hb1.y0m1 : hb.y0m1, x0m1 = j1 ? hb1.x0m1 : hb.x0m1;
+            const bool ok = hp < 120u && (unsigned)(y0m1 + (int)hy) < (unsigned)a.H && (unsigned)(x0m1 + (int)hx) < (unsigned)a.W;
+            const unsigned rel = __umul24(hy, rowb) + __umul24(hx, pixb) + ((((unsigned)lane_t & 3u) ^ (hy & 3u)) << 4);
+            return ok ? (unsigned)(j1 ? hb1.base : hb.base) + rel : OOB;
+        }
         const unsigned hp = (unsigned)(u * 16) + ((unsigned)lane_t >> 2);
         const unsigned hy = __umul24(hp, 205u) >> 11;  // hp / 10 for hp < 1029
         const unsigned hx = hp - hy * 10u;
@@ -280,12 +323,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
     };
 
     PPTile cur, nxt;
-    PPHalo hb_nxt;
-    unsigned xo[7], wv_cur, wv_nxt;  // xo: halo source offsets of the tile whose halo is being prefetched (the current one, the next one in the last channel block)
+    PPHalo hb_nxt, hb1_nxt;  // (hb1_nxt: the second sub-patch of a GEO = 1 wave; unused otherwise)
+    unsigned xo[XU], wv_cur, wv_nxt;  // xo: halo source offsets of the tile whose halo is being prefetched (the current one, the next one in the last channel block)
     int local = blockIdx.x >> 3;
-    decode_tile(local, cur, hb_nxt, wv_cur);
+    decode_tile(local, cur, hb_nxt, hb1_nxt, wv_cur);
 #pragma unroll
-    for (int u = 0; u < 7; ++u) xo[u] = unit_off(u, hb_nxt);
+    for (int u = 0; u < XU; ++u) xo[u] = unit_off(u, hb_nxt, hb1_nxt);
     if (!cur.valid) return;  // workgroup-uniform: no barrier has been executed yet
 
     if constexpr (PP_STAGGER != 0) {
@@ -313,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = (n32 >> 3) + ky;
-            bofs[ky][h] = w * (2 * XST) + (r * 10 + (n32 & 7)) * 64 + (((2 * h + hi) ^ (r & 3)) * 16);
+            bofs[ky][h] = w * (2 * XST) + (r * 10 + (n32 & 7)) * 64 + (((2 * h + hi) ^ (r & 3)) * 16);  // (GEO = 1: the same formula inside a 6 x 10 halo)
         }
     int aofs[2];
 #pragma unroll
@@ -323,11 +366,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 
     // ---- prologue: halo of channel block 0 and the first two taps of the first tile ----
 #pragma unroll
-    for (int u = 0; u < 7; ++u) dma16(a.in, xo[u], 0, xw + u * 1024);
+    for (int u = 0; u < XU; ++u) dma16(a.in, xo[u], 0, xw + u * 1024);
     dma16(wbase_cur, wv_cur, (unsigned)(0 * ncb) * wkstride, wdst + 0 * wdst_step);
     dma16(wbase_cur, wv_cur, (unsigned)(1 * ncb) * wkstride, wdst + 1 * wdst_step);
     if constexpr (V == 2) dma16(wbase_cur, wv_cur, (unsigned)(2 * ncb) * wkstride, wdst + 2 * wdst_step);
-    dma16(a.bias, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::BIAS + w * 1024);
+    // (GEO = 1: the bias region is 4 KB = cout_pad <= 1024; waves 4 .. 7 land their all-zero unit in the dummy)
+    dma16(a.bias, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, (w * 1024 < G::BIASB) ? smem + G::BIAS + w * 1024 : smem + G::DUMMY);
     if constexpr (SC) {
         if (!DG || w < 4) dma16(a.gscale, (lane * 16 + w * 1024 < a.cout_pad * 4) ? (unsigned)(lane * 16 + w * 1024) : OOB, 0, smem + G::GS + w * 1024);
     }
@@ -430,11 +474,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             // prefetch targets of this channel block: halo of (cb + 1) or of the next tile's block 0; weights two taps ahead
             unsigned rpo = OOB;  // byte offset of this lane's pixel (lane = pixel of the 8 x 8 sub-patch) in the residual tensor, for the L2 touches
             if (last) {
-                decode_tile(local + gpx, nxt, hb_nxt, wv_nxt);  // its halo offsets: unit by unit in the L phases below
+                decode_tile(local + gpx, nxt, hb_nxt, hb1_nxt, wv_nxt);  // its halo offsets: unit by unit in the L phases below
                 wbase_nxt = (const char*)a.wpack + (int64_t)nxt.c0 * 64;
-                const int y = cur.y0 + (lane >> 3), x = cur.x0 + (lane & 7);
-                const int64_t ro = ((((int64_t)cur.b * a.Ho + y) * a.Wo + x) * a.res_pitch + a.res_coff + cur.c0) * 2;
-                if (a.res && cur.spok && y < a.Ho && x < a.Wo && ro + 2 * BC <= 0x7fffffff) rpo = (unsigned)ro;
+                if constexpr (PP_RES_PREFETCH != 0) {
+                    const int y = cur.y0 + (lane >> 3), x = cur.x0 + (lane & 7);
+                    const int64_t ro = ((((int64_t)cur.b * a.Ho + y) * a.Wo + x) * a.res_pitch + a.res_coff + cur.c0) * 2;
+                    if (a.res && cur.spok && y < a.Ho && x < a.Wo && ro + 2 * BC <= 0x7fffffff) rpo = (unsigned)ro;
+                }
             }
             const char* const xsrc = last ? (const char*)a.in : (const char*)a.in + (cb + 1) * 64;
             const char* const wb_n = last ? wbase_nxt : wbase_cur;
@@ -456,16 +502,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wd);
                     if constexpr (PP_XFRONT) {
                         if constexpr (T < 3) {
-                            if (last) xo[2 * T] = unit_off(2 * T, hb_nxt), xo[2 * T + 1] = unit_off(2 * T + 1, hb_nxt);
+                            if (last) xo[2 * T] = unit_off(2 * T, hb_nxt, hb1_nxt), xo[2 * T + 1] = unit_off(2 * T + 1, hb_nxt, hb1_nxt);
                             dma16(xsrc, xo[2 * T], 0, xpre + (2 * T) * 1024);
                             dma16(xsrc, xo[2 * T + 1], 0, xpre + (2 * T + 1) * 1024);
                         } else if constexpr (T == 3) {
-                            if (last) xo[6] = unit_off(6, hb_nxt);
+                            if (last) xo[6] = unit_off(6, hb_nxt, hb1_nxt);
                             dma16(xsrc, xo[6], 0, xpre + 6 * 1024);
                         }
                     } else {
                         if constexpr (T < 7) {
-                            if (last) xo[T] = unit_off(T, hb_nxt);
+                            if (last) xo[T] = unit_off(T, hb_nxt, hb1_nxt);
                             dma16(xsrc, xo[T], 0, xpre + T * 1024);
                         }
                     }
@@ -523,8 +569,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         }
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            b0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + j * 2560 + kx * 64);
-                            b1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + j * 2560 + kx * 64);
+                            b0[j] = *(const bf16x8_t*)(smem + bofs[ky][0] + j * JOFF + kx * 64);
+                            b1[j] = *(const bf16x8_t*)(smem + bofs[ky][1] + j * JOFF + kx * 64);
                         }
                     } else {  // experiments build: the loop without its fragment traffic (MFMAs on whatever the registers hold)
 #pragma unroll
@@ -539,17 +585,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                         else
                             dma16(wb_n, wv_n, (unsigned)((TT - 9) * ncb + cb_n) * wkstride, wdst + ws * wdst_step);
                         if constexpr (PP_XFRONT) {
-                            if constexpr (T < 3) {
-                                if (last) xo[2 * T] = unit_off(2 * T, hb_nxt), xo[2 * T + 1] = unit_off(2 * T + 1, hb_nxt);
+                            if constexpr (T < (GEO ? 4 : 3)) {  // (GEO = 1: eight units, two per tap in taps 0 - 3)
+                                if (last) xo[2 * T] = unit_off(2 * T, hb_nxt, hb1_nxt), xo[2 * T + 1] = unit_off(2 * T + 1, hb_nxt, hb1_nxt);
                                 dma16(xsrc, xo[2 * T], 0, xpre + (2 * T) * 1024);
                                 dma16(xsrc, xo[2 * T + 1], 0, xpre + (2 * T + 1) * 1024);
                             } else if constexpr (T == 3) {
-                                if (last) xo[6] = unit_off(6, hb_nxt);
+                                if (last) xo[6] = unit_off(6, hb_nxt, hb1_nxt);
                                 dma16(xsrc, xo[6], 0, xpre + 6 * 1024);
                             }
                         } else {
                             if constexpr (T < 7) {
-                                if (last) xo[T] = unit_off(T, hb_nxt);
+                                if (last) xo[T] = unit_off(T, hb_nxt, hb1_nxt);
                                 dma16(xsrc, xo[T], 0, xpre + T * 1024);
                             }
                         }
@@ -560,9 +606,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
                     wait_lgkm0();  // this wave's reads of stage st / of its halo are complete before the barrier that releases them for re-filling
                     // the weight unit issued first in L(T-1) (tap T+1) has landed; younger and allowed in flight: the rest of L(T-1) and all of L(T)
                     {
-                        constexpr int XN_T = PP_XFRONT ? (T < 3 ? 2 : T == 3 ? 1 : 0) : (T < 7 ? 1 : 0);
+                        constexpr int XN_T = GEO ? (T < 4 ? 2 : 0) : PP_XFRONT ? (T < 3 ? 2 : T == 3 ? 1 : 0) : (T < 7 ? 1 : 0);
                         constexpr int TP = (T + 8) % 9;  // the previous phase
-                        constexpr int XN_P = PP_XFRONT ? (TP < 3 ? 2 : TP == 3 ? 1 : 0) : (TP < 7 ? 1 : 0);
+                        constexpr int XN_P = GEO ? (TP < 4 ? 2 : 0) : PP_XFRONT ? (TP < 3 ? 2 : TP == 3 ? 1 : 0) : (TP < 7 ? 1 : 0);
                         constexpr int PN_T = (LAST && T < 3) ? 1 : 0, PN_P = (LAST && TP < 3) ? 1 : 0;
                         constexpr int NW = XN_P + PN_P + 1 + XN_T + PN_T;
                         if constexpr (T == 0 && PP_RELAX_FIRST_WAIT != 0) {
@@ -673,9 +719,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
             };
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int y = cur.y0 + 4 * j + (n32 >> 3), x = cur.x0 + (n32 & 7);
-                const bool okpx = cur.spok && y < a.Ho && x < a.Wo;
-                const int opix = (cur.b * a.Ho + y) * a.Wo + x;
+                const int y = (GEO && j ? cur.y01 : cur.y0 + 4 * j) + (n32 >> 3), x = (GEO && j ? cur.x01 : cur.x0) + (n32 & 7);
+                const bool okpx = (GEO && j ? cur.spok1 : cur.spok) && y < a.Ho && x < a.Wo;
+                const int opix = ((GEO && j ? cur.b1 : cur.b) * a.Ho + y) * a.Wo + x;
                 // bf16: a lane ends up with couts cbase + 32 i + 16 m + 8 hi .. + 7; e4m3: with couts cbase + 32 i + 16 hi .. + 15
                 ovb[j] = okpx ? (unsigned)((opix * (int)a.out_pitch + a.out_coff + cbase + (O8 ? 16 : 8) * hi) * OS) : OOB;
                 rvb[j] = okpx ? (unsigned)((opix * (int)a.res_pitch + a.res_coff + cbase + 8 * hi) * 2) : OOB;
@@ -921,14 +967,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(const ConvArgs a, co
 }
 
 constexpr int kMaxDev = 16;
-template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0, int DG = 0>
+template <int TI, int V, int F8 = 0, int O8 = 0, int H16 = 0, int DG = 0, int GEO = 0>
 int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, int chunk, int max_blocks_per_xcd, hipStream_t st) {
-    using G = PPGeo<TI, V, (F8 || O8) ? 1 : 0>;
+    using G = PPGeo<TI, V, (F8 || O8) ? 1 : 0, GEO>;
     static std::atomic<int> done[kMaxDev];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
     if (!done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V, F8, O8, H16, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (G::LDS)));
+        VGH_HIP(hipFuncSetAttribute((const void*)conv3x3_pp_kernel<TI, V, F8, O8, H16, DG, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, (G::LDS)));
         done[dev].store(1, std::memory_order_release);
     }
     int gpx = 32;  // one workgroup per CU, 32 CUs per XCD
@@ -938,7 +984,7 @@ int launch_pp(const ConvArgs& a, int ntc, int nsx, int nsy, int nsp, int total, 
     vgh_fastdiv_magic((unsigned)ntc, &dv.m_ntc, &dv.s_ntc);
     vgh_fastdiv_magic((unsigned)(nsy * nsx), &dv.m_per, &dv.s_per);
     vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
-    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V, F8, O8, H16, DG>), dim3(gpx * 8), dim3(512), (G::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
+    hipLaunchKernelGGL((conv3x3_pp_kernel<TI, V, F8, O8, H16, DG, GEO>), dim3(gpx * 8), dim3(512), (G::LDS), st, a, ntc, nsx, nsy, nsp, total, chunk, dv);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -953,6 +999,7 @@ int vgh_conv_pp_fits(const ConvArgs& a) {
 }
 int vgh_conv_pp_lds(int bc) { return bc == 128 ? PPGeo<4, 2>::LDS : bc == 96 ? PPGeo<3, 2>::LDS : bc == 64 ? PPGeo<2, 2>::LDS : 0; }
 static_assert(PPGeo<4, 1, 1>::LDS <= 160 * 1024, "e4m3 g tiles: bias + factor vectors must fit the 160 KB LDS");
+static_assert(PPGeo<4, 1, 0, 1>::LDS <= 160 * 1024, "4 x 8 sub-patch tiles: two 8-KB halo stages per wave + the weight ring must fit the 160 KB LDS");
 
 int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_per_xcd, hipStream_t stream) {
     const bool h16 = a.split == VGH_FMT_F16X2 && a.nseg == 1;  // single-plane fp16 (VGH_FMT_F16) through conv_split.hip's pseudo-tiles
@@ -968,9 +1015,11 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
     }
     VGH_REQUIRE(a.cout_pad % bc == 0 && a.cout_pad <= 2048, "conv: cout_pad %d is not a multiple of the %d-cout ping-pong tile (or above 2048)", a.cout_pad, bc);
     VGH_REQUIRE(vgh_conv_pp_fits(a), "conv: output / residual tensor above 2 GiB (32-bit buffer offsets), or an input row above 16 MiB");
-    const int nsx = (a.Wo + 7) / 8, nsy = (a.Ho + 7) / 8, ntc = a.cout_pad / bc;
+    const bool geo = version == 3;  // "s" tiles: two 4 x 8 sub-patches per wave
+    VGH_REQUIRE(!geo || (a.Wo >= 8 && a.Ho >= 4 && a.cout_pad <= 1024 && !a.in_fp8 && !a.out_fp8 && !h16), "conv: the 4 x 8 sub-patch tiles need a bf16 map of at least 4 x 8 pixels and cout_pad <= 1024");
+    const int nsx = (a.Wo + 7) / 8, nsy = geo ? (a.Ho + 3) / 4 : (a.Ho + 7) / 8, ntc = a.cout_pad / bc;
     const int64_t nsp = (int64_t)a.B * nsy * nsx;
-    const int64_t total = (nsp + 7) / 8 * ntc;
+    const int64_t total = (nsp + (geo ? 15 : 7)) / (geo ? 16 : 8) * ntc;
     VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
     const int chunk = (int)((total + 7) / 8);
     if (a.in_fp8 || a.out_fp8) {
@@ -1011,6 +1060,14 @@ int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version, int max_blocks_pe
             case 64: return launch_pp<2, 1, 0, 0, 1>(ah, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
         }
         VGH_REQUIRE(false, "conv: no fp16 ping-pong tile with %d couts", bc);
+    }
+    if (geo) {
+        switch (bc) {
+            case 128: return launch_pp<4, 1, 0, 0, 0, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+            case 96: return launch_pp<3, 1, 0, 0, 0, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+            case 64: return launch_pp<2, 1, 0, 0, 0, 0, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);
+        }
+        VGH_REQUIRE(false, "conv: no 4 x 8 ping-pong tile with %d couts", bc);
     }
     switch (bc + (version == 2 ? 1 : 0)) {
         case 128: return launch_pp<4, 1>(a, ntc, nsx, nsy, (int)nsp, (int)total, chunk, max_blocks_per_xcd, stream);

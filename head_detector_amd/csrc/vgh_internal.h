@@ -118,7 +118,7 @@ void vgh_pack_conv_weights_i8_host(const float* w, int cout_pad, int ksize, int 
 static inline int vgh_fmt_is_q8(int fmt) { return fmt == VGH_FMT_FP8 || fmt == VGH_FMT_I8; }    // an 8-bit link format
 static inline int vgh_fmt_q8_kind(int fmt) { return fmt == VGH_FMT_FP8 ? 1 : fmt == VGH_FMT_I8 ? 2 : 0; }  // ConvArgs::in_fp8 / out_fp8 code
 // conv_pp.hip: the 8-wave ping-pong 3x3 / stride-1 tiles ("g" tiles; bc = 128 / 96 / 64 couts per workgroup); `a` must be prepared
-int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version /* 1: "g" (two barriers per tap), 2: "h" (one) */, int max_blocks_per_xcd, hipStream_t stream);
+int vgh_launch_conv_pp(const ConvArgs& a, int bc, int version /* 1: "g" (two barriers per tap), 2: "h" (one), 3: "s" (g with two 4 x 8 sub-patches per wave) */, int max_blocks_per_xcd, hipStream_t stream);
 int vgh_conv_pp_lds(int bc);
 int vgh_conv_max_blocks_per_xcd();  // the process-wide cap of vgh_conv_set_max_blocks_per_xcd (0 = none)
 int vgh_conv_pp_fits(const ConvArgs& a);

@@ -487,7 +487,7 @@ class VGHeadsEngine:
             return False
         if self.cfg_names()[cfg].startswith("t") and (op.get("res_buf", -1) >= 0 or op.get("grp_cout") or op.get("act") == 2):
             return False  # streaming 1x1 tiles: plain bf16 -> bf16 convs only (the executor would fall back to another tile)
-        if self.cfg_names()[cfg][0] in "gh" and (op.get("grp_cout") or op.get("act") == 2):
+        if self.cfg_names()[cfg][0] in "ghs" and (op.get("grp_cout") or op.get("act") == 2):
             return False  # ping-pong 3x3 tiles: dense convs, ReLU / none
         return not op.get("grp_cout") or op["grp_cout"] % self.lib.vgh_conv_cfg_cout_tile(cfg) == 0
 

@@ -422,7 +422,7 @@ def test_conv_persistent_multi_tile(gpu_lib, cin, res):
         for cap in (2, 5):
             assert gpu_lib.vgh_conv_set_max_blocks_per_xcd(cap) == 0
             for cfg, name in enumerate(names):
-                if name[0] not in "pqgh" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, Cout, 1, 0):
+                if name[0] not in "pqghs" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 1, Cout, 1, 0):
                     continue
                 out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, cfg=cfg, res=r, alpha=0.37 if res else 0.0)
                 _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"multi-tile cfg={name} cap={cap} cin={cin} res={res}")
@@ -1431,14 +1431,15 @@ def test_letterbox_kernel_vs_oracle(gpu_lib):
 
 
 @pytest.mark.parametrize("variant,B,probe,S", [("vgg_heads_m", 32, (0, 13, 31), 640), ("vgg_heads_l", 64, (0, 31, 63), 640), ("vgg_heads_l", 8, (0, 5, 7), 640),
-                                               ("vgg_heads_l", 16, (0, 9, 15), 1280), ("vgg_heads_l", 32, (0, 26, 27, 31), 1280)],
-                         ids=["m32", "l64", "l8", "l16_1280", "l32_1280_chunked"])
+                                               ("vgg_heads_l", 16, (0, 9, 15), 1280), ("vgg_heads_l", 32, (0, 26, 27, 31), 1280), ("vgg_heads_l", 256, (0, 27, 255), 1280)],
+                         ids=["m32", "l64", "l8", "l16_1280", "l32_1280_chunked", "l256_1280_configs4_stated_batch"])
 def test_full_size_batch_independence_property(gpu_lib, flame_model, variant, B, probe, S):
     """BASELINE configs[1] (VGGHeads_M, B = 32) and configs[2] (VGGHeads_L, B = 64 + FLAME decode: the benchmark line) at 640x640
     with the tuned tile tables, two lanes + overlap, plus the b8 tile bucket; configs[4] (VGGHeads_L @ 1280x1280 CROWD images:
     33 600 anchors, the confidence threshold calibrated so that >= 32 heads per image survive NMS and are decoded through the
     device-side head count) in its own tile bucket (b8, m102400 tiles) at B = 16 and -- B = 32 -- through the chunked arena (a
-    1280 activation tensor passes 2 GiB beyond 27 images: the batch runs as 27 + 5).  The oracle cannot run these sizes in seconds,
+    1280 activation tensor passes 2 GiB beyond 27 images: the batch runs as 27 + 5), and (r06) at configs[4]'s STATED batch, 256 images
+    on one GPU = ten arena chunks (9 x 27 + 13).  The oracle cannot run these sizes in seconds,
     so parity rests on a size-independent property -- images are independent, hence every image's candidates and detections in
     the full batch equal those of the same image run alone (same engine, same tile choices), bit for bit."""
     from head_detector_amd.engine import VGHeadsEngine

@@ -277,9 +277,9 @@ def test_ping_pong_tiles_qualify_only_for_their_conv_class():
 
     lib = _lib.load()
     names = [lib.vgh_conv_cfg_name(i).decode() for i in range(lib.vgh_conv_num_cfgs())]
-    for fam in "gh":
+    for fam in "ghs":  # s (r06): the g tiles with two 4 x 8 sub-patches per wave
         for bc in (128, 96, 64):
-            c = names.index(f"{fam}8x8x{bc}_n8")
+            c = names.index(f"{fam}8x8x{bc}_n8" if fam != "s" else f"s4x8x{bc}_n8")
             assert lib.vgh_conv_cfg_cout_tile(c) == bc
             assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc, 1, 0) == 1
             assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc + 32, 1, 0) == 0  # cout_pad not a multiple of the tile
@@ -287,6 +287,7 @@ def test_ping_pong_tiles_qualify_only_for_their_conv_class():
             assert lib.vgh_conv_cfg_ok(c, 1, 1, 3 * bc, 1, 0) == 0  # 1x1
             assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc, 0, 0) == 0  # fp32 / unaligned store
             assert lib.vgh_conv_cfg_ok(c, 3, 1, 3 * bc, 1, 1) == 0  # ConvTranspose pixel shuffle
+    assert lib.vgh_conv_cfg_ok(names.index("s4x8x128_n8"), 3, 1, 1024, 1, 0) == 1 and lib.vgh_conv_cfg_ok(names.index("s4x8x128_n8"), 3, 1, 1152, 1, 0) == 0  # 4-KB bias vector
 
 
 def test_save_meshes_matches_reference_obj_bytes(tmp_path):

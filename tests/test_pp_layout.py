@@ -146,3 +146,76 @@ def test_just_in_time_halo_offsets_equal_the_full_pixel_address():
                             if ok:
                                 full = 2 * (((b * H + iy) * W + ix) * pitch + coff) + (((lane & 3) ^ (hy & 3)) << 4)
                                 assert (base % M32 + rel) % M32 == full and full < (1 << 31)
+
+
+# ---- "s" tiles (r06, conv3x3_pp_kernel<..., GEO = 1>): the wave's 64 pixels are TWO 4-row x 8-column sub-patches with origins of their own ----
+XU_S, JOFF_S = 8, 60 * 64  # units of a halo stage (two 6 x 10 halos = 120 of 128 records); bytes from pixel group 0's records to pixel group 1's
+
+
+def halo_stage_s():
+    """LDS image of a GEO = 1 halo stage: lane l of unit u writes record hp = 16 u + (l >> 2), slot l & 3, and fetches chunk (l & 3) ^ (hy & 3) of halo pixel
+    (hy, hx) = divmod(hp % 60, 10) of sub-patch hp // 60 (conv_pp.hip::unit_off, GEO branch)."""
+    img = {}
+    for u in range(XU_S):
+        for lane in range(64):
+            hp = u * 16 + (lane >> 2)
+            j, hl = divmod(hp, 60)
+            hy, hx = divmod(hl, 10)
+            img[(hp, lane & 3)] = (j, hy, hx, (lane & 3) ^ (hy & 3)) if hp < 120 else None
+    return img
+
+
+def frag_byte_s(lane, j, ky, kx, h):
+    n32, hi = lane & 31, lane >> 5
+    r = (n32 >> 3) + ky
+    return (r * PITCH + (n32 & 7)) * 64 + (((2 * h + hi) ^ (r & 3)) * 16) + j * JOFF_S + kx * 64
+
+
+def test_s_tiles_fragment_reads_fetch_the_im2col_operand_and_are_conflict_free():
+    img = halo_stage_s()
+    assert all((hl * 205) >> 11 == hl // 10 for hl in range(60))
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[g + 32 for g in grp] for grp in groups]
+    for j in range(2):
+        for ky in range(3):
+            for kx in range(3):
+                for h in range(2):
+                    for lane in range(64):
+                        rec, slot = divmod(frag_byte_s(lane, j, ky, kx, h), 64)
+                        jj, hy, hx, chunk = img[(rec, slot // 16)]
+                        n32, hi = lane & 31, lane >> 5
+                        assert jj == j and (hy, hx) == ((n32 >> 3) + ky, (n32 & 7) + kx) and chunk == 2 * h + hi  # pixel (n32 >> 3, n32 & 7) of sub-patch j, tap (ky, kx)
+                    for grp in groups:
+                        assert len({(frag_byte_s(lane, j, ky, kx, h) // 16) % 16 for lane in grp}) == 16, (j, ky, kx, h)
+    # eight units issued two per tap in taps 0 - 3; the counted waits of the g tiles with that schedule (test_weight_ring_and_vmcnt_schedule's simulation)
+    xn = lambda T: 2 if T < 4 else 0  # noqa: E731
+    issued = []
+    for g in range(3 * 9):
+        cb, T = divmod(g, 9)
+        issued.append(("W", g + 2))
+        issued += [("X", (cb + 1, u)) for u in range(xn(T))]
+        landed = issued[: len(issued) - (xn((T + 8) % 9) + 1 + xn(T))]
+        if g >= 1:
+            assert ("W", g + 1) in landed
+        if T == 8:
+            assert sum(1 for k, t in landed if k == "X" and t[0] == cb + 1) == XU_S
+    assert sum(xn(T) for T in range(9)) == XU_S
+    # LDS budget of the 128-cout variant: 8 waves x 2 stages x 8 KB + 3 weight stages + dummy unit + a 4-KB bias vector (cout_pad <= 1024)
+    assert 8 * 2 * XU_S * 1024 + 3 * 128 * 64 + 1024 + 4096 <= 160 * 1024
+
+
+def test_s_tiles_cover_every_pixel_once_or_with_identical_duplicates():
+    """4 x 8 sub-patches: the last one of a row / the last band is MOVED BACK inside the map (x0 = W - 8, y0 = H - 4), never cut: every output pixel is owned by at
+    least one sub-patch, and a pixel owned twice is computed from the same 3 x 3 window both times (its value does not depend on the sub-patch origin)."""
+    for H, W in ((20, 20), (10, 10), (40, 40), (21, 37), (4, 8), (7, 9)):
+        nsx, nsy = (W + 7) // 8, (H + 3) // 4
+        owners = np.zeros((H, W), dtype=int)
+        for sy in range(nsy):
+            for sx in range(nsx):
+                y0, x0 = min(sy * 4, H - 4), min(sx * 8, W - 8)
+                assert y0 >= 0 and x0 >= 0
+                owners[y0:y0 + 4, x0:x0 + 8] += 1
+        assert owners.min() >= 1
+        assert owners.sum() == nsy * nsx * 32
+    # the 20-wide maps of the 640 configuration: 15 sub-patches = 480 pixels for 400 (1.2 x); 8 x 8 patches cover 24 x 24 = 576 (1.44 x)
+    assert ((20 + 7) // 8) * ((20 + 3) // 4) * 32 == 480 and ((20 + 7) // 8) ** 2 * 64 == 576

@@ -28,6 +28,14 @@ def run(variant, B, prec, S=640, nf=40):
         eng.candidates(B)
         eng.select(B, confidence_threshold=0.6, iou_threshold=0.5, flame=flame, unpad=unpad)
     for _ in range(5): step()
+    def mark():  # one spin kernel of a role-specific length per stream (main 37 us, lane 47, side 57): tools/queue_trace_summary.py finds them in a rocprofv3
+        if os.environ.get("SEQ_MARK"):  # --kernel-trace of this script and reads the hardware queue (Queue_Id) each role's stream sits on; once before and once after the engine's loops
+            eng.join()
+            sts = eng.streams_in_use()  # [main, lanes of the batch split ..., side stream when the post stages overlap]
+            for i, s_ in enumerate(sts):
+                us = 37 if i == 0 else 57 if (B >= 8 and i == len(sts) - 1) else 47
+                torch.cuda.synchronize(); _lib_check(eng.lib.vgh_stream_spin(s_.cuda_stream, us)); torch.cuda.synchronize()
+    mark()
     eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
     for i in range(nf): step(i)
     eng.join(); torch.cuda.synchronize(); dt = (time.perf_counter() - t) / nf * 1e3
@@ -78,12 +86,14 @@ def run(variant, B, prec, S=640, nf=40):
         tab = {r["name"]: r["ms"] for r in rows}
         PROF.setdefault(prec, []).append(tab)
         print(f"   single-stream sum {sum(tab.values()):.3f} ms", flush=True)
+    mark()
     eng.close()
 PROF = {}
 seq = [("vgg_heads_l", 64, "bf16", 640), ("vgg_heads_m", 32, "bf16", 640), ("vgg_heads_l", 16, "bf16", 1280), ("vgg_heads_l", 32, "fp16x3", 640), ("vgg_heads_l", 8, "fp32", 640),
        ("vgg_heads_l", 64, "fp8", 640), ("vgg_heads_l", 64, "fp16", 640), ("vgg_heads_l", 64, "int8", 640), ("vgg_heads_l", 64, "bf16", 640), ("vgg_heads_l", 64, "int8", 640), ("vgg_heads_l", 64, "fp8", 640), ("vgg_heads_l", 64, "int8", 640)]
+NF = int(os.environ.get("SEQ_NF", "40"))
 for v, B, p, S in seq:
-    run(v, B, p, S, nf=10 if p in ("fp32",) else 40)
+    run(v, B, p, S, nf=min(NF, 10) if p in ("fp32",) else NF)
 
 for prec, tabs in PROF.items():
     base = tabs[0]
