@@ -141,6 +141,83 @@ def layer_specs(variant: str) -> List[Spec]:
     return s
 
 
+def module_graph(variant: str) -> List[dict]:
+    """The reference network as a MODULE-level dataflow graph in forward (= export) order: one entry per conv module of ``layer_specs`` plus the tensor ops
+    between them.  ``{"op": "conv" | "convT" | "add" | "concat" | "maxpool", "name": output tensor (= the module name for convs), "inputs": [tensor names, "image" first],
+    "spec": Spec of a conv, "relu": a ReLU follows, "alpha": name of the bottleneck-alpha spec scaling inputs[0] of an add, "k": pool size}``.
+    What it restates (the forward bodies of super_gradients' YoloNASStage / CSPLayer / Bottleneck / SPP / UpStage / DownStage as oracle/net_oracle.py states them, and
+    yolo_head_training/yolo_head/yolo_head_dfl_head.py:143-164 for the heads); used by onnx_graph.py to bind the anonymous Conv nodes of a simplified ONNX export by
+    graph position, and by the tests' exporter stand-in.  ``tests/test_host_logic.py`` pins it against the oracle's module tree run under forward hooks."""
+    v = VARIANTS[variant]
+    sp = {s.name: s for s in layer_specs(variant)}
+    g: List[dict] = []
+
+    def conv(name, x, relu=True):
+        s = sp[name]
+        g.append(dict(op="convT" if s.kind == "convT" else "conv", name=name, inputs=[x], spec=s, relu=relu and s.kind not in ("plain", "convT")))
+        return name
+
+    def csp(p, x, n, ci):
+        x1 = conv(f"{p}.conv1", x)
+        outs = [x1]
+        for i in range(n):
+            a = conv(f"{p}.bottlenecks.{i}.cv1", x1)
+            b = conv(f"{p}.bottlenecks.{i}.cv2", a)
+            g.append(dict(op="add", name=f"{p}.bottlenecks.{i}", inputs=[x1, b], alpha=f"{p}.bottlenecks.{i}.alpha"))
+            x1 = f"{p}.bottlenecks.{i}"
+            outs.append(x1)
+        if not ci:
+            outs = outs[-1:]
+        x2 = conv(f"{p}.conv2", x)
+        g.append(dict(op="concat", name=f"{p}.cat", inputs=outs + [x2]))
+        return conv(f"{p}.conv3", f"{p}.cat")
+
+    x = conv("backbone.stem.conv", "image")
+    feats = []
+    for i, (co, n, hid, ci) in enumerate(v["stages"]):
+        p = f"backbone.stage{i + 1}"
+        x = csp(f"{p}.blocks", conv(f"{p}.downsample", x), n, ci)
+        feats.append(x)
+    c2, c3, c4, _ = feats
+    y = conv("backbone.context_module.cv1", x)
+    pools = []
+    for k in (5, 9, 13):
+        g.append(dict(op="maxpool", name=f"backbone.context_module.m{k}", inputs=[y], k=k))
+        pools.append(f"backbone.context_module.m{k}")
+    g.append(dict(op="concat", name="backbone.context_module.cat", inputs=[y] + pools))
+    c5 = conv("backbone.context_module.cv2", "backbone.context_module.cat")
+
+    def up(p, x, s1, s2, n):
+        a, b = conv(f"{p}.reduce_skip1", s1), conv(f"{p}.reduce_skip2", s2)
+        inter = conv(f"{p}.conv", x)
+        u = conv(f"{p}.upsample", inter)
+        d = conv(f"{p}.downsample", b)
+        g.append(dict(op="concat", name=f"{p}.cat", inputs=[u, a, d]))
+        return inter, csp(f"{p}.blocks", conv(f"{p}.reduce_after_concat", f"{p}.cat"), n, False)
+
+    def down(p, x, skip, n):
+        c = conv(f"{p}.conv", x)
+        g.append(dict(op="concat", name=f"{p}.cat", inputs=[c, skip]))
+        return csp(f"{p}.blocks", f"{p}.cat", n, False)
+
+    (_, n1, _), (_, n2, _), (_, n3, _), (_, n4, _) = v["neck"]
+    i1, x = up("neck.neck1", c5, c4, c3, n1)
+    i2, p3 = up("neck.neck2", x, c3, c2, n2)
+    p4 = down("neck.neck3", p3, i2, n3)
+    p5 = down("neck.neck4", p4, i1, n4)
+    for lv, f in enumerate((p3, p4, p5)):
+        p = f"heads.head{lv + 1}"
+        nb = head_dims(v, lv)["blocks"]
+        pose, bb = conv(f"{p}.pose_stem", f), conv(f"{p}.bbox_stem", f)
+        conv(f"{p}.cls_pred", conv(f"{p}.cls_convs.0", bb))  # yolo_head_dfl_head.py:147-153: the cls tower first, then the reg tower
+        conv(f"{p}.reg_pred", conv(f"{p}.reg_convs.0", bb))
+        for br in ("shape", "expression", "rotation", "jaw", "translation", "scale"):  # :155-160
+            t = pose
+            for b in range(nb + 1):
+                t = conv(f"{p}.flame_{br}_pred.{b}", t)
+    return g
+
+
 def _bn_names(p: str) -> List[str]:
     return [f"{p}.weight", f"{p}.bias", f"{p}.running_mean", f"{p}.running_var"]
 

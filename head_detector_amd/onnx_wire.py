@@ -8,9 +8,14 @@ yolo_head_training/yolo_head/exportable_mesh_model.py:398-411).  All the engine 
 tests build their files with ``write_model``: there is no ONNX file of the released model in this image, so ingest of a REAL
 export is unpinned -- see ``load_initializers`` on what an exporter may have folded away).
 
-Field numbers (onnx/onnx.proto3):  ModelProto.graph = 7;  GraphProto.node = 1, .name = 2, .initializer = 5;
+Field numbers (onnx/onnx.proto3):  ModelProto.graph = 7;  GraphProto.node = 1, .name = 2, .initializer = 5, .input = 11, .output = 12;
 TensorProto.dims = 1, .data_type = 2, .float_data = 4, .int32_data = 5, .int64_data = 7, .name = 8, .raw_data = 9, .double_data = 10,
-.external_data = 13, .data_location = 14;  NodeProto.input = 1, .output = 2, .name = 3, .op_type = 4.
+.external_data = 13, .data_location = 14;  NodeProto.input = 1, .output = 2, .name = 3, .op_type = 4, .attribute = 5;
+AttributeProto.name = 1, .f = 2, .i = 3, .s = 4, .t = 5, .floats = 7, .ints = 8;  ValueInfoProto.name = 1.
+
+r06: ``load_graph`` reads the NODES too (op type, inputs, outputs, the integer / float / tensor attributes), which is what a file that went through
+``onnxsim.simplify`` needs (exportable_mesh_model.py:483-488): its Conv weights are ``onnx::Conv_NNN`` initializers with the BatchNorm already merged, so they can
+only be bound to the op program by graph position -- head_detector_amd/onnx_graph.py does that.
 """
 from __future__ import annotations
 
@@ -52,8 +57,12 @@ def _fields(buf: memoryview) -> Iterator[Tuple[int, int, object]]:
         if wt == 0:
             v, pos = _varint(buf, pos)
         elif wt == 1:
+            if pos + 8 > len(buf):
+                raise OnnxWireError(f"field {fno}: truncated 64-bit record")
             v, pos = struct.unpack_from("<Q", buf, pos)[0], pos + 8
         elif wt == 5:
+            if pos + 4 > len(buf):
+                raise OnnxWireError(f"field {fno}: truncated 32-bit record")
             v, pos = struct.unpack_from("<I", buf, pos)[0], pos + 4
         elif wt == 2:
             n, pos = _varint(buf, pos)
@@ -173,6 +182,79 @@ def load_initializers(path: str) -> Tuple[Dict[str, np.ndarray], List[Tuple[str,
     return tensors, nodes
 
 
+def _attribute(buf: memoryview) -> Tuple[str, object]:
+    name, val = "", None
+    ints: List[int] = []
+    floats: List[float] = []
+    for fno, wt, v in _fields(buf):
+        if fno == 1:
+            name = bytes(v).decode("utf-8")
+        elif fno == 2:
+            val = struct.unpack("<f", struct.pack("<I", v))[0]
+        elif fno == 3:
+            val = _signed64(v)
+        elif fno == 4:
+            val = bytes(v)
+        elif fno == 5:
+            val = _tensor(v)[1]
+        elif fno == 7:
+            floats += list(np.frombuffer(bytes(v), dtype="<f4")) if wt == 2 else [struct.unpack("<f", struct.pack("<I", v))[0]]
+        elif fno == 8:
+            ints += [_signed64(x) for x in _packed_varints(v, wt)]
+    if ints:
+        val = ints
+    elif floats:
+        val = floats
+    return name, val
+
+
+def load_graph(path: str) -> dict:
+    """The whole GraphProto the binder needs: ``{"tensors": {name: array}, "nodes": [{"op", "name", "inputs", "outputs", "attrs"}] in file order (= a topological
+    order: the ONNX spec requires it), "inputs": [graph input names that are not initializers], "outputs": [...]}``.  ``Constant`` nodes are folded into
+    ``tensors`` under their output name (an exporter is free to keep a scalar as either)."""
+    with open(path, "rb") as f:
+        data = memoryview(f.read())
+    graph = None
+    for fno, wt, v in _fields(data):
+        if fno == 7 and wt == 2:
+            graph = v
+    if graph is None:
+        raise OnnxWireError(f"{path}: no ModelProto.graph (field 7): not an ONNX model")
+    tensors: Dict[str, np.ndarray] = {}
+    nodes: List[dict] = []
+    gin: List[str] = []
+    gout: List[str] = []
+    for fno, wt, v in _fields(graph):
+        if fno == 5 and wt == 2:
+            name, arr = _tensor(v)
+            if name in tensors:
+                raise OnnxWireError(f"{path}: initializer {name!r} appears twice")
+            tensors[name] = arr
+        elif fno == 1 and wt == 2:
+            nd = {"op": "", "name": "", "inputs": [], "outputs": [], "attrs": {}}
+            for nf, nw, nv in _fields(v):
+                if nf == 1:
+                    nd["inputs"].append(bytes(nv).decode("utf-8"))
+                elif nf == 2:
+                    nd["outputs"].append(bytes(nv).decode("utf-8"))
+                elif nf == 3:
+                    nd["name"] = bytes(nv).decode("utf-8")
+                elif nf == 4:
+                    nd["op"] = bytes(nv).decode("utf-8")
+                elif nf == 5:
+                    k, a = _attribute(nv)
+                    nd["attrs"][k] = a
+            if nd["op"] == "Constant" and isinstance(nd["attrs"].get("value"), np.ndarray) and nd["outputs"]:
+                tensors[nd["outputs"][0]] = nd["attrs"]["value"]
+            else:
+                nodes.append(nd)
+        elif fno in (11, 12) and wt == 2:
+            for vf, vw, vv in _fields(v):
+                if vf == 1:
+                    (gin if fno == 11 else gout).append(bytes(vv).decode("utf-8"))
+    return {"tensors": tensors, "nodes": nodes, "inputs": [n for n in gin if n not in tensors], "outputs": gout}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # writer (tests, and `python -m head_detector_amd.onnx_wire out.onnx <variant> <seed>`): the same wire format, initializers only
 def _enc_varint(x: int) -> bytes:
@@ -217,11 +299,37 @@ def encode_tensor(name: str, a: np.ndarray, how: str = "raw") -> bytes:
     return body + _ld(8, name.encode("utf-8"))
 
 
-def write_model(path: str, tensors: Dict[str, np.ndarray], how: Dict[str, str] = None, graph_name: str = "vgg_heads", prefix: str = "") -> None:
+def encode_node(op: str, inputs: List[str], outputs: List[str], name: str = "", attrs: Dict[str, object] = None, packed_ints: bool = True) -> bytes:
+    """NodeProto; attrs: int -> i, float -> f, list of int -> ints (packed, or one varint record each as proto2 writers emit), ndarray -> t."""
+    body = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
+    if name:
+        body += _ld(3, name.encode())
+    body += _ld(4, op.encode())
+    for k, v in (attrs or {}).items():
+        a = _ld(1, k.encode())
+        if isinstance(v, np.ndarray):
+            a += _ld(5, encode_tensor("", v)) + _vi(20, 4)
+        elif isinstance(v, float):
+            a += _enc_varint((2 << 3) | 5) + struct.pack("<f", v) + _vi(20, 1)
+        elif isinstance(v, int):
+            a += _vi(3, v) + _vi(20, 2)
+        else:
+            a += (_ld(8, b"".join(_enc_varint(int(x)) for x in v)) if packed_ints else b"".join(_vi(8, int(x)) for x in v)) + _vi(20, 7)
+        body += _ld(5, a)
+    return body
+
+
+def write_model(path: str, tensors: Dict[str, np.ndarray], how: Dict[str, str] = None, graph_name: str = "vgg_heads", prefix: str = "", nodes: List[bytes] = None,
+                inputs: List[str] = None, outputs: List[str] = None) -> None:
+    """``nodes``: encoded NodeProto records (``encode_node``) written ahead of the initializers, ``inputs`` / ``outputs``: graph value names."""
     how = how or {}
-    graph = _ld(2, graph_name.encode())
+    graph = b"".join(_ld(1, n) for n in (nodes or [])) + _ld(2, graph_name.encode())
     for k, v in tensors.items():
         graph += _ld(5, encode_tensor(prefix + k, np.asarray(v), how.get(k, "raw")))
+    for n in inputs or []:
+        graph += _ld(11, _ld(1, n.encode()))
+    for n in outputs or []:
+        graph += _ld(12, _ld(1, n.encode()))
     model = _vi(1, 8) + _ld(2, b"head_detector_amd.onnx_wire") + _ld(7, graph) + _ld(8, _vi(2, 17))  # ir_version 8, producer, graph, opset 17
     with open(path, "wb") as f:
         f.write(model)

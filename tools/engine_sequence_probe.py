@@ -14,6 +14,25 @@ from head_detector_amd.flame import FLAMELayer
 from head_detector_amd.synthetic import synthetic_flame_model
 dev = torch.device("cuda", 0)
 flame = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=6400)
+# SEQ_CLASS: hardware-queue CLASS of every stream an engine uses.  Two streams on one hardware queue never overlap (vgh_streams_overlap = 0), so a handful of reference streams
+# created up front split into classes (= the runtime's 4 normal-priority queues), and any later stream belongs to the class of the reference it does not overlap with;
+# "null" = the class of the legacy default stream.  Printed per engine next to its timing: does the starved state go with one class? (r06; no profiler needed)
+REFS, REF_CLASS = [], []
+def _ovl(a, b):
+    return int(lib_.vgh_streams_overlap(a, b))
+def stream_class(ptr):
+    for r, c in zip(REFS, REF_CLASS):
+        if r.cuda_stream == ptr: return c
+        if not _ovl(r.cuda_stream, ptr): return c
+    return -1
+if os.environ.get("SEQ_CLASS"):
+    from head_detector_amd import _lib as _l
+    lib_ = _l.load()
+    for _ in range(int(os.environ.get("SEQ_CLASS"))):
+        s_ = torch.cuda.Stream(device=dev)
+        c_ = next((c for r, c in zip(REFS, REF_CLASS) if not _ovl(r.cuda_stream, s_.cuda_stream)), None)
+        REF_CLASS.append(len(set(REF_CLASS)) if c_ is None else c_); REFS.append(s_)
+    print("SEQ_CLASS reference streams -> classes", REF_CLASS, "; class of the default (null) stream:", stream_class(0), "; of torch's current stream:", stream_class(torch.cuda.current_stream().cuda_stream), flush=True)
 def run(variant, B, prec, S=640, nf=40):
     eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=1, precision=prec)
     x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
@@ -28,12 +47,12 @@ def run(variant, B, prec, S=640, nf=40):
         eng.candidates(B)
         eng.select(B, confidence_threshold=0.6, iou_threshold=0.5, flame=flame, unpad=unpad)
     for _ in range(5): step()
-    def mark():  # one spin kernel of a role-specific length per stream (main 37 us, lane 47, side 57): tools/queue_trace_summary.py finds them in a rocprofv3
+    def mark():  # one spin kernel of a role-specific length per stream (main 211 us, lane 223, side 239: far from the 1-us / 150-us spins of the stream acquisition): tools/queue_trace_summary.py finds them in a rocprofv3
         if os.environ.get("SEQ_MARK"):  # --kernel-trace of this script and reads the hardware queue (Queue_Id) each role's stream sits on; once before and once after the engine's loops
             eng.join()
             sts = eng.streams_in_use()  # [main, lanes of the batch split ..., side stream when the post stages overlap]
             for i, s_ in enumerate(sts):
-                us = 37 if i == 0 else 57 if (B >= 8 and i == len(sts) - 1) else 47
+                us = 211 if i == 0 else 239 if (B >= 8 and i == len(sts) - 1) else 223
                 torch.cuda.synchronize(); _lib_check(eng.lib.vgh_stream_spin(s_.cuda_stream, us)); torch.cuda.synchronize()
     mark()
     eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
@@ -59,6 +78,8 @@ def run(variant, B, prec, S=640, nf=40):
     eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
     for i in range(nf): step(i)
     eng.join(); torch.cuda.synchronize(); dt2 = (time.perf_counter() - t) / nf * 1e3
+    if REFS:
+        print(f"CLS {variant} b{B} @{S} {prec:6s}: queue class of [main, lanes.., side] = {[stream_class(s_.cuda_stream) for s_ in st]} (side is low priority: its class is among the low-priority queues' images)", flush=True)
     print(f"SEQ {variant} b{B} @{S} {prec:6s}: {dt:7.3f} ms per forward, network part {net:7.3f}; again {dt2:7.3f}; stream overlap matrix {ov}; tiny kernel on stream j done at / busy chain on stream i done at (ms) {starv}; arena {eng.lib.vgh_net_buffer(eng._net, 0):#x}", flush=True)
     if prec in ("int8", "fp8"):
         def timed(label):

@@ -4,7 +4,7 @@
     cd /tmp && SEQ_MARK=1 SEQ_NF=12 rocprofv3 --kernel-trace --output-format csv -d DIR -o q -- python tools/engine_sequence_probe.py > seq.log
     python tools/queue_trace_summary.py DIR seq.log [OUT.txt]
 
-tools/engine_sequence_probe.py (SEQ_MARK) launches one spin kernel of a role-specific length on every stream of every engine (main 37 us, lane 47 us, side 57 us):
+tools/engine_sequence_probe.py (SEQ_MARK) launches one spin kernel of a role-specific length on every stream of every engine (main 211 us, lane 223 us, side 239 us):
 the kernel trace carries Queue_Id (and Stream_Id where this rocprofv3 writes it), so the marks give stream -> queue per engine, and the kernels between two mark
 groups -- that engine's forwards -- give the queues its network kernels and its post-network kernels ACTUALLY ran on, next to the engine's measured ms per forward."""
 import csv
@@ -24,7 +24,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 has_stream = "Stream_Id" in rows[0]
 seq = [l.strip() for l in open(log) if l.startswith("SEQ ")]
-ROLES = {37: "main", 47: "lane", 57: "side", 67: "lane2"}
+ROLES = {211: "main", 223: "lane", 239: "side"}
 
 
 def role_of(r):
@@ -32,7 +32,7 @@ def role_of(r):
         return None
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     for k, v in ROLES.items():
-        if abs(us - k) < 3.0:
+        if abs(us - k) < 4.0:
             return v
     return None
 
