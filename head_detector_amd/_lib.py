@@ -173,6 +173,7 @@ SYMBOLS = {
     "vgh_stream_acquire": (_I, [_I, C.POINTER(_P), _I, C.POINTER(_P)]),
     "vgh_stream_release": (_I, [_I, _P]),
     "vgh_streams_overlap": (_I, [_P, _P]),
+    "vgh_stream_blocked_behind": (_I, [_P, _P]),
     "vgh_stream_spin": (_I, [_P, _I]),
     "vgh_detector_streams": (_I, [_P, _P, C.POINTER(_P)]),
     "vgh_stream_destroy": (_I, [_P]),

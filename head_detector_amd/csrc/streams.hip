@@ -78,10 +78,60 @@ bool runs_concurrently(hipStream_t a, hipStream_t b) {
     return false;
 }
 
-int overlap_score(hipStream_t c, const hipStream_t* avoid, int n_avoid) {
+// Head-of-line blocking inside a compute pipe (r06: the "starved side stream" of r05, profiles/r06_starved_side_stream_classes.txt, r06_queue_trace.txt).
+// The runtime gives every priority class its own hardware queues -- a low-priority stream never SHARES a queue with a normal one, which is all runs_concurrently can
+// see -- but the queues are spread over the device's compute pipes in creation order (the trace shows normal queues 1 - 4, low-priority queues 5, 6, ...), so the first
+// low-priority queue sits on the pipe of the first normal queue.  A pipe places the workgroups of ONE dispatch at a time: while a lane keeps that pipe busy with
+// kernels whose workgroups do not all fit on the chip (every conv of the network), a kernel of the low-priority queue behind it is not even looked at, whatever free
+// wave slots the chip has -- the post-network stages then only run when the next forward stalls at its prediction guard (14.0 instead of 11.5 ms per forward).  On any
+// OTHER pipe the same low-priority kernels slip in beside the network.  Measured here the way it bites: `a` gets two multi-round kernels whose workgroups are limited
+// by LDS (wave slots stay free), `b` one single-wave kernel that becomes eligible when the first of them starts; on another pipe it is done in ~10 us, behind `a`'s
+// pipe only when `a`'s dispatches have been placed.
+bool blocked_behind(hipStream_t a, hipStream_t b) {
+    if (a == b) return true;
+    static bool attr = false;
+    const int lds = 80 * 1024;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)spin_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipEvent_t e0, ea, eb;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return false;
+    const int grid = cus * 2 * 6;  // six rounds of the LDS-limited residency, 10 us each
+    int votes = 0;
+    for (int pass = 0; pass < 3; ++pass) {  // pass 0 warms both streams up; "blocked" is believed when seen in both timed passes
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        (void)hipEventRecord(e0, a);
+        hipLaunchKernelGGL(spin_grid_kernel, dim3(grid), dim3(64), lds, a, 1000);
+        hipLaunchKernelGGL(spin_grid_kernel, dim3(grid), dim3(64), lds, a, 1000);
+        (void)hipEventRecord(ea, a);
+        (void)hipStreamWaitEvent(b, e0, 0);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 100);
+        (void)hipEventRecord(eb, b);
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        float ta = 0, tb = 0;
+        (void)hipEventElapsedTime(&ta, e0, ea);
+        (void)hipEventElapsedTime(&tb, e0, eb);
+        if (pass > 0 && tb > 0.3f * ta) ++votes;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    (void)hipGetLastError();
+    return votes == 2;
+}
+
+int overlap_score(hipStream_t c, const hipStream_t* avoid, int n_avoid, bool low_priority) {
     int score = 0;
     for (int i = 0; i < n_avoid; ++i)
-        if (runs_concurrently(avoid[i], c)) score += 1 << (n_avoid - 1 - i);  // earlier entries of `avoid` weigh more
+        // (the pipe test covers the first two entries -- the caller's stream and the first lane, what a two-lane forward runs on: with three or four lanes in use
+        //  every pipe carries one and no low-priority queue can be clear of them all)
+        if (runs_concurrently(avoid[i], c) && !(low_priority && i < 2 && blocked_behind(avoid[i], c))) score += 1 << (n_avoid - 1 - i);  // earlier entries of `avoid` weigh more
     return score;
 }
 
@@ -102,7 +152,7 @@ int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoi
     if (low_priority) (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     int best = -1, best_score = -1;
     for (int i = 0; i < (int)park.size() && best_score < perfect; ++i) {
-        const int s = overlap_score(park[i], avoid, n_avoid);
+        const int s = overlap_score(park[i], avoid, n_avoid, low_priority);
         if (s > best_score) best = i, best_score = s;
     }
     for (int t = 0; t < kMaxTries && best_score < perfect && (int)park.size() < kMaxPark; ++t) {
@@ -112,7 +162,7 @@ int vgh_stream_acquire_internal(int device, const hipStream_t* avoid, int n_avoi
         else
             VGH_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
         park.push_back(c);
-        const int s = overlap_score(c, avoid, n_avoid);
+        const int s = overlap_score(c, avoid, n_avoid, low_priority);
         if (s > best_score) best = (int)park.size() - 1, best_score = s;
     }
     VGH_REQUIRE(best >= 0, "stream_acquire: no candidate stream");
@@ -146,6 +196,9 @@ int vgh_stream_release(int device, void* stream) {
 }
 
 int vgh_streams_overlap(void* a, void* b) { return runs_concurrently((hipStream_t)a, (hipStream_t)b) ? 1 : 0; }
+
+// 1 when a kernel on `b` cannot start while `a`'s dispatches are being placed (same compute pipe: see blocked_behind)
+int vgh_stream_blocked_behind(void* a, void* b) { return blocked_behind((hipStream_t)a, (hipStream_t)b) ? 1 : 0; }
 
 // first-kernel completion time / pair completion time for two multi-round kernels launched back to back on a and b:
 // ~1.0 = their workgroups interleave, ~0.5 = b's only start when a's are all dispatched.  *1000 (integer per-mille).

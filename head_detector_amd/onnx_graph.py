@@ -8,9 +8,10 @@ reads it by STRUCTURE instead:
   * ``arch.module_graph(variant)`` is the network as a module-level dataflow graph in forward order;
   * every Conv / ConvTranspose node of the file gets its set of nearest upstream Conv nodes (through Relu / Add / Mul / Concat / MaxPool / Cast / ...);
   * the modules are walked in forward order and each takes the FIRST unbound node (file order = a topological order) whose operator, weight shape, strides and
-    group match its Spec and whose upstream set is exactly the nodes its producers were bound to.  Siblings that agree in all of that (CSP conv1 / conv2; the cls /
-    reg towers; the jaw / translation branches) are told apart by file order alone, i.e. by the exporter's trace order = the forward order of
-    yolo_head_dfl_head.py:143-164 -- stated here because nothing in the file can confirm it;
+    group match its Spec, whose upstream set is exactly the nodes its producers were bound to, and whose nearest downstream convs include the ones the module feeds
+    (that separates CSP conv1 from conv2 and the cls tower from the reg tower whatever their order in the file).  Only the rotation / jaw / translation / scale
+    branches of a head -- same shapes from the stem to the last 1x1, jaw and translation even in their 3 outputs -- are told apart by file order alone, i.e. by the
+    exporter's trace order = the forward order of yolo_head_dfl_head.py:155-160 -- stated here because nothing in the file can confirm it;
   * a bottleneck's residual scale is read off the graph: the Add behind cv2 takes ``Mul(x, alpha)`` (a one-element tensor) or ``x`` itself (alpha = 1);
   * the first module that finds no node stops the ingest with what it expected and which candidates it rejected -- not with a list of names.
 
@@ -85,6 +86,35 @@ def bind_graph(variant: str, graph: dict) -> Tuple[Dict[str, np.ndarray], dict]:
             out |= anchors(x)
         return frozenset(out)
 
+    # what consumes a conv: the weight shapes of its nearest DOWNSTREAM convs, in the file and in the architecture.  Siblings with one producer and one signature differ
+    # there (CSP conv1 feeds the bottlenecks' 3x3 convs, conv2 only conv3; the cls tower ends in a 1-channel prediction, the reg tower in 68), so their order in the
+    # file does not matter; what the file adds behind the network (a DFL projection conv behind reg_pred) may come on top: expected must be CONTAINED in found
+    conv_ids = [i for i, nd in enumerate(nodes) if nd["op"] in CONV_OPS and len(nd["inputs"]) > 1 and nd["inputs"][1] in tensors]
+    down_found: Dict[int, List[tuple]] = {i: [] for i in conv_ids}
+    for j in conv_ids:
+        for a in upstream(nodes[j]["inputs"][0]):
+            if a != "image" and a in down_found:
+                down_found[a].append(tuple(tensors[nodes[j]["inputs"][1]].shape))
+
+    def wshape(m):
+        sp_ = m["spec"]
+        return (sp_.cin, sp_.cout, 2, 2) if m["op"] == "convT" else (sp_.cout, sp_.cin, sp_.k, sp_.k)
+
+    down_want: Dict[str, List[tuple]] = {m["name"]: [] for m in mg if m["op"] in ("conv", "convT")}
+    for m in mg:
+        if m["op"] in ("conv", "convT"):
+            for a in anchors(m["inputs"][0]):
+                if a != "image":
+                    down_want[a].append(wshape(m))
+
+    def contains(found: List[tuple], want: List[tuple]) -> bool:
+        left = list(found)
+        for w_ in want:
+            if w_ not in left:
+                return False
+            left.remove(w_)
+        return True
+
     bound: Dict[str, int] = {}
     used = set()
     sd: Dict[str, np.ndarray] = {}
@@ -108,7 +138,7 @@ def bind_graph(variant: str, graph: dict) -> Tuple[Dict[str, np.ndarray], dict]:
             w = tensors[nd["inputs"][1]]
             ok_shape = tuple(w.shape) == want_w
             ok_attr = _ints(nd["attrs"].get("strides"), [1, 1]) == [sp.stride, sp.stride] and int(nd["attrs"].get("group", 1) or 1) == 1
-            ok_up = upstream(nd["inputs"][0]) == want_up
+            ok_up = upstream(nd["inputs"][0]) == want_up and contains(down_found[i], down_want[sp.name])
             if ok_shape and ok_attr and ok_up:
                 pick = i
                 break

@@ -323,13 +323,14 @@ def write_model(path: str, tensors: Dict[str, np.ndarray], how: Dict[str, str] =
                 inputs: List[str] = None, outputs: List[str] = None) -> None:
     """``nodes``: encoded NodeProto records (``encode_node``) written ahead of the initializers, ``inputs`` / ``outputs``: graph value names."""
     how = how or {}
-    graph = b"".join(_ld(1, n) for n in (nodes or [])) + _ld(2, graph_name.encode())
+    parts = [_ld(1, n) for n in (nodes or [])] + [_ld(2, graph_name.encode())]  # (one join at the end: appending to a growing bytes object copies it every time)
     for k, v in tensors.items():
-        graph += _ld(5, encode_tensor(prefix + k, np.asarray(v), how.get(k, "raw")))
+        parts.append(_ld(5, encode_tensor(prefix + k, np.asarray(v), how.get(k, "raw"))))
     for n in inputs or []:
-        graph += _ld(11, _ld(1, n.encode()))
+        parts.append(_ld(11, _ld(1, n.encode())))
     for n in outputs or []:
-        graph += _ld(12, _ld(1, n.encode()))
+        parts.append(_ld(12, _ld(1, n.encode())))
+    graph = b"".join(parts)
     model = _vi(1, 8) + _ld(2, b"head_detector_amd.onnx_wire") + _ld(7, graph) + _ld(8, _vi(2, 17))  # ir_version 8, producer, graph, opset 17
     with open(path, "wb") as f:
         f.write(model)

@@ -470,6 +470,11 @@ int vgh_stream_create(int device, void** stream_out);
 int vgh_stream_acquire(int device, void* const* avoid, int n_avoid, void** stream_out);
 int vgh_stream_release(int device, void* stream);
 int vgh_streams_overlap(void* stream_a, void* stream_b);
+/* r06: 1 when a kernel queued on stream_b cannot START while stream_a's dispatches are being placed, although the two streams sit on different hardware queues:
+ * the queues share a compute pipe (queues are spread over the pipes in creation order; a pipe places one dispatch at a time and serves its higher-priority queue
+ * first).  This is what starved the detector's low-priority side stream in r05 (csrc/streams.hip, profiles/r06_starved_side_stream_classes.txt); the side stream is
+ * now acquired clear of the pipes of the caller's stream and the first lane, by this measurement. */
+int vgh_stream_blocked_behind(void* stream_a, void* stream_b);
 /* One wave busy-waiting for `microseconds` on `stream`: the probe behind vgh_streams_overlap, exported so that a host can test
  * streams it does not own (e.g. a communication library's internal stream) for a shared hardware queue. */
 int vgh_stream_spin(void* stream, int microseconds);

@@ -75,6 +75,8 @@ def run(variant, B, prec, S=640, nf=40):
         return round(e0.elapsed_time(e1), 3), round(e0.elapsed_time(e2), 3)
     starv = {f"{i}->{j}": lat(st[i], st[j]) for i in range(len(st)) for j in range(len(st)) if i != j} if os.environ.get("SEQ_STARV") else {}
     ov = [[int(eng.lib.vgh_streams_overlap(a.cuda_stream, b.cuda_stream)) if a is not b else 1 for b in st] for a in st]
+    if hasattr(eng.lib, "vgh_stream_blocked_behind") and len(st) > 1:  # r06: is the side stream (last) held up behind the pipe of main / a lane?
+        print(f"HOL {variant} b{B} @{S} {prec:6s}: side stream blocked behind [main, lanes..] = {[int(eng.lib.vgh_stream_blocked_behind(a.cuda_stream, st[-1].cuda_stream)) for a in st[:-1]]}", flush=True)
     eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
     for i in range(nf): step(i)
     eng.join(); torch.cuda.synchronize(); dt2 = (time.perf_counter() - t) / nf * 1e3
