@@ -35,25 +35,57 @@ from .utils import calculate_rpy
 REPO_ID = "okupyn/vgg_heads"
 
 
-def load_weights(path: str) -> Dict[str, np.ndarray]:
-    """state_dict of a released TorchScript archive (.trcd), of a torch checkpoint, or the initializers of an ONNX export (.onnx) -> {name: ndarray} with the
+LAST_LOAD_REPORT: Dict[str, Any] = {}  # diagnostics of the most recent load_weights call (how an .onnx was read, which initializers were not weights)
+
+
+def _known_keys() -> set:
+    """Every parameter name any supported archive form may carry, over all variants: the unfused state dict, `rbr_reparam.*` of fused RepVGG blocks, `conv.bias` of
+    Conv + BatchNorm blocks an exporter merged."""
+    from . import arch
+
+    keys = set()
+    for v in arch.VARIANTS:
+        keys |= set(arch.random_state_dict(v, 0))
+        for sp in arch.layer_specs(v):
+            if sp.kind == "qarep":
+                keys |= {f"{sp.name}.rbr_reparam.weight", f"{sp.name}.rbr_reparam.bias"}
+            elif sp.kind in ("conv", "cbr"):
+                keys.add((sp.name if sp.kind == "conv" else f"{sp.name}.seq") + ".conv.bias")
+    return keys
+
+
+def load_weights(path: str, variant: Optional[str] = None) -> Dict[str, np.ndarray]:
+    """state_dict of a released TorchScript archive (.trcd), of a torch checkpoint, or of an ONNX export (.onnx) -> {name: ndarray} with the
     ``model.`` prefix of ConvertableCompletePipelineModel stripped (exportable_mesh_model.py:421-427).  A training checkpoint's
-    EMA weights win over the raw ones (they are what the export pipeline serialises)."""
+    EMA weights win over the raw ones (they are what the export pipeline serialises).
+
+    ``.onnx`` (README.md:23,199): read by a protobuf wire reader of our own (onnx_wire.py; the `onnx` package is not a dependency), two ways.  A file whose initializers
+    still carry parameter names is read BY NAME (initializers that are not parameters -- shape constants, anchors, ``onnx::`` scalars -- are set aside and listed in
+    ``LAST_LOAD_REPORT["not_weights"]``, not reported as unexpected keys).  A file that went through the exporter's ``onnxsim.simplify`` (:483-488) has anonymous,
+    BatchNorm-merged ``onnx::Conv_NNN`` tensors: it is read BY GRAPH POSITION (onnx_graph.py: Conv nodes bound to the architecture by topology + shape; ``variant``
+    narrows the search, default: every known architecture) into the fused naming arch.fold_state_dict accepts.  Both are UNPINNED against a real export (none in this image)."""
     if not os.path.exists(path):
         raise FileNotFoundError(path)
     if path.lower().endswith(".onnx"):
-        # the reference also publishes ONNX exports (README.md:23,199): their graph.initializer tensors, read by a protobuf wire reader of our own
-        # (onnx_wire.py: the `onnx` package is not a dependency); same key convention as the archive's state_dict
-        from . import onnx_wire
+        from . import onnx_graph, onnx_wire
 
-        tensors, _ = onnx_wire.load_initializers(path)
-        out = {}
-        for k, v in tensors.items():
-            if v.dtype.kind not in "fiu" or v.dtype == np.bool_:
-                continue
-            k = k[len("model."):] if k.startswith("model.") else k
-            out[k] = np.ascontiguousarray(v, dtype=np.float32)
-        return out
+        graph = onnx_wire.load_graph(path)
+        known = _known_keys()
+        named, extras = {}, []
+        for k, v in graph["tensors"].items():
+            kk = k[len("model."):] if k.startswith("model.") else k
+            if kk in known and v.dtype.kind in "fiu" and v.dtype != np.bool_:
+                named[kk] = np.ascontiguousarray(v, dtype=np.float32)
+            else:
+                extras.append(k)
+        n4 = sum(1 for v in graph["tensors"].values() if getattr(v, "ndim", 0) == 4)
+        LAST_LOAD_REPORT.clear()
+        if named and sum(1 for v in named.values() if v.ndim == 4) * 2 >= n4:  # the parameter names survived the export
+            LAST_LOAD_REPORT.update(path=path, how="by name", not_weights=extras)
+            return named
+        v_, sd, rep = onnx_graph.load_by_graph(path, variant)
+        LAST_LOAD_REPORT.update(path=path, how="by graph position", variant=v_, **rep)
+        return sd
     try:
         sd = torch.jit.load(path, map_location="cpu").state_dict()
     except (RuntimeError, ValueError) as jit_err:  # not a TorchScript archive: a plain checkpoint?
@@ -146,7 +178,7 @@ class HeadDetector:
             warnings.warn(f"HeadDetector({model!r}): seeded SYNTHETIC weights (seed {seed}) -- detections are meaningless; supply the released {model}.trcd for real use", stacklevel=3)
             sd = None
         else:
-            sd = load_weights(weights)
+            sd = load_weights(weights, model)
             diff = weight_manifest_diff(model, sd)
             if any(diff.values()):
                 raise ValueError(f"{weights} does not match the {model} architecture this engine lowers:\n" + "\n".join(f"  {k}: {v[:12]}{' ...' if len(v) > 12 else ''}" for k, v in diff.items() if v))

@@ -123,7 +123,7 @@ def _weights_arg(spec: str, variant: str) -> Dict[str, np.ndarray]:
         return arch.random_state_dict(variant, int(spec[5:]))
     from .detector import load_weights
 
-    return load_weights(spec)
+    return load_weights(spec, variant)
 
 
 def _flame_arg(spec: str) -> Optional[Dict[str, Any]]:

@@ -168,7 +168,8 @@ def _iou(a, b):
     return inter / ((a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]) + (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1]) - inter)
 
 
-def test_archives_against_the_unfused_oracle_at_north_star_tolerances(gpu_lib, flame_model, tmp_path):
+@pytest.mark.parametrize("variant,okey", [("vgg_heads_m", "m"), ("vgg_heads_l", "l")])
+def test_archives_against_the_unfused_oracle_at_north_star_tolerances(gpu_lib, flame_model, tmp_path, variant, okey):
     """N1 as an ORACLE test: the network the library builds FROM THE ARCHIVE (load_weights -> build_program(fp16x3) -> pack -> vgh_create) against
     oracle/net_oracle.YoloHeadsOracle loaded from the SAME archive's state dict -- strictly (every key of the unfused archive must be an oracle key and vice versa;
     head_detector/detector.py:25-30 loads the blob, the oracle is the unfused super_gradients module graph).  Bars: north_star's IoU >= 0.999, scores 1e-5, parameters 1e-4."""
@@ -177,7 +178,7 @@ def test_archives_against_the_unfused_oracle_at_north_star_tolerances(gpu_lib, f
     from head_detector_amd.engine import _alias
     from oracle import net_oracle
 
-    variant, okey, S, B = "vgg_heads_m", "m", 256, 2
+    S, B = 256, 2
     sd = arch.random_state_dict(variant, 23)
     x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(6))
     full, _ = fused_variants(variant, sd)
@@ -210,6 +211,18 @@ def test_archives_against_the_unfused_oracle_at_north_star_tolerances(gpu_lib, f
     p = str(tmp_path / "bn_folded.onnx")
     onnx_wire.write_model(p, folded, prefix="model.")
     archives["onnx, Conv+BN merged by the exporter"] = (p, False)
+    # N4, the graph half (r06): what the reference's exporter actually leaves -- RepVGG blocks fused, BatchNorms merged, onnxsim-simplified, `onnx::Conv_NNN` names
+    # (exportable_mesh_model.py:392-393,440-453,483-488) -- bound to the architecture by graph position (head_detector_amd/onnx_graph.py), L and M
+    import os as _os
+
+    sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+    from onnx_export_standin import write_simplified_export
+
+    p = str(tmp_path / "simplified.onnx")
+    write_simplified_export(p, variant, sd, seed=8)
+    archives["onnx, fused + simplified + anonymous names (graph ingest)"] = (p, False)
+    if variant == "vgg_heads_l":  # L: the graph ingest (this round's row) and one archive of each other kind
+        archives = {k: v for k, v in archives.items() if k in ("torchscript unfused", "onnx, fused + simplified + anonymous names (graph ingest)")}
 
     for what, (path, unfused) in archives.items():
         got = load_weights(path)
