@@ -107,10 +107,6 @@ SYMBOLS = {
     "vgh_net_buffer_bytes": (_I64, [_P, _I]),
     "vgh_net_set_cfg": (_I, [_P, _I, _I]),
     "vgh_net_set_split": (_I, [_P, _I]),
-    "vgh_net_set_lane_lag": (_I, [_I]),
-    "vgh_net_set_fuse_stem": (_I, [_P, _I]),
-    "vgh_net_set_pred_guard": (_I, [_P, _P]),
-    "vgh_stem_set_mfma": (_I, [_I]),
     "vgh_net_max_batch": (_I, [_P]),
     "vgh_net_image_size": (_I, [_P]),
     "vgh_conv2d": (_I, [C.POINTER(ConvCall), _P]),
@@ -126,7 +122,6 @@ SYMBOLS = {
     "vgh_conv_split_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "vgh_conv_cfg_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "vgh_conv_set_max_blocks_per_xcd": (_I, [_I]),
-    "vgh_conv_set_nt_store": (_I, [_I]),
     "vgh_net_set_i8_diag": (_I, [_I]),
     "vgh_net_op_has_diag": (_I, [_P, _I]),
     "vgh_head_decode": (_I, [C.POINTER(HeadLevel), _I, _I, _P, _P, _P]),
@@ -149,8 +144,6 @@ SYMBOLS = {
     "vgh_detector_scratch": (_P, [_P, _I]),
     "vgh_detector_select": (_I, [_P, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_detector_set_overlap": (_I, [_P, _I]),
-    "vgh_detector_set_side_priority": (_I, [_P, _I]),
-    "vgh_detector_renew_side": (_I, [_P, _P]),
     "vgh_detector_join": (_I, [_P, _P]),
     "vgh_detector_record": (_I, [_P, _P, _P]),
     "vgh_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),
@@ -184,6 +177,16 @@ SYMBOLS = {
     "vgh_event_elapsed_ms": (_I, [_P, _P, C.POINTER(_F)]),
 }
 
+# A/B knobs of the -DVGH_EXPERIMENTS build (libvgh_exp.so, include/vgh.h's last block): bound when the loaded library has them, absent from the product library
+EXPERIMENT_SYMBOLS = {
+    "vgh_net_set_lane_lag": (_I, [_I]),
+    "vgh_net_set_fuse_stem": (_I, [_P, _I]),
+    "vgh_stem_set_mfma": (_I, [_I]),
+    "vgh_conv_set_nt_store": (_I, [_I]),
+    "vgh_detector_set_side_priority": (_I, [_P, _I]),
+    "vgh_streams_interleave_permille": (_I, [_P, _P]),
+}
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -212,6 +215,11 @@ def load() -> C.CDLL:
             raise VghError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENT_SYMBOLS.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     if lib.vgh_abi_version() != ABI_VERSION:  # the ctypes structs below mirror include/vgh.h at this revision: another one means other struct sizes
         raise VghError(f"{LIB_PATH} has ABI revision {lib.vgh_abi_version()}, this binding is written for {ABI_VERSION} (stale build?)")
     _lib = lib

@@ -9,7 +9,8 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvgh.so")
-SOURCES = ["conv_igemm.hip", "conv_pp.hip", "conv_split.hip", "conv_f32.hip", "stem_pool.hip", "stem_ds.hip", "postproc.hip", "flame.hip", "net.hip", "detect.hip", "raster.hip", "letterbox.hip", "ctx.hip", "streams.hip"]
+SOURCES = ["conv_igemm.hip", "conv_pp.hip", "conv_split.hip", "conv_f32.hip", "stem_pool.hip", "postproc.hip", "flame.hip", "net.hip", "detect.hip", "raster.hip", "letterbox.hip", "ctx.hip", "streams.hip"]
+EXPERIMENT_SOURCES = ["stem_ds.hip"]  # measured losers kept for tools/: part of libvgh_exp.so (-DVGH_EXPERIMENTS) only
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-unused-value"]
 
 
@@ -46,7 +47,7 @@ def _build(LIB: str, extra, objdir: str, verbose: bool) -> str:
     objs, procs = [], []
     t0 = time.time()
     os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
-    for src in SOURCES:
+    for src in SOURCES + (EXPERIMENT_SOURCES if "-DVGH_EXPERIMENTS" in extra else []):
         obj = os.path.join(HERE, objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]

@@ -80,6 +80,7 @@ void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, i
     hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
 
+#ifdef VGH_EXPERIMENTS
 template <int TW, int TH, int BC, int NWP, int NWC>
 void launch_patch_s2_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
     static std::atomic<int> per_cu[kMaxDevices];
@@ -87,6 +88,7 @@ void launch_patch_s2_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total
     const int gpx = persistent_blocks_per_xcd(a, chunk, n);
     hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC, 0, 1>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
+#endif
 
 template <int TW, int TH, int BC, int NWP, int NWC>
 void launch_patch3_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
@@ -142,8 +144,10 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
 #define QCFG(TW, TH, BC, NWP, NWC) \
     { "q" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, Patch3<TW, TH, BC, NWP, NWC>::LDS, nullptr, 2, TW, TH, launch_patch3_cfg<TW, TH, BC, NWP, NWC> }
 
+#ifdef VGH_EXPERIMENTS
 #define DCFG(TW, TH, BC, NWP, NWC) \
     { "d" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC, 1>(), nullptr, 4, TW, TH, launch_patch_s2_cfg<TW, TH, BC, NWP, NWC> }
+#endif
 #define TCFG(BP, BC, WP, WC, KBS, NST) \
     { "t" #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, Stream1<BP, BC, WP, WC, KBS, NST>::LDS, launch_stream_cfg<BP, BC, WP, WC, KBS, NST>, 3, 0, 0, nullptr }
 
@@ -271,6 +275,7 @@ const CfgEntry g_cfgs[] = {
     TCFG(128, 64, 32, 64, 2, 3),   // 110
     TCFG(256, 64, 64, 64, 1, 3),   // 111
     TCFG(128, 96, 32, 96, 1, 4),   // 112
+#ifdef VGH_EXPERIMENTS
     // halo-patch tiles for 3x3 / stride-2 convs (conv3x3_patch_kernel<..., S2 = 1>: the input patch de-interleaved into four parity planes).
     // Measured (profiles/r03_tune_d_*.json): correct and conflict-free, but 10 - 60 % SLOWER than the implicit-GEMM rings on every stride-2 layer
     // (stage-1 downsample 439 vs 368 us): a 64-pixel tile has 0.3 us of MFMAs per (channel block, kernel row) step against a 1 us L2 round trip for
@@ -279,6 +284,7 @@ const CfgEntry g_cfgs[] = {
     DCFG(16, 4, 64, 2, 2),    // 114  4 waves x (32 px x 32)
     DCFG(16, 8, 128, 4, 2),   // 115  128 output px: 8 waves x (32 px x 64)
     DCFG(32, 4, 128, 4, 2),   // 116
+#endif
     // 64-pixel halo-patch tiles for the 20^2 / 40^2 maps at small batch (M b32: 12 800 pixels = 100 tiles of 128 px per cout tile, i.e. one partial
     // round of the chip; twice the tiles of half the length fill it better)
     PCFG(16, 4, 64, 2, 2),    // 117  4 waves x (32 px x 32)
@@ -314,10 +320,12 @@ extern "C" int vgh_conv_set_trace(void* dev_buffer) {
 }
 #endif
 int vgh_conv_num_cfgs() { return kNumCfgs; }
+#ifdef VGH_EXPERIMENTS
 int vgh_conv_set_nt_store(int on) {
     g_nt_store.store(on ? 1 : 0, std::memory_order_relaxed);
     return VGH_OK;
 }
+#endif
 
 int vgh_conv_max_blocks_per_xcd() { return g_max_blocks_per_xcd.load(std::memory_order_relaxed); }
 int vgh_conv_set_max_blocks_per_xcd(int blocks) {

@@ -281,34 +281,20 @@ int vgh_detector_select(vgh_detector* d, int B, float conf_thr, float iou_thr, v
     return rc;
 }
 
-// The side stream's priority class (default: lowest) -- takes effect at the next overlapped call, which picks a new side stream.  Call between batches (after vgh_detector_join).
+#ifdef VGH_EXPERIMENTS
+// The side stream's priority class (default: lowest) -- takes effect at the next overlapped call, which picks a new side stream.  Between batches: a pending select is joined
+// into nothing (the side stream is drained) before the stream is given back.
 int vgh_detector_set_side_priority(vgh_detector* d, int low) {
     VGH_REQUIRE(d, "detector_set_side_priority: null handle");
     if ((low != 0) == d->side_low) return VGH_OK;
+    if (d->side) VGH_HIP(hipStreamSynchronize(d->side));
     release_side(d);
-    vgh_net_set_pred_guard(d->net, nullptr);
+    if (d->net) vgh_net_set_pred_guard(d->net, nullptr);
     d->side_pending = false;
     d->side_low = low != 0;
     return VGH_OK;
 }
-// Replaces the side stream by one created now, for this detector alone (same priority class; no overlap measurement, not from the park): the way out for an engine whose
-// parked side stream turns out to be starved under the network.  Call between batches.
-int vgh_detector_renew_side(vgh_detector* d, void* main_stream) {
-    VGH_REQUIRE(d, "detector_renew_side: null handle");
-    release_side(d);
-    vgh_net_set_pred_guard(d->net, nullptr);
-    d->side_pending = false;
-    int least = 0, greatest = 0;
-    if (d->side_low) {
-        VGH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        VGH_HIP(hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, least));
-    } else {
-        VGH_HIP(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
-    }
-    d->side_own = true;
-    d->side_main = (hipStream_t)main_stream;
-    return VGH_OK;
-}
+#endif
 
 int vgh_detector_set_overlap(vgh_detector* d, int enable) {
     VGH_REQUIRE(d, "detector_set_overlap: null handle");

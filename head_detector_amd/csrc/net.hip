@@ -161,11 +161,13 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
     const bool fused = n->fuse_stem && n->stem_pair >= 0;
     switch (d.kind) {
         case VGH_OP_STEM: {
+#ifdef VGH_EXPERIMENTS  // (stem_ds.hip is part of the experiments build only)
             if (fused && op_index == n->stem_pair) {
                 const NetOp& ds = n->ops[op_index + 1];
                 const vgh_buf_desc& db = n->bufs[ds.d.out_buf];
                 return vgh_launch_stem_ds(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, ds.wds, ds.bias, (uint16_t*)bp(ds.d.out_buf), db.pitch, ds.d.out_coff, st);
             }
+#endif
             const vgh_buf_desc& ob = n->bufs[d.out_buf];
             if (ob.is_f32 == VGH_FMT_F32)  // fp32 parity mode
                 return vgh_launch_stem_f32(image, fmt, B, n->image_size, n->image_size, op.wf32, op.bias, (float*)bp(d.out_buf), ob.pitch, d.out_coff, st);
@@ -360,7 +362,12 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     }
     // stem + stage-1 downsample pair (see vgh_net::stem_pair)
     int64_t wds_off = -1;
-    for (int i = 0; i + 1 < n_ops; ++i) {
+#ifdef VGH_EXPERIMENTS
+    const int n_pair_scan = n_ops;
+#else
+    const int n_pair_scan = 0;  // product build: no fused stem + downsample kernel, no second weight image
+#endif
+    for (int i = 0; i + 1 < n_pair_scan; ++i) {
         const vgh_op_desc &a = ops[i], &d = ops[i + 1];
         if (a.kind != VGH_OP_STEM || d.kind != VGH_OP_CONV) continue;
         bool ok = image_size % 4 == 0 /* vgh_launch_stem_ds tiles 4 x 16 outputs of the 1/4-resolution map */ && d.in_buf == a.out_buf && d.in_coff == a.out_coff && d.ksize == 3 && d.stride == 2 && d.cin == 64 && d.cout_pad == 96 && d.cout_store == 96 && d.res_buf < 0 && !d.shuffle &&
@@ -377,7 +384,9 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     }
     std::vector<char> host(wbytes > 0 ? wbytes : 1, 0);
     std::vector<float> oscale(n_ops, 1.0f);
+#ifdef VGH_EXPERIMENTS
     if (n->stem_pair >= 0) vgh_pack_stem_ds_weights_host(weights_host + ops[n->stem_pair + 1].w_off, (uint16_t*)(host.data() + wds_off));
+#endif
     for (int i = 0; i < n_ops; ++i) {
         const vgh_op_desc& d = ops[i];
         if (d.kind == VGH_OP_CONV) {
@@ -611,11 +620,13 @@ int vgh_net_forward_graph(vgh_net* n, void* stream) {
 void* vgh_net_buffer(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_ptr.size()) ? n->buf_ptr[buf_id] : nullptr; }
 int64_t vgh_net_buffer_bytes(vgh_net* n, int buf_id) { return (n && buf_id >= 0 && buf_id < (int)n->buf_bytes.size()) ? n->buf_bytes[buf_id] : -1; }
 
+#ifdef VGH_EXPERIMENTS
 int vgh_net_set_lane_lag(int ops) {
     VGH_REQUIRE(ops >= 0, "net_set_lane_lag: negative");
     g_lane_lag.store(ops, std::memory_order_relaxed);
     return VGH_OK;
 }
+#endif
 
 int vgh_net_set_split(vgh_net* n, int nsplit) {
     VGH_REQUIRE(n, "net_set_split: null handle");
@@ -624,11 +635,13 @@ int vgh_net_set_split(vgh_net* n, int nsplit) {
     return VGH_OK;
 }
 
+#ifdef VGH_EXPERIMENTS
 int vgh_net_set_fuse_stem(vgh_net* n, int enable) {
     VGH_REQUIRE(n, "net_set_fuse_stem: null handle");
     n->fuse_stem = enable ? 1 : 0;
     return VGH_OK;
 }
+#endif
 
 int vgh_net_set_pred_guard(vgh_net* n, void* event) {
     VGH_REQUIRE(n, "net_set_pred_guard: null handle");

@@ -72,12 +72,19 @@ __device__ __forceinline__ uint32_t float_key(float f) {
 }
 __device__ __forceinline__ uint64_t composite(float f, int idx) { return ((uint64_t)float_key(f) << 32) | (uint32_t)(~(uint32_t)idx); }
 
+// r06 (profiles/r06_latency_trace_l1.txt: 47 us of a 2.0-ms single-image call): (i) RC composites per thread live in registers when the row fits (A <= RC * 1024: the
+// 8 400 anchors of a 640 image; the 33 600 of a 1280 image re-read the scores as before), so the scores are read once instead of once per pass; (ii) the radix
+// select STOPS at the first pass whose selected bin holds exactly the remaining count -- every element of that bin is then selected, the threshold is the bin's lower
+// edge, and with distinct scores that is the 3rd or 4th of the 8 passes (the index bits only matter when the k-th score is tied).  Same selected set, same order.
+template <bool CACHED>
 __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ scores, int A, int k, int32_t* __restrict__ out_idx,
                                                     float* __restrict__ out_scores) {
+    constexpr int RC = 9;
     __shared__ uint32_t hist[256];
     __shared__ uint64_t s_prefix;
     __shared__ int s_kk;
     __shared__ int s_count;
+    __shared__ int s_done;
     __shared__ uint64_t sel[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* sc = scores + (int64_t)b * A;
@@ -85,19 +92,37 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ sc
         s_prefix = 0;
         s_kk = k;
         s_count = 0;
+        s_done = 0;
     }
     sel[tid] = 0;
+    uint64_t cache[RC];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const int i = tid + r * 1024;
+            cache[r] = i < A ? composite(sc[i], i) : 0ull;  // 0 is below every real composite (its low word would be the index 0xffffffff)
+        }
+    }
     __syncthreads();
-    // 8 passes x 8 bits, MSB first: after the last pass s_prefix == the k-th largest composite
+    // up to 8 passes x 8 bits, MSB first: after the last pass s_prefix == the k-th largest composite (or the lower edge of a bin that is selected as a whole)
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const uint64_t prefix = s_prefix;
-        for (int i = tid; i < A; i += 1024) {
-            const uint64_t c = composite(sc[i], i);
-            const bool match = (pass == 0) || ((c >> (shift + 8)) == (prefix >> (shift + 8)));
-            if (match) atomicAdd(&hist[(c >> shift) & 255], 1u);
+        if constexpr (CACHED) {
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                const uint64_t c = cache[r];
+                const bool match = c != 0ull && ((pass == 0) || ((c >> (shift + 8)) == (prefix >> (shift + 8))));
+                if (match) atomicAdd(&hist[(c >> shift) & 255], 1u);
+            }
+        } else {
+            for (int i = tid; i < A; i += 1024) {
+                const uint64_t c = composite(sc[i], i);
+                const bool match = (pass == 0) || ((c >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(c >> shift) & 255], 1u);
+            }
         }
         __syncthreads();
         const int kk = s_kk;
@@ -109,16 +134,29 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ sc
             if ((int)above < kk && kk <= (int)(above + mine)) {
                 s_prefix = prefix | ((uint64_t)tid << shift);
                 s_kk = kk - (int)above;
+                if (kk == (int)(above + mine)) s_done = 1;  // the whole bin is selected: its lower edge is a valid threshold
             }
         }
         __syncthreads();
+        if (s_done) break;  // (block-uniform: read after the barrier)
     }
     const uint64_t T = s_prefix;
-    for (int i = tid; i < A; i += 1024) {
-        const uint64_t c = composite(sc[i], i);
-        if (c >= T) {
-            const int slot = atomicAdd(&s_count, 1);
-            if (slot < 1024) sel[slot] = c;
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const uint64_t c = cache[r];
+            if (c != 0ull && c >= T) {
+                const int slot = atomicAdd(&s_count, 1);
+                if (slot < 1024) sel[slot] = c;
+            }
+        }
+    } else {
+        for (int i = tid; i < A; i += 1024) {
+            const uint64_t c = composite(sc[i], i);
+            if (c >= T) {
+                const int slot = atomicAdd(&s_count, 1);
+                if (slot < 1024) sel[slot] = c;
+            }
         }
     }
     __syncthreads();
@@ -336,7 +374,10 @@ int vgh_topk(const float* scores_dev, int B, int A, int k, int32_t* idx_dev, flo
     VGH_REQUIRE(k >= 1 && k <= 1024, "topk: k=%d must be in [1,1024]", k);
     VGH_REQUIRE(k <= A, "topk: k=%d exceeds the number of anchors %d (torch.topk raises too)", k, A);
     if (B == 0) return VGH_OK;
-    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores_dev, A, k, idx_dev, topk_scores_dev);
+    if (A <= 9 * 1024)
+        hipLaunchKernelGGL(topk_kernel<true>, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores_dev, A, k, idx_dev, topk_scores_dev);
+    else
+        hipLaunchKernelGGL(topk_kernel<false>, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores_dev, A, k, idx_dev, topk_scores_dev);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 4) void stem_kernel(const void* __restrict__ i
     }
 }
 
+#ifdef VGH_EXPERIMENTS  // measured slower than the VALU kernel (442 vs 306 us per 64 images): experiments build only since r06
 // ---- stem on the matrix cores (r05, bf16 throughput mode, u8 images) ----------------------------------------------------------------------
 // The VALU kernel above is exact fp32 and VALU-bound: 27 x 48 FMAs per output pixel = 17 GFLOP per 64 images at ~35 % of the vector rate is 0.31 ms, 2.6 x the
 // time its 0.7 GB of traffic needs.  In the bf16 mode the stem's OUTPUT is rounded to bf16 anyway, so here the layer is a K = 27 (padded
@@ -326,6 +327,8 @@ __global__ __launch_bounds__(256, 4) void stem_mfma_kernel(const uint8_t* __rest
     }
 }
 
+#endif  // VGH_EXPERIMENTS
+
 // ---- SPP ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8_t max8(bf16x8_t a, bf16x8_t b) {
     bf16x8_t r;
@@ -442,11 +445,13 @@ __global__ __launch_bounds__(256) void spp_pool_split_kernel(uint16_t* __restric
 // default OFF: measured r05 (tools/ab_knob.py vgh_stem_set_mfma, one box, alternating) the matrix-core stem is correct but SLOWER -- 442 vs 306 us per 64 images
 // (M b32: 232 vs 168 us; two-lane forward L b64 12.47 vs 12.25 ms): with 25 600 blocks of 256 pixels the kernel is a chain of latencies per block (image bytes ->
 // LDS -> 32 scattered 2-byte LDS gathers per lane -> 8 MFMAs -> LDS transpose -> stores), not the VALU-bound loop the FMA count suggested (EXPERIMENTS.md 8e)
+#ifdef VGH_EXPERIMENTS
 static std::atomic<int> g_stem_mfma{0};
 extern "C" int vgh_stem_set_mfma(int on) {
     g_stem_mfma.store(on ? 1 : 0, std::memory_order_relaxed);
     return VGH_OK;
 }
+#endif
 
 int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const float* w, const float* bias, uint16_t* out, int64_t out_pitch,
                     int out_coff, int store_ch, int fmt, int plane, hipStream_t stream) {
@@ -474,6 +479,7 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
         else VGH_STEM_LAUNCH(VGH_IMG_F32_NCHW, 0, VGH_FMT_BF16X2, 1.0f);
     } else {
         VGH_REQUIRE(fmt == VGH_FMT_BF16, "stem: output format %d", fmt);
+#ifdef VGH_EXPERIMENTS
         if (u8 && g_stem_mfma.load(std::memory_order_relaxed)) {  // bf16 mode, u8 image: the layer on the matrix cores (stem_mfma_kernel)
             if (store_ch == 48)
                 hipLaunchKernelGGL((stem_mfma_kernel<6>), grid, dim3(256), 0, stream, (const uint8_t*)image, H, W, w, bias, out, out_pitch, out_coff);
@@ -482,6 +488,7 @@ int vgh_launch_stem(const void* image, int image_fmt, int B, int H, int W, const
             VGH_HIP(hipGetLastError());
             return VGH_OK;
         }
+#endif
         if (store_ch == 48) {
             if (u8) VGH_STEM_LAUNCH48(VGH_IMG_U8_NHWC);
             else VGH_STEM_LAUNCH48(VGH_IMG_F32_NCHW);

@@ -200,6 +200,7 @@ int vgh_streams_overlap(void* a, void* b) { return runs_concurrently((hipStream_
 // 1 when a kernel on `b` cannot start while `a`'s dispatches are being placed (same compute pipe: see blocked_behind)
 int vgh_stream_blocked_behind(void* a, void* b) { return blocked_behind((hipStream_t)a, (hipStream_t)b) ? 1 : 0; }
 
+#ifdef VGH_EXPERIMENTS
 // first-kernel completion time / pair completion time for two multi-round kernels launched back to back on a and b:
 // ~1.0 = their workgroups interleave, ~0.5 = b's only start when a's are all dispatched.  *1000 (integer per-mille).
 int vgh_streams_interleave_permille(void* a, void* b) {
@@ -239,6 +240,8 @@ int vgh_streams_interleave_permille(void* a, void* b) {
     (void)hipGetLastError();
     return result;
 }
+
+#endif
 
 int vgh_stream_spin(void* stream, int microseconds) {
     VGH_REQUIRE(microseconds >= 0 && microseconds <= 100000, "stream_spin: 0..100000 us");

@@ -75,7 +75,8 @@ struct ConvArgs {
     float out_scale;  // undoes the per-op power-of-two weight prescale (fp16), applied to the accumulator before the bias
     // ---- e4m3 links (conv_pp.hip, r05): the input view / the output tensor hold OCP e4m3 bytes (pitches and channel offsets then count bytes); the residual stays
     //      bf16.  gscale[cout_pad]: per-cout output factor applied to the accumulator (which starts at bias / gscale when the input is e4m3) ----
-    //      in_fp8 / out_fp8: 0 = 16-bit, 1 = e4m3, 2 = int8 (VGH_FMT_I8: int32 accumulator from 0, out = act(acc * gscale + bias), bias in output units) ----
+    //      in_fp8 / out_fp8: 0 = 16-bit, 1 = e4m3, 2 = int8 (VGH_FMT_I8: the `bias` vector of an int8-INPUT conv holds int32 BIT PATTERNS in accumulator units,
+    //      rn(bias[c] / (wscale[c] * scale(in))); the int32 accumulator starts there and out = act(float(acc) * gscale[c]) -- include/vgh.h, conv_pp.hip PP_INIT_ROWS) ----
     int in_fp8, out_fp8;
     const float* gscale;
     const float* dvec;  // int8 -> bf16 only (or nullptr): the diagonal bypass, out[c] += dvec[c] * code(input pixel, channel c) before the activation (conv_pp.hip DG)
@@ -171,4 +172,6 @@ void vgh_stream_release_internal(int device, hipStream_t s, bool low_priority = 
 struct vgh_net;
 // net.hip: the net's lane streams for work entering on `main` (picked on first use, re-picked when `main` changes); out[3]
 int vgh_net_lane_streams(vgh_net* n, hipStream_t main, hipStream_t* out);
-extern "C" int vgh_net_device(vgh_net* n);
+extern "C" __attribute__((visibility("hidden"))) int vgh_net_device(vgh_net* n);  // library-internal
+// net.hip, library-internal since r06 (was exported): the first op of the next forwards that writes a prediction buffer waits for `event` (or nullptr) on its stream
+extern "C" __attribute__((visibility("hidden"))) int vgh_net_set_pred_guard(vgh_net* n, void* event);

@@ -102,6 +102,12 @@ class VGHeadsEngine:
         if precision in arch.Q8_PRECISIONS:
             if fp8_scales is None:
                 if calib_images is None:
+                    # not silent: with real weights and real photographs, activations above the random-image maximum times the headroom are CLAMPED in
+                    # the epilogue -- the caller has to know that these scales are for plumbing and the synthetic benchmark only
+                    import warnings
+
+                    warnings.warn(f"VGHeadsEngine(precision={precision!r}) without fp8_scales / calib_images: the 8-bit link scales are calibrated on two seeded RANDOM "
+                                  "images -- adequate for the synthetic benchmark, not for real weights and photographs (pass calib_images or fp8_scales)", stacklevel=2)
                     calib_images = torch.randint(0, 256, (2, image_size, image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(12345)).to(torch.device("cuda", self.device_index))
                 fp8_scales = calibrate_fp8(variant, state_dict, image_size, calib_images, self.device_index, fp8_min_px)
             self.fp8_scales = dict(fp8_scales)
@@ -258,8 +264,10 @@ class VGHeadsEngine:
             self.load_tuning()  # the table may hold tile choices measured in this split mode
 
     def set_fuse_stem(self, enable: bool = True):
-        """vgh_net_set_fuse_stem: stem + stage-1 downsample as one kernel (opt-in: less HBM traffic, same time; the stem buffer is then not written)
-        or as the two launches (default).  Results are bit-identical."""
+        """EXPERIMENTS build only (VGH_LIB_PATH=libvgh_exp.so; r06): stem + stage-1 downsample as one kernel (csrc/stem_ds.hip: less HBM traffic, same time --
+        measured r03, not part of the product library) or as the two launches.  Results are bit-identical."""
+        if not hasattr(self.lib, "vgh_net_set_fuse_stem"):
+            raise _lib.VghError("set_fuse_stem: the fused stem + downsample kernel exists in the -DVGH_EXPERIMENTS build only (python -m head_detector_amd.build --experiments)")
         _lib.check(self.lib.vgh_net_set_fuse_stem(self._net, int(bool(enable))))
         self._graph_key = None
 
@@ -338,8 +346,14 @@ class VGHeadsEngine:
         B, kk = batch or self.max_batch, self.keep_k
         f32 = dict(dtype=torch.float32, device=self.device)
         i32 = dict(dtype=torch.int32, device=self.device)
-        slot = dict(boxes=torch.zeros(B, kk, 4, **f32), scores=torch.zeros(B, kk, **f32), flame=torch.zeros(B, kk, _lib.NUM_FLAME_PARAMS, **f32), counts=torch.zeros(B, **i32),
-                    n_heads=torch.zeros(1, **i32))
+        # ONE zero-filled block, five views (r06: five torch.zeros were five fill kernels queued ahead of the network -- 75 us of a 2.0-ms single-image call,
+        # profiles/r06_latency_trace_l1.txt); every view starts 16-byte aligned
+        nb, ns, nf = B * kk * 4, (B * kk + 3) // 4 * 4, B * kk * _lib.NUM_FLAME_PARAMS
+        nf4, nc = (nf + 3) // 4 * 4, (B + 3) // 4 * 4
+        flat = torch.zeros(nb + ns + nf4 + nc + 4, **f32)
+        ints = flat.view(torch.int32)
+        slot = dict(boxes=flat[:nb].view(B, kk, 4), scores=flat[nb:nb + B * kk].view(B, kk), flame=flat[nb + ns:nb + ns + nf].view(B, kk, _lib.NUM_FLAME_PARAMS),
+                    counts=ints[nb + ns + nf4:nb + ns + nf4 + B], n_heads=ints[nb + ns + nf4 + nc:nb + ns + nf4 + nc + 1])
         if flame is not None:
             cap = min(B * self.keep_k, flame.max_heads)  # per-head rows beyond the live count are never written: no need to clear them
             slot.update(cap=cap, head_image=torch.empty(cap, **i32), proj=torch.empty(cap, flame.num_vertices, 3, **f32), rpy=torch.empty(cap, 3, **f32))
@@ -515,17 +529,30 @@ class VGHeadsEngine:
 def calibrate_fp8(variant: str, state_dict: Optional[Dict[str, np.ndarray]], image_size: int, images: torch.Tensor, device: Optional[int] = None, fp8_min_px: int = 40) -> Dict[str, float]:
     """{e4m3 link name: max|activation|} of the "fp8" program, measured on ``images`` with the bf16 engine (every tensor of a forward stays in the arena: single
     assignment), for ``VGHeadsEngine(precision="fp8", fp8_scales=...)`` / ``arch.build_program(..., fp8_scales=...)``.  Pass images like the ones the detector will see."""
-    B = int(images.shape[0])
-    eng = VGHeadsEngine(variant, state_dict, image_size, max_batch=B, device=device, precision="bf16", use_tuning=False)
+    # chunks of at most CALIB_CHUNK images through one temporary bf16 engine, a running maximum per link (ADVICE r05: one batch of every calibration image sized the arena by
+    # their count -- a few hundred photographs ran out of memory or past arena_batch)
+    n = int(images.shape[0])
+    if n == 0:
+        raise ValueError("calibrate_fp8: no calibration image")
+    chunk = min(n, CALIB_CHUNK)
+    eng = VGHeadsEngine(variant, state_dict, image_size, max_batch=chunk, device=device, precision="bf16", use_tuning=False)
     try:
-        eng.forward_net(images)
-        eng.stream.synchronize()
-        out = {}
-        for link, (src, live) in arch.fp8_link_names(variant, image_size, fp8_min_px).items():
-            out[link] = float(eng.buffer(src, B)[..., :live].float().abs().max())
+        links = arch.fp8_link_names(variant, image_size, fp8_min_px)
+        out = {link: 0.0 for link in links}
+        for at in range(0, n, chunk):
+            x = images[at:at + chunk].contiguous()
+            for a0 in range(0, x.shape[0], eng.arena_batch):  # (an engine whose tensors pass 2 GiB runs its batch in arena chunks: the buffers hold the last one)
+                xa = x[a0:a0 + eng.arena_batch].contiguous()
+                eng.forward_net(xa)
+                eng.stream.synchronize()
+                for link, (src, live) in links.items():
+                    out[link] = max(out[link], float(eng.buffer(src, xa.shape[0])[..., :live].float().abs().max()))
         return out
     finally:
         eng.close()
+
+
+CALIB_CHUNK = 8  # images per calibration forward
 
 
 def tuning_key(op: dict, batch: int, nsplit: int = 1, bucket: Optional[int] = None, res: Optional[bool] = None) -> str:

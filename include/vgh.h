@@ -117,21 +117,6 @@ int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
  * latency, epilogue store burst, tail -- of one sub-batch hides under the main loops of the others.  Results are identical
  * (images are independent; every op keeps its tile configuration). */
 int vgh_net_set_split(vgh_net* net, int nsplit);
-/* Process-wide: with a batch split, lane l starts when lane l-1 has finished its first `ops` ops and stays that far behind, so that different layers
- * run side by side (0 = the lanes advance together).  Results do not change. */
-int vgh_net_set_lane_lag(int ops);
-/* Opt-in: the stem (3 -> 48, stride 2) and the first backbone downsample (48 -> 96, stride 2) as ONE kernel (csrc/stem_ds.hip) when the program has that
- * pair in bf16: the 48-channel stem activation then never goes to HBM and its arena buffer is not written.  Results are bit-identical either way.
- * Default off: measured (r03) it removes 1.5 GB of traffic per 64-image forward but is no faster than the two launches (latency-bound small tiles). */
-int vgh_net_set_fuse_stem(vgh_net* net, int enable);
-/* Process-wide opt-in (default 0): in the bf16 mode the stem of a u8 image runs as a K = 27 bf16 GEMM on the matrix cores (csrc/stem_pool.hip::stem_mfma_kernel: pixel
- * values are exact in bf16, /255 folded into bf16-rounded weights, fp32 accumulate) instead of the exact-fp32 VALU kernel.  Correct (2^-9 relative on a weight, below
- * the bf16 rounding of the stem's output) but measured SLOWER in r05 (442 vs 306 us per 64 images: per-block latency chain), hence off; float images and the parity
- * modes always use the exact kernel. */
-int vgh_stem_set_mfma(int on);
-/* Borrowed HIP event (or NULL): the first op of the next forwards that writes a prediction buffer waits for it on its stream.
- * Lets a consumer of the previous forward's predictions run on another stream underneath this forward's backbone / neck. */
-int vgh_net_set_pred_guard(vgh_net* net, void* event);
 int vgh_net_max_batch(vgh_net* net);  /* images the activation arena was planned for */
 int vgh_net_image_size(vgh_net* net);
 
@@ -195,9 +180,6 @@ int vgh_conv_split_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast
 /* Cap on the persistent 3x3 kernels' grid: at most `blocks` workgroups per XCD (0 = as many as stay resident, the default).
  * Process-wide.  Leaves CUs to other work; the parity tests use it to drive many tiles through one workgroup. */
 int vgh_conv_set_max_blocks_per_xcd(int blocks);
-/* Process-wide: bf16 conv outputs are stored with the non-temporal hint (evict-first in L2, so the input lines neighbouring tiles re-read survive).
- * Results do not change. */
-int vgh_conv_set_nt_store(int on);
 /* Process-wide, read by vgh_net_create (default on): an int8 -> bf16 3x3 conv whose rows are dominated by w[c][centre][c] -- at least half of the live rows have it as
  * their largest weight: the identity branch a RepVGG block folds into its kernel -- keeps that element out of the int8 image and applies it in fp32 in the epilogue
  * (vgh_conv_call.diag_dev).  Off: the plain per-cout int8 grid (for the comparison; ~17 dB less weight precision on such rows). */
@@ -374,11 +356,6 @@ int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, fl
  * stream); the caller must not reuse the vgh_detect_out buffers of call s for call s+1 unless it joined in between (or does
  * not read them). */
 int vgh_detector_set_overlap(vgh_detector* d, int enable);
-/* r05, both between batches (after vgh_detector_join).  set_side_priority: the priority class of the side stream the overlapped post stages run on (1 = lowest, the default; 0 = the
- * caller's); renew_side: replace the side stream by one created now for this detector alone (work entering on main_stream).  For an engine whose side stream is starved under
- * the network (the forward then stalls at the prediction guard for milliseconds): measure, as head_detector_amd.engine.VGHeadsEngine.tune_overlap does. */
-int vgh_detector_set_side_priority(vgh_detector* d, int low);
-int vgh_detector_renew_side(vgh_detector* d, void* main_stream);
 int vgh_detector_join(vgh_detector* d, void* stream);
 /* Records the caller's HIP event behind everything queued so far for the post-network stages (overlap mode: on the detector's side stream; else on `stream`)
  * WITHOUT making any stream wait for it: a host that synchronises on the event of an EARLIER batch can queue that batch's consumers (e.g. the N>1 exchange) with no
@@ -484,6 +461,33 @@ int vgh_event_create(void** ev_out);
 int vgh_event_destroy(void* ev);
 int vgh_event_record(void* ev, void* stream);
 int vgh_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
+
+/* ------------------------------------------------------------------------------------------------
+ * EXPERIMENT KNOBS (r06): declared and compiled ONLY in the -DVGH_EXPERIMENTS build (head_detector_amd/libvgh_exp.so, `python -m head_detector_amd.build --experiments`),
+ * which tools/ drive through VGH_LIB_PATH.  Every one is an A/B switch for something that was measured and did not pay (EXPERIMENTS.md); the product library neither
+ * exports them nor contains the kernels behind them (the fused stem + downsample kernel, the matrix-core stem, the stride-2 parity-plane "d" tiles).
+ * ------------------------------------------------------------------------------------------------ */
+#ifdef VGH_EXPERIMENTS
+/* Process-wide: with a batch split, lane l starts when lane l-1 has finished its first `ops` ops and stays that far behind, so that different layers
+ * run side by side (0 = the lanes advance together).  Results do not change. */
+int vgh_net_set_lane_lag(int ops);
+/* Opt-in: the stem (3 -> 48, stride 2) and the first backbone downsample (48 -> 96, stride 2) as ONE kernel (csrc/stem_ds.hip) when the program has that
+ * pair in bf16: the 48-channel stem activation then never goes to HBM and its arena buffer is not written.  Results are bit-identical either way.
+ * Default off: measured (r03) it removes 1.5 GB of traffic per 64-image forward but is no faster than the two launches (latency-bound small tiles). */
+int vgh_net_set_fuse_stem(vgh_net* net, int enable);
+/* Process-wide opt-in (default 0): in the bf16 mode the stem of a u8 image runs as a K = 27 bf16 GEMM on the matrix cores (csrc/stem_pool.hip::stem_mfma_kernel: pixel
+ * values are exact in bf16, /255 folded into bf16-rounded weights, fp32 accumulate) instead of the exact-fp32 VALU kernel.  Correct (2^-9 relative on a weight, below
+ * the bf16 rounding of the stem's output) but measured SLOWER in r05 (442 vs 306 us per 64 images: per-block latency chain), hence off; float images and the parity
+ * modes always use the exact kernel. */
+int vgh_stem_set_mfma(int on);
+/* Process-wide: bf16 conv outputs are stored with the non-temporal hint (evict-first in L2, so the input lines neighbouring tiles re-read survive).
+ * Results do not change. */
+int vgh_conv_set_nt_store(int on);
+/* the priority class of the side stream the overlapped post stages run on (1 = lowest, the default; 0 = the caller's); between batches (after vgh_detector_join) */
+int vgh_detector_set_side_priority(vgh_detector* d, int low);
+/* first-kernel completion / pair completion (per mille) of two multi-round kernels launched back to back on a and b: ~1000 = their workgroups interleave */
+int vgh_streams_interleave_permille(void* stream_a, void* stream_b);
+#endif
 
 #ifdef __cplusplus
 }

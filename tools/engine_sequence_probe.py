@@ -93,10 +93,9 @@ def run(variant, B, prec, S=640, nf=40):
         eng.join(); eng.set_overlap(False); timed("split 2, post stages NOT overlapped")
         eng.join(); eng.set_overlap(True); eng.set_split(1); timed("split 1, overlapped")
         eng.join(); eng.set_split(2); timed("split 2, overlapped (back)")
-        if os.environ.get("SEQ_RENEW"):
-            eng.join(); _lib_check(eng.lib.vgh_detector_renew_side(eng._det, eng._sp())); timed("split 2, overlapped, side stream RENEWED (fresh low-priority stream)")
-        eng.join(); _lib_check(eng.lib.vgh_detector_set_side_priority(eng._det, 0)); timed("split 2, overlapped, side stream at NORMAL priority")
-        eng.join(); _lib_check(eng.lib.vgh_detector_set_side_priority(eng._det, 1)); timed("split 2, overlapped, low priority again (from the park)")
+        if hasattr(eng.lib, "vgh_detector_set_side_priority"):  # experiments build (VGH_LIB_PATH=head_detector_amd/libvgh_exp.so)
+            eng.join(); _lib_check(eng.lib.vgh_detector_set_side_priority(eng._det, 0)); timed("split 2, overlapped, side stream at NORMAL priority")
+            eng.join(); _lib_check(eng.lib.vgh_detector_set_side_priority(eng._det, 1)); timed("split 2, overlapped, low priority again (from the park)")
         def net_only(label):
             for _ in range(3): eng.forward_net(x)
             eng.join(); torch.cuda.synchronize(); t = time.perf_counter()
