@@ -262,12 +262,19 @@ def make_step(eng, flame, images, unpad, conf, B, slots, gat, overlap, use_graph
             gat.wait_slot_free(s, eng.stream)  # the exchange that last read this output slot (nslots batches ago) is over
         if i is not None and ev0 is not None:
             ev0[i].record(eng.stream)  # HIP events on the stream the kernels are launched on
-        eng.forward_net(images, use_graph=use_graph)
-        if i is not None and ev1 is not None:
-            ev1[i].record(eng.stream)
-        # post-network stages: decode/top-k/gather, then ONE library call for NMS + compaction + head list + FLAME decode of every
-        # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
-        eng.candidates(B)
+        if B > getattr(eng, "arena_batch", B):
+            # a batch whose tensors pass 2 GiB (configs[4] at its stated batch: 256 images @1280 = ten arena chunks): network + candidate stages chunk by chunk
+            # (vgh_detector_candidates); the "network part" between the two events then includes the chunks' decode / top-k / gather kernels
+            eng.forward_candidates(images, use_graph=use_graph)
+            if i is not None and ev1 is not None:
+                ev1[i].record(eng.stream)
+        else:
+            eng.forward_net(images, use_graph=use_graph)
+            if i is not None and ev1 is not None:
+                ev1[i].record(eng.stream)
+            # post-network stages: decode/top-k/gather, then ONE library call for NMS + compaction + head list + FLAME decode of every
+            # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
+            eng.candidates(B)
         k = i if i is not None else 0
         det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1],
                          slot=slots[s] if slots else None)

@@ -741,12 +741,42 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     return dict(read=float(rd), write=float(wr))
 
 
-def program_algorithmic_bytes(P: "Program", batch: int, fused_stem: Optional[bool] = None) -> Dict[str, float]:
-    """fused_stem (the executor's opt-in vgh_net_set_fuse_stem): the stem tensor is neither written nor read."""
+def b2b_pairs(P: "Program") -> List[int]:
+    """Indices i of the ops the executor runs with op i + 1 as ONE back-to-back-GEMM launch (csrc/net.hip, vgh_net_create; r06): a plain bf16 conv with all of its 96
+    output channels in one tile whose whole output tensor is read by exactly one op, the next one, a plain 1x1 / stride-1 bf16 conv with 128, 192 or 256 output channels.
+    The same predicate as the library's (the engine checks the counts agree): PMC tools and the algorithmic-bytes accounting use it."""
+    out = []
+    for i in range(len(P.ops) - 1):
+        a, b = P.ops[i], P.ops[i + 1]
+        if a["kind"] != 1 or b["kind"] != 1:
+            continue
+        ab, ai, bo = P.bufs[a["out_buf"]], P.bufs[a["in_buf"]], P.bufs[b["out_buf"]]
+        ok = (ab["is_f32"] == FMT_BF16 and ai["is_f32"] == FMT_BF16 and bo["is_f32"] == FMT_BF16 and a["ksize"] in (1, 3) and a["cout_pad"] == 96 and b["cout_pad"] in (128, 192, 256)
+              and a["cout_store"] == a["cout_pad"] and a["out_coff"] == 0 and a["out_split"] >= a["cout_pad"] and ab["pitch"] == a["cout_pad"] and a["res_buf"] < 0 and not a["shuffle"]
+              and not a.get("grp_cout") and a["act"] != 2 and b["ksize"] == 1 and b["stride"] == 1 and b["in_buf"] == a["out_buf"] and b["in_coff"] == 0 and b["cin"] == a["cout_pad"]
+              and b["res_buf"] < 0 and not b["shuffle"] and not b.get("grp_cout") and b["act"] != 2 and b["out_coff"] % 8 == 0 and b["out_coff2"] % 8 == 0 and b["out_split"] % 8 == 0
+              and b["cout_store"] % 8 == 0 and bo["pitch"] % 8 == 0 and (not out or out[-1] != i - 1))
+        for j, o in enumerate(P.ops):
+            if ok and j not in (i, i + 1) and o["kind"] in (1, 2) and a["out_buf"] in (o["in_buf"], o["out_buf"], o.get("res_buf", -1)):
+                ok = False
+        if ok:
+            out.append(i)
+    return out
+
+
+def program_algorithmic_bytes(P: "Program", batch: int, fused_stem: Optional[bool] = None, b2b: bool = True) -> Dict[str, float]:
+    """fused_stem (the executor's opt-in vgh_net_set_fuse_stem): the stem tensor is neither written nor read.  b2b (r06, the executor's default): the tensor between
+    the two convs of a back-to-back pair is neither written nor read -- the pair is ONE op of the engine's layer-by-layer accounting."""
     fused_stem = bool(fused_stem)
     tot = dict(read=0.0, write=0.0)
+    pairs = set(b2b_pairs(P)) if b2b else set()
     for i, op in enumerate(P.ops):
         b = op_algorithmic_bytes(P, op, batch)
+        if i in pairs:
+            b["write"] = 0.0
+        if i - 1 in pairs:
+            ib = P.bufs[op["in_buf"]]
+            b["read"] -= batch * ib["h"] * ib["w"] * op["cin"] * FMT_BYTES[ib["is_f32"]]
         if fused_stem and op["kind"] == 0:
             b["write"] = 0.0
         if fused_stem and i > 0 and P.ops[i - 1]["kind"] == 0 and op["kind"] == 1 and op["in_buf"] == P.ops[i - 1]["out_buf"]:

@@ -510,6 +510,41 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
     return VGH_OK;
 }
 
+// ---- back-to-back GEMM (conv_kernels.inc, T2 > 0): a conv whose 96 output channels fit ONE cout tile, fused with the 1x1 conv that is its only reader ----
+namespace {
+template <int T2>
+int launch_b2b_96(const ConvArgs& a, hipStream_t st) {
+    constexpr int BP = 128, BC = 96, WP = 32, WC = 96, KBS = 1, NST = 2;
+    constexpr int lds0 = lds_bytes(BP, BC, WP, WC, KBS, NST), w2 = 3 * T2 * 2048;
+    constexpr int lds = lds0 > w2 ? lds0 : w2;
+    static_assert(lds <= 64 * 1024, "b2b: within the default dynamic-LDS limit");
+    const int64_t total = ((int64_t)a.P + BP - 1) / BP;
+    VGH_REQUIRE(total < (1ll << 30), "conv b2b: too many tiles");
+    const int chunk = (int)((total + 7) / 8);
+    hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, 0, T2>), dim3(chunk * 8), dim3((BP / WP) * 64), lds, st, a, 1, (int)total, chunk);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+}  // namespace
+
+int vgh_conv_b2b_ok(int ksize, int stride, int cout_pad, int cout2_pad) {
+    (void)stride;
+    return (ksize == 1 || ksize == 3) && cout_pad == 96 && (cout2_pad == 256 || cout2_pad == 192 || cout2_pad == 128);
+}
+
+int vgh_launch_conv_b2b(const ConvArgs& a0, hipStream_t stream) {
+    ConvArgs a = a0;
+    if (int rc = vgh_conv_prepare(a)) return rc;
+    if (a.P == 0) return VGH_OK;
+    VGH_REQUIRE(a.w2pack && a.bias2 && a.out2, "conv b2b: the second conv's weights / bias / output are missing");
+    VGH_REQUIRE(vgh_conv_b2b_ok(a.ksize, a.stride, a.cout_pad, a.cout2_pad), "conv b2b: no tile for %d -> %d channels", a.cout_pad, a.cout2_pad);
+    VGH_REQUIRE(!a.split && !a.res && !a.shuffle && !a.grp_cout && !a.in_fp8 && !a.out_fp8 && !a.out_f32 && a.act != VGH_ACT_SILU && a.act2 != VGH_ACT_SILU,
+                "conv b2b: plain bf16 convs with ReLU / no activation only");
+    VGH_REQUIRE(a.out2_pitch % 8 == 0 && a.out2_coff % 8 == 0 && a.out2_coff2 % 8 == 0 && a.out2_split % 8 == 0 && a.cout2_store % 8 == 0 && a.cout2_store <= a.cout2_pad,
+                "conv b2b: the second output needs 16-byte aligned channel offsets");
+    return a.cout2_pad == 256 ? launch_b2b_96<8>(a, stream) : a.cout2_pad == 192 ? launch_b2b_96<6>(a, stream) : launch_b2b_96<4>(a, stream);
+}
+
 void vgh_pack_conv_weights_host(const float* w, int cout_pad, int ksize, int cin, uint16_t* dst) {
     // dst[kb][cout][slot][8] with slot = chunk ^ ((cout>>2)&3), kb = (ky*ks + kx)*(cin/32) + cb
     const int cblocks = cin / 32, taps = ksize * ksize;

@@ -1003,13 +1003,22 @@ int launch_mfma(const VertArgs& va, hipStream_t st) {
 //            16-byte basis load per lane and 4 pairs; vertex blocks of one head tile run on one XCD (40 blocks per tile row, 40 % 8 = 0) and share its L2.
 //   (r04, measured and removed: the prologue in the first blocks of the SAME launch, released to the vertex blocks by per-head flags -- agent-scope release /
 //    acquire = buffer_wbl2 / buffer_inv of a whole L2 and hundreds of polling waves: the flag of a lone head became visible 14 us into the launch, EXPERIMENTS 8d)
-template <int NPW, int NHL, int VG, int MT = 1>
+//   Q = 1 ("quad" tiles, r06; VG = 1, MT = 1): a compute wave owns 16 heads x 16 vertices of its plane and runs v_mfma_f32_16x16x4_f32 -- FOUR k per instruction at a
+//            dependent-chain latency of 44 cycles where v_mfma_f32_32x32x2_f32 takes 64 cycles for two (profiles/r04_mfma_f32_chain.txt: 11.0 vs 32.1 cycles per k;
+//            both are the ascending fmaf chain, bit for bit).  Below ~32 heads a decode is ONE WAVE'S CHAIN long, so the chain is what there is to shorten: 109
+//            instructions instead of 218, 4.8 k instead of 14 k cycles.  Same operands: a lane (vertex = lane & 15, kq = lane >> 4) loads the 16 bytes of basis8 row
+//            kq & 1 -- its vertex at k = 8g + (kq & 1) + {0, 2, 4, 6} -- and uses element kq >> 1 for the quad 8g .. 8g + 3 and 2 + (kq >> 1) for 8g + 4 .. 8g + 7 (half of
+//            the loaded bytes are unused: the price of keeping one basis layout); the coefficient tile is read at rows kq and 4 + kq of the group.  Twice the vertex
+//            blocks (314 groups of 16), head tiles of 16.
+template <int NPW, int NHL, int VG, int MT = 1, int Q = 0>
 __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(VertArgs a, PrepArgs pa) {
 #pragma clang fp contract(off)
     static_assert(!(NPW > 0 && NHL > 0) && (VG == 1 || NPW == 0) && (MT == 1 || (NPW == 0 && NHL == 0 && VG > 1)), "prologue waves or helper waves; the fused variant has one vertex group; two head tiles per wave only in the large blocks");
+    static_assert(!Q || (VG == 1 && MT == 1), "quad tiles: one 16-vertex group, one 16-head tile per block");
     constexpr int NCW = 3 * VG;             // compute waves: wave w = vertex group w / 3, coordinate plane w % 3
     constexpr int NW = NCW + NPW + NHL;
-    constexpr int NH = NPW > 0 ? NPW : 32 * MT;  // head packs held by the block (MT = 2: each compute wave runs TWO head tiles' chains on one basis operand -- half the
+    constexpr int VW = Q ? 16 : 32;         // vertices of a vertex group
+    constexpr int NH = NPW > 0 ? NPW : Q ? 16 : 32 * MT;  // head packs held by the block (MT = 2: each compute wave runs TWO head tiles' chains on one basis operand -- half the
                                                  // operand bytes per MFMA: a CU's L1 fill rate, ~16 B/clk, is what a block of twelve one-tile waves runs into)
     constexpr int AS = NPW > 0 ? 33 : 32;   // row stride of the coefficient tile: 32 = what an LDS-DMA instruction writes (8 rows x 128 bytes; the two half-waves of an
                                             // operand read then cover the 64 banks); 33 for the fused variant's k-major register staging
@@ -1021,7 +1030,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     if (a.n_dev) a.n = min(a.n, *a.n_dev);
     // block -> (head tile by, vertex block bx) so that the tiles of ONE vertex block run on one XCD and share its L2 copy of the basis rows: workgroups go to the
     // XCDs round-robin (XCD = blockIdx.x % 8); inside an XCD's sequence the vertex blocks bx = x, x + 8, ... of a tile row come first, then the next row
-    const int vgroups = (a.V + 31) >> 5, vblocks = (vgroups + VG - 1) / VG, vb8 = (vblocks + 7) >> 3;
+    const int vgroups = (a.V + VW - 1) / VW, vblocks = (vgroups + VG - 1) / VG, vb8 = (vblocks + 7) >> 3;
     const int bid = (int)blockIdx.x, bq = bid >> 3;
     const int by = bq / vb8, bx = (bq - by * vb8) * 8 + (bid & 7);
     if (bx >= vblocks) return;  // (the row is padded to a multiple of 8 blocks)
@@ -1043,10 +1052,13 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     float* const s_x = XOWN ? s_hp + NH * HP_SIZE : fsm;
     int* const s_cnt = (int*)(s_x + VG * MT * 3 * 16 * 64);  // XOWN: one arrival counter per vertex group
     if (XOWN && threadIdx.x < VG) s_cnt[threadIdx.x] = 0;     // (ahead of the staging barrier)
-    const int h0 = by * (32 * MT);
+    const int h0 = by * (Q ? 16 : 32 * MT);
     if (h0 >= a.n) return;
-    const int j = lane & 31, half = lane >> 5;
-    const int v = min(bx * VG + cvg, vgroups - 1) * 32 + j;  // < Vp (a multiple of 32); helper / prologue waves: the (one) vertex group, idle compute waves: a valid one
+    // 32 x 32 x 2: lane = (head / vertex j = lane & 31, k parity half = lane >> 5); quad tiles: lane = (head / vertex j = lane & 15, k within the quad kq = lane >> 4),
+    // whose basis8 row is kq & 1 ("half") and whose element inside the 16 loaded bytes is kq >> 1 (+ 2 for the group's second quad)
+    const int j = Q ? lane & 15 : lane & 31, half = Q ? (lane >> 4) & 1 : lane >> 5;
+    const int kq = lane >> 4;
+    const int v = min(bx * VG + cvg, vgroups - 1) * VW + j;  // < Vp (a multiple of 32); helper / prologue waves: the (one) vertex group, idle compute waves: a valid one
     const int64_t plane = a.Vp;
     C3MARK(0);
     // ---- blend operands: the k-interleaved basis copy [k / 8][c][k & 1][Vp][4]: 16 bytes of a lane = its vertex at k = 8g + half + {0, 2, 4, 6} -- the B operands of
@@ -1055,6 +1067,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     const f32x4_t* const bl = (const f32x4_t*)a.basis8 + ((int64_t)cpl * 2 + half) * plane + v;  // + g * 6 * plane
     f32x4_t B0[UQ], B1[UQ], B2[UQ];
     f32x16_t acc[MT];
+    f32x4_t accq;  // quad tiles: D[head 4 (lane >> 4) + r][vertex lane & 15]
     auto fetch = [&](f32x4_t (&B)[UQ], int g0) {
         if (g0 >= ng || !cw) return;
 #pragma unroll
@@ -1095,6 +1108,7 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = tv;
+        accq = f32x4_t{tv, tv, tv, tv};
     }
     if constexpr (NPW > 0) {
         // fused: the raw betas of the block's heads, read in place.  Every compute wave stages the whole (small) tile itself -- identical values from every
@@ -1179,7 +1193,33 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         };
         // the A operands of a group are read while the previous group's four MFMAs run (one wave-uniform branch per group; a read right in front of its MFMA
         // behind a branch per pair cost ~150 cycles per 64-cycle MFMA)
+        // quad tiles: two instructions per group (k = 8g + kq, then 8g + 4 + kq), their A operands = rows kq and 4 + kq of the group's tile rows
+        const float* const saq = s_A + kq * AS + j;
+        auto consume_q = [&](const f32x4_t (&B)[UQ], int g0) {
+            if (g0 >= ng || !cw) return;
+            const bool hi2 = (kq >> 1) != 0;
+            float a0 = (NPW == 0 || j < NH) ? saq[g0 * 8 * AS] : 0.0f, a1 = (NPW == 0 || j < NH) ? saq[(g0 * 8 + 4) * AS] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < UQ; ++u) {
+                float n0 = 0.0f, n1 = 0.0f;
+                if (u + 1 < UQ) {  // the next group's operands under this group's two instructions (never past the burst: see consume)
+                    const int gn = min(g0 + u + 1, ng - 1);
+                    n0 = (NPW == 0 || j < NH) ? saq[gn * 8 * AS] : 0.0f;
+                    n1 = (NPW == 0 || j < NH) ? saq[(gn * 8 + 4) * AS] : 0.0f;
+                }
+                if (g0 + u < ng) {  // wave-uniform
+                    accq = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, hi2 ? B[u][1] : B[u][0], accq, 0, 0, 0);
+                    accq = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, hi2 ? B[u][3] : B[u][2], accq, 0, 0, 0);
+                }
+                a0 = n0;
+                a1 = n1;
+            }
+        };
         auto consume = [&](const f32x4_t (&B)[UQ], int g0) {
+            if constexpr (Q) {
+                consume_q(B, g0);
+                return;
+            }
             if (g0 >= ng || !cw) return;
             float Ac[MT][4], An[MT][4];
             read_a(g0, Ac);
@@ -1241,10 +1281,15 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     } else {
         __syncthreads();  // every wave is done with the coefficient tile: its memory becomes the exchange buffer
         if (wv < NCW) {
+            if constexpr (Q) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
+                for (int r = 0; r < 4; ++r) s_x[(cpl * 4 + r) * 64 + lane] = accq[r];
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_x[(((cvg * MT + t) * 3 + cpl) * 16 + r) * 64 + lane] = acc[t][r];
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s_x[(((cvg * MT + t) * 3 + cpl) * 16 + r) * 64 + lane] = acc[t][r];
+            }
         }
         __syncthreads();
     }
@@ -1257,14 +1302,17 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
         if (a.proj && tid == 0) a.proj[((int64_t)h0 * a.V + v) * 3] = s_x[lane];
         return;
     }
-    for (int sl = (VG == 1 ? wv : cpl); sl < (VG == 1 || cw ? 16 * MT : 0); sl += (VG == 1 ? NW : 3)) {
+    for (int sl = (VG == 1 ? wv : cpl); sl < (Q ? 4 : VG == 1 || cw ? 16 * MT : 0); sl += (VG == 1 ? NW : 3)) {
         const int t = sl >> 4, r = sl & 15;
         const float* const s_xg = s_x + (cvg * MT + t) * (3 * 16 * 64);
-        const int hlo = t * 32 + (r & 3) + 8 * (r >> 2);  // head of the lower half-wave; the upper one has hlo + 4
-        if (h0 + hlo >= a.n) continue;           // wave-uniform: neither half has a live head
-        const int hh = hlo + 4 * half;
+        // 32 x 32 tiles: slot = one accumulator register = heads hlo (lower half-wave) and hlo + 4 (upper) x 32 vertices; quad tiles: register r = heads r, 4 + r,
+        // 8 + r, 12 + r (one per 16 lanes) x 16 vertices
+        const int hlo = Q ? r : t * 32 + (r & 3) + 8 * (r >> 2);
+        if (h0 + hlo >= a.n) continue;           // wave-uniform: no lane has a live head
+        const int hh = Q ? 4 * kq + r : hlo + 4 * half;
         const float* const hp = s_hp + min(hh, NH - 1) * HP_SIZE;
-        const float px = s_xg[(0 * 16 + r) * 64 + lane], py = s_xg[(1 * 16 + r) * 64 + lane], pz = s_xg[(2 * 16 + r) * 64 + lane];
+        const float px = Q ? s_x[(0 * 4 + r) * 64 + lane] : s_xg[(0 * 16 + r) * 64 + lane], py = Q ? s_x[(1 * 4 + r) * 64 + lane] : s_xg[(1 * 16 + r) * 64 + lane],
+                    pz = Q ? s_x[(2 * 4 + r) * 64 + lane] : s_xg[(2 * 16 + r) * 64 + lane];
         float T[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) T[q] = 0.0f;
@@ -1304,9 +1352,9 @@ __global__ __launch_bounds__((3 * VG + NPW + NHL) * 64) void flame_c3_kernel(Ver
     C3MARK(4);
 }
 
-template <int NPW, int NHL, int VG = 1, int MT = 1>
+template <int NPW, int NHL, int VG = 1, int MT = 1, int Q = 0>
 int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
-    constexpr int NH = NPW > 0 ? NPW : 32 * MT, NW = 3 * VG + NPW + NHL;
+    constexpr int NH = NPW > 0 ? NPW : Q ? 16 : 32 * MT, NW = 3 * VG + NPW + NHL, VW = Q ? 16 : 32;
     const int ngmax = (va.Kp + 7) / 8;  // live groups <= all groups
     const int g0e = (va.r0_end + 7) >> 3;
     const int g1b = va.r1_end > va.r1_begin ? std::max(va.r1_begin >> 3, g0e) : g0e, g1e = va.r1_end > va.r1_begin ? std::max((va.r1_end + 7) >> 3, g1b) : g0e;
@@ -1319,15 +1367,15 @@ int launch_c3(const VertArgs& va, const PrepArgs& pa, hipStream_t st) {
     int dev = 0;
     VGH_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !attr_done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NPW, NHL, VG, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VGH_HIP(hipFuncSetAttribute((const void*)flame_c3_kernel<NPW, NHL, VG, MT, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev].store(1, std::memory_order_release);
     }
     if (lds > 160 * 1024) {
         vgh_set_error("flame c3 tiles: %zu bytes of LDS for %d coefficient rows", lds, nrows8);
         return VGH_ERR_INVALID;
     }
-    const int vblocks = ((va.V + 31) / 32 + VG - 1) / VG, hgroups = NPW > 0 ? 1 : (va.n + 32 * MT - 1) / (32 * MT);
-    hipLaunchKernelGGL((flame_c3_kernel<NPW, NHL, VG, MT>), dim3((vblocks + 7) / 8 * 8 * hgroups), dim3(NW * 64), lds, st, va, pa);
+    const int vblocks = ((va.V + VW - 1) / VW + VG - 1) / VG, hgroups = NPW > 0 ? 1 : Q ? (va.n + 15) / 16 : (va.n + 32 * MT - 1) / (32 * MT);
+    hipLaunchKernelGGL((flame_c3_kernel<NPW, NHL, VG, MT, Q>), dim3((vblocks + 7) / 8 * 8 * hgroups), dim3(NW * 64), lds, st, va, pa);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -1374,6 +1422,7 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         //  VALU kernel's 8-heads-per-basis-load reuse is ahead again; with a device-side count the launch is capacity-sized and mostly
         //  exits at once, so the tile count that matters is the live one)
         const int mode = g_flame_mode.load(std::memory_order_relaxed);
+        const int amode = (mode == 8 || mode == 9) ? 1 : mode;  // 8 / 9: the automatic choice with the quad tiles forced on / off
         const int npairs = ((detector_mode ? shape_live + expr_live : f->NB) + f->NP + 1) / 2;
         // crowd scale: operands staged through LDS (its k-pair table holds 256 entries: FLAME has 218; a model with more coefficients keeps the other kernels)
         // r04: 32-head blocks of the LDS-staged kernel (mode 5 only).  Hypothesis: the register-fed kernel keeps at most 63 dword loads (8 KB) in flight per wave
@@ -1381,8 +1430,8 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         // coefficients 63.0 / 64.5 us against 59.4 / 60.2 for the register-fed kernel -- the mid range is bound by its ~30 us of K-independent work (prologue
         // kernel, two launches, head-pack staging, per-head skinning epilogue), not by loads in flight.  Kept selectable (bit-identical), not automatic.
         const bool lds32 = even && npairs <= 248 && mode == 5;
-        const bool lds = lds32 || (even && npairs <= 248 && (mode == 3 || mode == 4 || (mode == 1 && !pa.n_dev && m >= kLdsMidHeads)));
-        const bool mfma = lds || (even && (mode == 2 || (mode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
+        const bool lds = lds32 || (even && npairs <= 248 && (mode == 3 || mode == 4 || (amode == 1 && !pa.n_dev && m >= kLdsMidHeads)));
+        const bool mfma = lds || (even && (mode == 2 || (amode == 1 && (pa.n_dev ? m <= 16384 : (m >= 5 && m < 2048)))));
         // c3 tiles (component-split waves, coefficient tile in LDS; K - NB pose features in one k-group run, NB a multiple of 8 so that the pose rows start a
         // group): mode 6 always with the prologue kernel, mode 7 the same with the fused variant (prologue waves inside the block) up to 8 heads.  Automatic
         // (measured, profiles/r04_flame_sweep.json; us per call, all 400 / L-live / M-live coefficients; old = the kernels above):
@@ -1393,7 +1442,7 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         // -> direct batches up to kC3MaxHeads; with a device-side count the launch is capacity-sized and the dead tile rows exit at once: any capacity the
         //    register-fed kernel took (the live count of a detector batch is a few hundred at most: 4-wave blocks up to a capacity of 128, 128-vertex blocks beyond).
         const bool c3_ok = even && f->K - f->NB <= 64 && (f->NB & 7) == 0 && f->basis8;
-        const bool c3_auto = mode == 1 && (pa.n_dev ? m <= 16384 : m <= kC3MaxHeads) && !(m <= 2 && npairs < 100);  // (1 - 2 heads of the M set: the VALU kernel)
+        const bool c3_auto = amode == 1 && (pa.n_dev ? m <= 16384 : m <= kC3MaxHeads) && !(m <= 2 && npairs < 100);  // (1 - 2 heads of the M set: the VALU kernel)
         const bool c3 = c3_ok && (mode == 6 || mode == 7 || c3_auto);
         const bool c3_fused = c3 && mode != 6 && !pa.n_dev && m <= 8 && (verts || proj);
         const bool fused = c3_fused || (!c3 && !mfma && !pa.n_dev && m <= 256);  // the vertex kernel computes its own heads' prologue
@@ -1453,7 +1502,22 @@ int run_decode_on(vgh_flame* f, const PrepArgs& pa_in, int n, int shape_live, in
         if (getenv("VGH_FLAME_ABLATE")) va.ablate = atoi(getenv("VGH_FLAME_ABLATE"));
 #endif
         int rc;
-        if (c3_fused) {
+        // quad tiles (16 x 16 x 4 MFMAs, r06): measured and NOT adopted -- bit-identical, but no faster at one head (14.8 vs 15.0 us, M set; 19.4 vs 19.7 with all 400
+        // coefficients) and 30 - 60 % slower from two heads on (profiles/r06_flame_quad_tiles.txt): a small decode is not its dependent MFMA chain long, it is the
+        // basis stream per wave.  Kept in the -DVGH_EXPERIMENTS build (mode 8 forces them up to 128 heads; mode 9 = mode 1 = without them).
+#ifdef VGH_EXPERIMENTS
+        const bool quad = c3 && mode == 8 && m <= 128;
+#else
+        const bool quad = false;
+#endif
+        if (false) {
+#ifdef VGH_EXPERIMENTS
+        } else if (c3_fused && quad) {
+            rc = m <= 1 ? launch_c3<1, 0, 1, 1, 1>(va, pa, st) : m <= 2 ? launch_c3<2, 0, 1, 1, 1>(va, pa, st) : m <= 4 ? launch_c3<4, 0, 1, 1, 1>(va, pa, st) : launch_c3<8, 0, 1, 1, 1>(va, pa, st);
+        } else if (c3 && quad && !c3_fused) {
+            rc = m <= 32 ? launch_c3<0, 5, 1, 1, 1>(va, pa, st) : launch_c3<0, 1, 1, 1, 1>(va, pa, st);
+#endif
+        } else if (c3_fused) {
             rc = m <= 1 ? launch_c3<1, 0>(va, pa, st) : m <= 2 ? launch_c3<2, 0>(va, pa, st) : m <= 4 ? launch_c3<4, 0>(va, pa, st) : launch_c3<8, 0>(va, pa, st);
         } else if (c3) {
             // one head tile: 3 + 5 waves; up to 96 heads: 3 + 1 (two blocks per CU; n = 112: 51.1 vs 50.1 us for the 128-vertex blocks); beyond: 128-vertex blocks of 12 compute waves (64-vertex blocks of 6 measured
@@ -1652,7 +1716,7 @@ int vgh_flame_set_trace(void* dev_buffer) {
 #endif
 
 int vgh_flame_set_matrix_path(int mode) {
-    VGH_REQUIRE(mode >= 0 && mode <= 7, "flame_set_matrix_path: mode %d outside 0..7", mode);
+    VGH_REQUIRE(mode >= 0 && mode <= 9, "flame_set_matrix_path: mode %d outside 0..9", mode);
     g_flame_mode.store(mode, std::memory_order_relaxed);
     return VGH_OK;
 }

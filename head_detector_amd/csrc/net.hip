@@ -32,6 +32,9 @@ struct NetOp {
     // pixel's first ones; vgh_net_create has verified that every weight row is exactly zero there (finite x 0 adds +-0 to the accumulator)
     int overhang_ok = 0;
     float* gscale = nullptr;  // device [cout_pad]: per-cout output factors of an op that reads or writes a VGH_FMT_FP8 buffer (conv_pp.hip), else nullptr
+    // back-to-back GEMM (r06, conv_kernels.inc T2 > 0): b2b = 1: this conv and the NEXT op (a 1x1 / stride-1 conv, the only reader of this conv's output tensor) run as ONE
+    // launch that never writes the tensor in between; b2b = 2: this op is that second conv (nothing to launch when the net fuses)
+    int b2b = 0;
     float* dvec = nullptr;    // device [cout_pad]: the diagonal bypass of an int8 -> bf16 conv whose rows are dominated by w[c][centre][c] (i8_peel_diag), else nullptr
 };
 
@@ -81,6 +84,7 @@ struct vgh_net {
     // stem + stage-1 downsample as ONE kernel (stem_ds.hip: the 48-channel stem activation stays in LDS): index of the stem op when the pair
     // qualifies (bf16 mode, the architecture's 3x3 / stride-2 / 64 -> 96 conv as the stem tensor's only reader), else -1; results are bit-identical
     int stem_pair = -1;
+    int fuse_b2b = 1;   // vgh_net_set_b2b: the back-to-back pairs found at create time run fused (default) or as their two launches (every intermediate tensor then exists)
     int fuse_stem = 0;  // opt-in (vgh_net_set_fuse_stem): measured r03, the fused kernel saves 1.5 GB of HBM traffic per L b64 forward but no time (EXPERIMENTS.md 8c)
 };
 
@@ -178,9 +182,26 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
         }
         case VGH_OP_CONV: {
             if (fused && op_index == n->stem_pair + 1) return VGH_OK;  // ran inside the stem's launch
+            if (n->fuse_b2b && op.b2b == 2) return VGH_OK;             // ran inside the previous conv's launch
             ConvArgs a;
             if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
             a.grid_share = share;
+            if (n->fuse_b2b && op.b2b == 1) {
+                const NetOp& nx = n->ops[op_index + 1];
+                ConvArgs a2;
+                if (int rc = net_conv_args(n, nx, B, at, &a2)) return rc;
+                a.w2pack = a2.wpack;
+                a.bias2 = a2.bias;
+                a.out2 = a2.out;
+                a.out2_pitch = a2.out_pitch;
+                a.out2_coff = a2.out_coff;
+                a.out2_coff2 = a2.out_coff2;
+                a.out2_split = a2.out_split;
+                a.cout2_pad = a2.cout_pad;
+                a.cout2_store = a2.cout_store;
+                a.act2 = a2.act;
+                return vgh_launch_conv_b2b(a, st);
+            }
             if (n->bufs[d.in_buf].is_f32 != VGH_FMT_F32) {
                 a.fallback_cfg1 = op.auto_cfg + 1;
                 return vgh_launch_conv(a, d.force_cfg >= 0 ? d.force_cfg : op.auto_cfg, st);
@@ -483,6 +504,25 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
         }
         op.auto_cfg = vgh_conv_pick_auto(ref);
     }
+    // back-to-back pairs (r06): a plain bf16 conv whose whole output tensor -- all of its channels in ONE cout tile -- is read by exactly one op, the next one, a plain
+    // 1x1 / stride-1 bf16 conv (the architecture's stage downsample -> the CSP layer's merged conv1|conv2); nothing else touches that tensor
+    for (int i = 0; i + 1 < (int)n->ops.size(); ++i) {
+        const vgh_op_desc &a = n->ops[i].d, &b = n->ops[i + 1].d;
+        if (a.kind != VGH_OP_CONV || b.kind != VGH_OP_CONV) continue;
+        const vgh_buf_desc &ab = n->bufs[a.out_buf], &ai = n->bufs[a.in_buf], &bo = n->bufs[b.out_buf];
+        bool ok = ab.is_f32 == VGH_FMT_BF16 && ai.is_f32 == VGH_FMT_BF16 && bo.is_f32 == VGH_FMT_BF16 && vgh_conv_b2b_ok(a.ksize, a.stride, a.cout_pad, b.cout_pad) && a.cout_store == a.cout_pad &&
+                  a.out_coff == 0 && a.out_split >= a.cout_pad && ab.pitch == a.cout_pad && a.res_buf < 0 && !a.shuffle && !a.grp_cout && a.act != VGH_ACT_SILU && b.ksize == 1 && b.stride == 1 &&
+                  b.in_buf == a.out_buf && b.in_coff == 0 && b.cin == a.cout_pad && b.res_buf < 0 && !b.shuffle && !b.grp_cout && b.act != VGH_ACT_SILU && b.out_coff % 8 == 0 && b.out_coff2 % 8 == 0 &&
+                  b.out_split % 8 == 0 && b.cout_store % 8 == 0 && bo.pitch % 8 == 0 && n->ops[i].b2b == 0;
+        for (int j = 0; ok && j < (int)n->ops.size(); ++j) {
+            const vgh_op_desc& o = n->ops[j].d;
+            if (j != i && j != i + 1 && (o.kind == VGH_OP_CONV || o.kind == VGH_OP_SPP_POOL) && (o.in_buf == a.out_buf || o.out_buf == a.out_buf || o.res_buf == a.out_buf)) ok = false;
+        }
+        if (ok) {
+            n->ops[i].b2b = 1;
+            n->ops[i + 1].b2b = 2;
+        }
+    }
     *out = n;
     return VGH_OK;
 }
@@ -647,6 +687,20 @@ int vgh_net_set_pred_guard(vgh_net* n, void* event) {
     VGH_REQUIRE(n, "net_set_pred_guard: null handle");
     n->pred_guard = (hipEvent_t)event;
     return VGH_OK;
+}
+
+// Back-to-back GEMM pairs (a stage's downsample + the CSP layer's conv1|conv2 behind it) as one launch each (default) or as two: the outputs are the same bits; unfused,
+// every intermediate tensor of the program exists in the arena (what the per-op parity tests read)
+int vgh_net_set_b2b(vgh_net* n, int enable) {
+    VGH_REQUIRE(n, "net_set_b2b: null handle");
+    n->fuse_b2b = enable ? 1 : 0;
+    return VGH_OK;
+}
+int vgh_net_b2b_pairs(vgh_net* n) {
+    int k = 0;
+    if (n)
+        for (const NetOp& op : n->ops) k += op.b2b == 1;
+    return k;
 }
 
 int vgh_net_max_batch(vgh_net* n) { return n ? n->max_batch : 0; }

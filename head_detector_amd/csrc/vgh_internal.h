@@ -83,6 +83,12 @@ struct ConvArgs {
     float bias_scale;  // fp16 ping-pong variant: 1 / out_scale (set by vgh_launch_conv_pp)
     int fallback_cfg1;  // 0: a forced tile that cannot run this conv is an error; k + 1: it falls back to tile k (network executor: a table may be stale)
     int nt_out;          // bf16 output stores carry the non-temporal hint (set by vgh_conv_prepare from vgh_conv_set_nt_store)
+    // ---- back-to-back GEMM (r06, conv_kernels.inc T2 > 0): this conv's output tile feeds a 1x1 / stride-1 conv inside the same launch; only that conv's output is stored ----
+    const uint16_t* w2pack;  // the second conv's packed weights [cout_pad / 32][cout2_pad][32] (vgh_pack_conv_weights_host), or nullptr
+    const float* bias2;      // [cout2_pad]
+    void* out2;              // the second conv's output tensor (bf16 NHWC), pitch / offsets / split / stored channels as for `out`
+    int64_t out2_pitch;
+    int out2_coff, out2_coff2, out2_split, cout2_pad, cout2_store, act2;
     int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
     unsigned long long* trace;  // -DVGH_EXPERIMENTS builds only: per-(block, tile) phase timestamps (s_memtime), or nullptr
 };
@@ -105,6 +111,9 @@ struct ConvArgs {
 #endif
 
 int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);
+// conv_igemm.hip: `a` with its b2b fields set (w2pack ...): the fused launch, or VGH_ERR_INVALID when the pair does not fit a b2b tile (vgh_conv_b2b_ok says so beforehand)
+int vgh_launch_conv_b2b(const ConvArgs& a, hipStream_t stream);
+int vgh_conv_b2b_ok(int ksize, int stride, int cout_pad, int cout2_pad);
 int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);  // conv_split.hip: a.split = VGH_FMT_BF16X2 / VGH_FMT_F16X2
 // dense [cout_pad][ks][ks][cin] f32 -> the three-segment 16-bit image [w_lo | w_hi | w_hi] (each segment laid out like
 // vgh_pack_conv_weights_host); fmt = VGH_FMT_BF16X2 / VGH_FMT_F16X2.  Returns through *out_scale the factor the kernel multiplies the

@@ -188,7 +188,8 @@ class HeadDetector:
                 # the letterboxed u8 canvases the network will see (detector.py:40-52), as one batch
                 calib = torch.cat([self._transform_image(self._convert_image(im))[0] for im in self._calibration_images]).contiguous()
             else:
-                pass  # VGHeadsEngine warns (two seeded random images: plumbing only)
+                warnings.warn(f"HeadDetector(precision={self._precision!r}) without calibration_images: the 8-bit links are scaled for two seeded RANDOM images -- pass images like the ones you will detect on",
+                              stacklevel=3)
         return VGHeadsEngine(model, state_dict=sd, image_size=self._image_size, max_batch=self._max_batch, seed=seed, precision=self._precision, calib_images=calib)
 
     # ---- host-side image handling (detector.py:32-56) ----------------------------------------------------

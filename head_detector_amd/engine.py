@@ -125,6 +125,8 @@ class VGHeadsEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.vgh_net_create(self.device_index, image_size, self.arena_batch, bufs, len(P.bufs), ops, len(P.ops), _lib.ptr(w), w.size, _lib.ptr(b), b.size, C.byref(h)))
         self._net = h
+        if int(self.lib.vgh_net_b2b_pairs(h)) != len(arch.b2b_pairs(P)):  # (the PMC tools and the algorithmic-bytes accounting use the Python predicate)
+            raise _lib.VghError(f"back-to-back pairs: the library found {int(self.lib.vgh_net_b2b_pairs(h))}, arch.b2b_pairs {len(arch.b2b_pairs(P))}")
         self.stream = torch.cuda.Stream(device=self.device)
         self.A = sum(lv["h"] * lv["w"] for lv in P.levels)
         self.pre_k, self.keep_k = min(pre_nms_top_k, self.A), keep_top_k
@@ -262,6 +264,16 @@ class VGHeadsEngine:
         self.nsplit = int(nsplit)
         if self._use_tuning:
             self.load_tuning()  # the table may hold tile choices measured in this split mode
+
+    def set_b2b(self, enable: bool = True):
+        """vgh_net_set_b2b (r06): a stage's downsample and the conv1|conv2 behind it as ONE back-to-back-GEMM launch (default) or as their two launches -- the same
+        output bits; unfused, the tensor between them exists in the arena (per-op inspection).  ``b2b_pairs``: how many such pairs the program has."""
+        _lib.check(self.lib.vgh_net_set_b2b(self._net, int(bool(enable))))
+        self._graph_key = None
+
+    @property
+    def b2b_pairs(self) -> int:
+        return int(self.lib.vgh_net_b2b_pairs(self._net))
 
     def set_fuse_stem(self, enable: bool = True):
         """EXPERIMENTS build only (VGH_LIB_PATH=libvgh_exp.so; r06): stem + stage-1 downsample as one kernel (csrc/stem_ds.hip: less HBM traffic, same time --

@@ -117,6 +117,12 @@ int vgh_net_set_cfg(vgh_net* net, int op_index, int cfg);
  * latency, epilogue store burst, tail -- of one sub-batch hides under the main loops of the others.  Results are identical
  * (images are independent; every op keeps its tile configuration). */
 int vgh_net_set_split(vgh_net* net, int nsplit);
+/* r06: BACK-TO-BACK GEMM.  A conv whose whole output (all channels in one 96-cout tile) is read by exactly one op -- the 1x1 conv behind it: a backbone stage's downsample
+ * and the CSP layer's merged conv1|conv2 -- runs with that op as ONE launch: the first conv's accumulators become, in registers, the B operands of the second GEMM, and the
+ * tensor between them is never written (csrc/conv_kernels.inc, T2 > 0).  vgh_net_create finds the pairs; they run fused by default.  enable = 0: the two launches (the same
+ * output bits; the intermediate tensor then exists in the arena, as the per-op parity tests need).  vgh_net_b2b_pairs: how many pairs the program has. */
+int vgh_net_set_b2b(vgh_net* net, int enable);
+int vgh_net_b2b_pairs(vgh_net* net);
 int vgh_net_max_batch(vgh_net* net);  /* images the activation arena was planned for */
 int vgh_net_image_size(vgh_net* net);
 

@@ -468,32 +468,6 @@ def test_conv_stream_tiles_multi_tile(gpu_lib, cin, cout, cap):
     assert tested >= 2
 
 
-@pytest.mark.parametrize("cin,H,W", [(64, 41, 57), (96, 40, 64), (32, 33, 35)])
-def test_conv_stride2_patch_tiles_multi_tile(gpu_lib, cin, H, W):
-    """Stride-2 halo-patch tiles ("d": the input patch de-interleaved into four parity planes in LDS) with many tiles per persistent workgroup: odd and
-    even input sizes (the last input row / column is or is not read), ragged output tiles, every cout tile width, all image borders zero-padded."""
-    g = torch.Generator().manual_seed(7 * cin + H)
-    B, Cout = 3, 384
-    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).float()
-    Wt = torch.randn(Cout, 3, 3, cin, generator=g) * (1.5 / np.sqrt(9 * cin)) * (1.0 + 0.5 * torch.arange(Cout).float()[:, None, None, None] / Cout)
-    b = torch.randn(Cout, generator=g)
-    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
-    tested = 0
-    try:
-        for cap in (2, 0):
-            assert gpu_lib.vgh_conv_set_max_blocks_per_xcd(cap) == 0
-            for cfg, name in enumerate(names):
-                if name[0] != "d" or not gpu_lib.vgh_conv_cfg_ok(cfg, 3, 2, Cout, 1, 0):
-                    continue
-                out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 2, cfg=cfg)
-                _assert_close(out[..., o0 : o0 + st], ref[..., :st], False, f"stride-2 patch cfg={name} cap={cap} cin={cin} {H}x{W}")
-                assert float((out[..., :o0] + 768.0).abs().max()) == 0.0 and float((out[..., o0 + st :] + 768.0).abs().max()) == 0.0, f"{name}: wrote outside its channels"
-                tested += 1
-    finally:
-        gpu_lib.vgh_conv_set_max_blocks_per_xcd(0)
-    assert tested >= 8
-
-
 def test_conv_silu_epilogue(gpu_lib):
     """VGH_ACT_SILU (north_star's "BN/SiLU fusion"; the VGGHeads graphs themselves are all-ReLU): x * sigmoid(x) with the hardware
     exp (__expf, ~2 ulp fp32 -- far below the bf16 output rounding, and within 1e-6 relative on the fp32 store path) in every
@@ -589,6 +563,7 @@ def test_network_every_op(gpu_lib, variant, S, B):
     from head_detector_amd.engine import VGHeadsEngine
 
     eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=7, use_tuning=False)
+    eng.set_b2b(False)  # every op as its own launch: every intermediate tensor exists (the fused back-to-back pairs: test_b2b_pairs_equal_their_two_launches)
     P = eng.program
     x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(2))
     eng.forward_net(x.to(_dev()))
@@ -611,6 +586,47 @@ def test_network_every_op(gpu_lib, variant, S, B):
     eng.close()
 
 
+@pytest.mark.parametrize("variant,S,B,tuned", [("vgg_heads_l", 160, 3, False), ("vgg_heads_m", 256, 2, False), ("vgg_heads_l", 640, 5, True), ("vgg_heads_m", 224, 7, True)])
+def test_b2b_pairs_equal_their_two_launches(gpu_lib, variant, S, B, tuned):
+    """Back-to-back GEMM (r06, csrc/conv_kernels.inc T2 > 0): a stage's downsample and the CSP layer's conv1|conv2 behind it as ONE launch -- the
+    first conv's accumulators become the second GEMM's B operands in registers, the 96-channel tensor between them is never written.  Against the two launches it
+    replaces: the second conv's output tensor, every later tensor and the network's outputs are THE SAME BITS (same k order, same roundings: the fragment a lane builds
+    is byte for byte what it would have read back), the tensor in between stays untouched (zeros), for a pixel count that is not a multiple of the 128-pixel tile,
+    with and without batch-split lanes, L (192 fused output channels) and M (128; M also has a 1x1 -> 1x1 pair in its neck)."""
+    from head_detector_amd import arch
+    from head_detector_amd.engine import VGHeadsEngine
+
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=11, use_tuning=tuned)
+    P = eng.program
+    pairs = arch.b2b_pairs(P)
+    assert eng.b2b_pairs == len(pairs) >= 1 and P.ops[pairs[0]]["name"] == "backbone.stage1.downsample"
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(S)).to(_dev())
+    outs = {}
+    for fused in (False, True):
+        eng.set_b2b(fused)
+        for ns in (1, 2):
+            eng.set_split(ns)
+            res = [t.clone() for t in eng.model(x)]
+            bufs = {i: eng.buffer(P.ops[i + 1]["out_buf"], B).clone() for i in pairs}
+            outs[(fused, ns)] = (res, bufs)
+    mid = eng.buffer(P.ops[pairs[0]]["out_buf"], B)
+    assert float(mid.float().abs().max()) > 0  # (the unfused runs above wrote it)
+    for ns in (1, 2):  # (a tuned engine may run other tiles -- other summation orders -- with two lanes than with one: fused against unfused at the SAME lane count)
+        ref, (res, bufs) = outs[(False, ns)], outs[(True, ns)]
+        for a, b in zip(res, ref[0]):
+            assert torch.equal(a, b), ns
+        for i in pairs:
+            assert float(bufs[i].float().abs().max()) > 0 and torch.equal(bufs[i], ref[1][i]), (ns, P.ops[i]["name"])
+    ref = outs[(False, 1)]
+    eng.close()
+    # a fresh engine that only ever ran fused: the tensor between the two convs is never written
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=11, use_tuning=tuned)
+    res = eng.model(x)
+    assert all(torch.equal(a, b) for a, b in zip(res, ref[0]))
+    assert float(eng.buffer(P.ops[pairs[0]]["out_buf"], B).float().abs().max()) == 0.0
+    eng.close()
+
+
 def test_stem_tensor_at_its_48_channel_pitch(gpu_lib, monkeypatch):
     """bf16 mode (r04): the stem tensor is stored as 96-byte pixels and the stage-1 downsample reads 64-channel K windows over it -- the last 16 channels of
     a window are the next pixel's first 16 and meet all-zero weight columns.  (i) the stem buffer holds the 48 channels of the fp32 reference, nothing else;
@@ -622,6 +638,7 @@ def test_stem_tensor_at_its_48_channel_pitch(gpu_lib, monkeypatch):
     S, B = 160, 3
     sd = arch.random_state_dict("vgg_heads_l", 5)
     eng = VGHeadsEngine("vgg_heads_l", state_dict=sd, image_size=S, max_batch=B, use_tuning=False)
+    eng.set_b2b(False)  # (ii) reads the stage-1 downsample's own output tensor
     P = eng.program
     assert P.bufs[0]["pitch"] == 48 and P.ops[0]["cout_store"] == 48 and P.ops[1]["cin"] == 64
     g = torch.Generator().manual_seed(11)
@@ -658,6 +675,7 @@ def test_u8_nhwc_input_equals_f32_nchw(gpu_lib):
 
     S = 128
     eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=1, seed=3, use_tuning=False)
+    eng.set_b2b(False)
     u8 = torch.randint(0, 256, (1, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
     f = (u8.permute(0, 3, 1, 2).float() / 255.0).contiguous()
     for name in ("stem", "backbone.stage1.ds"):  # the stem kernel's own output, and the first conv behind it
@@ -1458,7 +1476,7 @@ def test_c_only_create_and_detect(gpu_lib, flame_model, tmp_path):
     assert gpu_lib.vgh_create(C.byref(bad), C.byref(h)) != 0 and b"not a readable" in gpu_lib.vgh_last_error()
 
 
-@pytest.mark.parametrize("n,live", [(1, (128, 64)), (2, (300, 100)), (3, (64, 32)), (4, (128, 64)), (7, (300, 100)), (8, (128, 64)), (5, (128, 64)), (12, (64, 32)), (33, (128, 64)), (100, (300, 100)), (191, (128, 64)), (192, (300, 100)), (255, (128, 64)), (256, (300, 100)), (257, (128, 64)), (1023, (128, 64)),
+@pytest.mark.parametrize("n,live", [(1, (128, 64)), (2, (300, 100)), (3, (64, 32)), (4, (128, 64)), (7, (300, 100)), (8, (128, 64)), (5, (128, 64)), (12, (64, 32)), (16, (128, 64)), (17, (300, 100)), (32, (64, 32)), (33, (128, 64)), (100, (300, 100)), (128, (128, 64)), (191, (128, 64)), (192, (300, 100)), (255, (128, 64)), (256, (300, 100)), (257, (128, 64)), (1023, (128, 64)),
                                     (1024, (300, 100)), (1300, (64, 32)), (1100, (300, 100))])
 def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame_model, n, live):
     """The FP32-MFMA vertex kernels (v_mfma_f32_32x32x2_f32 = an exact k-ordered fmaf chain; register-fed for small / medium batches,
@@ -1474,12 +1492,12 @@ def test_flame_matrix_core_kernel_is_bit_identical_to_valu_kernel(gpu_lib, flame
     unpad = torch.tensor([[3.0, 7.0, 1.3]], device=_dev()).expand(n, 3).contiguous()
     outs = {}
     try:
-        for mode in (1, 0, 2, 3, 4, 5, 6, 7):
+        for mode in (1, 0, 2, 3, 4, 5, 6, 7, 8, 9):  # 8 / 9 (r06): the 16 x 16 x 4 quad tiles forced on (experiments build; measured slower, profiles/r06_flame_quad_tiles.txt) / off; = 1 in the product library
             assert gpu_lib.vgh_flame_set_matrix_path(mode) == 0
             outs[mode] = [t.clone() for t in fl.decode(p, unpad=unpad, shape_live=live[0], expr_live=live[1])]
     finally:
         gpu_lib.vgh_flame_set_matrix_path(1)
-    for mode in (1, 2, 3, 4, 5, 6, 7):
+    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         for a, b in zip(outs[mode], outs[0]):
             assert torch.equal(a, b), mode
     _, _, q = fo.reproject(fo.FlameConstants(flame_model, torch.float64), p.cpu().double())

@@ -23,6 +23,14 @@ disp = [by[k] for k in sorted(by)]
 P = arch.build_program(variant, arch.random_state_dict(variant, 1), 640)
 ops = list(P.ops)
 per = len(disp) // forwards
+pairs = arch.b2b_pairs(P)
+if per == len(ops) - len(pairs) and pairs:  # the back-to-back pairs ran as one launch each (the engine's default): one row per launch, both convs' FLOPs
+    merged = []
+    for i, op in enumerate(ops):
+        if i - 1 in pairs:
+            continue
+        merged.append(dict(op, name=op["name"] + " + " + ops[i + 1]["name"].split(".")[-1], macs=op["macs"] + ops[i + 1]["macs"]) if i in pairs else op)
+    ops = merged
 assert per == len(ops), (per, len(ops))
 print(f"# {variant} batch {batch}, one lane, mean of {forwards} forwards: MFMA-busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) per dispatch", file=out)
 print(f"# ideal = the op's algorithmic MFMA cycles (FLOPs / 32768 per v_mfma_f32_32x32x16_bf16 * 32 cycles) over the same denominator: busy above ideal = padded or re-computed work", file=out)

@@ -32,6 +32,15 @@ P = arch.build_program(variant, arch.random_state_dict(variant, 1), 640)
 ops = [op for op in P.ops]
 fr, wr = load("FETCH_SIZE"), load("WRITE_SIZE")
 per = len(fr) // forwards
+pairs = arch.b2b_pairs(P)
+fused = per == len(ops) - len(pairs) and pairs  # the back-to-back pairs ran as one launch each (the engine's default): one row per launch
+if fused:
+    merged = []
+    for i, op in enumerate(ops):
+        if i - 1 in pairs:
+            continue
+        merged.append(dict(op, name=op["name"] + " + " + ops[i + 1]["name"].split(".")[-1], _second=ops[i + 1]) if i in pairs else op)
+    ops = merged
 assert per == len(ops) and len(wr) == len(fr), (per, len(ops), len(wr))
 tot = [0.0] * 4
 print(f"# {variant} batch {batch}: HBM bytes per op, mean of {forwards} forwards (MB); excess = measured - algorithmic", file=out)
@@ -39,6 +48,10 @@ print(f"{'op':44s} {'alg_rd':>8s} {'rd':>8s} {'alg_wr':>8s} {'wr':>8s} {'excess'
 table = []
 for i, op in enumerate(ops):
     a = arch.op_algorithmic_bytes(P, op, batch)
+    if "_second" in op:  # a fused pair: the first conv's input + weights in, the second conv's weights in and output out; the tensor between them does not exist
+        a2 = arch.op_algorithmic_bytes(P, op["_second"], batch)
+        ib2 = P.bufs[op["_second"]["in_buf"]]
+        a = dict(read=a["read"] + a2["read"] - batch * ib2["h"] * ib2["w"] * op["_second"]["cin"] * 2, write=a2["write"])
     rd = sum(float(fr[f * per + i]["Counter_Value"]) for f in range(forwards)) * 2048 / forwards
     w = sum(float(wr[f * per + i]["Counter_Value"]) for f in range(forwards)) * 1024 / forwards
     k = fr[i]["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")

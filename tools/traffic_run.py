@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--forwards", type=int, default=8)
     ap.add_argument("--split", type=int, default=2)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--b2b", type=int, default=1, help="0: the back-to-back pairs as two launches each (one dispatch per op: what the per-op PMC tools expect)")
     ap.add_argument("--knob", action="append", default=[], help="process-wide library knob, e.g. vgh_conv_set_nt_store=1")
     args = ap.parse_args()
     import torch
@@ -36,13 +37,15 @@ def main():
         _lib.check(getattr(_lib.load(), name)(int(val)))
     eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, seed=1, precision=args.precision)
     eng.set_split(args.split)
+    eng.set_b2b(bool(args.b2b))
     x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
     for _ in range(args.forwards):
         eng.forward_net(x)
     torch.cuda.synchronize()
-    alg = arch.program_algorithmic_bytes(eng.program, args.batch)
+    alg = arch.program_algorithmic_bytes(eng.program, args.batch, b2b=bool(args.b2b))
     print(json.dumps(dict(variant=args.variant, batch=args.batch, forwards=args.forwards, split=args.split, precision=args.precision,
-                          ops_per_forward=sum(1 for op in eng.program.ops if op["kind"] in (0, 1, 2)), algorithmic_read_bytes=alg["read"], algorithmic_write_bytes=alg["write"])))
+                          ops_per_forward=sum(1 for op in eng.program.ops if op["kind"] in (0, 1, 2)) - (eng.b2b_pairs if args.b2b else 0), b2b_pairs=eng.b2b_pairs if args.b2b else 0,
+                          algorithmic_read_bytes=alg["read"], algorithmic_write_bytes=alg["write"])))
     eng.close()
 
 
