@@ -512,9 +512,9 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
 
 // ---- back-to-back GEMM (conv_kernels.inc, T2 > 0): a conv whose 96 output channels fit ONE cout tile, fused with the 1x1 conv that is its only reader ----
 namespace {
-template <int T2>
+template <int T2, int NST>
 int launch_b2b_96(const ConvArgs& a, hipStream_t st) {
-    constexpr int BP = 128, BC = 96, WP = 32, WC = 96, KBS = 1, NST = 2;
+    constexpr int BP = 128, BC = 96, WP = 32, WC = 96, KBS = 1;
     constexpr int lds0 = lds_bytes(BP, BC, WP, WC, KBS, NST), w2 = 3 * T2 * 2048;
     constexpr int lds = lds0 > w2 ? lds0 : w2;
     static_assert(lds <= 64 * 1024, "b2b: within the default dynamic-LDS limit");
@@ -524,6 +524,15 @@ int launch_b2b_96(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, 0, T2>), dim3(chunk * 8), dim3((BP / WP) * 64), lds, st, a, 1, (int)total, chunk);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
+}
+template <int T2>
+int launch_b2b_96_any(const ConvArgs& a, hipStream_t st) {
+#ifdef VGH_EXPERIMENTS
+    static const int nst = getenv("VGH_B2B_NST") ? atoi(getenv("VGH_B2B_NST")) : 2;
+    if (nst == 4) return launch_b2b_96<T2, 4>(a, st);
+    if (nst == 3) return launch_b2b_96<T2, 3>(a, st);
+#endif
+    return launch_b2b_96<T2, 2>(a, st);
 }
 }  // namespace
 
@@ -542,7 +551,7 @@ int vgh_launch_conv_b2b(const ConvArgs& a0, hipStream_t stream) {
                 "conv b2b: plain bf16 convs with ReLU / no activation only");
     VGH_REQUIRE(a.out2_pitch % 8 == 0 && a.out2_coff % 8 == 0 && a.out2_coff2 % 8 == 0 && a.out2_split % 8 == 0 && a.cout2_store % 8 == 0 && a.cout2_store <= a.cout2_pad,
                 "conv b2b: the second output needs 16-byte aligned channel offsets");
-    return a.cout2_pad == 256 ? launch_b2b_96<8>(a, stream) : a.cout2_pad == 192 ? launch_b2b_96<6>(a, stream) : launch_b2b_96<4>(a, stream);
+    return a.cout2_pad == 256 ? launch_b2b_96_any<8>(a, stream) : a.cout2_pad == 192 ? launch_b2b_96_any<6>(a, stream) : launch_b2b_96_any<4>(a, stream);
 }
 
 void vgh_pack_conv_weights_host(const float* w, int cout_pad, int ksize, int cin, uint16_t* dst) {
