@@ -741,6 +741,52 @@ def op_algorithmic_bytes(P: "Program", op: dict, batch: int) -> Dict[str, float]
     return dict(read=float(rd), write=float(wr))
 
 
+def schedule_latency(P: "Program") -> "Program":
+    """Single-image latency (r06; HeadDetector.__call__ is the reference's API shape, head_detector/detector.py:97-102): at batch 1 the network is a chain of ~133
+    launches of 5 - 20 us each with the chip mostly idle (profiles/r06_latency_trace_l1.txt), and the three detection heads -- 39 launches, ~440 us -- depend on nothing
+    but their own pyramid level.  This pass (i) moves each head's ops right behind the op that produces its level (p3 is ready before neck3 / neck4 run), and (ii) puts
+    them on the executor's lane streams with EXACT dependencies: `lane` = stream index | (1 + index of the ONE op this op waits for) << 8 (csrc/net.hip records an event
+    behind that op and makes this op's stream wait for it).  Per head: [stems -> towers -> box / score predictions -> transform branch] on one lane, [FLAME layer 0 ->
+    shape branch] on a second, [expression branch] on a third; heads 1 and 2 use the three side lanes while the neck goes on on the caller's stream, head 3 starts on
+    it.  Same kernels, same tiles, same bits; the order of P.ops stays a valid serial order (the batch-split executor and the per-op profiler run it as such)."""
+    ops = P.ops
+    if any(op["kind"] == 3 for op in ops):
+        return P  # already forked (head_lanes)
+    heads = {lv: [op for op in ops if op["name"].startswith(f"heads.head{lv + 1}.")] for lv in range(3)}
+    anchors = {0: "neck.neck2.blocks.conv3", 1: "neck.neck3.blocks.conv3", 2: "neck.neck4.blocks.conv3"}
+    if not all(heads.values()) or not all(any(op["name"] == a for op in ops) for a in anchors.values()):
+        return P
+    new: List[dict] = []
+    for op in ops:
+        if op["name"].startswith("heads."):
+            continue
+        new.append(op)
+        for lv, a in anchors.items():
+            if op["name"] == a:
+                new += heads[lv]
+    pos = {op["name"]: i for i, op in enumerate(new)}
+    for lv in range(3):
+        p = f"heads.head{lv + 1}"
+        la, lb, lc = (1, 2, 3) if lv < 2 else (0, 1, 2)
+        stem, f0 = f"{p}.pose_stem|bbox_stem", f"{p}.flame_*_pred.0"
+        seen_first = set()
+        for op in heads[lv]:
+            n = op["name"]
+            if n in (stem, f"{p}.cls_convs|reg_convs", f"{p}.reg_pred|cls_pred"):
+                lane, dep, br = la, (anchors[lv] if n == stem else None), None
+            elif n == f0:
+                lane, dep, br = lb, stem, None
+            else:
+                br = "shape" if ".flame_shape_pred." in n else "expr" if ".flame_expression_pred." in n else "tr"
+                lane = {"shape": lb, "expr": lc, "tr": la}[br]
+                # the first layer of a branch that does not share FLAME layer 0's lane waits for it (the ungrouped fp32 program has four transform ops per layer: each first one)
+                first = n.rsplit(".", 1)[-1] == "1"
+                dep = f0 if (first and lane != lb) else None
+            op["lane"] = lane | (((pos[dep] + 1) << 8) if dep is not None and (new[pos[dep]].get("lane", 0) & 0xFF) != lane else 0)
+    P.ops = new
+    return P
+
+
 def b2b_pairs(P: "Program") -> List[int]:
     """Indices i of the ops the executor runs with op i + 1 as ONE back-to-back-GEMM launch (csrc/net.hip, vgh_net_create; r06): a plain bf16 conv with all of its 96
     output channels in one tile whose whole output tensor is read by exactly one op, the next one, a plain 1x1 / stride-1 bf16 conv with 128, 192 or 256 output channels.

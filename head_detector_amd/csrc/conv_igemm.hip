@@ -305,6 +305,12 @@ const CfgEntry g_cfgs[] = {
     SCFG(128),  // 128
     SCFG(96),   // 129
     SCFG(64),   // 130
+    // 192-cout tiles (r06): the stride-2 3x3 layers with 192 couts ran two 96-cout tiles per pixel tile, i.e. loaded every activation k-block twice; what bounds the
+    // implicit-GEMM family below the MFMA rate is the bytes a CU pulls through its LDS-DMA path (~12 - 16 B / clk / CU measured against 64 nominal), so flop per byte counts
+    CFG(256, 192, 64, 96, 1),      // 131  8 waves x (64 px x 96)
+    CFGR(256, 192, 64, 96, 1, 3),  // 132
+    CFG(128, 192, 32, 96, 1),      // 133  8 waves x (32 px x 96)
+    CFGR(128, 192, 32, 96, 1, 3),  // 134
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };

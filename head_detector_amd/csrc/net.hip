@@ -35,6 +35,9 @@ struct NetOp {
     // back-to-back GEMM (r06, conv_kernels.inc T2 > 0): b2b = 1: this conv and the NEXT op (a 1x1 / stride-1 conv, the only reader of this conv's output tensor) run as ONE
     // launch that never writes the tensor in between; b2b = 2: this op is that second conv (nothing to launch when the net fuses)
     int b2b = 0;
+    // exact cross-lane dependencies (r06, arch.schedule_latency): vgh_op_desc.lane = lane | (1 + producer op index) << 8.  ev_done: recorded behind this op when a later op
+    // on ANOTHER lane names it as its producer (created at vgh_net_create), else nullptr
+    hipEvent_t ev_done = nullptr;
     float* dvec = nullptr;    // device [cout_pad]: the diagonal bypass of an int8 -> bf16 conv whose rows are dominated by w[c][centre][c] (i8_peel_diag), else nullptr
 };
 
@@ -504,6 +507,21 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
         }
         op.auto_cfg = vgh_conv_pick_auto(ref);
     }
+    // events of the ops that a later op on another lane waits for (arch.schedule_latency)
+    for (int i = 0; i < (int)n->ops.size(); ++i) {
+        const int dep = (n->ops[i].d.lane >> 8) - 1;
+        if (dep < 0) continue;
+        if (dep >= i) {
+            vgh_net_destroy(n);
+            vgh_set_error("net_create: op %d waits for op %d, which does not precede it", i, dep);
+            return VGH_ERR_INVALID;
+        }
+        if (!n->ops[dep].ev_done && hipEventCreateWithFlags(&n->ops[dep].ev_done, hipEventDisableTiming) != hipSuccess) {
+            vgh_net_destroy(n);
+            vgh_set_error("net_create: hipEventCreate failed");
+            return VGH_ERR_HIP;
+        }
+    }
     // back-to-back pairs (r06): a plain bf16 conv whose whole output tensor -- all of its channels in ONE cout tile -- is read by exactly one op, the next one, a plain
     // 1x1 / stride-1 bf16 conv (the architecture's stage downsample -> the CSP layer's merged conv1|conv2); nothing else touches that tensor
     for (int i = 0; i + 1 < (int)n->ops.size(); ++i) {
@@ -541,6 +559,8 @@ void vgh_net_destroy(vgh_net* n) {
     for (int l = 0; l < vgh_net::kLanes; ++l)
         if (n->ev_lag[l]) hipEventDestroy(n->ev_lag[l]);
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
+    for (NetOp& op : n->ops)
+        if (op.ev_done) hipEventDestroy(op.ev_done);
     hipFree(n->arena);
     hipFree(n->wblob);
     hipFree(n->zeros);
@@ -571,7 +591,8 @@ int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
             for (int l = 1; l < vgh_net::kLanes; ++l) pending[l] = true;
             continue;
         }
-        const int lane = (op.d.lane > 0 && op.d.lane < vgh_net::kLanes) ? op.d.lane : 0;
+        const int lane_f = op.d.lane & 0xff, dep = (op.d.lane >> 8) - 1;
+        const int lane = (lane_f > 0 && lane_f < vgh_net::kLanes) ? lane_f : 0;
         hipStream_t st = main;
         if (lane > 0) {
             st = n->side[lane];
@@ -581,7 +602,9 @@ int vgh_net_forward(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
             }
             used[lane] = true;
         }
+        if (dep >= 0 && dep < (int)n->ops.size() && n->ops[dep].ev_done) VGH_HIP(hipStreamWaitEvent(st, n->ops[dep].ev_done, 0));  // the ONE op this op waits for, on another lane
         if (int rc = net_run_op(n, op, image_dev, image_fmt, B, 0, st)) return rc;
+        if (op.ev_done) VGH_HIP(hipEventRecord(op.ev_done, st));
     }
     for (int l = 1; l < vgh_net::kLanes; ++l)
         if (used[l]) {

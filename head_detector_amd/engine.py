@@ -81,7 +81,7 @@ class VGHeadsEngine:
     def __init__(self, variant: str = "vgg_heads_l", state_dict: Optional[Dict[str, np.ndarray]] = None, image_size: int = 640, max_batch: int = 1,
                  device: Optional[int] = None, seed: int = 1, pre_nms_top_k: int = 1000, keep_top_k: int = 100, use_tuning: bool = True,
                  arena_batch: Optional[int] = None, precision: str = "bf16", fp8_scales: Optional[Dict[str, float]] = None, calib_images: Optional[torch.Tensor] = None,
-                 fp8_min_px: int = 40):
+                 fp8_min_px: int = 40, latency_lanes: bool = True):
         """``precision="fp8"`` (r05): the bf16 network with OCP-e4m3 links between 3x3 / stride-1 convs (arch.build_program).  Every link needs the largest
         activation it will carry: ``fp8_scales`` {link name: max|x|} from an earlier ``calibrate_fp8``, or ``calib_images`` (u8 NHWC / f32 NCHW GPU batch of
         representative inputs) to run that calibration now; with neither, two seeded random images are used -- adequate for the synthetic benchmark, NOT for
@@ -112,6 +112,9 @@ class VGHeadsEngine:
                 fp8_scales = calibrate_fp8(variant, state_dict, image_size, calib_images, self.device_index, fp8_min_px)
             self.fp8_scales = dict(fp8_scales)
         self.program = arch.build_program(variant, state_dict, image_size, precision, fp8_scales=self.fp8_scales, fp8_min_px=fp8_min_px)
+        if max_batch <= LATENCY_MAX_BATCH and latency_lanes:
+            # single-image engines (HeadDetector's default): the three heads on lane streams with exact dependencies, each right behind its pyramid level (r06)
+            arch.schedule_latency(self.program)
         P = self.program
         # the conv loader addresses an input tensor with 32-bit byte offsets: keep every arena tensor below 2 GiB by running
         # large batches through the network in chunks (post-network stages always see the whole batch)
@@ -565,6 +568,7 @@ def calibrate_fp8(variant: str, state_dict: Optional[Dict[str, np.ndarray]], ima
 
 
 CALIB_CHUNK = 8  # images per calibration forward
+LATENCY_MAX_BATCH = 2  # engines built for at most this many images schedule their heads on lane streams (arch.schedule_latency)
 
 
 def tuning_key(op: dict, batch: int, nsplit: int = 1, bucket: Optional[int] = None, res: Optional[bool] = None) -> str:

@@ -91,7 +91,8 @@ typedef struct vgh_op_desc {
     int64_t w_off;                       /* offset (floats) of [cout_pad][k][k][cin] in `weights`      */
     int64_t b_off;                       /* offset (floats) of [cout_pad] in `biases`                  */
     int32_t force_cfg;                   /* -1: heuristic tile choice; else kernel config index        */
-    int32_t lane;                        /* 0: main stream; 1..3: side stream (independent branch, see VGH_OP_FORK) */
+    int32_t lane;                        /* bits 0-7: 0 = main stream, 1..3 = side stream (independent branch, see VGH_OP_FORK); bits 8-31 (r06, additive): 0, or 1 + the index of */
+                                         /*   the ONE earlier op on another lane this op waits for (an event recorded behind that op) -- arch.schedule_latency                      */
     int32_t grp_cout, grp_in_stride;     /* grouped conv (sibling branches in one launch): output channels [g*grp_cout, (g+1)*grp_cout) read  */
                                          /*   the `cin` input channels starting at in_coff + g*grp_in_stride; 0: dense                      */
 } vgh_op_desc;

@@ -619,7 +619,8 @@ def test_b2b_pairs_equal_their_two_launches(gpu_lib, variant, S, B, tuned):
             if tuned:
                 # a TUNED engine may run the second conv on a streaming 1x1 tile, whose accumulators START at the bias (bias + sum instead of sum + bias: another fp32
                 # rounding in ~0.2 % of the outputs): the fused launch keeps the implicit-GEMM convention, so here the two agree to one bf16 ulp, almost everywhere exactly
-                assert not ((a - b).abs() > 1e-2 + b.abs() / 64).any() and float((a != b).float().mean()) < 0.01, (ns, P.ops[i]["name"])
+                # (when the FIRST conv of a pair runs on such a tile too -- L's neck pair -- a flipped ulp of the tensor in between reaches the second output times a weight)
+                assert not ((a - b).abs() > 5e-2 + b.abs() / 32).any() and float((a != b).float().mean()) < 0.05, (ns, P.ops[i]["name"], float((a - b).abs().max()), float((a != b).float().mean()))
             else:
                 assert torch.equal(bufs[i], ref[1][i]), (ns, P.ops[i]["name"])
         if not tuned:
@@ -1273,6 +1274,44 @@ def test_gatherer_collectives_on_rccl_single_rank(gpu_lib):
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant,B,prec", [("vgg_heads_l", 1, "bf16"), ("vgg_heads_m", 2, "bf16"), ("vgg_heads_m", 1, "fp32"), ("vgg_heads_l", 1, "fp16x3")])
+def test_latency_lanes_are_invisible(gpu_lib, flame_model, variant, B, prec):
+    """Single-image engines (r06, arch.schedule_latency): each head's ops right behind its pyramid level, on the executor's lane streams with exact one-op
+    dependencies (vgh_op_desc.lane bits 8+).  Against the same engine built WITHOUT the pass: every network output and every detection bit for bit, eagerly and as a
+    replayed hipGraph (whose capture follows the cross-lane events), call after call; the reordered program is still a valid serial order (the per-op profiler runs it)."""
+    from head_detector_amd import arch
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+
+    S = 320
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(B + 40)).to(_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=256)
+    ref_eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=9, precision=prec, latency_lanes=False)
+    assert all((op.get("lane", 0) >> 8) == 0 for op in ref_eng.program.ops)
+    ref = [t.clone() for t in ref_eng.model(x)]
+    conf = float(ref[1][:, 6, 0].max())
+    d0 = ref_eng.detect(x, confidence_threshold=conf, flame=fl)
+    ref_det = [t.clone() for t in (d0.boxes, d0.counts, d0.vertices_3d)]
+    ref_eng.close()
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=9, precision=prec)
+    P = eng.program
+    deps = [(i, (op["lane"] >> 8) - 1) for i, op in enumerate(P.ops) if op.get("lane", 0) >> 8]
+    assert len(deps) >= 9 and all(0 <= d < i and (P.ops[d].get("lane", 0) & 255) != (P.ops[i]["lane"] & 255) for i, d in deps)  # every wait names an EARLIER op on ANOTHER lane
+    assert {op.get("lane", 0) & 255 for op in P.ops} == {0, 1, 2, 3}
+    names = [op["name"] for op in P.ops]
+    assert names.index("heads.head1.pose_stem|bbox_stem") == names.index("neck.neck2.blocks.conv3") + 1 < names.index("neck.neck3.conv")
+    for graph in (False, True, False):
+        for _ in range(3):
+            got = eng.model(x, use_graph=graph)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), graph
+        d = eng.detect(x, confidence_threshold=conf, flame=fl, use_graph=graph)
+        assert all(torch.equal(a, b) for a, b in zip((d.boxes, d.counts, d.vertices_3d), ref_det)), graph
+    rows = eng.profile_ops(x)
+    assert len(rows) == len(P.ops) and all(r["ms"] >= 0 for r in rows)
+    assert all(torch.equal(a, b) for a, b in zip(eng.model(x), ref))
+    eng.close()
 
 
 def test_batch_split_lanes_are_invisible(gpu_lib, flame_model):
