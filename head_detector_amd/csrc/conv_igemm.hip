@@ -119,10 +119,24 @@ void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipSt
         }
     }
     const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64);
+    constexpr int nw = (BP / WP) * (BC / WC);
+    constexpr int loop_lds = NST * KBS * (BP + BC) * 64 + (NST > 2 ? nw * 1024 : 0), epi_lds = nw * 32 * (WC + 4) * 4;
     if (NST == 2 && (a.nkb + KBS - 1) / KBS == 1) {  // the whole K fits one stage: no second buffer -> more blocks per CU
         const int one = KBS * (BP + BC) * 64, epi = (BP / WP) * (BC / WC) * 32 * (WC + 4) * 4;
         lds = one > epi ? one : epi;
     }
+    // r06: tiles whose LDS-transposed epilogue strips outweigh their stage buffers (the 96-cout wave tiles) take the REGISTER epilogue (EPI = 3, no LDS) for plain bf16
+    // convs: the block's LDS drops to its stages and more blocks share a CU
+#ifdef VGH_EXPERIMENTS  // measured r06 (profiles/r06_ab_regepi.txt): single-stream sum -0.9 % (L) / -1.5 % (M), the two-lane forward unchanged, stage1.conv3 33 us slower: not adopted
+    static const int regepi = getenv("VGH_REGEPI") ? atoi(getenv("VGH_REGEPI")) : 0;
+    if constexpr (epi_lds > loop_lds && loop_lds <= 64 * 1024) {
+        if (regepi && a.fast_epi && !a.out_f32 && !a.res && !a.shuffle && a.act != VGH_ACT_SILU) {
+            const int l3 = (NST == 2 && (a.nkb + KBS - 1) / KBS == 1) ? KBS * (BP + BC) * 64 : loop_lds;
+            hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 3, NST>), grid, block, l3, st, a, ntc, total, chunk);
+            return;
+        }
+    }
+#endif
     if (a.fast_epi)
         hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>), grid, block, lds, st, a, ntc, total, chunk);
     else

@@ -614,7 +614,9 @@ def test_b2b_pairs_equal_their_two_launches(gpu_lib, variant, S, B, tuned):
     for ns in (1, 2):  # (a tuned engine may run other tiles -- other summation orders -- with two lanes than with one: fused against unfused at the SAME lane count)
         ref, (res, bufs) = outs[(False, ns)], outs[(True, ns)]
         for i in pairs:
-            a, b = bufs[i].float(), ref[1][i].float()
+            o2 = P.ops[i + 1]  # the second conv's own channels of its output buffer (a CSP concat buffer: later ops write the rest of it)
+            seg = lambda t: torch.cat([t[..., o2["out_coff"]:o2["out_coff"] + o2["out_split"]], t[..., o2["out_coff2"]:o2["out_coff2"] + o2["cout_store"] - o2["out_split"]]], -1)  # noqa: E731
+            a, b = seg(bufs[i]).float(), seg(ref[1][i]).float()
             assert float(a.abs().max()) > 0
             if tuned:
                 # a TUNED engine may run the second conv on a streaming 1x1 tile, whose accumulators START at the bias (bias + sum instead of sum + bias: another fp32
