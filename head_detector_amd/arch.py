@@ -746,8 +746,8 @@ def schedule_latency(P: "Program") -> "Program":
     launches of 5 - 20 us each with the chip mostly idle (profiles/r06_latency_trace_l1.txt), and the three detection heads -- 39 launches, ~440 us -- depend on nothing
     but their own pyramid level.  This pass (i) moves each head's ops right behind the op that produces its level (p3 is ready before neck3 / neck4 run), and (ii) puts
     them on the executor's lane streams with EXACT dependencies: `lane` = stream index | (1 + index of the ONE op this op waits for) << 8 (csrc/net.hip records an event
-    behind that op and makes this op's stream wait for it).  Per head: [stems -> towers -> box / score predictions -> transform branch] on one lane, [FLAME layer 0 ->
-    shape branch] on a second, [expression branch] on a third; heads 1 and 2 use the three side lanes while the neck goes on on the caller's stream, head 3 starts on
+    behind that op and makes this op's stream wait for it).  Per head: [stems -> FLAME layer 0 -> shape branch] on one lane, [towers -> box / score predictions ->
+    transform branch] on a second, [expression branch] on a third; heads 1 and 2 use the three side lanes while the neck goes on on the caller's stream, head 3 starts on
     it.  Same kernels, same tiles, same bits; the order of P.ops stays a valid serial order (the batch-split executor and the per-op profiler run it as such)."""
     ops = P.ops
     if any(op["kind"] == 3 for op in ops):
@@ -768,21 +768,23 @@ def schedule_latency(P: "Program") -> "Program":
     for lv in range(3):
         p = f"heads.head{lv + 1}"
         la, lb, lc = (1, 2, 3) if lv < 2 else (0, 1, 2)
-        stem, f0 = f"{p}.pose_stem|bbox_stem", f"{p}.flame_*_pred.0"
-        seen_first = set()
+        stem, f0, towers = f"{p}.pose_stem|bbox_stem", f"{p}.flame_*_pred.0", f"{p}.cls_convs|reg_convs"
         for op in heads[lv]:
             n = op["name"]
-            if n in (stem, f"{p}.cls_convs|reg_convs", f"{p}.reg_pred|cls_pred"):
-                lane, dep, br = la, (anchors[lv] if n == stem else None), None
-            elif n == f0:
-                lane, dep, br = lb, stem, None
+            if n in (stem, f0):
+                lane, dep = la, (anchors[lv] if n == stem else None)
+            elif n in (towers, f"{p}.reg_pred|cls_pred"):
+                lane, dep = lb, (stem if n == towers else None)
             else:
                 br = "shape" if ".flame_shape_pred." in n else "expr" if ".flame_expression_pred." in n else "tr"
-                lane = {"shape": lb, "expr": lc, "tr": la}[br]
+                lane = {"shape": la, "expr": lc, "tr": lb}[br]
                 # the first layer of a branch that does not share FLAME layer 0's lane waits for it (the ungrouped fp32 program has four transform ops per layer: each first one)
                 first = n.rsplit(".", 1)[-1] == "1"
-                dep = f0 if (first and lane != lb) else None
+                dep = f0 if (first and lane != la) else None
             op["lane"] = lane | (((pos[dep] + 1) << 8) if dep is not None and (new[pos[dep]].get("lane", 0) & 0xFF) != lane else 0)
+    # the side lanes only ever wait for the caller's stream or for lane `la`: the wait-for relation among them is acyclic.  (It has to be: under stream capture the HIP
+    # runtime links a non-origin stream to the stream of EVERY event it waits for, and two side streams waiting for each other's events make hipStreamEndCapture recurse
+    # without end -- measured r06, ROCm 7.0's libamdhip64; csrc/net.hip refuses to capture such a program.)
     P.ops = new
     return P
 

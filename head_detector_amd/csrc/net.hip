@@ -87,6 +87,9 @@ struct vgh_net {
     // stem + stage-1 downsample as ONE kernel (stem_ds.hip: the 48-channel stem activation stays in LDS): index of the stem op when the pair
     // qualifies (bf16 mode, the architecture's 3x3 / stride-2 / 64 -> 96 conv as the stem tensor's only reader), else -1; results are bit-identical
     int stem_pair = -1;
+    // two SIDE lanes that wait for each other's ops (lane bits 8+): fine eagerly, but under stream capture ROCm 7.0's runtime links a non-origin stream to the stream of
+    // every event it waits for and hipStreamEndCapture then recurses without end (measured r06: a stack overflow inside hip::Stream::EndCapture) -> vgh_net_capture refuses
+    bool lane_wait_cycle = false;
     int fuse_b2b = 1;   // vgh_net_set_b2b: the back-to-back pairs found at create time run fused (default) or as their two launches (every intermediate tensor then exists)
     int fuse_stem = 0;  // opt-in (vgh_net_set_fuse_stem): measured r03, the fused kernel saves 1.5 GB of HBM traffic per L b64 forward but no time (EXPERIMENTS.md 8c)
 };
@@ -522,6 +525,19 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             return VGH_ERR_HIP;
         }
     }
+    {
+        bool w[vgh_net::kLanes][vgh_net::kLanes] = {};  // w[a][b]: side lane a waits for an op of side lane b (directly, then transitively)
+        for (const NetOp& op : n->ops) {
+            const int dep = (op.d.lane >> 8) - 1, a = op.d.lane & 0xff;
+            if (dep < 0) continue;
+            const int b = n->ops[dep].d.lane & 0xff;
+            if (a > 0 && a < vgh_net::kLanes && b > 0 && b < vgh_net::kLanes && a != b) w[a][b] = true;
+        }
+        for (int k = 1; k < vgh_net::kLanes; ++k)
+            for (int a = 1; a < vgh_net::kLanes; ++a)
+                for (int b = 1; b < vgh_net::kLanes; ++b) w[a][b] = w[a][b] || (w[a][k] && w[k][b]);
+        for (int a = 1; a < vgh_net::kLanes; ++a) n->lane_wait_cycle = n->lane_wait_cycle || w[a][a];
+    }
     // back-to-back pairs (r06): a plain bf16 conv whose whole output tensor -- all of its channels in ONE cout tile -- is read by exactly one op, the next one, a plain
     // 1x1 / stride-1 bf16 conv (the architecture's stage downsample -> the CSP layer's merged conv1|conv2); nothing else touches that tensor
     for (int i = 0; i + 1 < (int)n->ops.size(); ++i) {
@@ -654,6 +670,8 @@ int vgh_net_profile(vgh_net* n, const void* image_dev, int image_fmt, int B, voi
 int vgh_net_capture(vgh_net* n, const void* image_dev, int image_fmt, int B, void* stream) {
     VGH_REQUIRE(n && stream, "net_capture: needs a non-null stream");
     VGH_REQUIRE(!n->pred_guard, "net_capture: a prediction guard event is set (detector overlap mode); graph replay cannot honour it");
+    VGH_REQUIRE(!n->lane_wait_cycle, "net_capture: two side lanes of this program wait for each other's ops; the HIP runtime cannot end the capture of such a program (run it eagerly, "
+                "or lay the lanes out so that the wait-for relation among lanes 1..3 is acyclic, as arch.schedule_latency does)");
     hipStream_t st = (hipStream_t)stream;
     if (n->graph_exec) {
         hipGraphExecDestroy(n->graph_exec);

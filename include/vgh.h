@@ -107,7 +107,8 @@ int vgh_net_forward(vgh_net* net, const void* image_dev, int image_fmt, int B, v
 /* As vgh_net_forward but host-synchronous, bracketing every op with HIP events on `stream`;
  * op_ms[n_ops] receives each op's device time in milliseconds (tuning / roofline reporting). */
 int vgh_net_profile(vgh_net* net, const void* image_dev, int image_fmt, int B, void* stream, float* op_ms);
-/* Capture vgh_net_forward into a hipGraph (replayed by vgh_net_forward_graph with the same B / image_dev). */
+/* Capture vgh_net_forward into a hipGraph (replayed by vgh_net_forward_graph with the same B / image_dev).  VGH_ERR_INVALID for a program in which two SIDE
+ * lanes wait for each other's ops (vgh_op_desc.lane bits 8+): the HIP runtime cannot end such a capture; waits on the main stream's ops are always fine. */
 int vgh_net_capture(vgh_net* net, const void* image_dev, int image_fmt, int B, void* stream);
 int vgh_net_forward_graph(vgh_net* net, void* stream);
 void* vgh_net_buffer(vgh_net* net, int buf_id);         /* device pointer of an activation buffer   */
@@ -121,7 +122,8 @@ int vgh_net_set_split(vgh_net* net, int nsplit);
 /* r06: BACK-TO-BACK GEMM.  A conv whose whole output (all channels in one 96-cout tile) is read by exactly one op -- the 1x1 conv behind it: a backbone stage's downsample
  * and the CSP layer's merged conv1|conv2 -- runs with that op as ONE launch: the first conv's accumulators become, in registers, the B operands of the second GEMM, and the
  * tensor between them is never written (csrc/conv_kernels.inc, T2 > 0).  vgh_net_create finds the pairs; they run fused by default.  enable = 0: the two launches (the same
- * output bits; the intermediate tensor then exists in the arena, as the per-op parity tests need).  vgh_net_b2b_pairs: how many pairs the program has. */
+ * output bits when the second conv runs on an implicit-GEMM tile -- the fused kernel's arithmetic; a tuning table that gives it a streaming "t" tile, whose accumulators
+ * start at the bias, differs in the last fp32 rounding before the bf16 store; the intermediate tensor then exists in the arena, as the per-op parity tests need).  vgh_net_b2b_pairs: how many pairs the program has. */
 int vgh_net_set_b2b(vgh_net* net, int enable);
 int vgh_net_b2b_pairs(vgh_net* net);
 int vgh_net_max_batch(vgh_net* net);  /* images the activation arena was planned for */

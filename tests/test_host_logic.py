@@ -614,6 +614,64 @@ def test_onnx_graph_ingest_binds_a_simplified_export_by_topology(tmp_path):
         load_weights(p)
 
 
+@pytest.mark.parametrize("variant,prec", [("vgg_heads_l", "bf16"), ("vgg_heads_m", "bf16"), ("vgg_heads_m", "fp32"), ("vgg_heads_l", "fp16x3")])
+def test_latency_schedule_is_a_valid_order_with_acyclic_lane_waits(variant, prec):
+    """arch.schedule_latency (r06): (i) the reordered program is a valid SERIAL order -- every op's input / residual tensor has been written by an earlier op --
+    (ii) every cross-lane reader of a tensor is ordered behind its writer by the one-op waits plus stream order, and (iii) the wait-for relation among the SIDE lanes
+    is acyclic: ROCm 7.0's hipStreamEndCapture recurses without end on two side streams that waited for each other's events, and csrc/net.hip refuses such a capture."""
+    sd = arch.random_state_dict(variant, seed=3)
+    P0 = arch.build_program(variant, sd, 320, prec)
+    names0 = sorted(op["name"] for op in P0.ops)
+    P = arch.schedule_latency(arch.build_program(variant, sd, 320, prec))
+    assert sorted(op["name"] for op in P.ops) == names0
+    lane = [op.get("lane", 0) & 255 for op in P.ops]
+    dep = [(op.get("lane", 0) >> 8) - 1 for op in P.ops]
+    assert all(-1 <= d < i for i, d in enumerate(dep)) and all(lane[d] != lane[i] for i, d in enumerate(dep) if d >= 0)
+    # happens-before: op j precedes op i if same lane and j < i, or i waits for j -- transitively
+    n = len(P.ops)
+    before = [set() for _ in range(n)]
+    last_on = {}
+    for i in range(n):
+        for j in ([last_on[lane[i]]] if lane[i] in last_on else []) + ([dep[i]] if dep[i] >= 0 else []):
+            before[i] |= before[j] | {j}
+        last_on[lane[i]] = i
+    def reads(op):  # (buffer, first channel, end channel) windows an op reads -- tests/program_ref.py's run_op
+        out = []
+        if op["kind"] in (1, 2) and op["in_buf"] >= 0:
+            g = op["cout_pad"] // op["grp_cout"] if op.get("grp_cout") else 1
+            out.append((op["in_buf"], op["in_coff"], op["in_coff"] + (g - 1) * op.get("grp_in_stride", 0) + op["cin"]))
+        if op.get("res_buf", -1) >= 0:
+            out.append((op["res_buf"], op["res_coff"], op["res_coff"] + op["cout_store"]))
+        return out
+
+    def writes(op):
+        if op["kind"] == 2:
+            return [(op["out_buf"], op["out_coff"], P.bufs[op["out_buf"]]["pitch"])]
+        store = op["cout_store"] if not op["shuffle"] else op["cout_pad"] // 4
+        split = min(op["out_split"], store)
+        return [(op["out_buf"], op["out_coff"], op["out_coff"] + split)] + ([(op["out_buf"], op["out_coff2"], op["out_coff2"] + store - split)] if store > split else [])
+
+    written, was_read = [], []
+    for i, op in enumerate(P.ops):
+        if op["kind"] not in (0, 1, 2):
+            continue
+        for b, lo, hi in reads(op):
+            for w, (wb, wlo, whi) in written:  # read after write
+                if wb == b and wlo < hi and lo < whi:
+                    assert w in before[i], (P.ops[w]["name"], "->", op["name"])
+        for b, lo, hi in writes(op):
+            for j, (ob, olo, ohi) in written + was_read:  # write after write / write after read: a window is written again only behind everything that touched it
+                if ob == b and olo < hi and lo < ohi and j != i:
+                    assert j in before[i], (P.ops[j]["name"], "touched before", op["name"], "rewrites it")
+        written += [(i, w) for w in writes(op)]
+        was_read += [(i, r) for r in reads(op)]
+    waits = {(lane[i], lane[d]) for i, d in enumerate(dep) if d >= 0 and lane[i] and lane[d]}
+    reach = set(waits)
+    for _ in range(4):
+        reach |= {(a, d) for a, b in reach for c, d in reach if b == c}
+    assert waits and not any(a == b for a, b in reach), sorted(waits)
+
+
 def test_module_graph_is_the_oracles_forward_order():
     """arch.module_graph (what the ONNX binder and the export stand-in walk) against oracle/net_oracle.py run under forward hooks: the same conv modules in the same
     execution order, with the same weight shapes -- the oracle is the checker here (its module tree restates super_gradients' forward bodies and

@@ -11,6 +11,8 @@ import re
 import sys
 
 FAMILIES = [
+    (r"conv3x3_pp_kernel<(\d), 1, 0, 0, 0, 0, 1>", "s  ping-pong 3x3, two 4x8 sub-patches per wave (r06)"),
+    (r"conv_igemm_kernel<[^>]*, [468]>$", "b2b  implicit GEMM + the 1x1 conv behind it in one launch (r06)"),
     (r"conv3x3_pp_kernel<(\d), 1", "g  ping-pong 3x3 (two barriers per tap)"),
     (r"conv3x3_pp_kernel<(\d), 2", "h  ping-pong 3x3 (one barrier per tap)"),
     (r"conv3x3_patch3_kernel", "q  halo-patch 3x3, cross-tile pipelined"),
@@ -38,11 +40,23 @@ def main():
     for ln in open(sys.argv[2]):
         if ln.startswith("#") or ln.startswith("op ") or ln.startswith("total"):
             continue
-        m = re.match(r"(\S+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(-?[\d.]+)\s+(.*)$", ln.rstrip())
+        m = re.match(r"(\S+(?: \+ \S+)?)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(-?[\d.]+)\s+(.*)$", ln.rstrip())
         if m:
             traffic[m.group(1)] = dict(alg_rd=float(m.group(2)), rd=float(m.group(3)), alg_wr=float(m.group(4)), wr=float(m.group(5)), kernel=m.group(7).strip())
     rows = {}
-    for op in per_layer:
+    # a back-to-back pair is ONE launch: its traffic row is named "<first> + <second's last name part>"; the per-layer table lists the two ops (the second at ~0 ms)
+    fused = {k.split(" + ")[0]: k for k in traffic if " + " in k}
+    merged, skip = [], False
+    for i, op in enumerate(per_layer):
+        if skip:
+            skip = False
+            continue
+        if op["name"] in fused and i + 1 < len(per_layer):
+            nx = per_layer[i + 1]
+            op = dict(op, name=fused[op["name"]], ms=op["ms"] + nx["ms"], gflop=op["gflop"] + nx["gflop"], read_mb=op["read_mb"] + nx["read_mb"] - op["write_mb"], write_mb=nx["write_mb"])
+            skip = True
+        merged.append(op)
+    for op in merged:
         t = traffic.get(op["name"])
         if t is None:
             continue
