@@ -702,7 +702,7 @@ def main():
         if per_layer_path and rank == 0:
             eng.join()
             eng.set_split(1)  # per-op events make sense on one stream only: the table is the single-stream view of every op
-            json.dump(eng.profile_ops(images), open(per_layer_path, "w"), indent=0)
+            json.dump(eng.profile_ops(images, repeats=7), open(per_layer_path, "w"), indent=0)  # per-op median of 7 profiled forwards
         alg = arch.program_algorithmic_bytes(eng.program, B)
         fp8_flops = 2.0 * sum(op["macs"] for op in eng.program.ops if arch.op_touches_fp8(eng.program, op) and eng.program.bufs[op["in_buf"]]["is_f32"] in arch.Q8_FMTS)
         out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, fp8_flops_per_image=fp8_flops, fp8_links=sum(bf["is_f32"] in arch.Q8_FMTS for bf in eng.program.bufs), heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,

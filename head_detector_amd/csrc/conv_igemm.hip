@@ -143,6 +143,25 @@ void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipSt
         hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST>), grid, block, lds, st, a, ntc, total, chunk);
 }
 
+// loader-wave tiles (conv_igemm_kernel<..., LF>): LF x the waves, the same LDS
+template <int BP, int BC, int WP, int WC, int KBS, int NST, int LF>
+void launch_cfg_lf(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
+    static std::atomic<int> attr_done[kMaxDevices];
+    if (lds > 64 * 1024) {
+        const int dev = current_device();
+        if (!attr_done[dev].load(std::memory_order_acquire)) {
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST, 0, 0, LF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, 0, 0, LF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_done[dev].store(1, std::memory_order_release);
+        }
+    }
+    const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64 * LF);
+    if (a.fast_epi)
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, 0, 0, LF>), grid, block, lds, st, a, ntc, total, chunk);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST, 0, 0, LF>), grid, block, lds, st, a, ntc, total, chunk);
+}
+
 constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
     const int nw = (BP / WP) * (BC / WC);
     const int loop = NST * KBS * (BP + BC) * 64 + (NST > 2 ? nw * 1024 : 0), epi = nw * 32 * (WC + 4) * 4;
@@ -152,6 +171,8 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
     { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, 2), launch_cfg<BP, BC, WP, WC, KBS, 2>, 0, 0, 0, nullptr }
 #define CFGR(BP, BC, WP, WC, KBS, NST) \
     { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg<BP, BC, WP, WC, KBS, NST>, 0, 0, 0, nullptr }
+#define LCFG(BP, BC, WP, WC, KBS, NST, LF) \
+    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST "_l" #LF, BP, BC, (BP / WP) * (BC / WC) * 64 * LF, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg_lf<BP, BC, WP, WC, KBS, NST, LF>, 0, 0, 0, nullptr }
 #define PCFG(TW, TH, BC, NWP, NWC) \
     { "p" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC>(), nullptr, 1, TW, TH, launch_patch_cfg<TW, TH, BC, NWP, NWC> }
 
@@ -325,6 +346,24 @@ const CfgEntry g_cfgs[] = {
     CFGR(256, 192, 64, 96, 1, 3),  // 132
     CFG(128, 192, 32, 96, 1),      // 133  8 waves x (32 px x 96)
     CFGR(128, 192, 32, 96, 1, 3),  // 134
+    // deep rings on the small tiles (r06, single-image latency): at B = 1 a 20^2 / 40^2 layer is 56 - 150 blocks, each walking K = 1728 - 4608 alone; a step of the
+    // 2-stage loop costs one L2 / HBM round trip (~0.85 us for 128 k: 31 us per stage-4 layer with 2 us of MFMAs in it) -- three stages of LDS-DMA in flight instead of one
+    CFGR(64, 64, 32, 32, 4, 3),    // 135
+    CFGR(64, 64, 32, 32, 4, 4),    // 136  128 KiB of stages: one block per CU (there are fewer blocks than CUs)
+    CFGR(64, 64, 32, 32, 2, 4),    // 137
+    CFGR(64, 32, 32, 32, 4, 4),    // 138  2 waves
+    CFGR(128, 32, 32, 32, 4, 3),   // 139
+    CFGR(128, 64, 32, 64, 2, 4),   // 140
+    // loader waves (r06): the same small tiles with 2 - 6 x the waves, all of them staging tiles (one wave loads ~14 GB/s whatever it keeps in flight)
+    LCFG(64, 64, 32, 32, 4, 3, 2),   // 141  8 waves
+    LCFG(64, 64, 32, 32, 4, 3, 4),   // 142  16 waves
+    LCFG(64, 64, 32, 32, 4, 4, 4),   // 143
+    LCFG(64, 64, 32, 32, 2, 4, 4),   // 144
+    LCFG(64, 32, 32, 32, 4, 3, 3),   // 145  6 waves
+    LCFG(64, 32, 32, 32, 4, 3, 6),   // 146  12 waves
+    LCFG(32, 64, 32, 32, 4, 3, 3),   // 147  32-pixel tiles: 13 instead of 7 pixel tiles over a 20^2 map
+    LCFG(32, 64, 32, 32, 4, 3, 6),   // 148
+    LCFG(128, 64, 32, 64, 2, 3, 3),  // 149  12 waves
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };

@@ -103,10 +103,29 @@ struct ConvArgs {
         if ((a).trace && threadIdx.x == 0 && (tile_no) < VGH_TRACE_TILES)                                                            \
             (a).trace[((size_t)blockIdx.x * VGH_TRACE_TILES + (tile_no)) * VGH_TRACE_MARKS + (k)] = __builtin_amdgcn_s_memtime();   \
     } while (0)
+// one tile per block (the implicit-GEMM kernel): row = blockIdx.x, tile 0; the tool's buffer holds 8192 rows
+#define VGH_MARK_BLOCK(a, k)                                                                                                  \
+    do {                                                                                                                      \
+        if ((a).trace && threadIdx.x == 0 && blockIdx.x < 8192)                                                               \
+            (a).trace[((size_t)blockIdx.x * VGH_TRACE_TILES) * VGH_TRACE_MARKS + (k)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+struct VghMarkAtExit {  // "epilogue done" on every return path of a kernel body
+    unsigned long long* t;
+    __device__ ~VghMarkAtExit() {
+        if (t && threadIdx.x == 0 && blockIdx.x < 8192) t[((size_t)blockIdx.x * VGH_TRACE_TILES) * VGH_TRACE_MARKS + 3] = __builtin_amdgcn_s_memtime();
+    }
+};
+#define VGH_MARK_EXIT(a) VghMarkAtExit vgh_mark_at_exit_{(a).trace}
 #else
 #define VGH_ABLATE(a, bit) 0
 #define VGH_MARK(a, tile_no, k) \
     do {                        \
+    } while (0)
+#define VGH_MARK_BLOCK(a, k) \
+    do {                     \
+    } while (0)
+#define VGH_MARK_EXIT(a) \
+    do {                 \
     } while (0)
 #endif
 

@@ -418,14 +418,25 @@ class VGHeadsEngine:
         # may still be read by kernels the caller queued earlier), and the tensors are recorded on the caller's stream before they are handed
         # out (the allocator then keeps a dropped block until the caller's reads of it have finished).
         self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            slot = None if reuse_outputs else self.new_output_slot(flame, B)
-        o, det = self._detect_out(B, flame, unpad, None, slot)
+        # r06: the network goes to the GPU FIRST; the result tensors are allocated, zero-filled and marshalled while it runs (vgh_detect IS vgh_detector_candidates +
+        # vgh_detector_select, csrc/detect.hip).  The other order left the GPU idle for the ~75 us of host work in front of a single-image call's first kernel
+        # (profiles/r06_latency_trace_l1.txt: 76 us between the fill kernel and the stem).
+        # (Overlap mode keeps the old order: its select runs on the side stream, ordered behind the NETWORK's event only -- a fill queued behind the network on the
+        # engine stream would race with it.)
+        net_first = not getattr(self, "_overlap", False)
+        slot = None
+        if not net_first and not reuse_outputs:
+            with torch.cuda.stream(self.stream):
+                slot = self.new_output_slot(flame, B)
         if use_graph and B <= self.arena_batch:
             self.forward_candidates(images, True)
-            _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         else:
-            _lib.check(self.lib.vgh_detect(self._det, images.data_ptr(), fmt, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
+            _lib.check(self.lib.vgh_detector_candidates(self._det, images.data_ptr(), fmt, B, self._sp()))
+        if net_first and not reuse_outputs:
+            with torch.cuda.stream(self.stream):
+                slot = self.new_output_slot(flame, B)
+        o, det = self._detect_out(B, flame, unpad, None, slot)
+        _lib.check(self.lib.vgh_detector_select(self._det, B, float(confidence_threshold), float(iou_threshold), C.byref(o), self._sp()))
         if getattr(self, "_overlap", False):
             _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))  # detect() keeps stream-ordered semantics
         cur.wait_stream(self.stream)
@@ -481,14 +492,19 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_detector_join(self._det, stream.cuda_stream))
 
     # ---------------------------------------------------------------------------------------------------
-    def profile_ops(self, images: torch.Tensor) -> List[dict]:
-        """Per-op device time (HIP events on the engine stream) with the algorithmic FLOPs of each op."""
+    def profile_ops(self, images: torch.Tensor, repeats: int = 1) -> List[dict]:
+        """Per-op device time (HIP events on the engine stream) with the algorithmic FLOPs of each op; repeats > 1: the per-op MEDIAN over that many profiled forwards
+        (one pass is one sample per op: a box's clock state moves every op of a pass by the same 5 - 10 %)."""
         B, fmt = self._check_images(images)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        ms = (C.c_float * len(self.program.ops))()
-        _lib.check(self.lib.vgh_net_profile(self._net, images.data_ptr(), fmt, B, self._sp(), ms))
+        passes = []
+        for _ in range(max(1, repeats)):
+            ms = (C.c_float * len(self.program.ops))()
+            _lib.check(self.lib.vgh_net_profile(self._net, images.data_ptr(), fmt, B, self._sp(), ms))
+            passes.append(list(ms))
+        med = [sorted(col)[len(col) // 2] for col in zip(*passes)]
         out = []
-        for op, t in zip(self.program.ops, ms):
+        for op, t in zip(self.program.ops, med):
             fl = 2.0 * op["macs"] * B
             by = arch.op_algorithmic_bytes(self.program, op, B)
             out.append(dict(name=op["name"], kind=op["kind"], ms=float(t), gflop=fl / 1e9, tflops=(fl / (t * 1e-3) / 1e12) if t > 0 else 0.0, gemm=op["gemm"],

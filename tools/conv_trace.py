@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-tile phase timeline of the persistent 3x3 kernels (s_memtime marks compiled into the -DVGH_EXPERIMENTS build only):
-   VGH_LIB_PATH=head_detector_amd/libvgh_exp.so python tools/conv_trace.py --shape 64,80,80,128,128,3,1 --cfgs p16x16x64_n4x1,q16x16x64_n4x1"""
+   VGH_LIB_PATH=head_detector_amd/libvgh_exp.so python tools/conv_trace.py --shape 64,80,80,128,128,3,1 --cfgs p16x16x64_n4x1,q16x16x64_n4x1
+r06: the implicit-GEMM kernel (one tile per block) carries the same four marks -- block top, first stage landed, K loop done, last store issued:
+   ... conv_trace.py --shape 64,320,320,64,96,3,2 --cfgs 128x96_w32x96_k1,128x96_w32x96_k1_r4      (the stage-1 downsample)"""
 import argparse
 import ctypes as C
 import os
@@ -22,6 +24,7 @@ def main():
     ap.add_argument("--cfgs", default="p16x16x64_n4x1,q16x16x64_n4x1")
     ap.add_argument("--res", action="store_true")
     ap.add_argument("--burst", type=int, default=40)
+    ap.add_argument("--pitch", type=int, default=0, help="channel pitch of the input tensor (>= Cin; default Cin): the K windows then use Cin / pitch of every pixel's bytes")
     args = ap.parse_args()
     lib = _lib.load()
     lib.vgh_conv_set_trace.restype = C.c_int
@@ -34,14 +37,15 @@ def main():
     _lib.check(lib.vgh_pack_conv_weights(_lib.ptr(w), rp, k, Cin, _lib.ptr(pack)))
     d_pack = torch.from_numpy(pack.view(np.int16)).to(dev)
     d_bias = torch.zeros(rp, device=dev)
-    x = torch.randn(B, H, W, Cin, device=dev).to(torch.bfloat16)
+    pitch = max(args.pitch, Cin)
+    x = torch.randn(B, H, W, pitch, device=dev).to(torch.bfloat16)
     out = torch.empty(B, H, W, rp, device=dev, dtype=torch.bfloat16)
     res = torch.randn(B, H, W, rp, device=dev).to(torch.bfloat16) if args.res else None
     names = [lib.vgh_conv_cfg_name(i).decode() for i in range(lib.vgh_conv_num_cfgs())]
     st = torch.cuda.current_stream().cuda_stream
     for name in args.cfgs.split(","):
         c = names.index(name)
-        call = _lib.ConvCall(in_dev=x.data_ptr(), in_pitch=Cin, in_coff=0, cin=Cin, B=B, H=H, W=W, wpack_dev=d_pack.data_ptr(), bias_dev=d_bias.data_ptr(),
+        call = _lib.ConvCall(in_dev=x.data_ptr(), in_pitch=pitch, in_coff=0, cin=Cin, B=B, H=H, W=W, wpack_dev=d_pack.data_ptr(), bias_dev=d_bias.data_ptr(),
                              out_dev=out.data_ptr(), out_pitch=rp, out_coff=0, cout_pad=rp, cout_store=rp, out_split=rp, out_coff2=0, out_f32=0,
                              res_dev=res.data_ptr() if res is not None else None, res_pitch=rp, res_coff=0, alpha=0.5, ksize=k, stride=stride, act=1, shuffle=0, force_cfg=c)
         lib.vgh_conv_set_trace(None)
@@ -78,6 +82,10 @@ def main():
             gap = (t[sel & (ntile > k_ + 1), k_ + 1, 0] - t[sel & (ntile > k_ + 1), k_, 3]) if k_ + 1 < ntile.max() else np.array([0])
             print(f"  tile {k_:2d} ({int(sel.sum()):4d} blocks): top->ready {d01.mean():7.0f} (max {d01.max():6d})  K loop {d12.mean():7.0f} (min {d12.min():6d} max {d12.max():6d})  "
                   f"epilogue {d23.mean():7.0f} (max {d23.max():6d})  ->next {gap.mean():6.0f}")
+        # blocks in flight: the sum of block lifetimes over the busiest XCD's span / its 32 CUs (one-tile-per-block kernels: how many tiles a CU holds at a time)
+        life = np.array([end[i] - t[i, 0, 0] for i in range(nb)], dtype=np.float64)
+        per_x = [(life[xcd == x].sum() / max(float(end[xcd == x].max() - t[xcd == x, 0, 0].min()), 1.0)) for x in range(8) if (xcd == x).any()]
+        print(f"  traced blocks alive at a time: {np.mean(per_x):.1f} per XCD = {np.mean(per_x) / 32:.2f} per CU (of the {nb} traced blocks; a launch with more than 8192 blocks is traced for its first 8192)")
         # s_memtime ticks are shader cycles (tools/micro/barrier_handoff: 1024.1 ticks per 32 back-to-back 32x32x16 MFMAs per SIMD): the busiest blocks' tick count
         # over the launch's wall time is the clock the kernel actually ran at; for the g / h tiles (marks: tile top, first channel block done, K loop done,
         # epilogue done) the steady K loop gives cycles per barrier slot against the 128 * BC / 32 matrix-pipe cycles a slot holds
