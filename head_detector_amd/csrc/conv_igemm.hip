@@ -17,6 +17,7 @@
 //   address for activations (which also implements im2col + zero padding), host pre-swizzled image for
 //   weights (vgh_pack_conv_weights_host).
 #include "conv_kernels.inc"
+#include "conv_cfg_list.h"
 
 namespace {
 
@@ -27,27 +28,6 @@ struct CfgEntry {
     int patch, TW, TH;  // 7: conv3x3_pp_kernel with two 4 x 8 sub-patches per wave; 5: conv3x3_pp_kernel (conv_pp.hip: 8-wave ping-pong, 8 x 8 sub-patch per wave); 1 / 2: conv3x3_patch_kernel / conv3x3_patch3_kernel (3x3, stride 1, tile TH x TW); 3: conv1x1_stream_kernel; 4: conv3x3_patch_kernel stride 2 (output tile TH x TW); fast epilogue only
     void (*launch_patch)(const ConvArgs&, int, int, int, int, int, int, hipStream_t);
 };
-
-// Per-device launch state: the >64 KiB dynamic-LDS opt-in and the occupancy query act on the CURRENT device, so they are cached
-// per device id (a second engine on another GPU of the same process needs its own opt-in).  Racing threads compute the same value.
-constexpr int kMaxDevices = 16;
-static int current_device() {
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
-    return d;
-}
-
-template <typename K>
-static int patch_blocks_per_cu(K kernel, int threads, int lds, std::atomic<int> (&cache)[kMaxDevices]) {
-    const int dev = current_device();
-    int n = cache[dev].load(std::memory_order_acquire);
-    if (n == 0) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kernel, threads, lds) != hipSuccess || n < 1) n = 1;
-        cache[dev].store(n, std::memory_order_release);
-    }
-    return n;
-}
 
 static std::atomic<int> g_max_blocks_per_xcd{0};
 static std::atomic<int> g_nt_store{0};
@@ -72,14 +52,6 @@ int vgh_conv_persistent_blocks_per_xcd(const ConvArgs& a, int chunk, int per_cu)
 namespace {
 
 
-template <int TW, int TH, int BC, int NWP, int NWC>
-void launch_patch_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
-    static std::atomic<int> per_cu[kMaxDevices];
-    const int n = patch_blocks_per_cu(conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>, NWP * NWC * 64, lds, per_cu);
-    const int gpx = persistent_blocks_per_xcd(a, chunk, n);
-    hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
-}
-
 #ifdef VGH_EXPERIMENTS
 template <int TW, int TH, int BC, int NWP, int NWC>
 void launch_patch_s2_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
@@ -89,23 +61,6 @@ void launch_patch_s2_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total
     hipLaunchKernelGGL((conv3x3_patch_kernel<TW, TH, BC, NWP, NWC, 0, 1>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
 }
 #endif
-
-template <int TW, int TH, int BC, int NWP, int NWC>
-void launch_patch3_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total, int chunk, int lds, hipStream_t st) {
-    static std::atomic<int> per_cu[kMaxDevices];
-    const int n = patch_blocks_per_cu(conv3x3_patch3_kernel<TW, TH, BC, NWP, NWC>, NWP * NWC * 64, lds, per_cu);
-    const int gpx = persistent_blocks_per_xcd(a, chunk, n);
-    hipLaunchKernelGGL((conv3x3_patch3_kernel<TW, TH, BC, NWP, NWC>), dim3(gpx * 8), dim3(NWP * NWC * 64), lds, st, a, ntc, ntx, nty, total, chunk);
-}
-
-template <int BP, int BC, int WP, int WC, int KBS, int NST>
-void launch_stream_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
-    static std::atomic<int> per_cu[kMaxDevices];
-    constexpr int threads = (BP / WP) * (BC / WC) * 64;
-    const int n = patch_blocks_per_cu(conv1x1_stream_kernel<BP, BC, WP, WC, KBS, NST>, threads, lds, per_cu);
-    const int gpx = persistent_blocks_per_xcd(a, chunk, n);
-    hipLaunchKernelGGL((conv1x1_stream_kernel<BP, BC, WP, WC, KBS, NST>), dim3(gpx * 8), dim3(threads), lds, st, a, ntc, total, chunk);
-}
 
 template <int BP, int BC, int WP, int WC, int KBS, int NST>
 void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
@@ -174,17 +129,17 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
 #define LCFG(BP, BC, WP, WC, KBS, NST, LF) \
     { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST "_l" #LF, BP, BC, (BP / WP) * (BC / WC) * 64 * LF, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg_lf<BP, BC, WP, WC, KBS, NST, LF>, 0, 0, 0, nullptr }
 #define PCFG(TW, TH, BC, NWP, NWC) \
-    { "p" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC>(), nullptr, 1, TW, TH, launch_patch_cfg<TW, TH, BC, NWP, NWC> }
+    { "p" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC>(), nullptr, 1, TW, TH, vghcfg::lp_##TW##_##TH##_##BC##_##NWP##_##NWC }
 
 #define QCFG(TW, TH, BC, NWP, NWC) \
-    { "q" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, Patch3<TW, TH, BC, NWP, NWC>::LDS, nullptr, 2, TW, TH, launch_patch3_cfg<TW, TH, BC, NWP, NWC> }
+    { "q" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, Patch3<TW, TH, BC, NWP, NWC>::LDS, nullptr, 2, TW, TH, vghcfg::lq_##TW##_##TH##_##BC##_##NWP##_##NWC }
 
 #ifdef VGH_EXPERIMENTS
 #define DCFG(TW, TH, BC, NWP, NWC) \
     { "d" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC, 1>(), nullptr, 4, TW, TH, launch_patch_s2_cfg<TW, TH, BC, NWP, NWC> }
 #endif
 #define TCFG(BP, BC, WP, WC, KBS, NST) \
-    { "t" #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, Stream1<BP, BC, WP, WC, KBS, NST>::LDS, launch_stream_cfg<BP, BC, WP, WC, KBS, NST>, 3, 0, 0, nullptr }
+    { "t" #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, Stream1<BP, BC, WP, WC, KBS, NST>::LDS, vghcfg::lt_##BP##_##BC##_##WP##_##WC##_##KBS##_##NST, 3, 0, 0, nullptr }
 
 #define GCFG(BC) \
     { "g8x8x" #BC "_n8", 512, BC, 512, 0, nullptr, 5, 8, 8, nullptr }

@@ -26,6 +26,7 @@ struct vgh_detector {
     int32_t* keep_idx = nullptr;   // [max_batch, keep_k]
     int32_t* head_row = nullptr;   // [max_batch * keep_k]
     int32_t* head_image = nullptr; // [max_batch * keep_k]
+    int32_t* ticket = nullptr;     // [1], zero between launches: vgh_nms_select's last-block ticket
     // overlap mode: the select half (NMS .. FLAME decode: small, latency-bound kernels) runs on a detector-owned side stream,
     // concurrently with the network of the NEXT batch on the caller's stream
     bool overlap = false, side_pending = false;
@@ -147,7 +148,13 @@ int vgh_detector_create(vgh_net* net, vgh_flame* flame, const vgh_detect_cfg* cf
     ALLOC(keep_idx, MB * KK);
     ALLOC(head_row, MB * KK);
     ALLOC(head_image, MB * KK);
+    ALLOC(ticket, 1);
 #undef ALLOC
+    if (hipMemset(d->ticket, 0, sizeof(int32_t)) != hipSuccess) {
+        vgh_set_error("detector_create: hipMemset failed");
+        vgh_detector_destroy(d);
+        return VGH_ERR_HIP;
+    }
     *out = d;
     return VGH_OK;
 }
@@ -163,6 +170,7 @@ void vgh_detector_destroy(vgh_detector* d) {
     hipFree(d->keep_idx);
     hipFree(d->head_row);
     hipFree(d->head_image);
+    hipFree(d->ticket);
     release_side(d);
     if (d->net) vgh_net_set_pred_guard(d->net, nullptr);
     if (d->ev_net) hipEventDestroy(d->ev_net);
@@ -251,18 +259,25 @@ int vgh_detector_set_flame(vgh_detector* d, vgh_flame* flame) {
 static int select_on(vgh_detector* d, int B, float conf_thr, float iou_thr, vgh_detect_out* o, void* stream) {
     const vgh_detect_cfg& c = d->cfg;
     int rc;
-    if ((rc = vgh_nms(d->cand_boxes, d->cand_scores, B, c.pre_k, conf_thr, iou_thr, c.keep_k, d->keep_idx, o->counts_dev, stream))) return rc;
-    if ((rc = vgh_compact(d->cand_boxes, d->cand_scores, d->cand_flame, B, c.pre_k, d->keep_idx, c.keep_k, o->boxes_dev, o->scores_dev, o->flame_dev, stream)))
-        return rc;
     const bool want_heads = o->proj_dev || o->verts_dev || o->rot_dev || o->rpy_dev || o->n_heads_dev || o->head_image_dev;
-    if (!want_heads) return VGH_OK;
-    VGH_REQUIRE(o->n_heads_dev, "detector_select: n_heads_dev is required when any per-head output is requested");
+    VGH_REQUIRE(!want_heads || o->n_heads_dev, "detector_select: n_heads_dev is required when any per-head output is requested");
     const int cap_all = B * c.keep_k;
     const int capacity = (o->head_capacity > 0 && o->head_capacity < cap_all) ? o->head_capacity : cap_all;
     int32_t* himg = o->head_image_dev ? o->head_image_dev : d->head_image;
-    hipLaunchKernelGGL(head_list_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int32_t*)o->counts_dev, B, c.keep_k, capacity, d->head_row, himg,
-                       o->n_heads_dev);
-    VGH_HIP(hipGetLastError());
+    if (c.keep_k <= 1024) {  // r06: NMS + compaction + head list as one launch
+        if ((rc = vgh_nms_select(d->cand_boxes, d->cand_scores, d->cand_flame, B, c.pre_k, conf_thr, iou_thr, c.keep_k, d->keep_idx, o->counts_dev, o->boxes_dev,
+                                 o->scores_dev, o->flame_dev, capacity, want_heads ? d->head_row : nullptr, himg, o->n_heads_dev, d->ticket, stream)))
+            return rc;
+        if (!want_heads) return VGH_OK;
+    } else {
+        if ((rc = vgh_nms(d->cand_boxes, d->cand_scores, B, c.pre_k, conf_thr, iou_thr, c.keep_k, d->keep_idx, o->counts_dev, stream))) return rc;
+        if ((rc = vgh_compact(d->cand_boxes, d->cand_scores, d->cand_flame, B, c.pre_k, d->keep_idx, c.keep_k, o->boxes_dev, o->scores_dev, o->flame_dev, stream)))
+            return rc;
+        if (!want_heads) return VGH_OK;
+        hipLaunchKernelGGL(head_list_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int32_t*)o->counts_dev, B, c.keep_k, capacity, d->head_row, himg,
+                           o->n_heads_dev);
+        VGH_HIP(hipGetLastError());
+    }
     if (!(o->proj_dev || o->verts_dev || o->rot_dev || o->rpy_dev)) return VGH_OK;
     VGH_REQUIRE(d->flame, "detector_select: per-head FLAME outputs requested but the detector was created without a FLAME handle");
     return vgh_flame_decode_indirect(d->flame, o->flame_dev, d->head_row, himg, o->n_heads_dev, capacity, c.shape_live, c.expr_live, o->unpad_dev, o->verts_dev,

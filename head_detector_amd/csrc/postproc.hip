@@ -160,23 +160,28 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ sc
         }
     }
     __syncthreads();
-    // bitonic sort, descending, 1024 entries (zeros = padding sink to the end)
+    // bitonic sort, descending, 1024 entries (zeros = padding sink to the end).  r06: every thread keeps ITS entry in registers; the 45 compare-exchange steps whose
+    // partner sits in the same wave (stride < 64) are cross-lane shuffles with no barrier, only the 10 steps with stride >= 64 go through LDS (20 barriers instead
+    // of 55: the sort was ~15 us of a 34-us launch whose single block per image has nothing else to hide behind).  Same network, same comparisons, same result.
+    uint64_t v = sel[tid];
     for (int size = 2; size <= 1024; size <<= 1) {
+        const bool desc = (tid & size) == 0;
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int partner = tid ^ stride;
-            if (partner > tid) {
-                const uint64_t x = sel[tid], y = sel[partner];
-                const bool desc = (tid & size) == 0;
-                if (desc ? (x < y) : (x > y)) {
-                    sel[tid] = y;
-                    sel[partner] = x;
-                }
+            uint64_t pv;
+            if (stride >= 64) {
+                __syncthreads();  // (everybody has read its partner of the previous LDS step)
+                sel[tid] = v;
+                __syncthreads();
+                pv = sel[tid ^ stride];
+            } else {
+                pv = __shfl_xor(v, stride, 64);
             }
-            __syncthreads();
+            const bool take_max = ((tid & stride) == 0) == desc;  // the lower index of a pair keeps the larger entry in a descending run
+            v = take_max ? (v > pv ? v : pv) : (v < pv ? v : pv);
         }
     }
     if (tid < k) {
-        const int idx = (int)(~(uint32_t)(sel[tid] & 0xffffffffu));
+        const int idx = (int)(~(uint32_t)(v & 0xffffffffu));
         out_idx[(int64_t)b * k + tid] = idx;
         if (out_scores) out_scores[(int64_t)b * k + tid] = sc[idx];
     }
@@ -280,6 +285,118 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
         ++i;
     }
     if (tid == 0) counts[b] = kept;
+}
+
+// r06 (single-image latency: profiles/r06_latency_trace_l1.txt shows nms -> compact -> head_list as three 5.7-us launches, each waiting for the one before): the three
+// as ONE launch.  Block b = image b: the same greedy loop as nms_kernel (kept positions also kept in LDS), then its 16 waves copy the image's keep_k survivor rows
+// (compact_kernel's copy, zeros behind the count); the block that finishes LAST (a ticket in device memory, reset for the next launch) builds the image-major head list
+// from counts[B] (head_list_kernel's scan).  Same decisions, same bytes: tests compare it with the staged entry points.
+__global__ __launch_bounds__(1024) void nms_select_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const float* __restrict__ flame, int n_in,
+                                                          float conf, float thr, int keep_k, int32_t* __restrict__ keep_idx, int32_t* __restrict__ counts,
+                                                          float* __restrict__ ob, float* __restrict__ os, float* __restrict__ of, int B, int capacity,
+                                                          int32_t* __restrict__ head_row, int32_t* __restrict__ head_image, int32_t* __restrict__ n_heads,
+                                                          int32_t* __restrict__ ticket) {
+    __shared__ float4 sb[1024];
+    __shared__ unsigned long long removed[16];
+    __shared__ int s_n;
+    __shared__ int s_keep[1024];
+    __shared__ int s_off[1025];
+    __shared__ int s_last;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 16) removed[tid] = 0ull;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    bool valid = false;
+    if (tid < n_in) {
+        sb[tid] = *(const float4*)(boxes + ((int64_t)b * n_in + tid) * 4);
+        valid = scores[(int64_t)b * n_in + tid] >= conf;
+    }
+    const unsigned long long bal = __ballot(valid);
+    if ((tid & 63) == 0) atomicAdd(&s_n, __popcll(bal));
+    __syncthreads();
+    const int n = s_n;
+    for (int j = tid; j < keep_k; j += 1024) keep_idx[(int64_t)b * keep_k + j] = -1;
+    int kept = 0;
+    int i = 0;
+    while (kept < keep_k) {
+        int nxt = -1;
+        for (int wd = i >> 6; wd < 16 && nxt < 0; ++wd) {
+            unsigned long long free_bits = ~removed[wd];
+            if (wd == (i >> 6)) free_bits &= ~0ull << (i & 63);
+            if (free_bits) nxt = wd * 64 + __ffsll((long long)free_bits) - 1;
+        }
+        if (nxt < 0 || nxt >= n) break;
+        i = nxt;
+        if (tid == 0) {
+            keep_idx[(int64_t)b * keep_k + kept] = i;
+            s_keep[kept] = i;
+        }
+        ++kept;
+        const float4 bi = sb[i];
+        float area_i;
+        {
+#pragma clang fp contract(off)
+            area_i = (bi.z - bi.x) * (bi.w - bi.y);
+        }
+        const bool sup = (tid > i) && (tid < n) && iou_gt(bi, area_i, sb[tid < n_in ? tid : 0], thr);
+        const unsigned long long m = __ballot(sup);
+        __syncthreads();
+        if ((tid & 63) == 0 && m) removed[tid >> 6] |= m;
+        __syncthreads();
+        ++i;
+    }
+    if (tid == 0) counts[b] = kept;
+    __syncthreads();  // s_keep is complete
+    // ---- the image's survivor rows ----
+    const int w = tid >> 6, lane = tid & 63;
+    for (int j = w; j < keep_k; j += 16) {
+        const int64_t o = (int64_t)b * keep_k + j;
+        if (j >= kept) {
+            if (lane < 4) ob[o * 4 + lane] = 0.0f;
+            if (lane == 0) os[o] = 0.0f;
+            if (of)
+                for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) of[o * VGH_NUM_FLAME_PARAMS + c] = 0.0f;
+            continue;
+        }
+        const int64_t sr = (int64_t)b * n_in + s_keep[j];
+        if (lane < 4) ob[o * 4 + lane] = boxes[sr * 4 + lane];
+        if (lane == 0) os[o] = scores[sr];
+        if (of)
+            for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) of[o * VGH_NUM_FLAME_PARAMS + c] = flame[sr * VGH_NUM_FLAME_PARAMS + c];
+    }
+    if (!head_row) return;
+    // ---- the head list, by the block that finishes last ----
+    __threadfence();  // this block's counts[b] is visible before its ticket
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(ticket, 1) == B - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) *ticket = 0;  // (every other block has taken its ticket: nobody touches it again in this launch)
+    __threadfence();
+    const int per = (B + 1023) / 1024;
+    const int b0 = tid * per, b1 = min(B, b0 + per);
+    int mine = 0;
+    for (int q = b0; q < b1; ++q) mine += min(max(__hip_atomic_load(counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0), keep_k);
+    s_off[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (tid >= d) ? s_off[tid - d] : 0;
+        __syncthreads();
+        s_off[tid] += v;
+        __syncthreads();
+    }
+    int at = s_off[tid] - mine;
+    if (tid == 1023) *n_heads = min(s_off[1023], capacity);
+    for (int q = b0; q < b1; ++q) {
+        const int c = min(max(__hip_atomic_load(counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0), keep_k);
+        for (int e = 0; e < c; ++e) {
+            if (at + e < capacity) {
+                head_row[at + e] = q * keep_k + e;
+                head_image[at + e] = q;
+            }
+        }
+        at += c;
+    }
 }
 
 __global__ __launch_bounds__(64) void compact_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const float* __restrict__ flame,
@@ -407,6 +524,21 @@ int vgh_nms(const float* boxes_dev, const float* scores_dev, int B, int n_in, fl
     return VGH_OK;
 }
 
+}  // extern "C"
+// (internal, C++ linkage: declared in vgh_internal.h)
+int vgh_nms_select(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int B, int n_in, float conf_thr, float iou_thr, int keep_k,
+                   int32_t* keep_idx_dev, int32_t* counts_dev, float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, int capacity, int32_t* head_row_dev,
+                   int32_t* head_image_dev, int32_t* n_heads_dev, int32_t* ticket_dev, void* stream) {
+    VGH_REQUIRE(n_in >= 0 && n_in <= 1024 && keep_k >= 1 && keep_k <= 1024, "nms_select: n_in=%d / keep_k=%d must be <= 1024", n_in, keep_k);
+    VGH_REQUIRE(!head_row_dev || (head_image_dev && n_heads_dev && ticket_dev), "nms_select: the head list needs head_image, n_heads and the ticket");
+    if (B == 0) return VGH_OK;
+    hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, boxes_dev, scores_dev, flame_dev, n_in, conf_thr, iou_thr, keep_k, keep_idx_dev,
+                       counts_dev, out_boxes_dev, out_scores_dev, out_flame_dev, B, capacity, head_row_dev, head_image_dev, n_heads_dev, ticket_dev);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
+extern "C" {
 int vgh_compact(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int B, int n_in, const int32_t* keep_idx_dev, int keep_k,
                 float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, void* stream) {
     if (B == 0) return VGH_OK;

@@ -554,6 +554,8 @@ class VGHeadsEngine:
             if name in names and self.cfg_ok(names[name], op):  # a stale entry (a tile that cannot run this op) is skipped here, not replaced -- and logged -- by the library
                 self.set_cfg(i, names[name])
                 applied += 1
+            else:
+                self.set_cfg(i, -1)  # back to the library's own choice: set_split(2) then set_split(1) must not leave the two-lane table's tile on a shape the one-lane table lacks
         return applied
 
 

@@ -586,7 +586,7 @@ def test_network_every_op(gpu_lib, variant, S, B):
     eng.close()
 
 
-@pytest.mark.parametrize("variant,S,B,tuned", [("vgg_heads_l", 160, 3, False), ("vgg_heads_m", 256, 2, False), ("vgg_heads_l", 640, 5, True), ("vgg_heads_m", 224, 7, True)])
+@pytest.mark.parametrize("variant,S,B,tuned", [("vgg_heads_l", 160, 3, False), ("vgg_heads_m", 256, 2, False), ("vgg_heads_l", 640, 2, False), ("vgg_heads_l", 640, 5, True), ("vgg_heads_m", 224, 7, True)])
 def test_b2b_pairs_equal_their_two_launches(gpu_lib, variant, S, B, tuned):
     """Back-to-back GEMM (r06, csrc/conv_kernels.inc T2 > 0): a stage's downsample and the CSP layer's conv1|conv2 behind it as ONE launch -- the
     first conv's accumulators become the second GEMM's B operands in registers, the 96-channel tensor between them is never written.  Against the two launches it
@@ -619,16 +619,16 @@ def test_b2b_pairs_equal_their_two_launches(gpu_lib, variant, S, B, tuned):
             a, b = seg(bufs[i]).float(), seg(ref[1][i]).float()
             assert float(a.abs().max()) > 0
             if tuned:
-                # a TUNED engine may run the second conv on a streaming 1x1 tile, whose accumulators START at the bias (bias + sum instead of sum + bias: another fp32
-                # rounding in ~0.2 % of the outputs): the fused launch keeps the implicit-GEMM convention, so here the two agree to one bf16 ulp, almost everywhere exactly
-                # (when the FIRST conv of a pair runs on such a tile too -- L's neck pair -- a flipped ulp of the tensor in between reaches the second output times a weight)
+                # a TUNED engine may run the unfused second conv on a streaming 1x1 tile, whose accumulators START at the bias (bias + sum instead of sum + bias: another fp32
+                # rounding, a flipped bf16 ulp in ~2e-5 of the outputs); the fused launch keeps the implicit-GEMM convention.  Only the FIRST pair sees the same input in
+                # both runs (the stem's tensor): those rare ulps of its output then travel through fifty layers of a random-weight network, and the later pairs' INPUTS
+                # already differ between the fused and the unfused run (measured: 42 % of the neck pair's outputs, 0.9 % in norm).  Every pair's bit-identity is what the
+                # untuned cases above prove; here: the first pair to one bf16 ulp, almost everywhere exactly.
+                if i != pairs[0]:
+                    continue
                 d = (a - b).abs()
-                if P.ops[i]["ksize"] == 3:  # the first conv is a 3x3 / stride-2 downsample: implicit-GEMM tiles in every table, only the second conv's bias order can differ
-                    assert not (d > 5e-2 + b.abs() / 32).any(), (ns, P.ops[i]["name"], float(d.max()))
-                    assert float((a != b).float().mean()) < 0.05, (ns, P.ops[i]["name"], float((a != b).float().mean()))
-                else:  # a 1x1 first conv on a streaming tile: flipped ulps of the tensor in between reach every output of the second conv times a weight -- rounding noise
-                    # of the bf16 tensor in between (2^-9 relative), measured against the size of the output tensor
-                    assert float(d.norm()) < 4e-3 * float(b.norm()), (ns, P.ops[i]["name"], float(d.norm()), float(b.norm()), float(d.max()))
+                assert not (d > 5e-2 + b.abs() / 32).any(), (ns, P.ops[i]["name"], float(d.max()))
+                assert float((a != b).float().mean()) < 1e-3, (ns, P.ops[i]["name"], float((a != b).float().mean()))
             else:
                 assert torch.equal(bufs[i], ref[1][i]), (ns, P.ops[i]["name"])
         if not tuned:
