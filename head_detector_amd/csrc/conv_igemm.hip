@@ -319,6 +319,8 @@ const CfgEntry g_cfgs[] = {
     LCFG(32, 64, 32, 32, 4, 3, 3),   // 147  32-pixel tiles: 13 instead of 7 pixel tiles over a 20^2 map
     LCFG(32, 64, 32, 32, 4, 3, 6),   // 148
     LCFG(128, 64, 32, 64, 2, 3, 3),  // 149  12 waves
+    CFGR(128, 96, 32, 96, 1, 3),     // 150  three stages = 46 KiB < the 51 KiB of epilogue strips: still three blocks per CU, two stages in flight each
+    CFGR(128, 192, 32, 96, 1, 4),    // 151
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
