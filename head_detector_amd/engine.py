@@ -527,6 +527,9 @@ class VGHeadsEngine:
         al = all(op[k] % 8 == 0 for k in ("out_coff", "out_coff2", "out_split", "cout_store", "res_coff")) and ob["pitch"] % 8 == 0
         fast = int(ob["is_f32"] != arch.FMT_F32 and al)
         if self.precision in ("fp16x3", "bf16x3", "fp16"):
+            if self.precision != "fp16" and self.cfg_names()[cfg][0] == "g":
+                return False  # the fp16 ping-pong pseudo-entries of the split table run single-plane fp16 nets only (vgh_conv_split_cfg_ok answers for those); a two-plane
+                # net would fall back to another tile at launch and a tuner would time the fallback under the g name
             return bool(self.lib.vgh_conv_split_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"], op.get("grp_cout", 0)))
         if not self.lib.vgh_conv_cfg_ok(cfg, op["ksize"], op["stride"], op["cout_pad"], fast, op["shuffle"]):
             return False

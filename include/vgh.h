@@ -185,6 +185,8 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
  * activation buffers are VGH_FMT_BF16X2 / VGH_FMT_F16X2. */
 int vgh_conv_split_num_cfgs(void);
 const char* vgh_conv_split_cfg_name(int cfg);
+/* (The last three entries, g8x8x{128,96,64}_n8, are the fp16 ping-pong tiles: the answer is for a SINGLE-PLANE fp16 net (VGH_FMT_F16); a two-plane net cannot run them
+ * and falls back to another tile at launch.) */
 int vgh_conv_split_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilogue, int shuffle, int grp_cout);
 /* Cap on the persistent 3x3 kernels' grid: at most `blocks` workgroups per XCD (0 = as many as stay resident, the default).
  * Process-wide.  Leaves CUs to other work; the parity tests use it to drive many tiles through one workgroup. */

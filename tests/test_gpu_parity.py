@@ -940,6 +940,34 @@ def test_fused_detect_matches_staged_pipeline(gpu_lib, flame_model):
     eng.close()
 
 
+def test_select_as_one_launch_with_many_images_and_empty_ones(gpu_lib, flame_model):
+    """r06: NMS + compaction + head list are ONE launch (nms_select_kernel: block per image, the LAST block to finish builds the head list behind a device-memory
+    ticket).  70 images -- more blocks than one round of anything -- with a threshold that leaves about half of them without a survivor, twice through the same
+    detector (the ticket is back at zero): counts, the image-major head list and every kept row against the oracle's post-processing of the engine's candidates."""
+    from head_detector_amd.engine import VGHeadsEngine
+    from head_detector_amd.flame import FLAMELayer
+    from oracle import postproc_oracle as po
+
+    S, B = 160, 70
+    x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(23)).to(_dev())
+    fl = FLAMELayer(model=flame_model, device=_dev(), max_heads=B * 100)
+    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=8)
+    boxes, scores, flame = [t.clone() for t in eng.model(x)]
+    conf = float(scores[:, 0, 0].median())  # the best score of about half of the images falls below it
+    ref = po.postprocess_batched(boxes.cpu(), scores.cpu(), flame.cpu(), conf, 0.5)
+    want = [r[0].shape[0] for r in ref]
+    assert 0 in want and max(want) >= 1
+    for _ in range(2):
+        det = eng.detect(x, confidence_threshold=conf, flame=fl)
+        assert det.counts.cpu().tolist() == want and det.num_heads == sum(want)
+        assert det.head_image.cpu().tolist() == [b for b, c in enumerate(want) for _ in range(c)]
+        for b in range(B):
+            n = want[b]
+            assert torch.equal(det.boxes[b, :n].cpu(), ref[b][0]) and torch.equal(det.flame_params[b, :n].cpu(), ref[b][2])
+            assert not bool(det.boxes[b, n:].any()) and not bool(det.flame_params[b, n:].any())  # rows behind the count are zeros
+    eng.close()
+
+
 def test_detect_batch_facade_equals_single_image_calls(gpu_lib, flame_model):
     """HeadDetector.detect_batch (fused device path for every image) returns, per image, what HeadDetector.__call__ returns."""
     from head_detector_amd.detector import HeadDetector

@@ -12,7 +12,7 @@ import sys
 
 FAMILIES = [
     (r"conv3x3_pp_kernel<(\d), 1, 0, 0, 0, 0, 1>", "s  ping-pong 3x3, two 4x8 sub-patches per wave (r06)"),
-    (r"conv_igemm_kernel<[^>]*, [468]>$", "b2b  implicit GEMM + the 1x1 conv behind it in one launch (r06)"),
+    (r"conv_igemm_kernel<[^>]*, [468], 1>$", "b2b  implicit GEMM + the 1x1 conv behind it in one launch (r06)"),
     (r"conv3x3_pp_kernel<(\d), 1", "g  ping-pong 3x3 (two barriers per tap)"),
     (r"conv3x3_pp_kernel<(\d), 2", "h  ping-pong 3x3 (one barrier per tap)"),
     (r"conv3x3_patch3_kernel", "q  halo-patch 3x3, cross-tile pipelined"),
