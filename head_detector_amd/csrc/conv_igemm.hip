@@ -62,60 +62,7 @@ void launch_patch_s2_cfg(const ConvArgs& a, int ntc, int ntx, int nty, int total
 }
 #endif
 
-template <int BP, int BC, int WP, int WC, int KBS, int NST>
-void launch_cfg(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
-    static std::atomic<int> attr_done[kMaxDevices];
-    if (lds > 64 * 1024) {
-        const int dev = current_device();
-        if (!attr_done[dev].load(std::memory_order_acquire)) {
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_done[dev].store(1, std::memory_order_release);
-        }
-    }
-    const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64);
-    constexpr int nw = (BP / WP) * (BC / WC);
-    constexpr int loop_lds = NST * KBS * (BP + BC) * 64 + (NST > 2 ? nw * 1024 : 0), epi_lds = nw * 32 * (WC + 4) * 4;
-    if (NST == 2 && (a.nkb + KBS - 1) / KBS == 1) {  // the whole K fits one stage: no second buffer -> more blocks per CU
-        const int one = KBS * (BP + BC) * 64, epi = (BP / WP) * (BC / WC) * 32 * (WC + 4) * 4;
-        lds = one > epi ? one : epi;
-    }
-    // r06: tiles whose LDS-transposed epilogue strips outweigh their stage buffers (the 96-cout wave tiles) take the REGISTER epilogue (EPI = 3, no LDS) for plain bf16
-    // convs: the block's LDS drops to its stages and more blocks share a CU
-#ifdef VGH_EXPERIMENTS  // measured r06 (profiles/r06_ab_regepi.txt): single-stream sum -0.9 % (L) / -1.5 % (M), the two-lane forward unchanged, stage1.conv3 33 us slower: not adopted
-    static const int regepi = getenv("VGH_REGEPI") ? atoi(getenv("VGH_REGEPI")) : 0;
-    if constexpr (epi_lds > loop_lds && loop_lds <= 64 * 1024) {
-        if (regepi && a.fast_epi && !a.out_f32 && !a.res && !a.shuffle && a.act != VGH_ACT_SILU) {
-            const int l3 = (NST == 2 && (a.nkb + KBS - 1) / KBS == 1) ? KBS * (BP + BC) * 64 : loop_lds;
-            hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 3, NST>), grid, block, l3, st, a, ntc, total, chunk);
-            return;
-        }
-    }
-#endif
-    if (a.fast_epi)
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST>), grid, block, lds, st, a, ntc, total, chunk);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST>), grid, block, lds, st, a, ntc, total, chunk);
-}
-
-// loader-wave tiles (conv_igemm_kernel<..., LF>): LF x the waves, the same LDS
-template <int BP, int BC, int WP, int WC, int KBS, int NST, int LF>
-void launch_cfg_lf(const ConvArgs& a, int ntc, int total, int chunk, int lds, hipStream_t st) {
-    static std::atomic<int> attr_done[kMaxDevices];
-    if (lds > 64 * 1024) {
-        const int dev = current_device();
-        if (!attr_done[dev].load(std::memory_order_acquire)) {
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST, 0, 0, LF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, 0, 0, LF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_done[dev].store(1, std::memory_order_release);
-        }
-    }
-    const dim3 grid(chunk * 8), block((BP / WP) * (BC / WC) * 64 * LF);
-    if (a.fast_epi)
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 1, NST, 0, 0, LF>), grid, block, lds, st, a, ntc, total, chunk);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BP, BC, WP, WC, KBS, 0, NST, 0, 0, LF>), grid, block, lds, st, a, ntc, total, chunk);
-}
+#include "conv_launch_igemm.inc"
 
 constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
     const int nw = (BP / WP) * (BC / WC);
@@ -125,9 +72,9 @@ constexpr int lds_bytes(int BP, int BC, int WP, int WC, int KBS, int NST) {
 #define CFG(BP, BC, WP, WC, KBS) \
     { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, 2), launch_cfg<BP, BC, WP, WC, KBS, 2>, 0, 0, 0, nullptr }
 #define CFGR(BP, BC, WP, WC, KBS, NST) \
-    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg<BP, BC, WP, WC, KBS, NST>, 0, 0, 0, nullptr }
+    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST, BP, BC, (BP / WP) * (BC / WC) * 64, lds_bytes(BP, BC, WP, WC, KBS, NST), vghcfg::lr_##BP##_##BC##_##WP##_##WC##_##KBS##_##NST, 0, 0, 0, nullptr }
 #define LCFG(BP, BC, WP, WC, KBS, NST, LF) \
-    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST "_l" #LF, BP, BC, (BP / WP) * (BC / WC) * 64 * LF, lds_bytes(BP, BC, WP, WC, KBS, NST), launch_cfg_lf<BP, BC, WP, WC, KBS, NST, LF>, 0, 0, 0, nullptr }
+    { #BP "x" #BC "_w" #WP "x" #WC "_k" #KBS "_r" #NST "_l" #LF, BP, BC, (BP / WP) * (BC / WC) * 64 * LF, lds_bytes(BP, BC, WP, WC, KBS, NST), vghcfg::ll_##BP##_##BC##_##WP##_##WC##_##KBS##_##NST##_##LF, 0, 0, 0, nullptr }
 #define PCFG(TW, TH, BC, NWP, NWC) \
     { "p" #TH "x" #TW "x" #BC "_n" #NWP "x" #NWC, (TW) * (TH), BC, (NWP) * (NWC) * 64, patch_lds<TW, TH, BC, NWP, NWC>(), nullptr, 1, TW, TH, vghcfg::lp_##TW##_##TH##_##BC##_##NWP##_##NWC }
 
