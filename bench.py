@@ -277,7 +277,7 @@ def make_step(eng, flame, images, unpad, conf, B, slots, gat, overlap, use_graph
                 ev1[i].record(eng.stream)
             # post-network stages: decode/top-k/gather, then ONE library call for NMS + compaction + head list + FLAME decode of every
             # survivor (vgh_detector_select); the head count stays on the device, so the host queues ahead of the GPU
-            eng.candidates(B)
+            eng.candidates(B, lazy_flame=True)  # (r06) the select below follows at once: the survivors' FLAME vectors come straight from the prediction buffers
         k = i if i is not None else 0
         det = eng.select(B, confidence_threshold=conf, iou_threshold=0.5, flame=flame, unpad=unpad, n_heads_out=n_heads_all[k : k + 1],
                          slot=slots[s] if slots else None)

@@ -146,6 +146,7 @@ SYMBOLS = {
     "vgh_detector_scratch": (_P, [_P, _I]),
     "vgh_detector_select": (_I, [_P, _I, _F, _F, C.POINTER(DetectOut), _P]),
     "vgh_detector_set_overlap": (_I, [_P, _I]),
+    "vgh_detector_set_lazy_flame": (_I, [_P, _I]),
     "vgh_detector_join": (_I, [_P, _P]),
     "vgh_detector_record": (_I, [_P, _P, _P]),
     "vgh_detect": (_I, [_P, _P, _I, _I, _F, _F, C.POINTER(DetectOut), _P]),

@@ -27,6 +27,9 @@ struct vgh_detector {
     int32_t* head_row = nullptr;   // [max_batch * keep_k]
     int32_t* head_image = nullptr; // [max_batch * keep_k]
     int32_t* ticket = nullptr;     // [1], zero between launches: vgh_nms_select's last-block ticket
+    // lazy FLAME gather (r06, vgh_detector_set_lazy_flame): the candidate stage gathers boxes only; the 413-vectors of the SURVIVORS are built by the select from the
+    // prediction buffers (106 MB of candidate vectors per 64 images for ~3 survivors per image otherwise).  flame_pending: a lazy candidate stage is waiting for its select
+    bool lazy_flame = false, flame_pending = false;
     // overlap mode: the select half (NMS .. FLAME decode: small, latency-bound kernels) runs on a detector-owned side stream,
     // concurrently with the network of the NEXT batch on the caller's stream
     bool overlap = false, side_pending = false;
@@ -185,13 +188,16 @@ int vgh_detector_candidates(vgh_detector* d, const void* images_dev, int image_f
     VGH_REQUIRE(image_fmt == VGH_IMG_F32_NCHW || image_fmt == VGH_IMG_U8_NHWC, "detector_candidates: unknown image format %d", image_fmt);
     const size_t img_bytes = (size_t)d->S * d->S * 3 * (image_fmt == VGH_IMG_F32_NCHW ? 4 : 1);
     // arena-sized chunks (the conv kernels address < 2 GiB per tensor; the arena is planned for arena_batch images)
-    for (int at = 0; at < B; at += d->arena_batch) {
+    const bool lazy = d->lazy_flame;
+    if (B > d->arena_batch) d->lazy_flame = false;  // chunks: the next chunk's forward overwrites the prediction buffers a lazy select would read
+    int rc = VGH_OK;
+    for (int at = 0; at < B && !rc; at += d->arena_batch) {
         const int n = (B - at < d->arena_batch) ? B - at : d->arena_batch;
-        int rc = vgh_net_forward(d->net, (const char*)images_dev + (size_t)at * img_bytes, image_fmt, n, stream);
-        if (rc) return rc;
-        if ((rc = vgh_detector_decode_candidates(d, n, at, stream))) return rc;
+        rc = vgh_net_forward(d->net, (const char*)images_dev + (size_t)at * img_bytes, image_fmt, n, stream);
+        if (!rc) rc = vgh_detector_decode_candidates(d, n, at, stream);
     }
-    return VGH_OK;
+    d->lazy_flame = lazy;
+    return rc;
 }
 
 int vgh_detector_decode_candidates(vgh_detector* d, int n, int at, void* stream) {
@@ -219,9 +225,11 @@ int vgh_detector_decode_candidates(vgh_detector* d, int n, int at, void* stream)
     int rc;
     if ((rc = vgh_head_decode(lv, c.n_levels, n, ba, sa, st))) return rc;
     if ((rc = vgh_topk(sa, n, d->A, c.pre_k, ix, d->cand_scores + (size_t)at * c.pre_k, st))) return rc;
+    const bool lazy = d->lazy_flame && at == 0;  // (rows at > 0 belong to a chunked batch)
     if ((rc = vgh_gather_candidates(lv, c.n_levels, n, d->A, c.shape_live, c.expr_live, ba, ix, c.pre_k, d->cand_boxes + (size_t)at * c.pre_k * 4,
-                                    d->cand_flame + (size_t)at * c.pre_k * VGH_NUM_FLAME_PARAMS, st)))
+                                    lazy ? nullptr : d->cand_flame + (size_t)at * c.pre_k * VGH_NUM_FLAME_PARAMS, st)))
         return rc;
+    d->flame_pending = lazy;
     if (d->overlap) {  // the next forward may run its backbone / neck now, but must not overwrite the predictions before this point
         VGH_HIP(hipEventRecord(d->ev_cand, d->side));
         if ((rc = vgh_net_set_pred_guard(d->net, d->ev_cand))) return rc;
@@ -264,10 +272,26 @@ static int select_on(vgh_detector* d, int B, float conf_thr, float iou_thr, vgh_
     const int cap_all = B * c.keep_k;
     const int capacity = (o->head_capacity > 0 && o->head_capacity < cap_all) ? o->head_capacity : cap_all;
     int32_t* himg = o->head_image_dev ? o->head_image_dev : d->head_image;
+    const bool lazy = d->flame_pending;
+    d->flame_pending = false;
+    VGH_REQUIRE(!lazy || c.keep_k <= 1024, "detector_select: the lazy FLAME gather needs keep_k <= 1024");
     if (c.keep_k <= 1024) {  // r06: NMS + compaction + head list as one launch
+        vgh_head_level lv[VGH_MAX_LEVELS];
+        for (int l = 0; l < c.n_levels; ++l) {
+            lv[l].pred_dev = (const float*)vgh_net_buffer(d->net, c.level_buf[l]);
+            lv[l].h = c.level_h[l];
+            lv[l].w = c.level_w[l];
+            lv[l].pitch = c.level_pitch[l];
+            lv[l].stride = c.level_stride[l];
+        }
         if ((rc = vgh_nms_select(d->cand_boxes, d->cand_scores, d->cand_flame, B, c.pre_k, conf_thr, iou_thr, c.keep_k, d->keep_idx, o->counts_dev, o->boxes_dev,
-                                 o->scores_dev, o->flame_dev, capacity, want_heads ? d->head_row : nullptr, himg, o->n_heads_dev, d->ticket, stream)))
+                                 o->scores_dev, o->flame_dev, capacity, want_heads ? d->head_row : nullptr, himg, o->n_heads_dev, d->ticket, lazy ? lv : nullptr,
+                                 c.n_levels, lazy ? d->idx : nullptr, c.shape_live, c.expr_live, stream)))
             return rc;
+        if (lazy && d->overlap && stream == (void*)d->side) {
+            // the select has just read the prediction buffers: the next forward's guard moves behind it (same event, recorded again; the net waits for the latest record)
+            VGH_HIP(hipEventRecord(d->ev_cand, d->side));
+        }
         if (!want_heads) return VGH_OK;
     } else {
         if ((rc = vgh_nms(d->cand_boxes, d->cand_scores, B, c.pre_k, conf_thr, iou_thr, c.keep_k, d->keep_idx, o->counts_dev, stream))) return rc;
@@ -324,6 +348,12 @@ int vgh_detector_set_overlap(vgh_detector* d, int enable) {
         d->side_pending = false;
     }
     d->overlap = enable != 0;
+    return VGH_OK;
+}
+
+int vgh_detector_set_lazy_flame(vgh_detector* d, int enable) {
+    VGH_REQUIRE(d, "detector_set_lazy_flame: null handle");
+    d->lazy_flame = enable != 0;
     return VGH_OK;
 }
 

@@ -188,9 +188,38 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ sc
 }
 
 // ---- K6b: gather boxes + FLAME 413-vector for selected anchors ----------------------------------
-__global__ __launch_bounds__(64) void gather_kernel(Levels L, int A, int S, int E, const float* __restrict__ boxes, const int32_t* __restrict__ idx,
-                                                    int k, float* __restrict__ out_boxes, float* __restrict__ out_flame) {
-    const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// channel c of the reference's 413-vector for the anchor whose prediction row is `pr` (yolo_head_dfl_head.py:162-184, yolo_head_ndfl_heads.py:143-172): tanh * 3 on the
+// live shape / expression channels (zeros behind them), the rotation / jaw permutation, translation += anchor centre * stride, exp(scale) / 0.05 * stride
+__device__ __forceinline__ float flame_channel(const float* __restrict__ pr, int c, int S, int E, int ax, int ay, float st) {
+    const int o_shape = VGH_PRED_FLAME_OFF, o_expr = o_shape + S, o_rot = o_expr + E, o_jaw = o_rot + 6, o_tr = o_jaw + 3, o_sc = o_tr + 3;
+    float v = 0.0f;
+    if (c < 300) {
+        if (c < S) v = tanhf(pr[o_shape + c]) * 3.0f;
+    } else if (c < 400) {
+        if (c - 300 < E) v = tanhf(pr[o_expr + c - 300]) * 3.0f;
+    } else if (c < 403) {
+        v = pr[o_rot + 3 + (c - 400)];  // T[400:403] = O[403:406] = rot branch [3:6]
+    } else if (c < 406) {
+        v = pr[o_jaw + (c - 403)];  // T[403:406] = O[406:409] = jaw branch
+    } else if (c < 409) {
+        v = pr[o_rot + (c - 406)];  // T[406:409] = O[400:403] = rot branch [0:3]
+    } else if (c == 409) {
+        v = pr[o_tr + 0] + ((float)ax + 0.5f) * st;  // translation[:, 0:2] += anchor * stride
+    } else if (c == 410) {
+        v = pr[o_tr + 1] + ((float)ay + 0.5f) * st;
+    } else if (c == 411) {
+        v = pr[o_tr + 2];
+    } else {
+        v = (expf(pr[o_sc]) / 0.05f) * st;  // exp(x)/0.05, then scale *= stride
+    }
+    return v;
+}
+
+// (r06: four candidate rows per 256-thread block, one wave each -- 16 000 blocks per 64 images instead of 64 000 one-wave blocks)
+__global__ __launch_bounds__(256) void gather_kernel(Levels L, int A, int S, int E, const float* __restrict__ boxes, const int32_t* __restrict__ idx,
+                                                     int k, float* __restrict__ out_boxes, float* __restrict__ out_flame) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y, lane = threadIdx.x & 63;
+    if (j >= k) return;
     const int a = idx[(int64_t)b * k + j];
     const int l = find_level(L, a);
     const int p = a - L.start[l];
@@ -198,32 +227,10 @@ __global__ __launch_bounds__(64) void gather_kernel(Levels L, int A, int S, int 
     const float* pr = L.pred[l] + ((int64_t)b * hw + p) * L.pitch[l];
     const int ay = p / L.w[l], ax = p - ay * L.w[l];
     const float st = (float)L.stride[l];
-    const int o_shape = VGH_PRED_FLAME_OFF, o_expr = o_shape + S, o_rot = o_expr + E, o_jaw = o_rot + 6, o_tr = o_jaw + 3, o_sc = o_tr + 3;
-    float* of = out_flame + ((int64_t)b * k + j) * VGH_NUM_FLAME_PARAMS;
     if (lane < 4) out_boxes[((int64_t)b * k + j) * 4 + lane] = boxes[((int64_t)b * A + a) * 4 + lane];
-    for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) {
-        float v = 0.0f;
-        if (c < 300) {
-            if (c < S) v = tanhf(pr[o_shape + c]) * 3.0f;
-        } else if (c < 400) {
-            if (c - 300 < E) v = tanhf(pr[o_expr + c - 300]) * 3.0f;
-        } else if (c < 403) {
-            v = pr[o_rot + 3 + (c - 400)];  // T[400:403] = O[403:406] = rot branch [3:6]
-        } else if (c < 406) {
-            v = pr[o_jaw + (c - 403)];  // T[403:406] = O[406:409] = jaw branch
-        } else if (c < 409) {
-            v = pr[o_rot + (c - 406)];  // T[406:409] = O[400:403] = rot branch [0:3]
-        } else if (c == 409) {
-            v = pr[o_tr + 0] + ((float)ax + 0.5f) * st;  // translation[:, 0:2] += anchor * stride
-        } else if (c == 410) {
-            v = pr[o_tr + 1] + ((float)ay + 0.5f) * st;
-        } else if (c == 411) {
-            v = pr[o_tr + 2];
-        } else {
-            v = (expf(pr[o_sc]) / 0.05f) * st;  // exp(x)/0.05, then scale *= stride
-        }
-        of[c] = v;
-    }
+    if (!out_flame) return;  // lazy mode (vgh_detector_set_lazy_flame): the 413-vector is built for the SURVIVORS only, inside nms_select_kernel
+    float* of = out_flame + ((int64_t)b * k + j) * VGH_NUM_FLAME_PARAMS;
+    for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) of[c] = flame_channel(pr, c, S, E, ax, ay, st);
 }
 
 // ---- K8: conf filter + greedy NMS + keep-k -------------------------------------------------------
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(1024) void nms_select_kernel(const float* __restric
                                                           float conf, float thr, int keep_k, int32_t* __restrict__ keep_idx, int32_t* __restrict__ counts,
                                                           float* __restrict__ ob, float* __restrict__ os, float* __restrict__ of, int B, int capacity,
                                                           int32_t* __restrict__ head_row, int32_t* __restrict__ head_image, int32_t* __restrict__ n_heads,
-                                                          int32_t* __restrict__ ticket) {
+                                                          int32_t* __restrict__ ticket, Levels L, const int32_t* __restrict__ lazy_idx, int S, int E) {
     __shared__ float4 sb[1024];
     __shared__ unsigned long long removed[16];
     __shared__ int s_n;
@@ -361,8 +368,19 @@ __global__ __launch_bounds__(1024) void nms_select_kernel(const float* __restric
         const int64_t sr = (int64_t)b * n_in + s_keep[j];
         if (lane < 4) ob[o * 4 + lane] = boxes[sr * 4 + lane];
         if (lane == 0) os[o] = scores[sr];
-        if (of)
-            for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) of[o * VGH_NUM_FLAME_PARAMS + c] = flame[sr * VGH_NUM_FLAME_PARAMS + c];
+        if (of) {
+            if (lazy_idx) {  // lazy mode: the candidate tensor was never filled; the survivor's vector straight from its prediction row (gather_kernel's arithmetic)
+                const int a = lazy_idx[sr];
+                const int l = find_level(L, a);
+                const int p = a - L.start[l];
+                const float* pr = L.pred[l] + ((int64_t)b * (L.h[l] * L.w[l]) + p) * L.pitch[l];
+                const int ay = p / L.w[l], ax = p - ay * L.w[l];
+                const float st = (float)L.stride[l];
+                for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) of[o * VGH_NUM_FLAME_PARAMS + c] = flame_channel(pr, c, S, E, ax, ay, st);
+            } else {
+                for (int c = lane; c < VGH_NUM_FLAME_PARAMS; c += 64) of[o * VGH_NUM_FLAME_PARAMS + c] = flame[sr * VGH_NUM_FLAME_PARAMS + c];
+            }
+        }
     }
     if (!head_row) return;
     // ---- the head list, by the block that finishes last ----
@@ -507,7 +525,7 @@ int vgh_gather_candidates(const vgh_head_level* levels, int n_levels, int B, int
     VGH_REQUIRE(shape_c >= 0 && shape_c <= 300 && expr_c >= 0 && expr_c <= 100, "gather: bad live channel counts");
     for (int i = 0; i < n_levels; ++i) VGH_REQUIRE(levels[i].pitch >= VGH_PRED_FLAME_OFF + shape_c + expr_c + 13, "gather: pitch too small");
     if (B == 0 || k == 0) return VGH_OK;
-    hipLaunchKernelGGL(gather_kernel, dim3(k, B), dim3(64), 0, (hipStream_t)stream, L, A, shape_c, expr_c, boxes_dev, idx_dev, k, out_boxes_dev,
+    hipLaunchKernelGGL(gather_kernel, dim3((k + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, L, A, shape_c, expr_c, boxes_dev, idx_dev, k, out_boxes_dev,
                        out_flame_dev);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
@@ -528,12 +546,20 @@ int vgh_nms(const float* boxes_dev, const float* scores_dev, int B, int n_in, fl
 // (internal, C++ linkage: declared in vgh_internal.h)
 int vgh_nms_select(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int B, int n_in, float conf_thr, float iou_thr, int keep_k,
                    int32_t* keep_idx_dev, int32_t* counts_dev, float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, int capacity, int32_t* head_row_dev,
-                   int32_t* head_image_dev, int32_t* n_heads_dev, int32_t* ticket_dev, void* stream) {
+                   int32_t* head_image_dev, int32_t* n_heads_dev, int32_t* ticket_dev, const vgh_head_level* lazy_levels, int n_levels, const int32_t* lazy_idx_dev,
+                   int shape_c, int expr_c, void* stream) {
     VGH_REQUIRE(n_in >= 0 && n_in <= 1024 && keep_k >= 1 && keep_k <= 1024, "nms_select: n_in=%d / keep_k=%d must be <= 1024", n_in, keep_k);
     VGH_REQUIRE(!head_row_dev || (head_image_dev && n_heads_dev && ticket_dev), "nms_select: the head list needs head_image, n_heads and the ticket");
     if (B == 0) return VGH_OK;
+    Levels L;
+    memset(&L, 0, sizeof(L));
+    if (lazy_idx_dev) {
+        VGH_REQUIRE(lazy_levels, "nms_select: the lazy FLAME gather needs the head levels");
+        if (int rc = make_levels(lazy_levels, n_levels, &L)) return rc;
+    }
     hipLaunchKernelGGL(nms_select_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, boxes_dev, scores_dev, flame_dev, n_in, conf_thr, iou_thr, keep_k, keep_idx_dev,
-                       counts_dev, out_boxes_dev, out_scores_dev, out_flame_dev, B, capacity, head_row_dev, head_image_dev, n_heads_dev, ticket_dev);
+                       counts_dev, out_boxes_dev, out_scores_dev, out_flame_dev, B, capacity, head_row_dev, head_image_dev, n_heads_dev, ticket_dev, L, lazy_idx_dev, shape_c,
+                       expr_c);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }

@@ -133,7 +133,8 @@ struct VghMarkAtExit {  // "epilogue done" on every return path of a kernel body
 // null: no head list).  ticket_dev: one zero-initialised int32 the kernel leaves at zero.
 int vgh_nms_select(const float* boxes_dev, const float* scores_dev, const float* flame_dev, int B, int n_in, float conf_thr, float iou_thr, int keep_k,
                    int32_t* keep_idx_dev, int32_t* counts_dev, float* out_boxes_dev, float* out_scores_dev, float* out_flame_dev, int capacity, int32_t* head_row_dev,
-                   int32_t* head_image_dev, int32_t* n_heads_dev, int32_t* ticket_dev, void* stream);
+                   int32_t* head_image_dev, int32_t* n_heads_dev, int32_t* ticket_dev, const vgh_head_level* lazy_levels, int n_levels, const int32_t* lazy_idx_dev,
+                   int shape_c, int expr_c, void* stream);  // lazy_idx_dev != null: flame_dev is not read, the survivors' vectors come from the prediction buffers
 int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);
 // conv_igemm.hip: `a` with its b2b fields set (w2pack ...): the fused launch, or VGH_ERR_INVALID when the pair does not fit a b2b tile (vgh_conv_b2b_ok says so beforehand)
 int vgh_launch_conv_b2b(const ConvArgs& a, hipStream_t stream);

@@ -325,19 +325,31 @@ class VGHeadsEngine:
         _lib.check(self.lib.vgh_detector_join(self._det, self._sp()))
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
-    def candidates(self, B: int, at: int = 0):
+    def candidates(self, B: int, at: int = 0, lazy_flame: bool = False):
         """K6 + K7 + K6b for the B images currently in the arena (vgh_detector_decode_candidates): boxes/scores for all anchors,
         top-k, gather + FLAME fix-up; results land in rows [at, at+B) of the batch-level candidate tensors.  In overlap mode
-        they are queued on the detector's side stream (``join()`` before reading them)."""
+        they are queued on the detector's side stream (``join()`` before reading them).
+
+        ``lazy_flame`` (r06, vgh_detector_set_lazy_flame): gather the candidates' BOXES only; the 413-vectors of the survivors are then built by the next ``select`` straight
+        from the prediction buffers (the candidate FLAME tensor -- 1.65 MB per image for typically a handful of survivors -- is neither written nor read; ``cand_flame``
+        is stale).  Contract: that ``select`` is queued before the next forward touches the arena.  Same bits in the detections."""
+        self._set_lazy_flame(lazy_flame)
         _lib.check(self.lib.vgh_detector_decode_candidates(self._det, B, at, self._sp()))
 
-    def forward_candidates(self, images: torch.Tensor, use_graph: bool = False) -> int:
-        """Network + candidate stages for a batch of any size <= max_batch (arena-sized chunks): one vgh_detector_candidates call."""
+    def _set_lazy_flame(self, enable: bool):
+        if getattr(self, "_lazy_flame", False) != bool(enable):
+            _lib.check(self.lib.vgh_detector_set_lazy_flame(self._det, int(bool(enable))))
+            self._lazy_flame = bool(enable)
+
+    def forward_candidates(self, images: torch.Tensor, use_graph: bool = False, lazy_flame: bool = False) -> int:
+        """Network + candidate stages for a batch of any size <= max_batch (arena-sized chunks): one vgh_detector_candidates call.  ``lazy_flame``: see ``candidates``
+        (a batch that runs in several arena chunks gathers eagerly whatever the flag says)."""
         B, fmt = self._check_images(images)
         if use_graph and B <= self.arena_batch:
             self.forward_net(images, True)
-            self.candidates(B)
+            self.candidates(B, lazy_flame=lazy_flame)
             return B
+        self._set_lazy_flame(lazy_flame)
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         _lib.check(self.lib.vgh_detector_candidates(self._det, images.data_ptr(), fmt, B, self._sp()))
         return B
@@ -428,9 +440,11 @@ class VGHeadsEngine:
         if not net_first and not reuse_outputs:
             with torch.cuda.stream(self.stream):
                 slot = self.new_output_slot(flame, B)
+        # (r06) lazy FLAME gather: detect() queues the select right behind the candidates, so the survivors' vectors come straight from the prediction buffers
         if use_graph and B <= self.arena_batch:
-            self.forward_candidates(images, True)
+            self.forward_candidates(images, True, lazy_flame=True)
         else:
+            self._set_lazy_flame(True)
             _lib.check(self.lib.vgh_detector_candidates(self._det, images.data_ptr(), fmt, B, self._sp()))
         if net_first and not reuse_outputs:
             with torch.cuda.stream(self.stream):

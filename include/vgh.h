@@ -367,6 +367,12 @@ int vgh_detect(vgh_detector* d, const void* images_dev, int image_fmt, int B, fl
  * stream); the caller must not reuse the vgh_detect_out buffers of call s for call s+1 unless it joined in between (or does
  * not read them). */
 int vgh_detector_set_overlap(vgh_detector* d, int enable);
+/* r06 (additive): LAZY FLAME GATHER.  enable = 1: vgh_detector_decode_candidates / vgh_detector_candidates gather the candidates' boxes only; the next
+ * vgh_detector_select builds the 413-vectors of the SURVIVORS straight from the prediction buffers (the [B, pre_k, 413] candidate tensor -- 106 MB per 64 images for a handful of
+ * survivors per image -- is neither written nor read: VGH_SCRATCH_CAND_FLAME is stale).  Contract: that select is queued before the next forward overwrites the prediction
+ * buffers (vgh_detect does; in overlap mode the prediction guard moves behind the select by itself).  A batch that runs in several arena chunks gathers eagerly whatever the
+ * flag says.  The detections are the same bits.  Default 0. */
+int vgh_detector_set_lazy_flame(vgh_detector* d, int enable);
 int vgh_detector_join(vgh_detector* d, void* stream);
 /* Records the caller's HIP event behind everything queued so far for the post-network stages (overlap mode: on the detector's side stream; else on `stream`)
  * WITHOUT making any stream wait for it: a host that synchronises on the event of an EARLIER batch can queue that batch's consumers (e.g. the N>1 exchange) with no

@@ -1097,13 +1097,19 @@ def test_overlap_mode_is_race_free_and_identical(gpu_lib, flame_model):
 
     ref_a, ref_b = snap(eng.detect(xa, confidence_threshold=conf, flame=fl)), snap(eng.detect(xb, confidence_threshold=conf, flame=fl))
     assert int(ref_a[3].sum()) > 0 and not torch.equal(ref_a[0], ref_b[0])
+    # the references again through the EAGER candidate stage (detect() gathers lazily since r06: the survivors' FLAME vectors straight from the prediction buffers)
+    for x, ref in ((xa, ref_a), (xb, ref_b)):
+        eng.forward_candidates(x)
+        for r, q in zip(ref, snap(eng.select(B, confidence_threshold=conf, flame=fl))):
+            assert torch.equal(r, q)
     eng.set_overlap(True)
-    for _ in range(3):
+    for it in range(6):
+        lazy = bool(it & 1)  # lazy: select(a) reads the prediction buffers on the side stream while the next forward is already queued -- the guard has to sit behind it
         eng.forward_net(xa)
-        eng.candidates(B)
+        eng.candidates(B, lazy_flame=lazy)
         da = eng.select(B, confidence_threshold=conf, flame=fl)  # side stream
         eng.forward_net(xb)                                      # next batch's network queued while select(a) may still run
-        eng.candidates(B)                                        # waits for select(a) before refilling the candidate buffers
+        eng.candidates(B, lazy_flame=lazy)                       # waits for select(a) before refilling the candidate buffers
         eng.join()
         got_a = snap(da)
         db = eng.select(B, confidence_threshold=conf, flame=fl)

@@ -53,7 +53,7 @@ class StandInEngine:
         self.step += 1
         self.calls.append("net")
 
-    def candidates(self, B):
+    def candidates(self, B, lazy_flame=False):
         self.calls.append("cand")
 
     def select(self, B, confidence_threshold, iou_threshold, flame, unpad, n_heads_out, slot):
