@@ -9,7 +9,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvgh.so")
-SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_rings.hip", "conv_pp.hip", "conv_split.hip", "conv_f32.hip", "stem_pool.hip", "postproc.hip", "flame.hip", "net.hip", "detect.hip", "raster.hip", "letterbox.hip", "ctx.hip", "streams.hip"]
+SOURCES = ["conv_igemm.hip", "conv_patch.hip", "conv_rings.hip", "conv_pp.hip", "ds_b2b.hip", "conv_split.hip", "conv_f32.hip", "stem_pool.hip", "postproc.hip", "flame.hip", "net.hip", "detect.hip", "raster.hip", "letterbox.hip", "ctx.hip", "streams.hip"]
 EXPERIMENT_SOURCES = ["stem_ds.hip"]  # measured losers kept for tools/: part of libvgh_exp.so (-DVGH_EXPERIMENTS) only
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-unused-value"]
 

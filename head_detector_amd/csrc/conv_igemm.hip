@@ -514,6 +514,7 @@ int vgh_launch_conv_b2b(const ConvArgs& a0, hipStream_t stream) {
                 "conv b2b: plain bf16 convs with ReLU / no activation only");
     VGH_REQUIRE(a.out2_pitch % 8 == 0 && a.out2_coff % 8 == 0 && a.out2_coff2 % 8 == 0 && a.out2_split % 8 == 0 && a.cout2_store % 8 == 0 && a.cout2_store <= a.cout2_pad,
                 "conv b2b: the second output needs 16-byte aligned channel offsets");
+    if (!a.b2b_igemm && vgh_conv_ds_b2b_ok(a)) return vgh_launch_conv_ds_b2b(a, stream);  // the stage-1 pair: persistent t tile (ds_b2b.hip)
     return a.cout2_pad == 256 ? launch_b2b_96_any<8>(a, stream) : a.cout2_pad == 192 ? launch_b2b_96_any<6>(a, stream) : launch_b2b_96_any<4>(a, stream);
 }
 

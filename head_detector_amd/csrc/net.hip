@@ -206,6 +206,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
                 a.cout2_pad = a2.cout_pad;
                 a.cout2_store = a2.cout_store;
                 a.act2 = a2.act;
+                a.b2b_igemm = n->fuse_b2b == 2;
                 return vgh_launch_conv_b2b(a, st);
             }
             if (n->bufs[d.in_buf].is_f32 != VGH_FMT_F32) {
@@ -734,7 +735,7 @@ int vgh_net_set_pred_guard(vgh_net* n, void* event) {
 // every intermediate tensor of the program exists in the arena (what the per-op parity tests read)
 int vgh_net_set_b2b(vgh_net* n, int enable) {
     VGH_REQUIRE(n, "net_set_b2b: null handle");
-    n->fuse_b2b = enable ? 1 : 0;
+    n->fuse_b2b = enable == 2 ? 2 : enable ? 1 : 0;  // 2: fused, but every pair on the implicit-GEMM b2b tile (no t tile)
     return VGH_OK;
 }
 int vgh_net_b2b_pairs(vgh_net* n) {

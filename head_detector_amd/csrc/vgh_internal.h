@@ -89,6 +89,7 @@ struct ConvArgs {
     void* out2;              // the second conv's output tensor (bf16 NHWC), pitch / offsets / split / stored channels as for `out`
     int64_t out2_pitch;
     int out2_coff, out2_coff2, out2_split, cout2_pad, cout2_store, act2;
+    int b2b_igemm;           // 1: keep the pair on the implicit-GEMM b2b tile even where the persistent t tile (ds_b2b.hip) could run it (vgh_net_set_b2b(n, 2): A/B, tests)
     int ablate;     // -DVGH_EXPERIMENTS builds only: bit0 skip tile loads, bit1 skip MFMAs, bit3 skip the epilogue (results are garbage)
     unsigned long long* trace;  // -DVGH_EXPERIMENTS builds only: per-(block, tile) phase timestamps (s_memtime), or nullptr
 };
@@ -139,6 +140,9 @@ int vgh_launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream);
 // conv_igemm.hip: `a` with its b2b fields set (w2pack ...): the fused launch, or VGH_ERR_INVALID when the pair does not fit a b2b tile (vgh_conv_b2b_ok says so beforehand)
 int vgh_launch_conv_b2b(const ConvArgs& a, hipStream_t stream);
 int vgh_conv_b2b_ok(int ksize, int stride, int cout_pad, int cout2_pad);
+// ds_b2b.hip ("t" tile): the stage-1 downsample + conv1|conv2 pair as one persistent launch with register-resident weights; `a` prepared, b2b fields set
+int vgh_conv_ds_b2b_ok(const ConvArgs& a);
+int vgh_launch_conv_ds_b2b(const ConvArgs& a, hipStream_t stream);
 int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);  // conv_split.hip: a.split = VGH_FMT_BF16X2 / VGH_FMT_F16X2
 // dense [cout_pad][ks][ks][cin] f32 -> the three-segment 16-bit image [w_lo | w_hi | w_hi] (each segment laid out like
 // vgh_pack_conv_weights_host); fmt = VGH_FMT_BF16X2 / VGH_FMT_F16X2.  Returns through *out_scale the factor the kernel multiplies the

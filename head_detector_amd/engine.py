@@ -268,10 +268,11 @@ class VGHeadsEngine:
         if self._use_tuning:
             self.load_tuning()  # the table may hold tile choices measured in this split mode
 
-    def set_b2b(self, enable: bool = True):
+    def set_b2b(self, enable=True):
         """vgh_net_set_b2b (r06): a stage's downsample and the conv1|conv2 behind it as ONE back-to-back-GEMM launch (default) or as their two launches -- the same
-        output bits; unfused, the tensor between them exists in the arena (per-op inspection).  ``b2b_pairs``: how many such pairs the program has."""
-        _lib.check(self.lib.vgh_net_set_b2b(self._net, int(bool(enable))))
+        output bits; unfused, the tensor between them exists in the arena (per-op inspection).  ``b2b_pairs``: how many such pairs the program has.
+        ``enable=2``: fused, but every pair on the implicit-GEMM b2b tile -- without the persistent "t" tile of the stage-1 pair (csrc/ds_b2b.hip; A/B and tests: same bits)."""
+        _lib.check(self.lib.vgh_net_set_b2b(self._net, 2 if enable == 2 and enable is not True else int(bool(enable))))
         self._graph_key = None
 
     @property

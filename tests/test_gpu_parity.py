@@ -635,6 +635,15 @@ def test_b2b_pairs_equal_their_two_launches(gpu_lib, variant, S, B, tuned):
             for a, b in zip(res, ref[0]):
                 assert torch.equal(a, b), ns
     ref = outs[(True, 1)]
+    # the stage-1 pair ran on the persistent "t" tile above (csrc/ds_b2b.hip: patch fetched once into parity planes, both convs' weights resident in registers); the same
+    # pair on the implicit-GEMM b2b tile (set_b2b(2)): the same bits again -- two independent implementations of one summation order
+    eng.set_b2b(2)
+    for ns in (1, 2):
+        eng.set_split(ns)
+        res = eng.model(x)
+        for i in pairs:
+            assert torch.equal(eng.buffer(P.ops[i + 1]["out_buf"], B), outs[(True, ns)][1][i]), (ns, P.ops[i]["name"])
+        assert all(torch.equal(a, b) for a, b in zip(res, outs[(True, ns)][0])), ns
     eng.close()
     # a fresh engine that only ever ran fused: the same bits as the fused runs above, and the tensor between the two convs is never written
     eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=11, use_tuning=tuned)
