@@ -34,6 +34,18 @@ constexpr int DT_LDS = DT_BIAS + 2048;
 constexpr unsigned DT_OOB = 0xC0000000u;   // out of the descriptors' 2-GiB range, and not wrapped past 2^32 by the scalar offsets added to it
 static_assert(2 * DT_LDS <= 160 * 1024, "two workgroups per CU");
 
+// experiments build: s_memtime marks per (workgroup, wave, tile) behind the 8192 rows the other conv kernels use of the tools' trace buffer (tools/ds_trace.py)
+#ifdef VGH_EXPERIMENTS
+#define DT_MARK(k)                                                                                                                                         \
+    do {                                                                                                                                                   \
+        if (a.trace && lane == 0 && tno < 8) a.trace[((size_t)8192 * VGH_TRACE_TILES * VGH_TRACE_MARKS) + ((size_t)(blockIdx.x * 3 + w) * 8 + tno) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define DT_MARK(k) \
+    do {           \
+    } while (0)
+#endif
+
 struct DtDiv {
     unsigned m_per, s_per, m_nsx, s_nsx;
 };
@@ -58,6 +70,19 @@ __device__ __forceinline__ void dt_sw32(unsigned& x, unsigned& y) {  // lanes 32
     const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
     x = r[0];
     y = r[1];
+}
+
+// 8 accumulator values (runs q = 2 m, 2 m + 1 of a 32-cout group) -> this lane's 16 bytes: + bias (packed fp32 adds), bf16, ReLU on the packed bf16 values (v_pk_max_i16
+// against 0: a bf16 is negative as int16 exactly when the float is; bound INT16_MIN = no activation) -- the same bits as max(x + b, 0) -> bf16 --, half-wave exchange
+__device__ __forceinline__ u32x4_t dt_epi8(const f32x16_t& acc, int m, const f32x4_t b0, const f32x4_t b1, unsigned bound) {
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    const f32x2_t a0 = {acc[8 * m + 0], acc[8 * m + 1]}, a1 = {acc[8 * m + 2], acc[8 * m + 3]}, a2 = {acc[8 * m + 4], acc[8 * m + 5]}, a3 = {acc[8 * m + 6], acc[8 * m + 7]};
+    const f32x2_t s0 = a0 + f32x2_t{b0[0], b0[1]}, s1 = a1 + f32x2_t{b0[2], b0[3]}, s2 = a2 + f32x2_t{b1[0], b1[1]}, s3 = a3 + f32x2_t{b1[2], b1[3]};
+    auto relu = [&](unsigned d) { return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, d), __builtin_bit_cast(s16x2, bound))); };
+    unsigned pa0 = relu(dt_pk(s0[0], s0[1])), pa1 = relu(dt_pk(s1[0], s1[1])), pb0 = relu(dt_pk(s2[0], s2[1])), pb1 = relu(dt_pk(s3[0], s3[1]));
+    dt_sw32(pa0, pb0);
+    dt_sw32(pa1, pb1);
+    return u32x4_t{pa0, pa1, pb0, pb1};
 }
 
 // T2 = cout groups (of 32) of the second conv: 4 (M) or 6 (L)
@@ -107,7 +132,7 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
         const int s = lane - ((q ^ w) & 1);
         const bool valid = (unsigned)s < 54u;
         const int col = s / 6, chn = s - col * 6;
-        const unsigned r = (unsigned)(col * 2 * pixb + chn * 16);
+        const unsigned r = VGH_ABLATE(a, 16) ? (unsigned)(s * 16) : (unsigned)(col * 2 * pixb + chn * 16);  // (16: timing experiment, contiguous source bytes -- wrong results)
         rel0[q] = valid ? r : DT_OOB;
         rel1[q] = (valid && col < 8) ? r : DT_OOB;
         relL[q] = (valid && col > 0) ? r : DT_OOB;
@@ -123,7 +148,10 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
     unsigned rb[2];  // fragment read offset of the lane for taps with ky >> 1 = 0 / 1 (the row parity moves the rotation)
 #pragma unroll
     for (int kyh = 0; kyh < 2; ++kyh) rb[kyh] = (unsigned)(ty4 * DT_ROW + (tx * 6 + hi + ((ty4 + kyh) & 1)) * 16);
-    const float act_lo = a.act == VGH_ACT_RELU ? 0.0f : -3.0e38f, act2_lo = a.act2 == VGH_ACT_RELU ? 0.0f : -3.0e38f;
+    const unsigned bound1 = a.act == VGH_ACT_RELU ? 0u : 0x80008000u, bound2 = a.act2 == VGH_ACT_RELU ? 0u : 0x80008000u;
+    unsigned ovo[2];  // byte offset of the lane's output pixel (+ its 8-channel half) of pixel group j from the tile's first pixel
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ovo[j] = (unsigned)(((4 * j + ty4) * a.Wo + tx) * (int)a.out2_pitch * 2 + hi * 16);
     uint16_t* const out2 = (uint16_t*)a.out2;
     const float* const bl = (const float*)(smem + DT_BIAS);
 
@@ -157,8 +185,11 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
     issue_patch(tile, 0);
     int cur = 0;
     bool first = true;
+    int tno = 0;
+    (void)tno;
     while (true) {
         const int nxt_tile = tile_of(local + gpx);
+        DT_MARK(0);
         // ---- this tile's patch has landed (counted: the previous tile's stores, issued behind it, may still be in flight) ----
         if (first) {
             dt_wait_vm<0>();
@@ -168,8 +199,11 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
             dt_wait_vm<4>();
         }
         first = false;
+        DT_MARK(1);
         dt_barrier();  // everybody's pieces landed; everybody is done with the other buffer (the previous tile's exchange area)
-        if (nxt_tile >= 0) issue_patch(nxt_tile, cur ^ 1);
+        DT_MARK(2);
+        if (nxt_tile >= 0 && !VGH_ABLATE(a, 1)) issue_patch(nxt_tile, cur ^ 1);
+        DT_MARK(3);
         const char* const xb = smem + cur * DT_BUF;
 
         // ---- 3x3 / stride-2 conv: 27 k steps x two pixel groups ----
@@ -191,6 +225,7 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
             for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) F[p][j] = frag(p, j);
+            if (!VGH_ABLATE(a, 2))
 #pragma unroll
             for (int s = 0; s < 27; ++s) {
                 if (s + 2 < 27) {
@@ -211,31 +246,27 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const f32x4_t b0 = *(const f32x4_t*)(bl + w * 32 + (2 * m) * 8 + half4), b1 = *(const f32x4_t*)(bl + w * 32 + (2 * m + 1) * 8 + half4);
-                float va[4], vb[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    va[e] = fmaxf(acc[j][8 * m + e] + b0[e], act_lo);
-                    vb[e] = fmaxf(acc[j][8 * m + 4 + e] + b1[e], act_lo);
-                }
-                unsigned pa0 = dt_pk(va[0], va[1]), pa1 = dt_pk(va[2], va[3]), pb0 = dt_pk(vb[0], vb[1]), pb1 = dt_pk(vb[2], vb[3]);
-                dt_sw32(pa0, pb0);
-                dt_sw32(pa1, pb1);
-                const u32x4_t v4 = {pa0, pa1, pb0, pb1};
-                B2[j][m] = __builtin_bit_cast(bf16x8_t, v4);
+                B2[j][m] = __builtin_bit_cast(bf16x8_t, dt_epi8(acc[j], m, b0, b1, bound1));
             }
+        DT_MARK(4);
         dt_barrier();  // every wave is done reading this patch: its first 12 KB become the exchange area [j][producer wave][m][lane]
         char* const ex = smem + cur * DT_BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int m = 0; m < 2; ++m) *(bf16x8_t*)(ex + ((j * 3 + w) * 2 + m) * 1024 + lane * 16) = B2[j][m];
+        DT_MARK(5);
         dt_barrier();
+        DT_MARK(6);
 
         // ---- 1x1 conv: K = 96 in the k order of a plain launch (k-block i, half m), cout groups w and w + 3; stores ----
         {
             const int b = dt_div(tile, dv.m_per, dv.s_per);
             const int rem = tile - b * per;
             const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+            // the tile's output through a buffer descriptor based at its first pixel: per-lane 32-bit offsets (set once), the channel offset is scalar
+            const __amdgpu_buffer_rsrc_t orsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(out2 + ((size_t)(b * a.Ho + tyi * 8) * a.Wo + txi * 8) * a.out2_pitch), 0, 0x80000000, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x16_t acc2[NT2];
@@ -251,8 +282,6 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
                         for (int tt = 0; tt < NT2; ++tt) acc2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[tt][i][m], bf, acc2[tt], 0, 0, 0);
                     }
-                const int oy = tyi * 8 + 4 * j + ty4, ox = txi * 8 + tx;
-                uint16_t* const op = out2 + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.out2_pitch;
 #pragma unroll
                 for (int tt = 0; tt < NT2; ++tt) {
                     const int t = w + 3 * tt;
@@ -260,25 +289,17 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
                         for (int m = 0; m < 2; ++m) {
                             const f32x4_t b0 = *(const f32x4_t*)(bl + 96 + t * 32 + (2 * m) * 8 + half4), b1 = *(const f32x4_t*)(bl + 96 + t * 32 + (2 * m + 1) * 8 + half4);
-                            float va[4], vb[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                va[e] = fmaxf(acc2[tt][8 * m + e] + b0[e], act2_lo);
-                                vb[e] = fmaxf(acc2[tt][8 * m + 4 + e] + b1[e], act2_lo);
-                            }
-                            unsigned pa0 = dt_pk(va[0], va[1]), pa1 = dt_pk(va[2], va[3]), pb0 = dt_pk(vb[0], vb[1]), pb1 = dt_pk(vb[2], vb[3]);
-                            dt_sw32(pa0, pb0);
-                            dt_sw32(pa1, pb1);
-                            const int c = t * 32 + 16 * m + 2 * half4;  // first of this lane's 8 consecutive couts
-                            if (c < a.cout2_store) {
-                                const int ochan = (c >= a.out2_split) ? a.out2_coff2 + (c - a.out2_split) : a.out2_coff + c;
-                                *(u32x4_t*)(op + ochan) = u32x4_t{pa0, pa1, pb0, pb1};
-                            }
+                            const u32x4_t v = dt_epi8(acc2[tt], m, b0, b1, bound2);
+                            const int c = t * 32 + 16 * m;  // first cout of the 16 this instruction stores per pixel (wave-uniform; this lane: + 8 hi)
+                            const int ochan = (c >= a.out2_split) ? a.out2_coff2 + (c - a.out2_split) : a.out2_coff + c;
+                            if (!VGH_ABLATE(a, 8)) __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovo[j], (unsigned)ochan * 2u, 0);
                         }
                     }
                 }
             }
         }
+        DT_MARK(7);
+        ++tno;
         if (nxt_tile < 0) break;
         tile = nxt_tile;
         local += gpx;
@@ -300,7 +321,7 @@ int launch_dt(const ConvArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.B * per;
     VGH_REQUIRE(total < (1ll << 30), "conv b2b: too many tiles");
     const int chunk = (int)((total + 7) / 8);
-    int gpx = vgh_conv_persistent_blocks_per_xcd(a, chunk, 2);  // two workgroups per CU (shared with the executor's other lane streams)
+    int gpx = vgh_conv_persistent_blocks_per_xcd(a, chunk, VGH_ABLATE(a, 32) ? 1 : 2);  // two workgroups per CU (shared with the executor's other lane streams)
     if (gpx > chunk) gpx = chunk;
     DtDiv dv;
     vgh_fastdiv_magic((unsigned)per, &dv.m_per, &dv.s_per);
