@@ -10,13 +10,14 @@
 //   * the patch lands de-interleaved into the four parity planes [iy & 1][ix & 1] (the LDS-DMA source address is free per lane), so tap (ky, kx) of the stride-2 conv
 //     reads plane (ky & 1, kx & 1) at a stride-1 offset: a plane row = one 1-KiB piece = 9 pixels x 6 sixteen-byte chunks, rotated by one chunk on odd rows -- the 16 lanes
 //     of every ds_read_b128 lane group (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27}, ...) then cover two adjacent rows x eight pixels = 16 distinct 16-byte slots;
-//   * wave w of the 3-wave workgroup owns couts 32 w .. + 31 of the 3x3 conv for both 32-pixel groups: 27 A fragments (9 taps x three 16-channel steps; the padded
+//   * compute wave w owns couts 32 w .. + 31 of the 3x3 conv for both 32-pixel groups: 27 A fragments (9 taps x three 16-channel steps; the padded
 //     channels 48 .. 63 of the implicit-GEMM launch carry zero weights and are skipped: they only ever added exact zeros) = 108 VGPRs, loaded once;
-//   * the three waves trade their bf16 results through LDS in fragment order (what the b2b tile's one wave holds in registers) and run the 1x1 conv with cout groups
-//     w and w + 3 from 24 more resident fragment registers each; only the second conv's output is stored.
+//   * the three compute waves trade their bf16 results through LDS in fragment order (what the b2b tile's one wave holds in registers) and run the 1x1 conv with cout
+//     groups 2 w and 2 w + 1 from 48 more resident fragment registers each; only the second conv's output is stored.
 // Same instructions (v_mfma_f32_32x32x16_bf16), same operand slots, same k order (tap major, channels ascending; then k-block, half) and same roundings as the two
 // implicit-GEMM launches: BIT-IDENTICAL outputs (tests/test_gpu_parity.py::test_b2b_pairs_equal_their_two_launches).
-// Two workgroups per CU (72 KB of LDS, <= 256 registers each): one computes while the other waits for its barrier.
+// Measured (profiles/r06_ab_ds_tile.txt, r06_ds_tile_ablation.txt): 487 -> 347 us per 64 images; without its stores the launch takes 165 us -- what is left is the write
+// path: 629 MB of 192-byte segments inside 768-byte pixels (EXPERIMENTS 8c: such a copy runs at 4.27 TB/s).
 #include <atomic>
 
 #include "vgh_internal.h"
@@ -29,21 +30,30 @@ namespace {
 constexpr int DT_ROW = 1024;               // bytes of one plane row (one LDS-DMA piece): 9 pixels x 96 B + the rotation chunk, padded to 64 chunks
 constexpr int DT_PLANE = 9 * DT_ROW;       // planes (0, x) hold 9 rows, planes (1, x) 8 (their ninth row is filled with zeros and never read)
 constexpr int DT_BUF = 4 * DT_PLANE;       // one patch
-constexpr int DT_BIAS = 2 * DT_BUF;        // bias vectors of both convs (fp32), staged once per workgroup
-constexpr int DT_LDS = DT_BIAS + 2048;
+constexpr int DT_EX = 3 * DT_BUF;          // two exchange areas (by tile parity): [pixel group][producer wave][half][lane] x 16 B
+constexpr int DT_EXB = 12 * 1024;
+constexpr int DT_LDS = DT_EX + 2 * DT_EXB;
+constexpr int DT_PIECES = 34;              // LDS-DMA pieces of a patch (the ninth row of planes (1, x) does not exist)
 constexpr unsigned DT_OOB = 0xC0000000u;   // out of the descriptors' 2-GiB range, and not wrapped past 2^32 by the scalar offsets added to it
-static_assert(2 * DT_LDS <= 160 * 1024, "two workgroups per CU");
+static_assert(DT_LDS <= 160 * 1024, "one workgroup per CU");
 
 // experiments build: s_memtime marks per (workgroup, wave, tile) behind the 8192 rows the other conv kernels use of the tools' trace buffer (tools/ds_trace.py)
 #ifdef VGH_EXPERIMENTS
 #define DT_MARK(k)                                                                                                                                         \
     do {                                                                                                                                                   \
-        if (a.trace && lane == 0 && tno < 8) a.trace[((size_t)8192 * VGH_TRACE_TILES * VGH_TRACE_MARKS) + ((size_t)(blockIdx.x * 3 + w) * 8 + tno) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (a.trace && lane == 0 && tno < 8) a.trace[((size_t)8192 * VGH_TRACE_TILES * VGH_TRACE_MARKS) + ((size_t)(blockIdx.x * 4 + w) * 8 + tno) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define DT_MARK(k) \
     do {           \
     } while (0)
+#endif
+
+// work-skipping switches of this kernel: runtime branches inside the K loop's slots cost the experiments build 2 x (measured), so these are compile-time
+#ifdef VGH_DT_ABLATE  // compile-time mask (tools: python -m head_detector_amd.build -DVGH_DT_ABLATE=8 ...): 1 no patch loads, 2 no K-loop MFMAs, 8 no stores
+#define DT_ABLATE(a, bit) ((VGH_DT_ABLATE) & (bit))
+#else
+#define DT_ABLATE(a, bit) 0
 #endif
 
 struct DtDiv {
@@ -86,9 +96,18 @@ __device__ __forceinline__ u32x4_t dt_epi8(const f32x16_t& acc, int m, const f32
 }
 
 // T2 = cout groups (of 32) of the second conv: 4 (M) or 6 (L)
+//
+// Execution structure (v2; tools/ds_trace.py showed v1 -- three waves doing everything in sequence, two workgroups per CU -- issue-bound: 7 000 cycles of one wave's
+// instruction stream per tile of which 2 500 are MFMAs, and two workgroups on a CU serialise because six such waves share four SIMDs):
+//   * ONE workgroup of FOUR waves per CU, one per SIMD, up to 512 registers each: waves 0-2 compute, wave 3 only LOADS -- it issues the 34 LDS-DMA pieces of a patch two
+//     tiles ahead (three patch buffers) and is the only wave that ever waits on vmcnt; the compute waves' stores drain on their own;
+//   * a compute wave runs the 1x1 conv, the second epilogue and the stores of tile k - 1 INSIDE the K loop of tile k: the 24 MFMAs of the second GEMM join the 54 of the
+//     3x3 conv in the matrix pipe and the VALU / store work of the epilogue sits in the shadow of those MFMAs (27 slots of two MFMAs each);
+//   * ONE barrier per tile: it publishes the loader's patch k AND the exchange area the compute waves wrote at the end of tile k - 1 (two exchange areas, by parity).
 template <int T2>
-__global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const int nsx, const int per, const int total_tiles, const int chunk, const DtDiv dv) {
-    constexpr int NT2 = (T2 + 2) / 3;  // cout groups of the second conv per wave (wave w: groups w, w + 3)
+__global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const int nsx, const int per, const int total_tiles, const int chunk, const DtDiv dv) {
+    constexpr int NT2 = 2;  // cout groups of the second conv per compute wave: wave w takes groups 2 w, 2 w + 1 = 64 consecutive couts = one whole 128-byte line of an output
+                        // pixel wherever the segment allows (T2 = 4: wave 2 has none)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,13 +115,74 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
     const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
     const int pixb = (int)a.in_pitch * 2;  // bytes per input pixel (96)
     const int rowb = a.W * pixb;
+    // this workgroup's tiles: xcd * chunk + first + k * gpx, k < n_my
+    const int first = blockIdx.x >> 3;
+    const int lim = (total_tiles - xcd * chunk) < chunk ? (total_tiles - xcd * chunk) : chunk;
+    const int n_my = first < lim ? (lim - first + gpx - 1) / gpx : 0;
+    if (n_my <= 0) return;
+    const int tile0 = xcd * chunk + first;
+    int tno = 0;
+    (void)tno;
 
-    // ---- once per workgroup: bias vectors -> LDS, weights -> registers ----
-    {
-        float* const bl = (float*)(smem + DT_BIAS);
-        for (int i = tid; i < 96; i += 192) bl[i] = a.bias[i];
-        for (int i = tid; i < 32 * T2; i += 192) bl[96 + i] = a.bias2[i];
+    if (w == 3) {
+        // =========================== loader wave ===========================
+        // LDS-DMA source offsets inside a plane row, by the row's parity (odd rows are rotated by one chunk): lane l holds chunk s = l - parity: pixel s / 6, chunk s % 6
+        unsigned rel0[2], rel1[2], relL[2];  // planes (y, 0) / planes (y, 1): eight pixels / planes (y, 0) of a tile on the left image edge (pixel 0 = column -1: zeros)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int s = lane - q;
+            const bool valid = (unsigned)s < 54u;
+            const int col = s / 6, chn = s - col * 6;
+            const unsigned r = (unsigned)(col * 2 * pixb + chn * 16);
+            rel0[q] = valid ? r : DT_OOB;
+            rel1[q] = (valid && col < 8) ? r : DT_OOB;
+            relL[q] = (valid && col > 0) ? r : DT_OOB;
+        }
+        auto issue_patch = [&](int tile, int buf) {
+            const int b = dt_div(tile, dv.m_per, dv.s_per);
+            const int rem = tile - b * per;
+            const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+            const int iy0 = 16 * tyi - 1, ix0 = 16 * txi - 1;  // input pixel of patch position (0, 0)
+            const bool top = tyi == 0, left = txi == 0;
+            const char* const base = (const char*)a.in + (int64_t)a.in_coff * 2 + ((int64_t)(b * a.H + iy0) * a.W + ix0) * pixb;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
+            char* const dst = smem + buf * DT_BUF;
+#pragma unroll
+            for (int plane = 0; plane < 4; ++plane)
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int py = plane >> 1, px = plane & 1, q = r & 1, lr = 2 * r + py;
+                    if (lr > 16) continue;  // the ninth row of planes (1, x) is never read
+                    unsigned vo = px ? rel1[q] : (left ? relL[q] : rel0[q]);
+                    if (lr == 0) vo = top ? DT_OOB : vo;  // row -1 of the image: zeros
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)(dst + (plane * 9 + r) * DT_ROW), 16, vo, (unsigned)(lr * rowb + px * pixb), 0, 0);
+                }
+        };
+        if (!DT_ABLATE(a, 1)) {
+            issue_patch(tile0, 0);
+            if (n_my > 1) issue_patch(tile0 + gpx, 1);
+        }
+        int nb = 2;  // buffer of patch k + 2
+        for (int k = 0; k < n_my; ++k) {
+            DT_MARK(0);
+            if (k + 1 < n_my)
+                dt_wait_vm<DT_PIECES>();  // patch k has landed (patch k + 1 may be in flight)
+            else
+                dt_wait_vm<0>();
+            DT_MARK(1);
+            dt_barrier();  // publishes patch k; every compute wave is done with patch k - 1 (whose buffer patch k + 2 takes)
+            DT_MARK(2);
+            if (k + 2 < n_my && !DT_ABLATE(a, 1)) issue_patch(tile0 + (k + 2) * gpx, nb);
+            DT_MARK(3);
+            nb = nb == 2 ? 0 : nb + 1;
+            ++tno;
+        }
+        dt_barrier();  // the compute waves' last barrier (before they drain the last tile's second GEMM)
+        return;
     }
+
+    // =========================== compute waves ===========================
+    // ---- once: weights and biases -> registers ----
     bf16x8_t W1[27];  // A fragments of the 3x3 conv: step s = tap * 3 + c covers channels 16 c .. + 15 of tap (ky, kx); lane (n32, hi) = cout 32 w + n32, k = 8 hi .. + 7
     {
         const int co = w * 32 + n32, sw = (co >> 2) & 3;
@@ -112,31 +192,27 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
             W1[s] = *(const bf16x8_t*)(a.wpack + ((size_t)kb * 96 + co) * 32 + ((ch ^ sw) * 8));
         }
     }
-    bf16x8_t W2[NT2][3][2];  // A fragments of the 1x1 conv: cout group w + 3 tt, k-block i (32 channels), half m
+    bf16x8_t W2[NT2][3][2];  // A fragments of the 1x1 conv: cout group 2 w + tt, k-block i (32 channels), half m
+    f32x4_t BV1[2][2], BV2[NT2][2][2];  // bias of this lane's channels: [m][run]: channels 32 g + 8 (2 m + run) + 4 hi .. + 3
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) BV1[m][u] = *(const f32x4_t*)(a.bias + w * 32 + (2 * m + u) * 8 + half4);
 #pragma unroll
     for (int tt = 0; tt < NT2; ++tt) {
-        const int t = w + 3 * tt;
-        const int co = (t < T2 ? t : 0) * 32 + n32, sw = (co >> 2) & 3;
+        const int t = 2 * w + tt;
+        const int tc = t < T2 ? t : 0;
+        const int co = tc * 32 + n32, sw = (co >> 2) & 3;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int m = 0; m < 2; ++m) W2[tt][i][m] = *(const bf16x8_t*)(a.w2pack + ((size_t)i * (32 * T2) + co) * 32 + (((2 * m + hi) ^ sw) * 8));
-    }
-
-    // ---- per-lane constants ----
-    // LDS-DMA source offsets inside a plane row, by the row's parity (odd rows are rotated by one chunk): lane l holds chunk s = l - parity: pixel s / 6, chunk s % 6.
-    // q = 0 / 1: rows whose parity equals / differs from this wave's (unit i of a wave fills plane row 3 (i % 3) + w)
-    unsigned rel0[2], rel1[2], relL[2];  // planes (y, 0) / planes (y, 1): eight pixels / planes (y, 0) of a tile on the left image edge (pixel 0 = column -1: zeros)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int s = lane - ((q ^ w) & 1);
-        const bool valid = (unsigned)s < 54u;
-        const int col = s / 6, chn = s - col * 6;
-        const unsigned r = VGH_ABLATE(a, 16) ? (unsigned)(s * 16) : (unsigned)(col * 2 * pixb + chn * 16);  // (16: timing experiment, contiguous source bytes -- wrong results)
-        rel0[q] = valid ? r : DT_OOB;
-        rel1[q] = (valid && col < 8) ? r : DT_OOB;
-        relL[q] = (valid && col > 0) ? r : DT_OOB;
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) BV2[tt][m][u] = *(const f32x4_t*)(a.bias2 + tc * 32 + (2 * m + u) * 8 + half4);
     }
+    // ---- per-lane constants ----
     // this lane's output pixel inside a pixel group: rows / columns chosen per ds_read_b128 lane group (two adjacent rows x eight columns each)
     int ty4, tx;
     if (n32 < 4) ty4 = 0, tx = n32;
@@ -153,68 +229,67 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
     for (int j = 0; j < 2; ++j) ovo[j] = (unsigned)(((4 * j + ty4) * a.Wo + tx) * (int)a.out2_pitch * 2 + hi * 16);
     uint16_t* const out2 = (uint16_t*)a.out2;
-    const float* const bl = (const float*)(smem + DT_BIAS);
-
-    // one tile's patch -> buffer `buf`: 12 pieces per wave (piece i of wave w = row 3 (i % 3) + w of plane i / 3)
-    auto issue_patch = [&](int tile, int buf) {
+    unsigned ochan2[NT2][2];  // byte offset of the 16 couts (group 2 w + tt, half m) in an output pixel: the second conv's two output segments
+#pragma unroll
+    for (int tt = 0; tt < NT2; ++tt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c = (2 * w + tt) * 32 + 16 * m;
+            ochan2[tt][m] = (unsigned)((c >= a.out2_split) ? a.out2_coff2 + (c - a.out2_split) : a.out2_coff + c) * 2u;
+        }
+    auto out_rsrc = [&](int tile) {  // the tile's output through a buffer descriptor based at its first pixel (per-lane 32-bit offsets, scalar channel offsets)
         const int b = dt_div(tile, dv.m_per, dv.s_per);
         const int rem = tile - b * per;
         const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
-        const int iy0 = 16 * tyi - 1, ix0 = 16 * txi - 1;  // input pixel of patch position (0, 0)
-        const bool top = tyi == 0, left = txi == 0;
-        const char* const base = (const char*)a.in + (int64_t)a.in_coff * 2 + ((int64_t)(b * a.H + iy0) * a.W + ix0) * pixb;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
-        char* const dst = smem + buf * DT_BUF;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int plane = i / 3, py = plane >> 1, px = plane & 1, q = (i % 3) & 1;
-            const int r = 3 * (i % 3) + w;
-            const int lr = 2 * r + py;
-            const bool row_ok = lr <= 16 && !(top && lr == 0);
-            unsigned vo = px ? rel1[q] : (left ? relL[q] : rel0[q]);
-            vo = row_ok ? vo : DT_OOB;
-            const unsigned so = row_ok ? (unsigned)(lr * rowb + px * pixb) : 0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)(dst + (plane * 9 + r) * DT_ROW), 16, vo, so, 0, 0);
-        }
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(out2 + ((size_t)(b * a.Ho + tyi * 8) * a.Wo + txi * 8) * a.out2_pitch), 0, 0x80000000, 0x00020000);
     };
 
-    int local = blockIdx.x >> 3;
-    auto tile_of = [&](int l) { return (l < chunk && xcd * chunk + l < total_tiles) ? xcd * chunk + l : -1; };
-    int tile = tile_of(local);
-    if (tile < 0) return;
-    issue_patch(tile, 0);
-    int cur = 0;
-    bool first = true;
-    int tno = 0;
-    (void)tno;
-    while (true) {
-        const int nxt_tile = tile_of(local + gpx);
-        DT_MARK(0);
-        // ---- this tile's patch has landed (counted: the previous tile's stores, issued behind it, may still be in flight) ----
-        if (first) {
-            dt_wait_vm<0>();
-        } else if (NT2 == 2 && (T2 == 6 || w == 0)) {
-            dt_wait_vm<8>();
-        } else {
-            dt_wait_vm<4>();
+    // ---- the work of the PREVIOUS tile, cut into the slots of a K loop: slot 0 / 6 read pixel group 0 / 1's six B fragments from the exchange area, slots 1-6 / 7-12
+    //      run its 6 k steps x NT2 cout groups of the 1x1 conv, slots 8-11 / 14-17 its 2 NT2 epilogue blocks (bias, bf16, ReLU, exchange, one 16-byte store each) ----
+    bf16x8_t XF[2][6];
+    f32x16_t acc2[2][NT2];
+    __amdgpu_buffer_rsrc_t prsrc = out_rsrc(tile0);
+    unsigned povo[2] = {DT_OOB, DT_OOB};  // (no previous tile yet: the stores of the first pass are out of range)
+    const char* pex = smem + DT_EX;
+    auto pend = [&](int s) {
+        if (s == 0 || s == 6) {
+            const int j = s / 6;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) XF[j][f] = *(const bf16x8_t*)(pex + (j * 6 + f) * 1024 + lane * 16);
+#pragma unroll
+            for (int tt = 0; tt < NT2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[j][tt][r] = 0.0f;
         }
-        first = false;
-        DT_MARK(1);
-        dt_barrier();  // everybody's pieces landed; everybody is done with the other buffer (the previous tile's exchange area)
-        DT_MARK(2);
-        if (nxt_tile >= 0 && !VGH_ABLATE(a, 1)) issue_patch(nxt_tile, cur ^ 1);
-        DT_MARK(3);
-        const char* const xb = smem + cur * DT_BUF;
+        if ((s >= 1 && s <= 6) || (s >= 7 && s <= 12)) {
+            const int j = s >= 7 ? 1 : 0, f = s >= 7 ? s - 7 : s - 1;  // f = 2 i + m: k-block i, half m
+#pragma unroll
+            for (int tt = 0; tt < NT2; ++tt) acc2[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[tt][f >> 1][f & 1], XF[j][f], acc2[j][tt], 0, 0, 0);
+        }
+        if ((s >= 8 && s < 8 + 2 * NT2) || (s >= 14 && s < 14 + 2 * NT2)) {
+            const int j = s >= 14 ? 1 : 0, e = s >= 14 ? s - 14 : s - 8, tt = e >> 1, m = e & 1;
+            if (T2 == 6 || 2 * w + tt < T2) {
+                const u32x4_t v = dt_epi8(acc2[j][tt], m, BV2[tt][m][0], BV2[tt][m][1], bound2);
+                if (!DT_ABLATE(a, 8)) __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, povo[j], ochan2[tt][m], 0);
+            }
+        }
+    };
+    static_assert(14 + 2 * NT2 <= 27, "the previous tile's work fits the K loop's slots");
 
-        // ---- 3x3 / stride-2 conv: 27 k steps x two pixel groups ----
+    int pb = 0;  // patch buffer of tile k
+    for (int k = 0; k < n_my; ++k) {
+        const int tile = tile0 + k * gpx;
+        DT_MARK(0);
+        dt_barrier();  // patch k is there, and so is the exchange area of tile k - 1
+        DT_MARK(2);
+        const char* const xb = smem + pb * DT_BUF;
+        // ---- 3x3 / stride-2 conv of tile k: 27 k steps x two pixel groups; fragment reads run two steps ahead of the MFMAs ----
         f32x16_t acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
         {
-            // fragment reads run two k steps ahead of the MFMAs (three pairs of registers): one wave has to cover its own LDS latency -- the CU's other workgroup is
-            // as likely at a barrier as in its K loop
             auto frag = [&](int s, int j) -> bf16x8_t {
                 const int ky = s / 9, kx = (s / 3) % 3, c = s % 3;
                 const int imm = ((ky & 1) * 2 + (kx & 1)) * DT_PLANE + (4 * j + (ky >> 1)) * DT_ROW + ((kx >> 1) * 6 + c * 2) * 16;
@@ -225,7 +300,6 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
             for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) F[p][j] = frag(p, j);
-            if (!VGH_ABLATE(a, 2))
 #pragma unroll
             for (int s = 0; s < 27; ++s) {
                 if (s + 2 < 27) {
@@ -233,78 +307,45 @@ __global__ __launch_bounds__(192, 2) void ds_b2b_kernel(const ConvArgs a, const 
                     for (int j = 0; j < 2; ++j) F[(s + 2) % 3][j] = frag(s + 2, j);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (!DT_ABLATE(a, 2)) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s], F[s % 3][j], acc[j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s], F[s % 3][j], acc[j], 0, 0, 0);
+                }
+                pend(s);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- its epilogue in registers: bias, ReLU, bf16, half-wave exchange -> lane (pixel n, half hi) holds channels 32 w + 16 m + 8 hi .. + 7: the B operand of
-        //      k step (w, m) of the second GEMM ----
-        bf16x8_t B2[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const f32x4_t b0 = *(const f32x4_t*)(bl + w * 32 + (2 * m) * 8 + half4), b1 = *(const f32x4_t*)(bl + w * 32 + (2 * m + 1) * 8 + half4);
-                B2[j][m] = __builtin_bit_cast(bf16x8_t, dt_epi8(acc[j], m, b0, b1, bound1));
-            }
         DT_MARK(4);
-        dt_barrier();  // every wave is done reading this patch: its first 12 KB become the exchange area [j][producer wave][m][lane]
-        char* const ex = smem + cur * DT_BUF;
+        // ---- its epilogue in registers: bias, bf16, ReLU, half-wave exchange -> lane (pixel n, half hi) holds channels 32 w + 16 m + 8 hi .. + 7: the B operand of
+        //      k step (w, m) of the second GEMM; into this tile's exchange area [j][producer wave][m][lane] ----
+        char* const ex = smem + DT_EX + (k & 1) * DT_EXB;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) *(bf16x8_t*)(ex + ((j * 3 + w) * 2 + m) * 1024 + lane * 16) = B2[j][m];
+            for (int m = 0; m < 2; ++m) *(u32x4_t*)(ex + ((j * 3 + w) * 2 + m) * 1024 + lane * 16) = dt_epi8(acc[j], m, BV1[m][0], BV1[m][1], bound1);
         DT_MARK(5);
-        dt_barrier();
-        DT_MARK(6);
-
-        // ---- 1x1 conv: K = 96 in the k order of a plain launch (k-block i, half m), cout groups w and w + 3; stores ----
-        {
-            const int b = dt_div(tile, dv.m_per, dv.s_per);
-            const int rem = tile - b * per;
-            const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
-            // the tile's output through a buffer descriptor based at its first pixel: per-lane 32-bit offsets (set once), the channel offset is scalar
-            const __amdgpu_buffer_rsrc_t orsrc =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(out2 + ((size_t)(b * a.Ho + tyi * 8) * a.Wo + txi * 8) * a.out2_pitch), 0, 0x80000000, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x16_t acc2[NT2];
-#pragma unroll
-                for (int tt = 0; tt < NT2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[tt][r] = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        const bf16x8_t bf = *(const bf16x8_t*)(ex + ((j * 3 + i) * 2 + m) * 1024 + lane * 16);
-#pragma unroll
-                        for (int tt = 0; tt < NT2; ++tt) acc2[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[tt][i][m], bf, acc2[tt], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int tt = 0; tt < NT2; ++tt) {
-                    const int t = w + 3 * tt;
-                    if (t < T2) {
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            const f32x4_t b0 = *(const f32x4_t*)(bl + 96 + t * 32 + (2 * m) * 8 + half4), b1 = *(const f32x4_t*)(bl + 96 + t * 32 + (2 * m + 1) * 8 + half4);
-                            const u32x4_t v = dt_epi8(acc2[tt], m, b0, b1, bound2);
-                            const int c = t * 32 + 16 * m;  // first cout of the 16 this instruction stores per pixel (wave-uniform; this lane: + 8 hi)
-                            const int ochan = (c >= a.out2_split) ? a.out2_coff2 + (c - a.out2_split) : a.out2_coff + c;
-                            if (!VGH_ABLATE(a, 8)) __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, ovo[j], (unsigned)ochan * 2u, 0);
-                        }
-                    }
-                }
-            }
-        }
+        // tile k becomes the previous tile
+        prsrc = out_rsrc(tile);
+        povo[0] = ovo[0];
+        povo[1] = ovo[1];
+        pex = ex;
+        pb = pb == 2 ? 0 : pb + 1;
         DT_MARK(7);
         ++tno;
-        if (nxt_tile < 0) break;
-        tile = nxt_tile;
-        local += gpx;
-        cur ^= 1;
     }
+    dt_barrier();  // the last tile's exchange area
+#pragma unroll
+    for (int s = 0; s < 14 + 2 * NT2; ++s) {
+        pend(s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef VGH_EXPERIMENTS
+    if (a.trace && lane == 0) {  // kernel end + the workgroup's tile count, in unused mark slots of trace tile 7
+        unsigned long long* const t7 = a.trace + ((size_t)8192 * VGH_TRACE_TILES * VGH_TRACE_MARKS) + ((size_t)(blockIdx.x * 4 + w) * 8 + 7) * 8;
+        t7[6] = __builtin_amdgcn_s_memtime();
+        t7[3] = (unsigned long long)n_my;
+    }
+#endif
 }
 
 constexpr int kMaxDev = 16;
@@ -321,12 +362,15 @@ int launch_dt(const ConvArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.B * per;
     VGH_REQUIRE(total < (1ll << 30), "conv b2b: too many tiles");
     const int chunk = (int)((total + 7) / 8);
-    int gpx = vgh_conv_persistent_blocks_per_xcd(a, chunk, VGH_ABLATE(a, 32) ? 1 : 2);  // two workgroups per CU (shared with the executor's other lane streams)
+    int gpx = 32 / (a.grid_share > 1 ? a.grid_share : 1);  // one workgroup per CU; the executor's lane streams take their share of the CUs each
+    if (gpx < 8) gpx = 8;
+    const int cap = vgh_conv_max_blocks_per_xcd();
+    if (cap > 0 && gpx > cap) gpx = cap;
     if (gpx > chunk) gpx = chunk;
     DtDiv dv;
     vgh_fastdiv_magic((unsigned)per, &dv.m_per, &dv.s_per);
     vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
-    hipLaunchKernelGGL((ds_b2b_kernel<T2>), dim3(gpx * 8), dim3(192), DT_LDS, st, a, nsx, per, (int)total, chunk, dv);
+    hipLaunchKernelGGL((ds_b2b_kernel<T2>), dim3(gpx * 8), dim3(256), DT_LDS, st, a, nsx, per, (int)total, chunk, dv);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
