@@ -36,6 +36,24 @@ constexpr int DT_LDS = DT_EX + 2 * DT_EXB;
 constexpr int DT_PIECES = 34;              // LDS-DMA pieces of a patch (the ninth row of planes (1, x) does not exist)
 constexpr unsigned DT_OOB = 0xC0000000u;   // out of the descriptors' 2-GiB range, and not wrapped past 2^32 by the scalar offsets added to it
 static_assert(DT_LDS <= 160 * 1024, "one workgroup per CU");
+// STEM = 1 ("u" tile): the stem conv (YoloNASStem, QARepVGG 3 -> 48, 3x3 / stride 2, arch yaml :8-10) in the same launch -- the stem tensor never exists.  A tile's 17 x 17
+// stem pixels are computed from the 35 x 35 x 3 image patch (fp32 in LDS, image / 255 by the correctly rounded division of detector.py:51 through a 256-entry table)
+// straight into the parity planes the LDS-DMA loader fills otherwise; the arithmetic is stem_kernel's fp32 FMA chain in ascending k on the FP32 matrix cores
+// (v_mfma_f32_32x32x2_f32 = two exact fmaf steps per instruction, k ordered), bias, ReLU, ONE rounding to bf16: bit-identical to the stem launch it replaces.
+// Two patch buffers (tile k + 1's stem pixels are computed while tile k's 3x3 conv runs), two fp32 image patches, the table.
+constexpr int ST_IW = 35, ST_IP = 36, ST_IC = ST_IW * ST_IP;  // image patch: 35 x 35 pixels, row pitch 36 floats, channel pitch
+constexpr int ST_IMGB = 3 * ST_IC * 4;                         // bytes of one fp32 image patch [3][35][36]
+constexpr int ST_EX = 2 * DT_BUF;
+constexpr int ST_IMG = ST_EX + 2 * DT_EXB;
+constexpr int ST_LUT = ST_IMG + 2 * ST_IMGB;
+constexpr int ST_LDS = ST_LUT + 1024;
+static_assert(ST_LDS <= 160 * 1024 && ST_IMGB % 16 == 0, "one workgroup per CU");
+struct StemArgs {
+    const uint8_t* image;  // u8 NHWC
+    const float* w;        // [27][48], k = (ky * 3 + kx) * 3 + ci
+    const float* b;        // [48]
+    int Hi, Wi;            // image size (the stem map is Hi / 2 x Wi / 2 = the 3x3 conv's input)
+};
 
 // experiments build: s_memtime marks per (workgroup, wave, tile) behind the 8192 rows the other conv kernels use of the tools' trace buffer (tools/ds_trace.py)
 #ifdef VGH_EXPERIMENTS
@@ -104,8 +122,9 @@ __device__ __forceinline__ u32x4_t dt_epi8(const f32x16_t& acc, int m, const f32
 //   * a compute wave runs the 1x1 conv, the second epilogue and the stores of tile k - 1 INSIDE the K loop of tile k: the 24 MFMAs of the second GEMM join the 54 of the
 //     3x3 conv in the matrix pipe and the VALU / store work of the epilogue sits in the shadow of those MFMAs (27 slots of two MFMAs each);
 //   * ONE barrier per tile: it publishes the loader's patch k AND the exchange area the compute waves wrote at the end of tile k - 1 (two exchange areas, by parity).
-template <int T2>
-__global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const int nsx, const int per, const int total_tiles, const int chunk, const DtDiv dv) {
+template <int T2, int STEM = 0>
+__global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const int nsx, const int per, const int total_tiles, const int chunk, const DtDiv dv, const StemArgs sa) {
+    constexpr int EXOFF = STEM ? ST_EX : DT_EX;  // exchange areas behind the patch buffers (two with the stem in the launch, three without)
     constexpr int NT2 = 2;  // cout groups of the second conv per compute wave: wave w takes groups 2 w, 2 w + 1 = 64 consecutive couts = one whole 128-byte line of an output
                         // pixel wherever the segment allows (T2 = 4: wave 2 has none)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,6 +143,143 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
     int tno = 0;
     (void)tno;
 
+
+    // ---- the stem's share of every wave (STEM = 1): pixel group g = stem pixels 32 g .. + 31 of the tile's 17 x 17 (row major), cout halves by mask (1: couts 0-31, 2: 32-47) ----
+    float SA[14][2];  // A operands: W[2 kp + h][32 r + r32] (zero beyond k = 26 / cout 47)
+    f32x4_t sbq[6];   // bias of this lane's output channels 8 q + 4 h .. + 3
+    unsigned soff[14];  // float offset of tap k = 2 kp + h inside the image patch: channel k % 3, row k / 9, column (k / 3) % 3
+    if constexpr (STEM) {
+        const int r32 = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kp = 0; kp < 14; ++kp) {
+            const int k = 2 * kp + h;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) SA[kp][r] = (k < 27 && 32 * r + r32 < 48) ? sa.w[k * 48 + 32 * r + r32] : 0.0f;
+            const int kk = k < 27 ? k : 26;  // (k = 27 is the zero pad of K: any finite pixel does)
+            soff[kp] = (unsigned)((kk % 3) * ST_IC + (kk / 9) * ST_IP + (kk / 3) % 3);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sbq[q] = *(const f32x4_t*)(sa.b + 8 * q + 4 * h);
+    }
+    auto stem_unit = [&](int tile, int ibuf, int xbuf, int g, int rmask) __attribute__((always_inline)) {
+        const int r32 = lane & 31, h = lane >> 5;
+        const int b = dt_div(tile, dv.m_per, dv.s_per);
+        const int rem = tile - b * per;
+        const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+        const int p = g * 32 + r32;
+        const int sp = p < 289 ? p : 288;
+        const int sy = (sp * 241) >> 12, sx = sp - sy * 17;  // sp / 17 for sp < 289
+        const int gy = 16 * tyi - 1 + sy, gx = 16 * txi - 1 + sx;  // position in the stem map; outside it: the 3x3 conv's zero padding (a multiply: a select would let
+        const float keep = ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? 1.0f : 0.0f;  // hipcc sink the chain into a branch)
+        const float* const imgf = (const float*)(smem + ST_IMG + ibuf * ST_IMGB) + (2 * sy) * ST_IP + 2 * sx;
+        f32x16_t acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+        float bx[14];
+#pragma unroll
+        for (int kp = 0; kp < 14; ++kp) bx[kp] = imgf[soff[kp]];
+#pragma unroll
+        for (int kp = 0; kp < 14; ++kp) {
+            if (rmask & 1) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(SA[kp][0], bx[kp], acc0, 0, 0, 0);
+            if (rmask & 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(SA[kp][1], bx[kp], acc1, 0, 0, 0);
+        }
+        if (p < 289) {
+            const int row = sy >> 1, col = sx >> 1;
+            char* const xp = smem + xbuf * DT_BUF + ((sy & 1) * 2 + (sx & 1)) * DT_PLANE + row * DT_ROW + (col * 6 + (row & 1)) * 16;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (!((q < 4 ? 1 : 2) & rmask)) continue;
+                bf16x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(fmaxf((q < 4 ? acc0[q * 4 + e] : acc1[(q - 4) * 4 + e]) + sbq[q][e], 0.0f) * keep);
+                *(bf16x4_t*)(xp + (8 * q + 4 * h) * 2) = o;
+#ifdef VGH_DT_DEBUG_STEM  // diagnostic build: the tile's own 16 x 16 stem pixels also go to the stem tensor (a.in)
+                if (keep != 0.0f) *(bf16x4_t*)((uint16_t*)a.in + (((size_t)b * a.H + gy) * a.W + gx) * a.in_pitch + a.in_coff + 8 * q + 4 * h) = o;
+#endif
+            }
+        }
+    };
+    // the ten pixel groups of a tile over the four waves: the loader wave has its image patch to convert, wave 2 one group less of the second GEMM's epilogue
+    auto stem_share = [&](int tile, int ibuf, int xbuf) __attribute__((always_inline)) {
+        if (w == 0) {
+            stem_unit(tile, ibuf, xbuf, 0, 3);
+            stem_unit(tile, ibuf, xbuf, 1, 3);
+            stem_unit(tile, ibuf, xbuf, 6, 1);
+        } else if (w == 1) {
+            stem_unit(tile, ibuf, xbuf, 2, 3);
+            stem_unit(tile, ibuf, xbuf, 3, 3);
+            stem_unit(tile, ibuf, xbuf, 6, 2);
+        } else if (w == 2) {
+            stem_unit(tile, ibuf, xbuf, 4, 3);
+            stem_unit(tile, ibuf, xbuf, 5, 3);
+        } else {
+            stem_unit(tile, ibuf, xbuf, 7, 3);
+            stem_unit(tile, ibuf, xbuf, 8, 3);
+            stem_unit(tile, ibuf, xbuf, 9, 3);
+        }
+    };
+
+    if (w == 3 && STEM) {
+        // =========================== loader wave, stem in the launch: image patches ===========================
+        float* const lut = (float*)(smem + ST_LUT);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lut[lane * 4 + t] = (float)(lane * 4 + t) / 255.0f;  // the true division of detector.py:51
+        // a patch row = 105 bytes from image byte 3 ix0 (= 3 mod 4 in every tile: rows are multiples of 96 bytes): dword d of the row covers row bytes 4 d - 3 .. 4 d;
+        // lane = (row parity, dword): 18 row pairs
+        const int d = lane & 31, rpar = lane >> 5;
+        int pos[4];  // float offset (channel, column) of byte t of this lane's dword inside a patch row, or -1
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = 4 * d - 3 + t;
+            const int c = j / 3;
+            pos[t] = (d <= 26 && j >= 0 && j <= 104) ? (j - 3 * c) * ST_IC + c : -1;
+        }
+        auto load_img = [&](int tile, unsigned (&q)[18]) __attribute__((always_inline)) {
+            const int b = dt_div(tile, dv.m_per, dv.s_per);
+            const int rem = tile - b * per;
+            const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+            const int iy0 = 32 * tyi - 3, ix0 = 32 * txi - 3;
+            const int64_t rowbytes = (int64_t)sa.Wi * 3;
+            const uint8_t* const base = sa.image + ((int64_t)b * sa.Hi + iy0) * rowbytes + (int64_t)ix0 * 3 - 3 + 4 * d;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const int r = 2 * i + rpar;
+                const bool ok = r < ST_IW && d <= 26 && iy0 + r >= 0 && !(txi == 0 && d < 3);  // rows above the image, the three columns left of it: zeros (the stem's padding)
+                q[i] = ok ? *(const unsigned*)(base + r * rowbytes) : 0u;
+            }
+        };
+        auto store_img = [&](int ibuf, const unsigned (&q)[18]) __attribute__((always_inline)) {
+            float* const img = (float*)(smem + ST_IMG + ibuf * ST_IMGB);
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const int r = 2 * i + rpar;
+                if (r < ST_IW) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (pos[t] >= 0) img[pos[t] + r * ST_IP] = lut[(q[i] >> (8 * t)) & 255u];
+                }
+            }
+        };
+        unsigned q[18];
+        load_img(tile0, q);
+        store_img(0, q);
+        dt_barrier();  // image patch 0
+        if (n_my > 1) load_img(tile0 + gpx, q);
+        stem_share(tile0, 0, 0);
+        if (n_my > 1) store_img(1, q);
+        for (int k = 0; k < n_my; ++k) {
+            DT_MARK(0);
+            dt_barrier();  // publishes stem patch k (every wave's share), the exchange area of tile k - 1 and image patch k + 1
+            DT_MARK(2);
+            if (k + 2 < n_my) load_img(tile0 + (k + 2) * gpx, q);
+            if (k + 1 < n_my) stem_share(tile0 + (k + 1) * gpx, (k + 1) & 1, (k + 1) & 1);
+            DT_MARK(3);
+            if (k + 2 < n_my) store_img(k & 1, q);
+            ++tno;
+        }
+        dt_barrier();
+        return;
+    }
     if (w == 3) {
         // =========================== loader wave ===========================
         // LDS-DMA source offsets inside a plane row, by the row's parity (odd rows are rotated by one chunk): lane l holds chunk s = l - parity: pixel s / 6, chunk s % 6
@@ -250,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
     f32x16_t acc2[2][NT2];
     __amdgpu_buffer_rsrc_t prsrc = out_rsrc(tile0);
     unsigned povo[2] = {DT_OOB, DT_OOB};  // (no previous tile yet: the stores of the first pass are out of range)
-    const char* pex = smem + DT_EX;
+    const char* pex = smem + EXOFF;
     auto pend = [&](int s) {
         if (s == 0 || s == 6) {
             const int j = s / 6;
@@ -270,12 +426,19 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
             const int j = s >= 14 ? 1 : 0, e = s >= 14 ? s - 14 : s - 8, tt = e >> 1, m = e & 1;
             if (T2 == 6 || 2 * w + tt < T2) {
                 const u32x4_t v = dt_epi8(acc2[j][tt], m, BV2[tt][m][0], BV2[tt][m][1], bound2);
-                if (!DT_ABLATE(a, 8)) __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, povo[j], ochan2[tt][m], 0);
+                // (the channel offset rides in the VECTOR offset: with a REGISTER scalar offset hipcc assumes that a 16-byte buffer store has no data hazard and may
+                // schedule a VALU write of the data registers right behind it -- measured on gfx950: v_pk_add_f32 into v[0:1] one instruction after the store, and lanes
+                // 12-15 / 28-31 stored the NEW value; with a constant scalar offset the compiler inserts the wait state itself)
+                if (!DT_ABLATE(a, 8)) __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, povo[j] + ochan2[tt][m], 0, 0);
             }
         }
     };
     static_assert(14 + 2 * NT2 <= 27, "the previous tile's work fits the K loop's slots");
 
+    if constexpr (STEM) {
+        dt_barrier();  // image patch 0
+        stem_share(tile0, 0, 0);
+    }
     int pb = 0;  // patch buffer of tile k
     for (int k = 0; k < n_my; ++k) {
         const int tile = tile0 + k * gpx;
@@ -318,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
         DT_MARK(4);
         // ---- its epilogue in registers: bias, bf16, ReLU, half-wave exchange -> lane (pixel n, half hi) holds channels 32 w + 16 m + 8 hi .. + 7: the B operand of
         //      k step (w, m) of the second GEMM; into this tile's exchange area [j][producer wave][m][lane] ----
-        char* const ex = smem + DT_EX + (k & 1) * DT_EXB;
+        char* const ex = smem + EXOFF + (k & 1) * DT_EXB;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -329,7 +492,10 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
         povo[0] = ovo[0];
         povo[1] = ovo[1];
         pex = ex;
-        pb = pb == 2 ? 0 : pb + 1;
+        pb = STEM ? (pb ^ 1) : (pb == 2 ? 0 : pb + 1);
+        if constexpr (STEM) {
+            if (k + 1 < n_my) stem_share(tile0 + (k + 1) * gpx, (k + 1) & 1, (k + 1) & 1);  // this wave's share of the next tile's stem pixels
+        }
         DT_MARK(7);
         ++tno;
     }
@@ -349,13 +515,14 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 }
 
 constexpr int kMaxDev = 16;
-template <int T2>
-int launch_dt(const ConvArgs& a, hipStream_t st) {
+template <int T2, int STEM = 0>
+int launch_dt(const ConvArgs& a, const StemArgs& sa, hipStream_t st) {
+    constexpr int LDS = STEM ? ST_LDS : DT_LDS;
     static std::atomic<int> done[kMaxDev];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
     if (!done[dev].load(std::memory_order_acquire)) {
-        VGH_HIP(hipFuncSetAttribute((const void*)ds_b2b_kernel<T2>, hipFuncAttributeMaxDynamicSharedMemorySize, DT_LDS));
+        VGH_HIP(hipFuncSetAttribute((const void*)ds_b2b_kernel<T2, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         done[dev].store(1, std::memory_order_release);
     }
     const int nsx = a.Wo / 8, nsy = a.Ho / 8, per = nsx * nsy;
@@ -370,7 +537,7 @@ int launch_dt(const ConvArgs& a, hipStream_t st) {
     DtDiv dv;
     vgh_fastdiv_magic((unsigned)per, &dv.m_per, &dv.s_per);
     vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
-    hipLaunchKernelGGL((ds_b2b_kernel<T2>), dim3(gpx * 8), dim3(256), DT_LDS, st, a, nsx, per, (int)total, chunk, dv);
+    hipLaunchKernelGGL((ds_b2b_kernel<T2, STEM>), dim3(gpx * 8), dim3(256), LDS, st, a, nsx, per, (int)total, chunk, dv, sa);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
 }
@@ -387,5 +554,21 @@ int vgh_conv_ds_b2b_ok(const ConvArgs& a) {
 // `a` prepared, with its b2b fields set and checked by vgh_launch_conv_b2b
 int vgh_launch_conv_ds_b2b(const ConvArgs& a, hipStream_t stream) {
     VGH_REQUIRE(vgh_conv_ds_b2b_ok(a), "conv b2b: not a stage-1 downsample pair (the t tile)");
-    return a.cout2_pad == 192 ? launch_dt<6>(a, stream) : launch_dt<4>(a, stream);
+    const StemArgs none{nullptr, nullptr, nullptr, 0, 0};
+    return a.cout2_pad == 192 ? launch_dt<6>(a, none, stream) : launch_dt<4>(a, none, stream);
 }
+
+// the same pair with the stem conv in front of it in the launch ("u" tile): `a` describes the pair as above (its input tensor -- the stem's output -- is neither written nor
+// read: a.in may be null), the stem comes as its fp32 weights [27][48] / bias [48] and the u8 NHWC image batch (Hi x Wi = 2 a.H x 2 a.W)
+#ifdef VGH_EXPERIMENTS  // (measured slower than the two launches it replaces: see the STEM comment above)
+int vgh_launch_stem_ds_b2b(const ConvArgs& a0, const void* image_u8, int Hi, int Wi, const float* wstem, const float* bstem, hipStream_t stream) {
+    ConvArgs a = a0;
+    if (int rc = vgh_conv_prepare(a)) return rc;
+    if (a.P == 0) return VGH_OK;
+    VGH_REQUIRE(a.w2pack && a.bias2 && a.out2 && vgh_conv_ds_b2b_ok(a), "stem + conv b2b: not a stage-1 downsample pair");
+    VGH_REQUIRE(a.out2_pitch % 8 == 0 && a.out2_coff % 8 == 0 && a.out2_coff2 % 8 == 0 && a.out2_split % 8 == 0, "stem + conv b2b: the second output needs 16-byte aligned channel offsets");
+    VGH_REQUIRE(image_u8 && wstem && bstem && Hi == 2 * a.H && Wi == 2 * a.W && Wi % 32 == 0 && a.act == VGH_ACT_RELU, "stem + conv b2b: image %d x %d for a %d x %d stem map", Hi, Wi, a.H, a.W);
+    const StemArgs sa{(const uint8_t*)image_u8, wstem, bstem, Hi, Wi};
+    return a.cout2_pad == 192 ? launch_dt<6, 1>(a, sa, stream) : launch_dt<4, 1>(a, sa, stream);
+}
+#endif

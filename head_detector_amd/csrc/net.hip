@@ -91,6 +91,7 @@ struct vgh_net {
     // every event it waits for and hipStreamEndCapture then recurses without end (measured r06: a stack overflow inside hip::Stream::EndCapture) -> vgh_net_capture refuses
     bool lane_wait_cycle = false;
     int fuse_b2b = 1;   // vgh_net_set_b2b: the back-to-back pairs found at create time run fused (default) or as their two launches (every intermediate tensor then exists)
+    int stem3_ok = -1;  // the stem + stage-1 pair as ONE launch (ds_b2b.hip, "u" tile; u8 images, fuse_b2b == 1): -1 not yet checked (first forward), 0 / 1
     int fuse_stem = 0;  // opt-in (vgh_net_set_fuse_stem): measured r03, the fused kernel saves 1.5 GB of HBM traffic per L b64 forward but no time (EXPERIMENTS.md 8c)
 };
 
@@ -162,6 +163,19 @@ static int net_conv_args(vgh_net* n, const NetOp& op, int B, int at, ConvArgs* a
     return VGH_OK;
 }
 
+static void net_b2b_fields(ConvArgs& a, const ConvArgs& a2) {  // the second conv of a back-to-back pair rides in the first one's descriptor
+    a.w2pack = a2.wpack;
+    a.bias2 = a2.bias;
+    a.out2 = a2.out;
+    a.out2_pitch = a2.out_pitch;
+    a.out2_coff = a2.out_coff;
+    a.out2_coff2 = a2.out_coff2;
+    a.out2_split = a2.out_split;
+    a.cout2_pad = a2.cout_pad;
+    a.cout2_store = a2.cout_store;
+    a.act2 = a2.act;
+}
+
 // runs one op for the `B` images starting at batch row `at` (image pointer and every activation buffer offset accordingly)
 static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, int B, int at, hipStream_t st, int share = 1) {
     const vgh_op_desc& d = op.d;
@@ -169,8 +183,27 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
     auto bp = [&](int id) { return (char*)n->buf_ptr[id] + at * buf_image_bytes(n->bufs[id]); };
     const int op_index = (int)(&op - n->ops.data());
     const bool fused = n->fuse_stem && n->stem_pair >= 0;
+    // stem + downsample + conv1|conv2 as one launch (r06, ds_b2b.hip): u8 images, the default b2b mode, the pair on its persistent tile
+    // (measured r06: 846 us against 307 + 347 for the stem launch + the pair's tile -- the exact fp32 stem chain on the matrix cores keeps one wave per SIMD busy for 18 000
+    // cycles per tile: experiments build only, vgh_net_set_b2b(n, 4))
+#ifdef VGH_EXPERIMENTS
+    const bool stem3 = n->fuse_b2b == 4 && !fused && n->stem_pair >= 0 && fmt == VGH_IMG_U8_NHWC && n->stem3_ok == 1 && n->ops[n->stem_pair + 1].b2b == 1;
+#else
+    const bool stem3 = false;
+#endif
     switch (d.kind) {
         case VGH_OP_STEM: {
+            if (stem3 && op_index == n->stem_pair) {
+                const NetOp &ds = n->ops[op_index + 1], &nx = n->ops[op_index + 2];
+                ConvArgs a, a2;
+                if (int rc = net_conv_args(n, ds, B, at, &a)) return rc;
+                if (int rc = net_conv_args(n, nx, B, at, &a2)) return rc;
+                a.grid_share = share;
+                net_b2b_fields(a, a2);
+#ifdef VGH_EXPERIMENTS
+                return vgh_launch_stem_ds_b2b(a, image, n->image_size, n->image_size, op.wf32, op.bias, st);
+#endif
+            }
 #ifdef VGH_EXPERIMENTS  // (stem_ds.hip is part of the experiments build only)
             if (fused && op_index == n->stem_pair) {
                 const NetOp& ds = n->ops[op_index + 1];
@@ -187,7 +220,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
                                    d.cout_store, ob.is_f32, ob.pitch, st);
         }
         case VGH_OP_CONV: {
-            if (fused && op_index == n->stem_pair + 1) return VGH_OK;  // ran inside the stem's launch
+            if ((fused || stem3) && op_index == n->stem_pair + 1) return VGH_OK;  // ran inside the stem's launch
             if (n->fuse_b2b && op.b2b == 2) return VGH_OK;             // ran inside the previous conv's launch
             ConvArgs a;
             if (int rc = net_conv_args(n, op, B, at, &a)) return rc;
@@ -196,16 +229,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
                 const NetOp& nx = n->ops[op_index + 1];
                 ConvArgs a2;
                 if (int rc = net_conv_args(n, nx, B, at, &a2)) return rc;
-                a.w2pack = a2.wpack;
-                a.bias2 = a2.bias;
-                a.out2 = a2.out;
-                a.out2_pitch = a2.out_pitch;
-                a.out2_coff = a2.out_coff;
-                a.out2_coff2 = a2.out_coff2;
-                a.out2_split = a2.out_split;
-                a.cout2_pad = a2.cout_pad;
-                a.cout2_store = a2.cout_store;
-                a.act2 = a2.act;
+                net_b2b_fields(a, a2);
                 a.b2b_igemm = n->fuse_b2b == 2;
                 return vgh_launch_conv_b2b(a, st);
             }
@@ -390,11 +414,7 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
     }
     // stem + stage-1 downsample pair (see vgh_net::stem_pair)
     int64_t wds_off = -1;
-#ifdef VGH_EXPERIMENTS
-    const int n_pair_scan = n_ops;
-#else
-    const int n_pair_scan = 0;  // product build: no fused stem + downsample kernel, no second weight image
-#endif
+    const int n_pair_scan = n_ops;  // (the pair is what the "u" tile of ds_b2b.hip fuses; the experiments build's stem_ds.hip needs a second weight image on top)
     for (int i = 0; i + 1 < n_pair_scan; ++i) {
         const vgh_op_desc &a = ops[i], &d = ops[i + 1];
         if (a.kind != VGH_OP_STEM || d.kind != VGH_OP_CONV) continue;
@@ -405,8 +425,10 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
             if (j != i && j != i + 1 && (ops[j].kind == VGH_OP_CONV || ops[j].kind == VGH_OP_SPP_POOL) && (ops[j].in_buf == a.out_buf || ops[j].out_buf == a.out_buf || ops[j].res_buf == a.out_buf)) ok = false;
         if (ok) {
             n->stem_pair = i;
+#ifdef VGH_EXPERIMENTS
             wds_off = wbytes;
             wbytes += align_up((int64_t)9 * 3 * 96 * 16 * 2, 256);
+#endif
         }
         break;
     }
@@ -556,6 +578,15 @@ int vgh_net_create(int device, int image_size, int max_batch, const vgh_buf_desc
         if (ok) {
             n->ops[i].b2b = 1;
             n->ops[i + 1].b2b = 2;
+        }
+    }
+    // the stem + the stage-1 pair as one launch ("u" tile): decided once, from the pair's descriptor
+    n->stem3_ok = 0;
+    if (n->stem_pair >= 0 && n->stem_pair + 2 < (int)n->ops.size() && n->ops[n->stem_pair + 1].b2b == 1 && image_size % 32 == 0) {
+        ConvArgs a, a2;
+        if (!net_conv_args(n, n->ops[n->stem_pair + 1], 1, 0, &a) && !net_conv_args(n, n->ops[n->stem_pair + 2], 1, 0, &a2)) {
+            net_b2b_fields(a, a2);
+            if (!vgh_conv_prepare(a)) n->stem3_ok = vgh_conv_ds_b2b_ok(a) && a.act == VGH_ACT_RELU ? 1 : 0;
         }
     }
     *out = n;
@@ -735,7 +766,7 @@ int vgh_net_set_pred_guard(vgh_net* n, void* event) {
 // every intermediate tensor of the program exists in the arena (what the per-op parity tests read)
 int vgh_net_set_b2b(vgh_net* n, int enable) {
     VGH_REQUIRE(n, "net_set_b2b: null handle");
-    n->fuse_b2b = enable == 2 ? 2 : enable ? 1 : 0;  // 2: fused, but every pair on the implicit-GEMM b2b tile (no t tile)
+    n->fuse_b2b = (enable == 2 || enable == 4) ? enable : enable ? 1 : 0;  // 2: fused, but every pair on the implicit-GEMM b2b tile (no t tile); 4 (experiments build): the stem conv in the t tile's launch
     return VGH_OK;
 }
 int vgh_net_b2b_pairs(vgh_net* n) {

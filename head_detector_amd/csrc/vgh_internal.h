@@ -143,6 +143,8 @@ int vgh_conv_b2b_ok(int ksize, int stride, int cout_pad, int cout2_pad);
 // ds_b2b.hip ("t" tile): the stage-1 downsample + conv1|conv2 pair as one persistent launch with register-resident weights; `a` prepared, b2b fields set
 int vgh_conv_ds_b2b_ok(const ConvArgs& a);
 int vgh_launch_conv_ds_b2b(const ConvArgs& a, hipStream_t stream);
+// ("u" tile) the same with the stem conv in the launch: u8 NHWC images in, the stem tensor never exists; `a` = the pair (b2b fields set, not yet prepared)
+int vgh_launch_stem_ds_b2b(const ConvArgs& a, const void* image_u8, int Hi, int Wi, const float* wstem, const float* bstem, hipStream_t stream);
 int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);  // conv_split.hip: a.split = VGH_FMT_BF16X2 / VGH_FMT_F16X2
 // dense [cout_pad][ks][ks][cin] f32 -> the three-segment 16-bit image [w_lo | w_hi | w_hi] (each segment laid out like
 // vgh_pack_conv_weights_host); fmt = VGH_FMT_BF16X2 / VGH_FMT_F16X2.  Returns through *out_scale the factor the kernel multiplies the

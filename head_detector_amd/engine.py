@@ -271,8 +271,9 @@ class VGHeadsEngine:
     def set_b2b(self, enable=True):
         """vgh_net_set_b2b (r06): a stage's downsample and the conv1|conv2 behind it as ONE back-to-back-GEMM launch (default) or as their two launches -- the same
         output bits; unfused, the tensor between them exists in the arena (per-op inspection).  ``b2b_pairs``: how many such pairs the program has.
-        ``enable=2``: fused, but every pair on the implicit-GEMM b2b tile -- without the persistent "t" tile of the stage-1 pair (csrc/ds_b2b.hip; A/B and tests: same bits)."""
-        _lib.check(self.lib.vgh_net_set_b2b(self._net, 2 if enable == 2 and enable is not True else int(bool(enable))))
+        Default (1): the stage-1 pair runs on its persistent "t" tile (csrc/ds_b2b.hip); ``enable=2``: every pair on the implicit-GEMM b2b tile (A/B and tests: the same
+        bits in every mode); ``enable=4`` (-DVGH_EXPERIMENTS build only): the stem conv inside the t tile's launch for u8 images (bit-identical, measured slower)."""
+        _lib.check(self.lib.vgh_net_set_b2b(self._net, int(enable) if enable in (2, 4) and enable is not True else int(bool(enable))))
         self._graph_key = None
 
     @property

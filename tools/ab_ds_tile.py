@@ -11,6 +11,10 @@ import torch  # noqa: E402
 from head_detector_amd.engine import VGHeadsEngine  # noqa: E402
 
 
+NAMES = {4: 'u tile (stem + pair; experiments build)', 1: 't tile', 2: 'igemm b2b'}
+MODES = (1, 2) + ((4,) if 'exp' in os.environ.get('VGH_LIB_PATH', '') else ())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=4)
@@ -24,15 +28,15 @@ def main():
         eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=1)
         x = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
         eng.set_split(1)
-        for mode in (1, 2):
+        for mode in MODES:
             eng.set_b2b(mode)
             eng.profile_ops(x)
             t = eng.profile_ops(x)
-            print(f"{variant} b{B}@{S} single stream, {'t tile' if mode == 1 else 'igemm b2b'}: stem {t[0]['ms'] * 1e3:.1f} us, stage1.downsample + conv1|conv2 {t[1]['ms'] * 1e3:.1f} us", flush=True)
+            print(f"{variant} b{B}@{S} single stream, {NAMES[mode]}: stem {t[0]['ms'] * 1e3:.1f} us, stage1.downsample + conv1|conv2 {t[1]['ms'] * 1e3:.1f} us", flush=True)
         eng.set_split(2)
-        res = {1: [], 2: []}
+        res = {m: [] for m in MODES}
         for r in range(args.rounds):
-            for mode in (1, 2):
+            for mode in MODES:
                 eng.set_b2b(mode)
                 for _ in range(8):
                     eng.forward_net(x)
@@ -43,9 +47,9 @@ def main():
                 e1.record(eng.stream)
                 torch.cuda.synchronize()
                 res[mode].append(e0.elapsed_time(e1) / args.steps)
-        for mode in (1, 2):
+        for mode in MODES:
             v = sorted(res[mode])
-            print(f"{variant} b{B}@{S} two lanes, {'t tile' if mode == 1 else 'igemm b2b'}: min {v[0]:.3f} median {v[len(v) // 2]:.3f} ms/forward = {eng.flops_per_image * B / v[len(v) // 2] / 1e9:.1f} TFLOP/s", flush=True)
+            print(f"{variant} b{B}@{S} two lanes, {NAMES[mode]}: min {v[0]:.3f} median {v[len(v) // 2]:.3f} ms/forward = {eng.flops_per_image * B / v[len(v) // 2] / 1e9:.1f} TFLOP/s", flush=True)
         eng.close()
 
 
