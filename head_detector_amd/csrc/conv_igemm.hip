@@ -268,6 +268,9 @@ const CfgEntry g_cfgs[] = {
     LCFG(128, 64, 32, 64, 2, 3, 3),  // 149  12 waves
     CFGR(128, 96, 32, 96, 1, 3),     // 150  three stages = 46 KiB < the 51 KiB of epilogue strips: still three blocks per CU, two stages in flight each
     CFGR(128, 192, 32, 96, 1, 4),    // 151
+    // "r" tile (r06, ds_b2b.hip): 3x3 / stride-2 convs with 96 input channels on the persistent 4-wave structure of the stage-1 pair's tile -- the input patch fetched once
+    // into parity planes, the wave's 32-cout slice of the weights (K = 864: 54 fragments) resident in registers
+    { "r8x8x96_n4", 64, 96, 256, 0, nullptr, 8, 8, 8, nullptr },  // 152
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
@@ -304,6 +307,7 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     if (e.patch == 7 && cout_pad > 1024) return 0;
     if (e.patch == 3 && !(ksize == 1 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 4 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle)) return 0;
+    if (e.patch == 8 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle && cout_pad <= 192)) return 0;
     return 1;
 }
 const char* vgh_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].name : "?"; }
@@ -317,6 +321,7 @@ static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if ((g_cfgs[cfg].patch == 5 || g_cfgs[cfg].patch == 6 || g_cfgs[cfg].patch == 7) && (a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || !vgh_conv_pp_fits(a))) return 0;  // ping-pong tiles: dense bf16 -> bf16, ReLU / none
     if (g_cfgs[cfg].patch == 7 && (a.Wo < 8 || a.Ho < 4)) return 0;  // 4 x 8 sub-patches are moved back inside the map, never cut
     if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
+    if (g_cfgs[cfg].patch == 8 && !vgh_conv_ds_ok(a)) return 0;  // r tile: 96 input channels, whole 8 x 8 tiles
     return 1;
 }
 
@@ -453,6 +458,7 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
         cfg = t;
     }
     const CfgEntry& e = g_cfgs[cfg];
+    if (e.patch == 8) return vgh_launch_conv_ds(a, stream);
     if (e.patch == 5 || e.patch == 6 || e.patch == 7) return vgh_launch_conv_pp(a, e.BC, e.patch == 7 ? 3 : e.patch == 6 ? 2 : 1, g_max_blocks_per_xcd.load(std::memory_order_relaxed), stream);
     if (e.patch == 1 || e.patch == 2 || e.patch == 4) {
         const int ntc = a.cout_pad / e.BC, ntx = (a.Wo + e.TW - 1) / e.TW, nty = (a.Ho + e.TH - 1) / e.TH;  // (Ho, Wo) = (H, W) for the stride-1 tiles

@@ -514,6 +514,160 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #endif
 }
 
+// ---- "r" tile (r06): the same execution structure for a PLAIN 3x3 / stride-2 conv with 96 input channels (stage-2 / neck-2 downsample: K = 864, HBM-bound on the
+//      implicit-GEMM rings at 2.0 - 2.4 TB/s): 54 resident A fragments (216 VGPRs) per compute wave, a pixel = 12 chunks at a 14-chunk pitch (even chunk offsets for the
+//      eight pixels of a row, the odd ones for the row below: one rotation chunk as before), a plane row = two LDS-DMA pieces, two patch buffers of 34 rows.  A workgroup
+//      owns 96 couts; a 192-cout conv runs as two workgroup classes (cout half = tile parity, fixed per workgroup), the second reading its patches from L2.  The first
+//      epilogue stores directly.  Bit-identical to the implicit-GEMM tiles (same instructions, k order, roundings). ----
+constexpr int DR_PP = 14, DR_ROW = 2048, DR_NROWS = 34, DR_BUF = DR_NROWS * DR_ROW, DR_LDS = 2 * DR_BUF;
+static_assert(DR_LDS <= 160 * 1024, "one workgroup per CU");
+__device__ __forceinline__ constexpr int dr_plane_row0(int plane) { return plane == 0 ? 0 : plane == 1 ? 9 : plane == 2 ? 18 : 26; }
+
+__global__ __launch_bounds__(256, 1) void ds_conv_kernel(const ConvArgs a, const int nsx, const int per, const int total_tiles, const int chunk, const DtDiv dv, const int nh) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, hi = lane >> 5, half4 = hi * 4;
+    const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
+    const int pixb = (int)a.in_pitch * 2;
+    const int rowb = a.W * pixb;
+    const int first = blockIdx.x >> 3;
+    const int lim = (total_tiles - xcd * chunk) < chunk ? (total_tiles - xcd * chunk) : chunk;
+    const int n_my = first < lim ? (lim - first + gpx - 1) / gpx : 0;
+    if (n_my <= 0) return;
+    const int tile0 = xcd * chunk + first;  // work item = (pixel tile, cout half): item / nh, item % nh -- the half is the same for every item of a workgroup (gpx is even)
+    const int half = nh > 1 ? tile0 % nh : 0;
+
+    if (w == 3) {
+        // =========================== loader wave ===========================
+        unsigned rel0[2][2], rel1[2][2], relL[2][2];  // [row parity][piece]: planes (y, 0) / planes (y, 1) / planes (y, 0) of a tile on the left image edge
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = h * 64 + lane - q;
+                const int col = s / DR_PP, chn = s - col * DR_PP;
+                const bool valid = s >= 0 && col < 9 && chn < 12;
+                const unsigned r = (unsigned)(col * 2 * pixb + chn * 16);
+                rel0[q][h] = valid ? r : DT_OOB;
+                rel1[q][h] = (valid && col < 8) ? r : DT_OOB;
+                relL[q][h] = (valid && col > 0) ? r : DT_OOB;
+            }
+        auto issue_patch = [&](int item, int buf) __attribute__((always_inline)) {
+            const int tile = nh > 1 ? item / nh : item;
+            const int b = dt_div(tile, dv.m_per, dv.s_per);
+            const int rem = tile - b * per;
+            const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+            const int iy0 = 16 * tyi - 1, ix0 = 16 * txi - 1;
+            const bool top = tyi == 0, left = txi == 0;
+            const char* const base = (const char*)a.in + (int64_t)a.in_coff * 2 + ((int64_t)(b * a.H + iy0) * a.W + ix0) * pixb;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000, 0x00020000);
+            char* const dst = smem + buf * DR_BUF;
+#pragma unroll
+            for (int plane = 0; plane < 4; ++plane)
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int py = plane >> 1, px = plane & 1, q = r & 1, lr = 2 * r + py;
+                    if (lr > 16) continue;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned vo = px ? rel1[q][h] : (left ? relL[q][h] : rel0[q][h]);
+                        if (lr == 0) vo = top ? DT_OOB : vo;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (AS3 void*)(dst + (dr_plane_row0(plane) + r) * DR_ROW + h * 1024), 16, vo, (unsigned)(lr * rowb + px * pixb), 0, 0);
+                    }
+                }
+        };
+        issue_patch(tile0, 0);
+        for (int k = 0; k < n_my; ++k) {
+            dt_wait_vm<0>();  // patch k (the only one in flight)
+            dt_barrier();     // publishes it; every compute wave is done with patch k - 1, whose buffer patch k + 1 takes
+            if (k + 1 < n_my) issue_patch(tile0 + (k + 1) * gpx, (k + 1) & 1);
+        }
+        return;
+    }
+
+    // =========================== compute waves ===========================
+    const int cg = half * 3 + w;  // this wave's cout group
+    bf16x8_t W1[54];  // step s = tap * 6 + c: channels 16 c .. + 15 of tap (ky, kx)
+    {
+        const int co = cg * 32 + n32, sw = (co >> 2) & 3;
+#pragma unroll
+        for (int s = 0; s < 54; ++s) {
+            const int tap = s / 6, c = s % 6, kb = tap * 3 + (c >> 1), ch = 2 * (c & 1) + hi;
+            W1[s] = *(const bf16x8_t*)(a.wpack + ((size_t)kb * a.cout_pad + co) * 32 + ((ch ^ sw) * 8));
+        }
+    }
+    f32x4_t BV1[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) BV1[m][u] = *(const f32x4_t*)(a.bias + cg * 32 + (2 * m + u) * 8 + half4);
+    int ty4, tx;
+    if (n32 < 4) ty4 = 0, tx = n32;
+    else if (n32 < 12) ty4 = 2, tx = n32 - 4;
+    else if (n32 < 16) ty4 = 0, tx = n32 - 8;
+    else if (n32 < 20) ty4 = 3, tx = n32 - 16;
+    else if (n32 < 28) ty4 = 1, tx = n32 - 20;
+    else ty4 = 3, tx = n32 - 24;
+    unsigned rb[2];
+#pragma unroll
+    for (int kyh = 0; kyh < 2; ++kyh) rb[kyh] = (unsigned)(ty4 * DR_ROW + (tx * DR_PP + hi + ((ty4 + kyh) & 1)) * 16);
+    const unsigned bound1 = a.act == VGH_ACT_RELU ? 0u : 0x80008000u;
+    unsigned ovo[2][2];  // byte offset of the lane's output pixel + its 8 couts of (pixel group j, half m) from the tile's first pixel
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c = cg * 32 + 16 * m;
+            const int oc = (c >= a.out_split) ? a.out_coff2 + (c - a.out_split) : a.out_coff + c;
+            ovo[j][m] = (unsigned)(((4 * j + ty4) * a.Wo + tx) * (int)a.out_pitch * 2 + hi * 16 + oc * 2);
+        }
+    uint16_t* const outp = (uint16_t*)a.out;
+
+    for (int k = 0; k < n_my; ++k) {
+        const int item = tile0 + k * gpx;
+        const int tile = nh > 1 ? item / nh : item;
+        dt_barrier();
+        const char* const xb = smem + (k & 1) * DR_BUF;
+        f32x16_t acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        {
+            auto frag = [&](int s, int j) __attribute__((always_inline)) -> bf16x8_t {
+                const int ky = s / 18, kx = (s / 6) % 3, c = s % 6;
+                const int imm = (dr_plane_row0((ky & 1) * 2 + (kx & 1)) + 4 * j + (ky >> 1)) * DR_ROW + ((kx >> 1) * DR_PP + c * 2) * 16;
+                return *(const bf16x8_t*)(xb + rb[ky >> 1] + imm);
+            };
+            bf16x8_t F[3][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) F[p][j] = frag(p, j);
+#pragma unroll
+            for (int s = 0; s < 54; ++s) {
+                if (s + 2 < 54) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) F[(s + 2) % 3][j] = frag(s + 2, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s], F[s % 3][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int b = dt_div(tile, dv.m_per, dv.s_per);
+        const int rem = tile - b * per;
+        const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(outp + ((size_t)(b * a.Ho + tyi * 8) * a.Wo + txi * 8) * a.out_pitch), 0, 0x80000000, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) __builtin_amdgcn_raw_buffer_store_b128(dt_epi8(acc[j], m, BV1[m][0], BV1[m][1], bound1), orsrc, ovo[j][m], 0, 0);
+    }
+}
+
 constexpr int kMaxDev = 16;
 template <int T2, int STEM = 0>
 int launch_dt(const ConvArgs& a, const StemArgs& sa, hipStream_t st) {
@@ -549,6 +703,44 @@ int vgh_conv_ds_b2b_ok(const ConvArgs& a) {
     return a.ksize == 3 && a.stride == 2 && a.pad == 1 && a.cin == 64 && a.in_pitch == 48 && a.in_coff % 8 == 0 && a.cout_pad == 96 && a.cout_store == 96 && (a.cout2_pad == 128 || a.cout2_pad == 192) && a.cout2_store == a.cout2_pad &&
            a.H == 2 * a.Ho && a.W == 2 * a.Wo && a.Ho % 8 == 0 && a.Wo % 8 == 0 && (int64_t)a.W * a.in_pitch * 2 * 20 < (1ll << 30) && !a.split && !a.res && !a.shuffle && !a.grp_cout &&
            !a.in_fp8 && !a.out_fp8 && !a.out_f32 && a.act != VGH_ACT_SILU && a.act2 != VGH_ACT_SILU;
+}
+
+
+// plain 3x3 / stride-2 / pad-1 conv, 96 input channels, whole 96-cout workgroup tiles, a map of whole 8 x 8 tiles ("r" tile)
+int vgh_conv_ds_ok(const ConvArgs& a) {
+    return a.ksize == 3 && a.stride == 2 && a.pad == 1 && a.cin == 96 && a.in_pitch % 8 == 0 && a.in_pitch >= 96 && a.in_coff % 8 == 0 && a.cout_pad % 96 == 0 && a.cout_pad <= 192 &&
+           a.cout_store == a.cout_pad && (a.out_split >= a.cout_pad || a.out_split % 16 == 0) && a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_pitch % 8 == 0 && a.H == 2 * a.Ho &&
+           a.W == 2 * a.Wo && a.Ho % 8 == 0 && a.Wo % 8 == 0 && (int64_t)a.W * a.in_pitch * 2 * 20 < (1ll << 30) && (int64_t)a.Wo * a.out_pitch * 2 * 9 < (1ll << 30) && !a.split && !a.res &&
+           !a.shuffle && !a.grp_cout && !a.in_fp8 && !a.out_fp8 && !a.out_f32 && a.act != VGH_ACT_SILU && !a.w2pack;
+}
+
+int vgh_launch_conv_ds(const ConvArgs& a, hipStream_t st) {
+    VGH_REQUIRE(vgh_conv_ds_ok(a), "conv: not a 96-channel stride-2 conv on whole 8 x 8 tiles (the r tile)");
+    static std::atomic<int> done[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    if (!done[dev].load(std::memory_order_acquire)) {
+        VGH_HIP(hipFuncSetAttribute((const void*)ds_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS));
+        done[dev].store(1, std::memory_order_release);
+    }
+    const int nsx = a.Wo / 8, nsy = a.Ho / 8, per = nsx * nsy, nh = a.cout_pad / 96;
+    const int64_t total = (int64_t)a.B * per * nh;
+    VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
+    int chunk = (int)((total + 7) / 8);
+    if (nh > 1) chunk += chunk & 1;  // even chunks: item parity = cout half, fixed per workgroup
+    int gpx = 32 / (a.grid_share > 1 ? a.grid_share : 1);
+    if (gpx < 8) gpx = 8;
+    const int cap = vgh_conv_max_blocks_per_xcd();
+    if (cap > 0 && gpx > cap) gpx = cap;
+    if (gpx > chunk) gpx = chunk;
+    if (nh > 1) gpx -= gpx & 1;
+    if (gpx < nh) gpx = nh;
+    DtDiv dv;
+    vgh_fastdiv_magic((unsigned)per, &dv.m_per, &dv.s_per);
+    vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
+    hipLaunchKernelGGL(ds_conv_kernel, dim3(gpx * 8), dim3(256), DR_LDS, st, a, nsx, per, (int)total, chunk, dv, nh);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
 }
 
 // `a` prepared, with its b2b fields set and checked by vgh_launch_conv_b2b

@@ -375,6 +375,8 @@ CONV_CASES = [
     (2, 40, 40, 64, 128, 3, 1),  # 40-wide map (row-strip patch tiles)
     (1, 21, 37, 32, 64, 3, 1),  # ragged in both directions for every patch tile shape
     (2, 16, 48, 96, 96, 3, 1),
+    (2, 32, 48, 96, 192, 3, 2),  # the r tile's shapes (csrc/ds_b2b.hip: 96 input channels, stride 2, whole 8 x 8 output tiles): two cout halves
+    (3, 16, 32, 96, 96, 3, 2),
 ]
 
 
@@ -396,12 +398,34 @@ def test_conv_all_configs_vs_torch(gpu_lib, case):
             fast = int(oc0 == 8 and Cout % 8 == 0 and not out_f32)
             if cfg >= 0 and not gpu_lib.vgh_conv_cfg_ok(cfg, k, stride, rp, fast, 0):
                 continue
+            if cfg >= 0 and gpu_lib.vgh_conv_cfg_name(cfg).decode()[0] == "r" and not (Cin == 96 and H % 16 == 0 and W % 16 == 0):
+                continue  # (the r tile's conditions on the input: vgh_conv_cfg_ok sees the output side only)
             out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, k, stride, cfg=cfg, out_f32=out_f32, out_coff=oc0)
             _assert_close(out[..., o0 : o0 + st], ref[..., :st], out_f32, f"{case} cfg={cfg} out_coff={oc0}")
             assert float((out[..., :o0] + 768.0).abs().max()) == 0.0, "wrote outside its channel range"
             assert float((out[..., o0 + st :] + 768.0).abs().max()) < 1.0, "wrote past cout_store"
             tested += 1
     assert tested >= 2
+
+
+@pytest.mark.parametrize("B,H,W,Cout,split", [(5, 48, 64, 96, None), (3, 32, 32, 192, None), (2, 32, 48, 192, (96, 104, 0)), (40, 16, 16, 96, None)])
+def test_conv_r_tile_equals_the_implicit_gemm_tiles(gpu_lib, B, H, W, Cout, split):
+    """The r tile (r06, csrc/ds_b2b.hip: a 3x3 / stride-2 conv with 96 input channels on the persistent 4-wave structure -- patch fetched once into parity planes,
+    the wave's weights resident in registers, one loader wave): against the torch reference AND bit for bit against an implicit-GEMM tile (same MFMA instruction,
+    operand slots, k order, roundings); many tiles per workgroup, image edges on all four sides, both cout halves, an output in two channel segments, an input
+    view inside a wider pixel (the neck's concat buffer)."""
+    g = torch.Generator().manual_seed(B * 1000 + Cout)
+    x = torch.randn(B, H, W, 96, generator=g).to(torch.bfloat16).float()
+    Wt = torch.randn(Cout, 3, 3, 96, generator=g) * (1.5 / np.sqrt(9 * 96)) * (1.0 + 0.5 * torch.arange(Cout).float()[:, None, None, None] / Cout)
+    b = torch.randn(Cout, generator=g)
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    r, ig = names.index("r8x8x96_n4"), names.index("128x96_w32x96_k1")
+    for in_coff, in_pitch in ((0, None), (32, 160)):
+        out_r, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 2, cfg=r, split=split, in_coff=in_coff, in_pitch=in_pitch)
+        out_i, _, _, _ = _run_conv(gpu_lib, x, Wt, b, 3, 2, cfg=ig, split=split, in_coff=in_coff, in_pitch=in_pitch)
+        assert torch.equal(out_r, out_i), (in_coff, float((out_r.float() - out_i.float()).abs().max()))
+        if split is None:
+            _assert_close(out_r[..., o0 : o0 + st], ref[..., :st], False, f"r tile {B}x{H}x{W} -> {Cout}")
 
 
 @pytest.mark.parametrize("cin,res", [(64, False), (64, True), (32, True), (96, False)])
