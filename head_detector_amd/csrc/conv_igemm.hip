@@ -271,6 +271,10 @@ const CfgEntry g_cfgs[] = {
     // "r" tile (r06, ds_b2b.hip): 3x3 / stride-2 convs with 96 input channels on the persistent 4-wave structure of the stage-1 pair's tile -- the input patch fetched once
     // into parity planes, the wave's 32-cout slice of the weights (K = 864: 54 fragments) resident in registers
     { "r8x8x96_n4", 64, 96, 256, 0, nullptr, 8, 8, 8, nullptr },  // 152
+    // "w" tiles (r06, ds_b2b.hip): 3x3 / stride-1 convs with 96 / 128 input channels, the weights resident in registers (K = 864 / 1 152: 54 / 72 fragments per wave), one
+    // wave per cout group and SIMD, no barrier inside a tile
+    { "w8x8x96_n3", 64, 96, 192, 0, nullptr, 9, 8, 8, nullptr },   // 153
+    { "w8x8x128_n4", 64, 128, 256, 0, nullptr, 9, 8, 8, nullptr },  // 154
     // (measured and dropped: one-block 16-wave shapes p8x32x128_n8x2 / p16x16x128_n8x2 700 / 650 TFLOP/s where two 8-wave blocks reach 840-880;
     //  p8x16x96_n4x1 654 vs 781 for p8x32x96)
 };
@@ -308,6 +312,7 @@ int vgh_conv_cfg_ok(int cfg, int ksize, int stride, int cout_pad, int fast_epilo
     if (e.patch == 3 && !(ksize == 1 && stride == 1 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 4 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle)) return 0;
     if (e.patch == 8 && !(ksize == 3 && stride == 2 && fast_epilogue && !shuffle && cout_pad <= 192)) return 0;
+    if (e.patch == 9 && !(ksize == 3 && stride == 1 && fast_epilogue && !shuffle && cout_pad <= 1024)) return 0;
     return 1;
 }
 const char* vgh_conv_cfg_name(int cfg) { return (cfg >= 0 && cfg < kNumCfgs) ? g_cfgs[cfg].name : "?"; }
@@ -322,6 +327,7 @@ static int cfg_ok_for(int cfg, const ConvArgs& a) {
     if (g_cfgs[cfg].patch == 7 && (a.Wo < 8 || a.Ho < 4)) return 0;  // 4 x 8 sub-patches are moved back inside the map, never cut
     if (g_cfgs[cfg].patch == 3 && (a.res || a.grp_cout || a.act == VGH_ACT_SILU || a.out_f32 || a.pad)) return 0;  // streaming 1x1 tiles: plain bf16 -> bf16 only
     if (g_cfgs[cfg].patch == 8 && !vgh_conv_ds_ok(a)) return 0;  // r tile: 96 input channels, whole 8 x 8 tiles
+    if (g_cfgs[cfg].patch == 9 && !(vgh_conv_w_ok(a) && a.cin == g_cfgs[cfg].BC)) return 0;  // w tiles: cin = the tile's 96 / 128, whole 8 x 8 tiles
     return 1;
 }
 
@@ -459,6 +465,7 @@ int vgh_launch_conv(const ConvArgs& a0, int force_cfg, hipStream_t stream) {
     }
     const CfgEntry& e = g_cfgs[cfg];
     if (e.patch == 8) return vgh_launch_conv_ds(a, stream);
+    if (e.patch == 9) return vgh_launch_conv_w(a, stream);
     if (e.patch == 5 || e.patch == 6 || e.patch == 7) return vgh_launch_conv_pp(a, e.BC, e.patch == 7 ? 3 : e.patch == 6 ? 2 : 1, g_max_blocks_per_xcd.load(std::memory_order_relaxed), stream);
     if (e.patch == 1 || e.patch == 2 || e.patch == 4) {
         const int ntc = a.cout_pad / e.BC, ntx = (a.Wo + e.TW - 1) / e.TW, nty = (a.Ho + e.TH - 1) / e.TH;  // (Ho, Wo) = (H, W) for the stride-1 tiles

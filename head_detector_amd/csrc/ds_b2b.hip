@@ -668,6 +668,231 @@ __global__ __launch_bounds__(256, 1) void ds_conv_kernel(const ConvArgs a, const
     }
 }
 
+// ---- "w" tile (r06): 3x3 / STRIDE-1 convs with 96 / 128 input channels and the weights resident in registers.  The ping-pong g / h tiles stream a layer's weights
+//      through an LDS ring (two barriers per tap, eight waves in two phase-shifted groups); with K = 9 x 96 = 864 or 9 x 128 = 1 152 a wave's 32-cout slice of the weights
+//      is 54 / 72 A fragments = 216 / 288 of its 512 registers, so they can simply stay: NCG = 3 / 4 waves per workgroup (one per cout group, one per SIMD), each running
+//      ds_read_b128 -> MFMA over the tile's two 32-pixel groups with NO barrier inside a tile and nothing but B fragments coming out of LDS.  A tile = 8 x 8 output pixels,
+//      its 10 x 10 halo patch fetched once by LDS-DMA (every wave issues its share, a tile ahead, two buffers; a pixel = CP chunks at a PP-chunk pitch with the one-chunk
+//      row rotation of the stride-2 tiles: the 16 lanes of a ds_read_b128 group cover two rows x eight pixels = 16 distinct slots).  Epilogue in registers as above; RES:
+//      + alpha * residual in fp32 before the one rounding.  Same instruction, operand slots, k order and roundings as the implicit-GEMM tiles. ----
+template <int CIN16>
+struct WGeo {
+    static constexpr int CP = 2 * CIN16;               // 16-byte chunks per input pixel
+    static constexpr int PP = CIN16 == 6 ? 14 : 18;    // pixel pitch in chunks: = 2 mod 4 (eight neighbours on distinct even slots), >= CP
+    static constexpr int PIECES = 3, ROWB = PIECES * 1024;  // a patch row: 10 pixels x PP + 1 <= 192 chunks
+    static constexpr int BUF = 10 * ROWB;
+    static constexpr int DUMMY = 2 * BUF;
+    static constexpr int LDS = DUMMY + 1024;
+    static constexpr unsigned DIVM = 65536 / PP + 1;   // s / PP == (s * DIVM) >> 16 for s < 192
+    static_assert(10 * PP + 1 <= 64 * PIECES && PP >= CP && PP % 4 == 2, "patch row layout");
+};
+
+template <int CIN16, int NCG, int RES>
+__global__ __launch_bounds__(64 * NCG, 1) void w_conv_kernel(const ConvArgs a, const int nsx, const int per, const int total_tiles, const int chunk, const DtDiv dv, const int nh) {
+    using G = WGeo<CIN16>;
+    constexpr int NS = 9 * CIN16, PP = G::PP, ROWB = G::ROWB;
+    constexpr int UPW = (30 + NCG - 1) / NCG;  // LDS-DMA pieces per wave and patch (30 real ones; the last waves' extras fill a dummy unit with zeros)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, hi = lane >> 5, half4 = hi * 4;
+    const int xcd = blockIdx.x & 7, gpx = gridDim.x >> 3;
+    const int pixb = (int)a.in_pitch * 2;
+    const int rowb = a.W * pixb;
+    const int first = blockIdx.x >> 3;
+    const int lim = (total_tiles - xcd * chunk) < chunk ? (total_tiles - xcd * chunk) : chunk;
+    const int n_my = first < lim ? (lim - first + gpx - 1) / gpx : 0;
+    if (n_my <= 0) return;
+    const int tile0 = xcd * chunk + first;  // work item = (pixel tile, cout part): item / nh, item % nh; the part is the same for every item of a workgroup (gpx % nh == 0)
+    const int part = nh > 1 ? tile0 % nh : 0;
+    const int cg = part * NCG + w;  // this wave's cout group
+
+    // ---- once: weights, bias -> registers ----
+    bf16x8_t W1[NS];  // step s = tap * CIN16 + c: channels 16 c .. + 15 of tap (ky, kx)
+    {
+        const int co = cg * 32 + n32, sw = (co >> 2) & 3;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tap = s / CIN16, c = s % CIN16, kb = tap * (CIN16 / 2) + (c >> 1), ch = 2 * (c & 1) + hi;
+            W1[s] = *(const bf16x8_t*)(a.wpack + ((size_t)kb * a.cout_pad + co) * 32 + ((ch ^ sw) * 8));
+        }
+    }
+    f32x4_t BV1[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) BV1[m][u] = *(const f32x4_t*)(a.bias + cg * 32 + (2 * m + u) * 8 + half4);
+    int ty4, tx;
+    if (n32 < 4) ty4 = 0, tx = n32;
+    else if (n32 < 12) ty4 = 2, tx = n32 - 4;
+    else if (n32 < 16) ty4 = 0, tx = n32 - 8;
+    else if (n32 < 20) ty4 = 3, tx = n32 - 16;
+    else if (n32 < 28) ty4 = 1, tx = n32 - 20;
+    else ty4 = 3, tx = n32 - 24;
+    unsigned rb[2];  // fragment read offset of the lane for taps with ky & 1 = 0 / 1 (the patch row's parity moves the rotation)
+#pragma unroll
+    for (int par = 0; par < 2; ++par) rb[par] = (unsigned)(ty4 * ROWB + (tx * PP + hi + ((ty4 + par) & 1)) * 16);
+    const unsigned bound1 = a.act == VGH_ACT_RELU ? 0u : 0x80008000u;
+    const float act_lo = a.act == VGH_ACT_RELU ? 0.0f : -3.0e38f;
+    unsigned ovo[2][2];   // byte offset of the lane's output pixel + its 8 couts of (pixel group j, half m) from the tile's first pixel
+    unsigned rvo[2][2][2];  // RES: byte offset of the lane's 4 residual channels of (j, m, run u) -- its accumulator rows, before the half-wave exchange
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c = cg * 32 + 16 * m;
+            const int oc = (c >= a.out_split) ? a.out_coff2 + (c - a.out_split) : a.out_coff + c;
+            ovo[j][m] = (unsigned)(((4 * j + ty4) * a.Wo + tx) * (int)a.out_pitch * 2 + hi * 16 + oc * 2);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) rvo[j][m][u] = RES ? (unsigned)(((4 * j + ty4) * a.Wo + tx) * (int)a.res_pitch * 2 + (a.res_coff + c + 8 * u + half4) * 2) : 0u;
+        }
+    uint16_t* const outp = (uint16_t*)a.out;
+
+    // Everything that is not an MFMA or a fragment read rides in the SLOTS of the K loop (one slot = one k step = two MFMAs = 64 matrix-pipe cycles): the LDS-DMA pieces
+    // of the NEXT tile's patch (slots 0 .. UPW - 1: ~12 VALU + one piece each), the epilogue blocks and stores of the PREVIOUS tile (slots EB0, EB0 + 2, ...: its
+    // accumulators were copied aside), the residual loads of the CURRENT tile (slot NS - 10).  One wave per SIMD has nobody to hide its non-MFMA instructions behind
+    // but its own MFMAs (measured without this: 9 300 cycles per tile for 4 608 cycles of MFMAs).
+    constexpr int EB0 = UPW + 2;
+    static_assert(EB0 + 8 < NS - 10, "slots");
+    f32x16_t acc[2], pacc[2];
+    bf16x4_t rres[2][2][2], pres[2][2][2];
+    unsigned pov[2][2] = {{DT_OOB, DT_OOB}, {DT_OOB, DT_OOB}};  // (no previous tile yet: the stores of the first pass are out of range)
+    __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, 0x80000000, 0x00020000);
+    // next tile's patch: wave-uniform part, set before the K loop that carries its pieces
+    bool has_next = false;
+    int n_iy0 = 0, n_ix0 = 0, n_buf = 0;
+    __amdgpu_buffer_rsrc_t nrsrc = prsrc, rrsrc = prsrc;
+    auto next_setup = [&](int item, int buf) __attribute__((always_inline)) {
+        const int tile = nh > 1 ? item / nh : item;
+        const int b = dt_div(tile, dv.m_per, dv.s_per);
+        const int rem = tile - b * per;
+        const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+        n_iy0 = 8 * tyi - 1;
+        n_ix0 = 8 * txi - 1;
+        n_buf = buf;
+        nrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in + (int64_t)a.in_coff * 2 + ((int64_t)(b * a.H + n_iy0) * a.W + n_ix0) * pixb), 0, 0x80000000, 0x00020000);
+    };
+    // piece u = w + NCG i of the patch set up by next_setup -> patch row u / 3, third u % 3 (the last waves' extras fill a dummy unit with zeros)
+    auto issue_piece = [&](int i) __attribute__((always_inline)) {
+        const int u = w + NCG * i;
+        const bool real = u < 30;
+        const int r = real ? u / 3 : 0, h = real ? u - 3 * r : 0;
+        const int sl = h * 64 + lane - (r & 1);
+        const int col = (int)(((unsigned)(sl < 0 ? 0 : sl) * G::DIVM) >> 16), chn = sl - col * PP;
+        const bool ok = real && sl >= 0 && col < 10 && chn < G::CP && (unsigned)(n_iy0 + r) < (unsigned)a.H && (unsigned)(n_ix0 + col) < (unsigned)a.W;
+        const unsigned vo = ok ? (unsigned)(col * pixb + chn * 16) : DT_OOB;
+        char* const dst = real ? smem + n_buf * G::BUF + r * ROWB + h * 1024 : smem + G::DUMMY;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(nrsrc, (AS3 void*)dst, 16, vo, real ? (unsigned)(r * rowb) : 0u, 0, 0);
+    };
+    // epilogue block (pixel group j, half m) of the tile whose accumulators sit in pacc
+    auto epi_block = [&](int j, int m) __attribute__((always_inline)) {
+        if constexpr (RES) {
+            // max(acc + bias, lo) + alpha * residual in fp32 (an fma, as the implicit-GEMM epilogue compiles), ONE rounding, then the half-wave exchange
+            unsigned pk[4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(a.alpha, (float)pres[j][m][u][e], fmaxf(pacc[j][8 * m + 4 * u + e] + BV1[m][u][e], act_lo));
+                pk[2 * u] = dt_pk(v[0], v[1]);
+                pk[2 * u + 1] = dt_pk(v[2], v[3]);
+            }
+            dt_sw32(pk[0], pk[2]);
+            dt_sw32(pk[1], pk[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pk[0], pk[1], pk[2], pk[3]}, prsrc, pov[j][m], 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(dt_epi8(pacc[j], m, BV1[m][0], BV1[m][1], bound1), prsrc, pov[j][m], 0, 0);
+        }
+    };
+    auto pend = [&](int s) __attribute__((always_inline)) {
+        if (s < UPW) {
+            if (has_next) issue_piece(s);
+        }
+        if (s >= EB0 && s < EB0 + 8 && ((s - EB0) & 1) == 0) epi_block((s - EB0) >> 2, ((s - EB0) >> 1) & 1);
+        if constexpr (RES) {
+            if (s == NS - 10) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                            rres[j][m][u] = __builtin_bit_cast(bf16x4_t, (u32x2_t)__builtin_amdgcn_raw_buffer_load_b64(rrsrc, rvo[j][m][u], 0, 0));
+                        }
+            }
+        }
+    };
+
+    next_setup(tile0, 0);
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) issue_piece(i);
+    for (int k = 0; k < n_my; ++k) {
+        const int item = tile0 + k * gpx;
+        const int tile = nh > 1 ? item / nh : item;
+        if (k == 0)
+            dt_wait_vm<0>();
+        else
+            dt_wait_vm<4 + 8 * RES>();  // this wave's pieces of patch k have landed (behind them in the queue: the stores of tile k - 2, the residual loads of tile k - 1)
+        dt_barrier();                   // everybody's pieces; everybody is done with patch k - 1
+        has_next = k + 1 < n_my;
+        if (has_next) next_setup(tile0 + (k + 1) * gpx, (k + 1) & 1);
+        const int b = dt_div(tile, dv.m_per, dv.s_per);
+        const int rem = tile - b * per;
+        const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+        const size_t pix0 = (size_t)(b * a.Ho + tyi * 8) * a.Wo + txi * 8;
+        if constexpr (RES) rrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res + pix0 * a.res_pitch), 0, 0x80000000, 0x00020000);
+        const char* const xb = smem + (k & 1) * G::BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        {
+            auto frag = [&](int s, int j) __attribute__((always_inline)) -> bf16x8_t {
+                const int tap = s / CIN16, c = s % CIN16, ky = tap / 3, kx = tap % 3;
+                const int imm = (4 * j + ky) * ROWB + (kx * PP + c * 2) * 16;
+                return *(const bf16x8_t*)(xb + rb[ky & 1] + imm);
+            };
+            constexpr int D = 3;  // fragment reads run D steps ahead of the MFMAs
+            bf16x8_t F[D + 1][2];
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) F[p][j] = frag(p, j);
+#pragma clang loop unroll(full)
+            for (int s = 0; s < NS; ++s) {
+                if (s + D < NS) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) F[(s + D) % (D + 1)][j] = frag(s + D, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[s], F[s % (D + 1)][j], acc[j], 0, 0, 0);
+                pend(s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // tile k becomes the previous tile: its accumulators (and residual values) move aside, its epilogue rides in the next K loop
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pacc[j] = acc[j];
+        if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) pres[j][m][u] = rres[j][m][u];
+        }
+        prsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(outp + pix0 * a.out_pitch), 0, 0x80000000, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) pov[j][m] = ovo[j][m];
+    }
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) epi_block(blk >> 1, blk & 1);  // the last tile's epilogue
+}
+
 constexpr int kMaxDev = 16;
 template <int T2, int STEM = 0>
 int launch_dt(const ConvArgs& a, const StemArgs& sa, hipStream_t st) {
@@ -741,6 +966,51 @@ int vgh_launch_conv_ds(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(ds_conv_kernel, dim3(gpx * 8), dim3(256), DR_LDS, st, a, nsx, per, (int)total, chunk, dv, nh);
     VGH_HIP(hipGetLastError());
     return VGH_OK;
+}
+
+// 3x3 / stride-1 / pad-1 conv with 96 (-> cout_pad a multiple of 96) or 128 (-> a multiple of 128) input channels on a map of whole 8 x 8 tiles ("w" tile)
+int vgh_conv_w_ok(const ConvArgs& a) {
+    const int ncg = a.cin == 96 ? 3 : a.cin == 128 ? 4 : 0;
+    return ncg && a.ksize == 3 && a.stride == 1 && a.pad == 1 && a.in_pitch % 8 == 0 && a.in_coff % 8 == 0 && a.cout_pad % (32 * ncg) == 0 && a.cout_pad <= 1024 && a.cout_store == a.cout_pad &&
+           (a.out_split >= a.cout_pad || a.out_split % 16 == 0) && a.out_coff % 8 == 0 && a.out_coff2 % 8 == 0 && a.out_pitch % 8 == 0 && a.Ho == a.H && a.Wo == a.W && a.H % 8 == 0 && a.W % 8 == 0 &&
+           (int64_t)a.W * a.in_pitch * 2 * 12 < (1ll << 30) && (int64_t)a.Wo * a.out_pitch * 2 * 9 < (1ll << 30) && (!a.res || ((int64_t)a.Wo * a.res_pitch * 2 * 9 < (1ll << 30) && a.res_pitch % 4 == 0 && a.res_coff % 4 == 0)) &&
+           !a.split && !a.shuffle && !a.grp_cout && !a.in_fp8 && !a.out_fp8 && !a.out_f32 && a.act != VGH_ACT_SILU && !a.w2pack;
+}
+
+template <int CIN16, int NCG, int RES>
+static int launch_w(const ConvArgs& a, hipStream_t st) {
+    using G = WGeo<CIN16>;
+    static std::atomic<int> done[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    if (!done[dev].load(std::memory_order_acquire)) {
+        VGH_HIP(hipFuncSetAttribute((const void*)w_conv_kernel<CIN16, NCG, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        done[dev].store(1, std::memory_order_release);
+    }
+    const int nsx = a.Wo / 8, nsy = a.Ho / 8, per = nsx * nsy, nh = a.cout_pad / (32 * NCG);
+    const int64_t total = (int64_t)a.B * per * nh;
+    VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
+    int chunk = (int)((total + 7) / 8);
+    chunk = (chunk + nh - 1) / nh * nh;  // chunks of whole pixel tiles: item % nh = cout part, fixed per workgroup
+    int gpx = 32 / (a.grid_share > 1 ? a.grid_share : 1);
+    if (gpx < 8) gpx = 8;
+    const int cap = vgh_conv_max_blocks_per_xcd();
+    if (cap > 0 && gpx > cap) gpx = cap;
+    if (gpx > chunk) gpx = chunk;
+    gpx = gpx / nh * nh;
+    if (gpx < nh) gpx = nh;
+    DtDiv dv;
+    vgh_fastdiv_magic((unsigned)per, &dv.m_per, &dv.s_per);
+    vgh_fastdiv_magic((unsigned)nsx, &dv.m_nsx, &dv.s_nsx);
+    hipLaunchKernelGGL((w_conv_kernel<CIN16, NCG, RES>), dim3(gpx * 8), dim3(64 * NCG), G::LDS, st, a, nsx, per, (int)total, chunk, dv, nh);
+    VGH_HIP(hipGetLastError());
+    return VGH_OK;
+}
+
+int vgh_launch_conv_w(const ConvArgs& a, hipStream_t st) {
+    VGH_REQUIRE(vgh_conv_w_ok(a), "conv: not a 96 / 128-channel 3x3 stride-1 conv on whole 8 x 8 tiles (the w tile)");
+    if (a.cin == 96) return a.res ? launch_w<6, 3, 1>(a, st) : launch_w<6, 3, 0>(a, st);
+    return a.res ? launch_w<8, 4, 1>(a, st) : launch_w<8, 4, 0>(a, st);
 }
 
 // `a` prepared, with its b2b fields set and checked by vgh_launch_conv_b2b

@@ -146,6 +146,9 @@ int vgh_launch_conv_ds_b2b(const ConvArgs& a, hipStream_t stream);
 // ("r" tile) a plain 3x3 / stride-2 conv with 96 input channels in the same execution structure; `a` prepared
 int vgh_conv_ds_ok(const ConvArgs& a);
 int vgh_launch_conv_ds(const ConvArgs& a, hipStream_t stream);
+// ("w" tile) 3x3 / stride-1 convs with 96 / 128 input channels, weights resident in registers; `a` prepared
+int vgh_conv_w_ok(const ConvArgs& a);
+int vgh_launch_conv_w(const ConvArgs& a, hipStream_t stream);
 // ("u" tile) the same with the stem conv in the launch: u8 NHWC images in, the stem tensor never exists; `a` = the pair (b2b fields set, not yet prepared)
 int vgh_launch_stem_ds_b2b(const ConvArgs& a, const void* image_u8, int Hi, int Wi, const float* wstem, const float* bstem, hipStream_t stream);
 int vgh_launch_conv_split(const ConvArgs& a, int force_cfg, hipStream_t stream);  // conv_split.hip: a.split = VGH_FMT_BF16X2 / VGH_FMT_F16X2

@@ -400,6 +400,8 @@ def test_conv_all_configs_vs_torch(gpu_lib, case):
                 continue
             if cfg >= 0 and gpu_lib.vgh_conv_cfg_name(cfg).decode()[0] == "r" and not (Cin == 96 and H % 16 == 0 and W % 16 == 0):
                 continue  # (the r tile's conditions on the input: vgh_conv_cfg_ok sees the output side only)
+            if cfg >= 0 and gpu_lib.vgh_conv_cfg_name(cfg).decode()[0] == "w" and not (Cin == gpu_lib.vgh_conv_cfg_cout_tile(cfg) and H % 8 == 0 and W % 8 == 0):
+                continue  # (the w tiles: cin = the tile's 96 / 128, whole 8 x 8 tiles)
             out, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, k, stride, cfg=cfg, out_f32=out_f32, out_coff=oc0)
             _assert_close(out[..., o0 : o0 + st], ref[..., :st], out_f32, f"{case} cfg={cfg} out_coff={oc0}")
             assert float((out[..., :o0] + 768.0).abs().max()) == 0.0, "wrote outside its channel range"
@@ -426,6 +428,27 @@ def test_conv_r_tile_equals_the_implicit_gemm_tiles(gpu_lib, B, H, W, Cout, spli
         assert torch.equal(out_r, out_i), (in_coff, float((out_r.float() - out_i.float()).abs().max()))
         if split is None:
             _assert_close(out_r[..., o0 : o0 + st], ref[..., :st], False, f"r tile {B}x{H}x{W} -> {Cout}")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res,split", [(5, 24, 32, 96, 96, False, None), (3, 16, 24, 128, 128, False, None), (2, 24, 16, 128, 256, False, (128, 136, 0)),
+                                                       (7, 16, 16, 96, 96, True, None), (3, 24, 24, 128, 128, True, None), (40, 8, 16, 128, 128, True, None), (2, 16, 16, 96, 192, False, None)])
+def test_conv_w_tiles_equal_the_implicit_gemm_tiles(gpu_lib, B, H, W, Cin, Cout, res, split):
+    """The w tiles (r06, csrc/ds_b2b.hip: 3x3 / stride-1 convs with 96 / 128 input channels, the wave's 32-cout slice of the weights resident in registers, no barrier
+    inside a tile): against the torch reference, and bit for bit against an implicit-GEMM tile -- plain, with a residual (+ alpha * residual in fp32 before the one
+    rounding), several cout parts, an output in two channel segments, an input view inside a wider pixel; many tiles per workgroup, image edges on all sides."""
+    g = torch.Generator().manual_seed(B * 1000 + Cout + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).float()
+    Wt = torch.randn(Cout, 3, 3, Cin, generator=g) * (1.5 / np.sqrt(9 * Cin)) * (1.0 + 0.5 * torch.arange(Cout).float()[:, None, None, None] / Cout)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).float() if res else None
+    names = [gpu_lib.vgh_conv_cfg_name(i).decode() for i in range(gpu_lib.vgh_conv_num_cfgs())]
+    wt, ig = names.index("w8x8x96_n3" if Cin == 96 else "w8x8x128_n4"), names.index("128x32_w32x32_k1")
+    for in_coff, in_pitch in ((0, None), (32, Cin + 64)):
+        out_w, ref, st, o0 = _run_conv(gpu_lib, x, Wt, b, 3, 1, cfg=wt, split=split, in_coff=in_coff, in_pitch=in_pitch, res=r, alpha=0.75)
+        out_i, _, _, _ = _run_conv(gpu_lib, x, Wt, b, 3, 1, cfg=ig, split=split, in_coff=in_coff, in_pitch=in_pitch, res=r, alpha=0.75)
+        if split is None:
+            _assert_close(out_w[..., o0 : o0 + st], ref[..., :st], False, f"w tile {B}x{H}x{W} {Cin} -> {Cout} res={res}")
+        assert torch.equal(out_w, out_i), (in_coff, res, float((out_w.float() - out_i.float()).abs().max()), float((out_w != out_i).float().mean()))
 
 
 @pytest.mark.parametrize("cin,res", [(64, False), (64, True), (32, True), (96, False)])
