@@ -701,7 +701,7 @@ def build_program(variant: str, sd: Dict[str, np.ndarray], image_size: int = 640
 
 # substrings of the HIP kernel names that run the op program (stem / conv / pool ops): what the PMC tooling (bench.py live_traffic, tools/pmc_*.py)
 # sums over.  Every op is ONE launch per lane, so a forward shows `ops x lanes` such dispatches -- the tools check that count.
-NET_KERNEL_MARKERS = ("conv_igemm", "pp_kernel", "patch_kernel", "patch3_kernel", "conv1x1_stream", "conv_f32", "stem_kernel", "stem_mfma", "stem_f32", "stem_ds", "spp_pool")
+NET_KERNEL_MARKERS = ("conv_igemm", "pp_kernel", "patch_kernel", "patch3_kernel", "conv1x1_stream", "conv_f32", "stem_kernel", "stem_mfma", "stem_f32", "stem_ds", "spp_pool", "ds_b2b_kernel", "ds_conv_kernel", "w_conv_kernel")
 
 
 def is_net_kernel(kernel_name: str) -> bool:

@@ -409,13 +409,13 @@ def test_tuning_lookup_precedence_and_kernel_name_list():
     split = {lib.vgh_conv_split_cfg_name(i).decode() for i in range(lib.vgh_conv_split_num_cfgs())}
     for key, name in table.items():
         assert name in (split if ":" in key else bf16), (key, name)
-    assert {n[0] for n in bf16} >= set("pqtghs") and "d" not in {n[0] for n in bf16} and any(n.startswith("t") for n in table.values())  # halo-patch v2 / v3, streaming 1x1, ping-pong g / h / s; the stride-2 "d" tiles: experiments build only (r06)
+    assert {n[0] for n in bf16} >= set("pqtghsrw") and "d" not in {n[0] for n in bf16} and any(n.startswith("t") for n in table.values())  # halo-patch v2 / v3, streaming 1x1, ping-pong g / h / s, register-resident r / w (csrc/ds_b2b.hip); the stride-2 "d" tiles: experiments build only (r06)
     # the parity mode's pack carries the tile names of ITS table
     P3 = arch.build_program("vgg_heads_l", arch.random_state_dict("vgg_heads_l", 1), 640, "fp16x3")
     n3 = pack.tile_names_for(P3, 32, 2)
     assert len(n3) > 40 and set(n3.values()) <= split
     for k in ("conv_igemm_kernel<256, 128, 64, 64, 1, 1, 3, 0>", "conv3x3_patch_kernel<16, 16, 64, 4, 1, 0, 0>", "conv3x3_patch3_kernel<16, 16, 96, 4, 1>", "conv1x1_stream_kernel<128, 96, 32, 96, 1, 3>",
-              "stem_kernel<1, 1, 0>", "stem_ds_kernel<0>", "spp_pool_kernel", "spp_pool_split_kernel<3>", "conv_f32_kernel", "stem_f32_kernel", "spp_pool_f32_kernel"):
+              "stem_kernel<1, 1, 0>", "stem_ds_kernel<0>", "ds_b2b_kernel<6, 0>", "ds_conv_kernel", "w_conv_kernel<8, 4, 1>", "spp_pool_kernel", "spp_pool_split_kernel<3>", "conv_f32_kernel", "stem_f32_kernel", "spp_pool_f32_kernel"):
         assert arch.is_net_kernel("void (anonymous namespace)::" + k + "(ConvArgs, int)"), k
     assert not arch.is_net_kernel("void (anonymous namespace)::flame_mfma_lds_kernel<2, 64>(VertArgs)") and not arch.is_net_kernel("__amd_rocclr_fillBufferAligned")
 

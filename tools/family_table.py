@@ -11,6 +11,9 @@ import re
 import sys
 
 FAMILIES = [
+    (r"ds_b2b_kernel", "t  stage-1 downsample + conv1|conv2, persistent, weights in registers (r06)"),
+    (r"ds_conv_kernel", "r  3x3 stride-2 from 96 channels, persistent, weights in registers (r06)"),
+    (r"w_conv_kernel", "w  3x3 stride-1 from 96 / 128 channels, weights in registers (r06)"),
     (r"conv3x3_pp_kernel<(\d), 1, 0, 0, 0, 0, 1>", "s  ping-pong 3x3, two 4x8 sub-patches per wave (r06)"),
     (r"conv_igemm_kernel<[^>]*, [468], 1>$", "b2b  implicit GEMM + the 1x1 conv behind it in one launch (r06)"),
     (r"conv3x3_pp_kernel<(\d), 1", "g  ping-pong 3x3 (two barriers per tap)"),
