@@ -123,7 +123,10 @@ int vgh_net_set_split(vgh_net* net, int nsplit);
  * and the CSP layer's merged conv1|conv2 -- runs with that op as ONE launch: the first conv's accumulators become, in registers, the B operands of the second GEMM, and the
  * tensor between them is never written (csrc/conv_kernels.inc, T2 > 0).  vgh_net_create finds the pairs; they run fused by default.  enable = 0: the two launches (the same
  * output bits when the second conv runs on an implicit-GEMM tile -- the fused kernel's arithmetic; a tuning table that gives it a streaming "t" tile, whose accumulators
- * start at the bias, differs in the last fp32 rounding before the bf16 store; the intermediate tensor then exists in the arena, as the per-op parity tests need).  vgh_net_b2b_pairs: how many pairs the program has. */
+ * start at the bias, differs in the last fp32 rounding before the bf16 store; the intermediate tensor then exists in the arena, as the per-op parity tests need).  vgh_net_b2b_pairs: how many pairs the program has.
+ * Late r06 (additive): with enable = 1 the stage-1 pair (3x3 / stride 2, 48 -> 96 channels + its 1x1) runs on a persistent tile of its own (csrc/ds_b2b.hip, "t" tile: input
+ * patch fetched once into parity planes, both convs' weights resident in registers; the same output bits); enable = 2: fused, but every pair on the implicit-GEMM tile
+ * (A/B, tests); enable = 4 is honoured by the -DVGH_EXPERIMENTS build only (the stem conv inside that launch: bit-identical, measured slower) and means 1 otherwise. */
 int vgh_net_set_b2b(vgh_net* net, int enable);
 int vgh_net_b2b_pairs(vgh_net* net);
 int vgh_net_max_batch(vgh_net* net);  /* images the activation arena was planned for */

@@ -54,9 +54,10 @@ def main():
                 better.append(i)
         print(f"{variant} b{B}@{S} single stream: sum of all ops {sum(r['ms'] for r in base):.3f} -> {sum(r['ms'] for r in new):.3f} ms; {len(better)} of {len(elig)} eligible ops faster", flush=True)
         eng.set_split(2)
-        res = {"table": [], "w_all": [], "w_better": []}
+        res80 = [i for i in elig if ops[i].get("res_buf", -1) >= 0 and ops[i]["cin"] == 128 and new[i]["ms"] < 0.92 * base[i]["ms"]]
+        res = {"table": [], "w_all": [], "w_better": [], "w_res_big_gain": []}
         for r in range(args.rounds):
-            for mode, idx in (("table", []), ("w_all", elig), ("w_better", better)):
+            for mode, idx in (("table", []), ("w_all", elig), ("w_better", better), ("w_res_big_gain", res80)):
                 apply(idx)
                 for _ in range(8):
                     eng.forward_net(x)
