@@ -74,6 +74,10 @@ struct StemArgs {
 #define DT_ABLATE(a, bit) 0
 #endif
 
+#ifndef DT_STORE_AUX
+#define DT_STORE_AUX 0  // cache-policy bits of the t tile's output stores (A/B knob: 2 = nt, 16 = sc1)
+#endif
+
 struct DtDiv {
     unsigned m_per, s_per, m_nsx, s_nsx;
 };
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
                 // (the channel offset rides in the VECTOR offset: with a REGISTER scalar offset hipcc assumes that a 16-byte buffer store has no data hazard and may
                 // schedule a VALU write of the data registers right behind it -- measured on gfx950: v_pk_add_f32 into v[0:1] one instruction after the store, and lanes
                 // 12-15 / 28-31 stored the NEW value; with a constant scalar offset the compiler inserts the wait state itself)
-                if (!DT_ABLATE(a, 8)) __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, povo[j] + ochan2[tt][m], 0, 0);
+                if (!DT_ABLATE(a, 8)) __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, povo[j] + ochan2[tt][m], 0, DT_STORE_AUX);
             }
         }
     };
