@@ -74,6 +74,9 @@ struct StemArgs {
 #define DT_ABLATE(a, bit) 0
 #endif
 
+#ifndef DT_FULL_WIDTH
+#define DT_FULL_WIDTH 0  // 1: every lane's launch takes all CUs (A/B knob) instead of its share
+#endif
 #ifndef DT_STORE_AUX
 #define DT_STORE_AUX 0  // cache-policy bits of the t tile's output stores (A/B knob: 2 = nt, 16 = sc1)
 #endif
@@ -912,7 +915,7 @@ int launch_dt(const ConvArgs& a, const StemArgs& sa, hipStream_t st) {
     const int64_t total = (int64_t)a.B * per;
     VGH_REQUIRE(total < (1ll << 30), "conv b2b: too many tiles");
     const int chunk = (int)((total + 7) / 8);
-    int gpx = 32 / (a.grid_share > 1 ? a.grid_share : 1);  // one workgroup per CU; the executor's lane streams take their share of the CUs each
+    int gpx = DT_FULL_WIDTH ? 32 : 32 / (a.grid_share > 1 ? a.grid_share : 1);  // one workgroup per CU; the executor's lane streams take their share of the CUs each
     if (gpx < 8) gpx = 8;
     const int cap = vgh_conv_max_blocks_per_xcd();
     if (cap > 0 && gpx > cap) gpx = cap;
@@ -957,7 +960,7 @@ int vgh_launch_conv_ds(const ConvArgs& a, hipStream_t st) {
     VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
     int chunk = (int)((total + 7) / 8);
     if (nh > 1) chunk += chunk & 1;  // even chunks: item parity = cout half, fixed per workgroup
-    int gpx = 32 / (a.grid_share > 1 ? a.grid_share : 1);
+    int gpx = DT_FULL_WIDTH ? 32 : 32 / (a.grid_share > 1 ? a.grid_share : 1);
     if (gpx < 8) gpx = 8;
     const int cap = vgh_conv_max_blocks_per_xcd();
     if (cap > 0 && gpx > cap) gpx = cap;
@@ -996,7 +999,7 @@ static int launch_w(const ConvArgs& a, hipStream_t st) {
     VGH_REQUIRE(total < (1ll << 30), "conv: too many tiles");
     int chunk = (int)((total + 7) / 8);
     chunk = (chunk + nh - 1) / nh * nh;  // chunks of whole pixel tiles: item % nh = cout part, fixed per workgroup
-    int gpx = 32 / (a.grid_share > 1 ? a.grid_share : 1);
+    int gpx = DT_FULL_WIDTH ? 32 : 32 / (a.grid_share > 1 ? a.grid_share : 1);
     if (gpx < 8) gpx = 8;
     const int cap = vgh_conv_max_blocks_per_xcd();
     if (cap > 0 && gpx > cap) gpx = cap;
