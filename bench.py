@@ -703,7 +703,7 @@ def main():
             eng.join()
             eng.set_split(1)  # per-op events make sense on one stream only: the table is the single-stream view of every op
             json.dump(eng.profile_ops(images, repeats=7), open(per_layer_path, "w"), indent=0)  # per-op median of 7 profiled forwards
-        alg = arch.program_algorithmic_bytes(eng.program, B)
+        alg = arch.program_algorithmic_bytes(eng.program, B, fused_stem=eng.stem_fused and images.dtype == torch.uint8)  # (the stem tensor does not exist when its conv runs inside the stage-1 pair's launch)
         fp8_flops = 2.0 * sum(op["macs"] for op in eng.program.ops if arch.op_touches_fp8(eng.program, op) and eng.program.bufs[op["in_buf"]]["is_f32"] in arch.Q8_FMTS)
         out = dict(variant=variant, B=B, steps=steps, warmup=warmup, dt=dt, net_ms=net_ms, fp8_flops_per_image=fp8_flops, fp8_links=sum(bf["is_f32"] in arch.Q8_FMTS for bf in eng.program.bufs), heads_per_img=heads / max(nfw * B, 1), overlap=overlap, inner=inner,
                    value=B * world * nfw / dt, flops_per_image=eng.flops_per_image, conv_tflops=eng.flops_per_image * B / (net_ms * 1e-3) / 1e12,

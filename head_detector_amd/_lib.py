@@ -107,6 +107,7 @@ SYMBOLS = {
     "vgh_net_buffer_bytes": (_I64, [_P, _I]),
     "vgh_net_set_cfg": (_I, [_P, _I, _I]),
     "vgh_net_set_b2b": (_I, [_P, _I]),
+    "vgh_net_stem_fused": (_I, [_P]),
     "vgh_net_b2b_pairs": (_I, [_P]),
     "vgh_net_set_split": (_I, [_P, _I]),
     "vgh_net_max_batch": (_I, [_P]),

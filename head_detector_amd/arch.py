@@ -813,7 +813,7 @@ def b2b_pairs(P: "Program") -> List[int]:
 
 
 def program_algorithmic_bytes(P: "Program", batch: int, fused_stem: Optional[bool] = None, b2b: bool = True) -> Dict[str, float]:
-    """fused_stem (the executor's opt-in vgh_net_set_fuse_stem): the stem tensor is neither written nor read.  b2b (r06, the executor's default): the tensor between
+    """fused_stem (engine.stem_fused: the default for u8 images since late r06 -- the stem conv runs inside the stage-1 pair's launch): the stem tensor is neither written nor read.  b2b (r06, the executor's default): the tensor between
     the two convs of a back-to-back pair is neither written nor read -- the pair is ONE op of the engine's layer-by-layer accounting."""
     fused_stem = bool(fused_stem)
     tot = dict(read=0.0, write=0.0)

@@ -37,17 +37,20 @@ constexpr int DT_PIECES = 34;              // LDS-DMA pieces of a patch (the nin
 constexpr unsigned DT_OOB = 0xC0000000u;   // out of the descriptors' 2-GiB range, and not wrapped past 2^32 by the scalar offsets added to it
 static_assert(DT_LDS <= 160 * 1024, "one workgroup per CU");
 // STEM = 1 ("u" tile): the stem conv (YoloNASStem, QARepVGG 3 -> 48, 3x3 / stride 2, arch yaml :8-10) in the same launch -- the stem tensor never exists.  A tile's 17 x 17
-// stem pixels are computed from the 35 x 35 x 3 image patch (fp32 in LDS, image / 255 by the correctly rounded division of detector.py:51 through a 256-entry table)
-// straight into the parity planes the LDS-DMA loader fills otherwise; the arithmetic is stem_kernel's fp32 FMA chain in ascending k on the FP32 matrix cores
-// (v_mfma_f32_32x32x2_f32 = two exact fmaf steps per instruction, k ordered), bias, ReLU, ONE rounding to bf16: bit-identical to the stem launch it replaces.
-// Two patch buffers (tile k + 1's stem pixels are computed while tile k's 3x3 conv runs), two fp32 image patches, the table.
-constexpr int ST_IW = 35, ST_IP = 36, ST_IC = ST_IW * ST_IP;  // image patch: 35 x 35 pixels, row pitch 36 floats, channel pitch
-constexpr int ST_IMGB = 3 * ST_IC * 4;                         // bytes of one fp32 image patch [3][35][36]
+// stem pixels are computed from the 35 x 35 x 3 image patch straight into the parity planes the LDS-DMA loader fills otherwise.
+// v2 (bf16 x 3): the first version ran stem_kernel's exact fp32 chain on v_mfma_f32_32x32x2_f32 -- bit-identical, and 846 us against 654 for the two launches: 280 fp32 MFMAs
+// of 64 cycles per tile.  A u8 pixel is an exact bf16, so the stem is ALSO an exact-product bf16 GEMM once the weights are split: w / 255 = hi + mid + lo, three bf16 values
+// carrying 24 significant bits.  Per 16 pixels: 3 cout tiles x 3 splits = 9 v_mfma_f32_16x16x32_bf16 of 16 cycles (K = 27 in ONE instruction, no cout padding), fp32 accumulate,
+// lo -> mid -> hi.  Every product is exact; what differs from the reference's fmaf chain is the order of the fp32 additions and where / 255 is rounded (the weights instead
+// of the pixels): ~1e-7 relative before the ONE rounding to bf16, i.e. a flipped bf16 ulp in ~1e-4 of the stem values (tests/test_gpu_parity.py::test_stem_in_the_pair_launch...).
+// K slots are assigned so that a lane's 8 B values are 16 contiguous bytes of the patch (a kernel row's first 8 of 9 (kx, ci) values); the three ninth values ride in the
+// fourth k group.  The image patch sits in LDS as bf16 NHWC rows (35 x 105 values at a 216-byte pitch), converted by the loader wave (v_cvt_f32_ubyte, upper half stored).
+constexpr int ST_IW = 35, ST_RP = 216;      // image patch: 35 x 35 pixels x 3 bf16 channels, row pitch in bytes
+constexpr int ST_IMGB = 7680;                // bytes of one image patch (35 x 216 = 7 560)
 constexpr int ST_EX = 2 * DT_BUF;
 constexpr int ST_IMG = ST_EX + 2 * DT_EXB;
-constexpr int ST_LUT = ST_IMG + 2 * ST_IMGB;
-constexpr int ST_LDS = ST_LUT + 1024;
-static_assert(ST_LDS <= 160 * 1024 && ST_IMGB % 16 == 0, "one workgroup per CU");
+constexpr int ST_LDS = ST_IMG + 2 * ST_IMGB + 256;
+static_assert(ST_LDS <= 160 * 1024 && ST_IW * ST_RP <= ST_IMGB, "one workgroup per CU");
 struct StemArgs {
     const uint8_t* image;  // u8 NHWC
     const float* w;        // [27][48], k = (ky * 3 + kx) * 3 + ci
@@ -151,95 +154,95 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
     (void)tno;
 
 
-    // ---- the stem's share of every wave (STEM = 1): pixel group g = stem pixels 32 g .. + 31 of the tile's 17 x 17 (row major), cout halves by mask (1: couts 0-31, 2: 32-47) ----
-    float SA[14][2];  // A operands: W[2 kp + h][32 r + r32] (zero beyond k = 26 / cout 47)
-    f32x4_t sbq[6];   // bias of this lane's output channels 8 q + 4 h .. + 3
-    unsigned soff[14];  // float offset of tap k = 2 kp + h inside the image patch: channel k % 3, row k / 9, column (k / 3) % 3
+    // ---- the stem's share of every wave (STEM = 1): unit g = stem pixels 16 g .. + 15 of the tile's 17 x 17 (row major), all 48 couts; lane = (pixel l % 16, k group l / 16) ----
+    bf16x8_t SAw[3][3];  // A operands [cout tile][split hi / mid / lo]: lane (cout 16 t + l % 16, k group kg): k slots 8 kg .. + 7 = kernel row kg, values (kx, ci) 0 .. 7;
+                         // kg = 3: the ninth value of rows 0, 1, 2, then zeros
+    f32x4_t sbq[3];      // bias of this lane's output channels 16 t + 4 kg .. + 3
     if constexpr (STEM) {
-        const int r32 = lane & 31, h = lane >> 5;
+        const int c16 = lane & 15, kg = lane >> 4;
 #pragma unroll
-        for (int kp = 0; kp < 14; ++kp) {
-            const int k = 2 * kp + h;
+        for (int t = 0; t < 3; ++t) {
+            float wv[8];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) SA[kp][r] = (k < 27 && 32 * r + r32 < 48) ? sa.w[k * 48 + 32 * r + r32] : 0.0f;
-            const int kk = k < 27 ? k : 26;  // (k = 27 is the zero pad of K: any finite pixel does)
-            soff[kp] = (unsigned)((kk % 3) * ST_IC + (kk / 9) * ST_IP + (kk / 3) % 3);
+            for (int e = 0; e < 8; ++e) {
+                const int ky = kg < 3 ? kg : e, j = kg < 3 ? e : 8;
+                const bool live = kg < 3 || e < 3;
+                wv[e] = live ? sa.w[((live ? ky : 0) * 9 + j) * 48 + 16 * t + c16] / 255.0f : 0.0f;
+            }
+            bf16x8_t h, m, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h[e] = (__bf16)wv[e];
+                const float r1 = wv[e] - (float)h[e];
+                m[e] = (__bf16)r1;
+                l[e] = (__bf16)(r1 - (float)m[e]);
+            }
+            SAw[t][0] = h;
+            SAw[t][1] = m;
+            SAw[t][2] = l;
+            sbq[t] = *(const f32x4_t*)(sa.b + 16 * t + 4 * kg);
         }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) sbq[q] = *(const f32x4_t*)(sa.b + 8 * q + 4 * h);
     }
-    auto stem_unit = [&](int tile, int ibuf, int xbuf, int g, int rmask) __attribute__((always_inline)) {
-        const int r32 = lane & 31, h = lane >> 5;
+    auto stem_unit = [&](int tile, int ibuf, int xbuf, int g) __attribute__((always_inline)) {
+        const int c16 = lane & 15, kg = lane >> 4;
         const int b = dt_div(tile, dv.m_per, dv.s_per);
         const int rem = tile - b * per;
         const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
-        const int p = g * 32 + r32;
+        const int p = g * 16 + c16;
         const int sp = p < 289 ? p : 288;
         const int sy = (sp * 241) >> 12, sx = sp - sy * 17;  // sp / 17 for sp < 289
-        const int gy = 16 * tyi - 1 + sy, gx = 16 * txi - 1 + sx;  // position in the stem map; outside it: the 3x3 conv's zero padding (a multiply: a select would let
-        const float keep = ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? 1.0f : 0.0f;  // hipcc sink the chain into a branch)
-        const float* const imgf = (const float*)(smem + ST_IMG + ibuf * ST_IMGB) + (2 * sy) * ST_IP + 2 * sx;
-        f32x16_t acc0, acc1;
+        const int gy = 16 * tyi - 1 + sy, gx = 16 * txi - 1 + sx;  // position in the stem map; outside it: the 3x3 conv's zero padding (a multiply, not a select)
+        const float keep = ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? 1.0f : 0.0f;
+        const char* const img = smem + ST_IMG + ibuf * ST_IMGB + (2 * sy) * ST_RP + 12 * sx;  // patch pixel (2 sy, 2 sx), channel 0
+        // four dwords per lane: k groups 0 - 2 read the 16 contiguous bytes of their kernel row; group 3 the ninth value of each row (the low half of a dword)
+        unsigned d[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
-        float bx[14];
+        for (int i = 0; i < 4; ++i) {
+            const int off = kg < 3 ? kg * ST_RP + 4 * i : (i < 3 ? i : 0) * ST_RP + 16;
+            d[i] = *(const unsigned*)(img + off);
+        }
+        const u32x4_t bv = kg < 3 ? u32x4_t{d[0], d[1], d[2], d[3]} : u32x4_t{(d[0] & 0xffffu) | (d[1] << 16), d[2] & 0xffffu, 0u, 0u};
+        const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, bv);
+        f32x4_t acc[3];
 #pragma unroll
-        for (int kp = 0; kp < 14; ++kp) bx[kp] = imgf[soff[kp]];
+        for (int t = 0; t < 3; ++t) {
+            acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int kp = 0; kp < 14; ++kp) {
-            if (rmask & 1) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(SA[kp][0], bx[kp], acc0, 0, 0, 0);
-            if (rmask & 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(SA[kp][1], bx[kp], acc1, 0, 0, 0);
+            for (int sp3 = 2; sp3 >= 0; --sp3) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SAw[t][sp3], bfr, acc[t], 0, 0, 0);
         }
         if (p < 289) {
             const int row = sy >> 1, col = sx >> 1;
             char* const xp = smem + xbuf * DT_BUF + ((sy & 1) * 2 + (sx & 1)) * DT_PLANE + row * DT_ROW + (col * 6 + (row & 1)) * 16;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                if (!((q < 4 ? 1 : 2) & rmask)) continue;
+            for (int t = 0; t < 3; ++t) {
                 bf16x4_t o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(fmaxf((q < 4 ? acc0[q * 4 + e] : acc1[(q - 4) * 4 + e]) + sbq[q][e], 0.0f) * keep);
-                *(bf16x4_t*)(xp + (8 * q + 4 * h) * 2) = o;
-#ifdef VGH_DT_DEBUG_STEM  // diagnostic build: the tile's own 16 x 16 stem pixels also go to the stem tensor (a.in)
-                if (keep != 0.0f) *(bf16x4_t*)((uint16_t*)a.in + (((size_t)b * a.H + gy) * a.W + gx) * a.in_pitch + a.in_coff + 8 * q + 4 * h) = o;
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(fmaxf(acc[t][e] + sbq[t][e], 0.0f) * keep);
+                *(bf16x4_t*)(xp + (16 * t + 4 * kg) * 2) = o;
+#ifdef VGH_DT_DEBUG_STEM  // diagnostic build: every in-map stem pixel also goes to the stem tensor (a.in)
+                if (keep != 0.0f) *(bf16x4_t*)((uint16_t*)a.in + (((size_t)b * a.H + gy) * a.W + gx) * a.in_pitch + a.in_coff + 16 * t + 4 * kg) = o;
 #endif
             }
         }
     };
-    // the ten pixel groups of a tile over the four waves: the loader wave has its image patch to convert, wave 2 one group less of the second GEMM's epilogue
+    // the 19 units of a tile over the four waves (the loader wave has the image patch to convert)
     auto stem_share = [&](int tile, int ibuf, int xbuf) __attribute__((always_inline)) {
-        if (w == 0) {
-            stem_unit(tile, ibuf, xbuf, 0, 3);
-            stem_unit(tile, ibuf, xbuf, 1, 3);
-            stem_unit(tile, ibuf, xbuf, 6, 1);
-        } else if (w == 1) {
-            stem_unit(tile, ibuf, xbuf, 2, 3);
-            stem_unit(tile, ibuf, xbuf, 3, 3);
-            stem_unit(tile, ibuf, xbuf, 6, 2);
-        } else if (w == 2) {
-            stem_unit(tile, ibuf, xbuf, 4, 3);
-            stem_unit(tile, ibuf, xbuf, 5, 3);
-        } else {
-            stem_unit(tile, ibuf, xbuf, 7, 3);
-            stem_unit(tile, ibuf, xbuf, 8, 3);
-            stem_unit(tile, ibuf, xbuf, 9, 3);
-        }
+        const int g0 = w * 5, n = w == 3 ? 4 : 5;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (i < n) stem_unit(tile, ibuf, xbuf, g0 + i);
     };
 
     if (w == 3 && STEM) {
         // =========================== loader wave, stem in the launch: image patches ===========================
-        float* const lut = (float*)(smem + ST_LUT);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) lut[lane * 4 + t] = (float)(lane * 4 + t) / 255.0f;  // the true division of detector.py:51
         // a patch row = 105 bytes from image byte 3 ix0 (= 3 mod 4 in every tile: rows are multiples of 96 bytes): dword d of the row covers row bytes 4 d - 3 .. 4 d;
         // lane = (row parity, dword): 18 row pairs
         const int d = lane & 31, rpar = lane >> 5;
-        int pos[4];  // float offset (channel, column) of byte t of this lane's dword inside a patch row, or -1
+        int pos[4];  // byte offset of byte t of this lane's dword inside a patch row (bf16 values), or -1
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int j = 4 * d - 3 + t;
-            const int c = j / 3;
-            pos[t] = (d <= 26 && j >= 0 && j <= 104) ? (j - 3 * c) * ST_IC + c : -1;
+            pos[t] = (d <= 26 && j >= 0 && j <= 104) ? 2 * j : -1;
         }
         auto load_img = [&](int tile, unsigned (&q)[18]) __attribute__((always_inline)) {
             const int b = dt_div(tile, dv.m_per, dv.s_per);
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
             }
         };
         auto store_img = [&](int ibuf, const unsigned (&q)[18]) __attribute__((always_inline)) {
-            float* const img = (float*)(smem + ST_IMG + ibuf * ST_IMGB);
+            char* const img = smem + ST_IMG + ibuf * ST_IMGB;
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
                 const int r = 2 * i + rpar;
                 if (r < ST_IW) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        if (pos[t] >= 0) img[pos[t] + r * ST_IP] = lut[(q[i] >> (8 * t)) & 255u];
+                        if (pos[t] >= 0) *(uint16_t*)(img + r * ST_RP + pos[t]) = (uint16_t)(__builtin_bit_cast(unsigned, (float)((q[i] >> (8 * t)) & 255u)) >> 16);  // an integer <= 255 is an exact bf16
                 }
             }
         };
@@ -1029,7 +1032,6 @@ int vgh_launch_conv_ds_b2b(const ConvArgs& a, hipStream_t stream) {
 
 // the same pair with the stem conv in front of it in the launch ("u" tile): `a` describes the pair as above (its input tensor -- the stem's output -- is neither written nor
 // read: a.in may be null), the stem comes as its fp32 weights [27][48] / bias [48] and the u8 NHWC image batch (Hi x Wi = 2 a.H x 2 a.W)
-#ifdef VGH_EXPERIMENTS  // (measured slower than the two launches it replaces: see the STEM comment above)
 int vgh_launch_stem_ds_b2b(const ConvArgs& a0, const void* image_u8, int Hi, int Wi, const float* wstem, const float* bstem, hipStream_t stream) {
     ConvArgs a = a0;
     if (int rc = vgh_conv_prepare(a)) return rc;
@@ -1040,4 +1042,3 @@ int vgh_launch_stem_ds_b2b(const ConvArgs& a0, const void* image_u8, int Hi, int
     const StemArgs sa{(const uint8_t*)image_u8, wstem, bstem, Hi, Wi};
     return a.cout2_pad == 192 ? launch_dt<6, 1>(a, sa, stream) : launch_dt<4, 1>(a, sa, stream);
 }
-#endif

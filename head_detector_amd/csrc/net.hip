@@ -184,13 +184,9 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
     const int op_index = (int)(&op - n->ops.data());
     const bool fused = n->fuse_stem && n->stem_pair >= 0;
     // stem + downsample + conv1|conv2 as one launch (r06, ds_b2b.hip): u8 images, the default b2b mode, the pair on its persistent tile
-    // (measured r06: 846 us against 307 + 347 for the stem launch + the pair's tile -- the exact fp32 stem chain on the matrix cores keeps one wave per SIMD busy for 18 000
-    // cycles per tile: experiments build only, vgh_net_set_b2b(n, 4))
-#ifdef VGH_EXPERIMENTS
-    const bool stem3 = n->fuse_b2b == 4 && !fused && n->stem_pair >= 0 && fmt == VGH_IMG_U8_NHWC && n->stem3_ok == 1 && n->ops[n->stem_pair + 1].b2b == 1;
-#else
-    const bool stem3 = false;
-#endif
+    // (u8 images, default mode: the stem is then a bf16 x 3 split GEMM on the matrix cores -- exact products, another fp32 summation order: a flipped bf16 ulp in ~4e-5 of the
+    // stem values; vgh_net_set_b2b(n, 3) keeps the stem launch and with it the bit-identity of every mode)
+    const bool stem3 = n->fuse_b2b == 1 && !fused && n->stem_pair >= 0 && fmt == VGH_IMG_U8_NHWC && n->stem3_ok == 1 && n->ops[n->stem_pair + 1].b2b == 1;
     switch (d.kind) {
         case VGH_OP_STEM: {
             if (stem3 && op_index == n->stem_pair) {
@@ -200,9 +196,7 @@ static int net_run_op(vgh_net* n, const NetOp& op, const void* image0, int fmt, 
                 if (int rc = net_conv_args(n, nx, B, at, &a2)) return rc;
                 a.grid_share = share;
                 net_b2b_fields(a, a2);
-#ifdef VGH_EXPERIMENTS
                 return vgh_launch_stem_ds_b2b(a, image, n->image_size, n->image_size, op.wf32, op.bias, st);
-#endif
             }
 #ifdef VGH_EXPERIMENTS  // (stem_ds.hip is part of the experiments build only)
             if (fused && op_index == n->stem_pair) {
@@ -766,8 +760,11 @@ int vgh_net_set_pred_guard(vgh_net* n, void* event) {
 // every intermediate tensor of the program exists in the arena (what the per-op parity tests read)
 int vgh_net_set_b2b(vgh_net* n, int enable) {
     VGH_REQUIRE(n, "net_set_b2b: null handle");
-    n->fuse_b2b = (enable == 2 || enable == 4) ? enable : enable ? 1 : 0;  // 2: fused, but every pair on the implicit-GEMM b2b tile (no t tile); 4 (experiments build): the stem conv in the t tile's launch
+    n->fuse_b2b = (enable == 2 || enable == 3) ? enable : enable ? 1 : 0;  // 1: pairs fused, the stem conv inside the stage-1 pair's launch for u8 images; 3: without the stem; 2: every pair on the implicit-GEMM b2b tile
     return VGH_OK;
+}
+int vgh_net_stem_fused(vgh_net* n) {  // 1: forwards of u8 images run the stem conv inside the stage-1 pair's launch (the stem tensor is not written)
+    return (n && n->fuse_b2b == 1 && n->stem_pair >= 0 && n->stem3_ok == 1 && n->ops[n->stem_pair + 1].b2b == 1) ? 1 : 0;
 }
 int vgh_net_b2b_pairs(vgh_net* n) {
     int k = 0;

@@ -271,10 +271,16 @@ class VGHeadsEngine:
     def set_b2b(self, enable=True):
         """vgh_net_set_b2b (r06): a stage's downsample and the conv1|conv2 behind it as ONE back-to-back-GEMM launch (default) or as their two launches -- the same
         output bits; unfused, the tensor between them exists in the arena (per-op inspection).  ``b2b_pairs``: how many such pairs the program has.
-        Default (1): the stage-1 pair runs on its persistent "t" tile (csrc/ds_b2b.hip); ``enable=2``: every pair on the implicit-GEMM b2b tile (A/B and tests: the same
-        bits in every mode); ``enable=4`` (-DVGH_EXPERIMENTS build only): the stem conv inside the t tile's launch for u8 images (bit-identical, measured slower)."""
-        _lib.check(self.lib.vgh_net_set_b2b(self._net, int(enable) if enable in (2, 4) and enable is not True else int(bool(enable))))
+        Default (1): the stage-1 pair runs on its persistent "t" tile (csrc/ds_b2b.hip) and, for u8 images, the STEM conv runs inside that launch as a bf16 x 3 split GEMM
+        (the stem tensor is never written either; exact products, another fp32 summation order: a flipped bf16 ulp in ~4e-5 of the stem values).  ``enable=3``: the t tile
+        fed by the stem launch -- bit-identical to ``enable=2`` (every pair on the implicit-GEMM b2b tile) and, for untuned engines, to ``enable=0``."""
+        _lib.check(self.lib.vgh_net_set_b2b(self._net, int(enable) if enable in (2, 3) and enable is not True else int(bool(enable))))
         self._graph_key = None
+
+    @property
+    def stem_fused(self) -> bool:
+        """u8 forwards run the stem conv inside the stage-1 pair's launch (vgh_net_stem_fused): the stem tensor is neither written nor read."""
+        return bool(self.lib.vgh_net_stem_fused(self._net))
 
     @property
     def b2b_pairs(self) -> int:

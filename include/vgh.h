@@ -125,9 +125,13 @@ int vgh_net_set_split(vgh_net* net, int nsplit);
  * output bits when the second conv runs on an implicit-GEMM tile -- the fused kernel's arithmetic; a tuning table that gives it a streaming "t" tile, whose accumulators
  * start at the bias, differs in the last fp32 rounding before the bf16 store; the intermediate tensor then exists in the arena, as the per-op parity tests need).  vgh_net_b2b_pairs: how many pairs the program has.
  * Late r06 (additive): with enable = 1 the stage-1 pair (3x3 / stride 2, 48 -> 96 channels + its 1x1) runs on a persistent tile of its own (csrc/ds_b2b.hip, "t" tile: input
- * patch fetched once into parity planes, both convs' weights resident in registers; the same output bits); enable = 2: fused, but every pair on the implicit-GEMM tile
- * (A/B, tests); enable = 4 is honoured by the -DVGH_EXPERIMENTS build only (the stem conv inside that launch: bit-identical, measured slower) and means 1 otherwise. */
+ * patch fetched once into parity planes, both convs' weights resident in registers; the same output bits), and for VGH_IMG_U8_NHWC images the STEM conv runs inside that launch
+ * too ("u" tile: a u8 pixel is an exact bf16, the weights / 255 are split into three bf16 values -- exact products, fp32 accumulation in another order than the stem kernel's
+ * fmaf chain: a flipped bf16 ulp in ~4e-5 of the stem values; the stem tensor is not written).  enable = 3: the t tile fed by the stem launch (bit-identical to enable = 2);
+ * enable = 2: fused, but every pair on the implicit-GEMM tile (A/B, tests). */
 int vgh_net_set_b2b(vgh_net* net, int enable);
+/* 1 when forwards of VGH_IMG_U8_NHWC images run the stem conv inside the stage-1 pair's launch (mode 1 and an eligible program): the stem tensor is then not written. */
+int vgh_net_stem_fused(vgh_net* net);
 int vgh_net_b2b_pairs(vgh_net* net);
 int vgh_net_max_batch(vgh_net* net);  /* images the activation arena was planned for */
 int vgh_net_image_size(vgh_net* net);

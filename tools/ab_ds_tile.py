@@ -11,8 +11,8 @@ import torch  # noqa: E402
 from head_detector_amd.engine import VGHeadsEngine  # noqa: E402
 
 
-NAMES = {4: 'u tile (stem + pair; experiments build)', 1: 't tile', 2: 'igemm b2b'}
-MODES = (1, 2) + ((4,) if 'exp' in os.environ.get('VGH_LIB_PATH', '') else ())
+NAMES = {1: 'u tile (stem + pair, default)', 3: 't tile (pair; stem launch)', 2: 'igemm b2b'}
+MODES = (1, 3, 2)
 
 
 def main():

@@ -24,12 +24,19 @@ P = arch.build_program(variant, arch.random_state_dict(variant, 1), 640)
 ops = list(P.ops)
 per = len(disp) // forwards
 pairs = arch.b2b_pairs(P)
-if per == len(ops) - len(pairs) and pairs:  # the back-to-back pairs ran as one launch each (the engine's default): one row per launch, both convs' FLOPs
+stem_in = per == len(ops) - len(pairs) - 1 and pairs and pairs[0] == 1 and ops[0]["kind"] == 0  # u8 images: the stem conv ran inside the stage-1 pair's launch too
+if (per == len(ops) - len(pairs) or stem_in) and pairs:  # the back-to-back pairs ran as one launch each (the engine's default): one row per launch, both convs' FLOPs
     merged = []
     for i, op in enumerate(ops):
-        if i - 1 in pairs:
+        if i - 1 in pairs or (stem_in and i == 0):
             continue
-        merged.append(dict(op, name=op["name"] + " + " + ops[i + 1]["name"].split(".")[-1], macs=op["macs"] + ops[i + 1]["macs"]) if i in pairs else op)
+        if i in pairs:
+            m = dict(op, name=op["name"] + " + " + ops[i + 1]["name"].split(".")[-1], macs=op["macs"] + ops[i + 1]["macs"])
+            if stem_in and i == 1:
+                m = dict(m, name="stem + " + m["name"], macs=m["macs"] + ops[0].get("macs", 0.0))
+            merged.append(m)
+        else:
+            merged.append(op)
     ops = merged
 assert per == len(ops), (per, len(ops))
 print(f"# {variant} batch {batch}, one lane, mean of {forwards} forwards: MFMA-busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) per dispatch", file=out)

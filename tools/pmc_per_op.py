@@ -33,13 +33,20 @@ ops = [op for op in P.ops]
 fr, wr = load("FETCH_SIZE"), load("WRITE_SIZE")
 per = len(fr) // forwards
 pairs = arch.b2b_pairs(P)
-fused = per == len(ops) - len(pairs) and pairs  # the back-to-back pairs ran as one launch each (the engine's default): one row per launch
+stem_in = per == len(ops) - len(pairs) - 1 and pairs and pairs[0] == 1 and ops[0]["kind"] == 0  # u8 images: the stem conv ran inside the stage-1 pair's launch too
+fused = (per == len(ops) - len(pairs) or stem_in) and pairs  # the back-to-back pairs ran as one launch each (the engine's default): one row per launch
 if fused:
     merged = []
     for i, op in enumerate(ops):
-        if i - 1 in pairs:
+        if i - 1 in pairs or (stem_in and i == 0):
             continue
-        merged.append(dict(op, name=op["name"] + " + " + ops[i + 1]["name"].split(".")[-1], _second=ops[i + 1]) if i in pairs else op)
+        if i in pairs:
+            m = dict(op, name=op["name"] + " + " + ops[i + 1]["name"].split(".")[-1], _second=ops[i + 1])
+            if stem_in and i == 1:
+                m = dict(m, name="stem + " + m["name"], _stem=ops[0])
+            merged.append(m)
+        else:
+            merged.append(op)
     ops = merged
 assert per == len(ops) and len(wr) == len(fr), (per, len(ops), len(wr))
 tot = [0.0] * 4
@@ -52,6 +59,10 @@ for i, op in enumerate(ops):
         a2 = arch.op_algorithmic_bytes(P, op["_second"], batch)
         ib2 = P.bufs[op["_second"]["in_buf"]]
         a = dict(read=a["read"] + a2["read"] - batch * ib2["h"] * ib2["w"] * op["_second"]["cin"] * 2, write=a2["write"])
+        if "_stem" in op:  # the stem's tensor does not exist either: the image in, the stem's weights, the pair's weights
+            a0 = arch.op_algorithmic_bytes(P, op["_stem"], batch)
+            ib1 = P.bufs[op["in_buf"]]
+            a["read"] += a0["read"] - batch * ib1["h"] * ib1["w"] * min(op["cin"], ib1["pitch"] - op["in_coff"]) * 2
     rd = sum(float(fr[f * per + i]["Counter_Value"]) for f in range(forwards)) * 2048 / forwards
     w = sum(float(wr[f * per + i]["Counter_Value"]) for f in range(forwards)) * 1024 / forwards
     k = fr[i]["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")

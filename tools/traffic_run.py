@@ -37,14 +37,14 @@ def main():
         _lib.check(getattr(_lib.load(), name)(int(val)))
     eng = VGHeadsEngine(args.variant, image_size=args.image_size, max_batch=args.batch, seed=1, precision=args.precision)
     eng.set_split(args.split)
-    eng.set_b2b(bool(args.b2b))
+    eng.set_b2b(args.b2b if args.b2b in (2, 3) else bool(args.b2b))
     x = torch.randint(0, 256, (args.batch, args.image_size, args.image_size, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
     for _ in range(args.forwards):
         eng.forward_net(x)
     torch.cuda.synchronize()
-    alg = arch.program_algorithmic_bytes(eng.program, args.batch, b2b=bool(args.b2b))
+    alg = arch.program_algorithmic_bytes(eng.program, args.batch, fused_stem=eng.stem_fused, b2b=bool(args.b2b))
     print(json.dumps(dict(variant=args.variant, batch=args.batch, forwards=args.forwards, split=args.split, precision=args.precision,
-                          ops_per_forward=sum(1 for op in eng.program.ops if op["kind"] in (0, 1, 2)) - (eng.b2b_pairs if args.b2b else 0), b2b_pairs=eng.b2b_pairs if args.b2b else 0,
+                          ops_per_forward=sum(1 for op in eng.program.ops if op["kind"] in (0, 1, 2)) - (eng.b2b_pairs if args.b2b else 0) - int(eng.stem_fused), b2b_pairs=eng.b2b_pairs if args.b2b else 0,
                           algorithmic_read_bytes=alg["read"], algorithmic_write_bytes=alg["write"])))
     eng.close()
 
