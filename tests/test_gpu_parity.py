@@ -1176,7 +1176,9 @@ def test_overlap_mode_is_race_free_and_identical(gpu_lib, flame_model):
     # the references again through the EAGER candidate stage (detect() gathers lazily since r06: the survivors' FLAME vectors straight from the prediction buffers)
     for x, ref in ((xa, ref_a), (xb, ref_b)):
         eng.forward_candidates(x)
-        for r, q in zip(ref, snap(eng.select(B, confidence_threshold=conf, flame=fl))):
+        det = eng.select(B, confidence_threshold=conf, flame=fl)
+        eng.join()  # (select() is queued on the engine's stream and returns at once: the caller's stream waits here -- detect() does that itself)
+        for r, q in zip(ref, snap(det)):
             assert torch.equal(r, q)
     eng.set_overlap(True)
     for it in range(6):
