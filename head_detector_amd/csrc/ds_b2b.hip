@@ -183,11 +183,9 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
             sbq[t] = *(const f32x4_t*)(sa.b + 16 * t + 4 * kg);
         }
     }
-    auto stem_unit = [&](int tile, int ibuf, int xbuf, int g) __attribute__((always_inline)) {
+    auto stem_unit = [&](int b, int tyi, int txi, int ibuf, int xbuf, int g) __attribute__((always_inline)) {
         const int c16 = lane & 15, kg = lane >> 4;
-        const int b = dt_div(tile, dv.m_per, dv.s_per);
-        const int rem = tile - b * per;
-        const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+        (void)b;
         const int p = g * 16 + c16;
         const int sp = p < 289 ? p : 288;
         const int sy = (sp * 241) >> 12, sx = sp - sy * 17;  // sp / 17 for sp < 289
@@ -226,11 +224,19 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
         }
     };
     // the 19 units of a tile over the four waves (the loader wave has the image patch to convert)
+    // (straight-line code per branch: the units' LDS reads, MFMA chains and epilogues interleave -- one unit at a time exposed every unit's read latency: 736 cycles each)
     auto stem_share = [&](int tile, int ibuf, int xbuf) __attribute__((always_inline)) {
-        const int g0 = w * 5, n = w == 3 ? 4 : 5;
+        const int b = dt_div(tile, dv.m_per, dv.s_per);
+        const int rem = tile - b * per;
+        const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+        if (w == 3) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (i < n) stem_unit(tile, ibuf, xbuf, g0 + i);
+            for (int i = 0; i < 4; ++i) stem_unit(b, tyi, txi, ibuf, xbuf, 15 + i);
+        } else {
+            const int g0 = w * 5;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) stem_unit(b, tyi, txi, ibuf, xbuf, g0 + i);
+        }
     };
 
     if (w == 3 && STEM) {
