@@ -11,6 +11,7 @@ import re
 import sys
 
 FAMILIES = [
+    (r"ds_b2b_kernel<\d, 1>", "u  stem + stage-1 downsample + conv1|conv2 in one persistent launch (r06)"),
     (r"ds_b2b_kernel", "t  stage-1 downsample + conv1|conv2, persistent, weights in registers (r06)"),
     (r"ds_conv_kernel", "r  3x3 stride-2 from 96 channels, persistent, weights in registers (r06)"),
     (r"w_conv_kernel", "w  3x3 stride-1 from 96 / 128 channels, weights in registers (r06)"),
@@ -43,13 +44,18 @@ def main():
     for ln in open(sys.argv[2]):
         if ln.startswith("#") or ln.startswith("op ") or ln.startswith("total"):
             continue
-        m = re.match(r"(\S+(?: \+ \S+)?)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(-?[\d.]+)\s+(.*)$", ln.rstrip())
+        m = re.match(r"((?:stem \+ )?\S+(?: \+ \S+)?)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(-?[\d.]+)\s+(.*)$", ln.rstrip())
         if m:
             traffic[m.group(1)] = dict(alg_rd=float(m.group(2)), rd=float(m.group(3)), alg_wr=float(m.group(4)), wr=float(m.group(5)), kernel=m.group(7).strip())
     rows = {}
     # a back-to-back pair is ONE launch: its traffic row is named "<first> + <second's last name part>"; the per-layer table lists the two ops (the second at ~0 ms)
     fused = {k.split(" + ")[0]: k for k in traffic if " + " in k}
     merged, skip = [], False
+    stem_row = next((k for k in traffic if k.startswith("stem + ")), None)  # u8 images: the stem conv ran inside the stage-1 pair's launch: one row for the three ops
+    if stem_row and len(per_layer) >= 3 and per_layer[0]["kind"] == 0:
+        a, b, c = per_layer[0], per_layer[1], per_layer[2]
+        merged.append(dict(a, name=stem_row, ms=a["ms"] + b["ms"] + c["ms"], gflop=a["gflop"] + b["gflop"] + c["gflop"], read_mb=traffic[stem_row]["alg_rd"], write_mb=c["write_mb"]))
+        per_layer = per_layer[3:]
     for i, op in enumerate(per_layer):
         if skip:
             skip = False
