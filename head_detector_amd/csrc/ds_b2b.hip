@@ -183,22 +183,39 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
             sbq[t] = *(const f32x4_t*)(sa.b + 16 * t + 4 * kg);
         }
     }
-    auto stem_unit = [&](int b, int tyi, int txi, int ibuf, int xbuf, int g) __attribute__((always_inline)) {
+#ifdef VGH_DT_DEBUG_STEM
+    int dbg_b = 0;
+#endif
+    // per-lane geometry of this wave's units (unit i = pixel group g0 + i), fixed for the whole launch: stem pixel (sy, sx), its byte offset in an image patch and in a patch's planes
+    int su_sy[5], su_sx[5];
+    unsigned su_img[5], su_xp[5];
+    unsigned su_rd[4];  // the lane's four dword offsets from its patch pixel: k groups 0 - 2 the 16 contiguous bytes of their kernel row; group 3 the ninth value of each row
+    if constexpr (STEM) {
         const int c16 = lane & 15, kg = lane >> 4;
-        (void)b;
-        const int p = g * 16 + c16;
-        const int sp = p < 289 ? p : 288;
-        const int sy = (sp * 241) >> 12, sx = sp - sy * 17;  // sp / 17 for sp < 289
-        const int gy = 16 * tyi - 1 + sy, gx = 16 * txi - 1 + sx;  // position in the stem map; outside it: the 3x3 conv's zero padding (a multiply, not a select)
-        const float keep = ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? 1.0f : 0.0f;
-        const char* const img = smem + ST_IMG + ibuf * ST_IMGB + (2 * sy) * ST_RP + 12 * sx;  // patch pixel (2 sy, 2 sx), channel 0
-        // four dwords per lane: k groups 0 - 2 read the 16 contiguous bytes of their kernel row; group 3 the ninth value of each row (the low half of a dword)
+        const int g0 = w == 3 ? 15 : w * 5;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int p = (g0 + i) * 16 + c16;
+            const int sp = p < 289 ? p : 288;
+            const int sy = (sp * 241) >> 12, sx = sp - sy * 17;  // sp / 17 for sp < 289
+            su_sy[i] = p < 289 ? sy : -100;                       // (a lane without a pixel: never inside the stem map)
+            su_sx[i] = sx;
+            su_img[i] = (unsigned)((2 * sy) * ST_RP + 12 * sx);
+            const int row = sy >> 1, col = sx >> 1;
+            su_xp[i] = (unsigned)(((sy & 1) * 2 + (sx & 1)) * DT_PLANE + row * DT_ROW + (col * 6 + (row & 1)) * 16 + 8 * kg);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) su_rd[i] = (unsigned)(kg < 3 ? kg * ST_RP + 4 * i : (i < 3 ? i : 0) * ST_RP + 16);
+    }
+    auto stem_unit = [&](int tyi, int txi, int ibuf, int xbuf, int i) __attribute__((always_inline)) {
+        const int kg = lane >> 4;
+        const bool has = su_sy[i] >= 0;
+        const int gy = 16 * tyi - 1 + su_sy[i], gx = 16 * txi - 1 + su_sx[i];  // position in the stem map; outside it: the 3x3 conv's zero padding
+        const unsigned keepm = (has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? 0xffffffffu : 0u;
+        const char* const img = smem + ST_IMG + ibuf * ST_IMGB + su_img[i];
         unsigned d[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = kg < 3 ? kg * ST_RP + 4 * i : (i < 3 ? i : 0) * ST_RP + 16;
-            d[i] = *(const unsigned*)(img + off);
-        }
+        for (int r = 0; r < 4; ++r) d[r] = *(const unsigned*)(img + su_rd[r]);
         const u32x4_t bv = kg < 3 ? u32x4_t{d[0], d[1], d[2], d[3]} : u32x4_t{(d[0] & 0xffffu) | (d[1] << 16), d[2] & 0xffffu, 0u, 0u};
         const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, bv);
         f32x4_t acc[3];
@@ -208,34 +225,38 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int sp3 = 2; sp3 >= 0; --sp3) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SAw[t][sp3], bfr, acc[t], 0, 0, 0);
         }
-        if (p < 289) {
-            const int row = sy >> 1, col = sx >> 1;
-            char* const xp = smem + xbuf * DT_BUF + ((sy & 1) * 2 + (sx & 1)) * DT_PLANE + row * DT_ROW + (col * 6 + (row & 1)) * 16;
+        if (has) {
+            typedef __attribute__((ext_vector_type(2))) short s16x2;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            char* const xp = smem + xbuf * DT_BUF + su_xp[i];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                bf16x4_t o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(fmaxf(acc[t][e] + sbq[t][e], 0.0f) * keep);
-                *(bf16x4_t*)(xp + (16 * t + 4 * kg) * 2) = o;
+                // + bias (packed fp32), ONE rounding to bf16, ReLU on the packed values (a bf16 is negative as int16 exactly when the float is), zero outside the stem map (a mask)
+                const f32x2_t s0 = f32x2_t{acc[t][0], acc[t][1]} + f32x2_t{sbq[t][0], sbq[t][1]}, s1 = f32x2_t{acc[t][2], acc[t][3]} + f32x2_t{sbq[t][2], sbq[t][3]};
+                const s16x2 z = {0, 0};
+                const unsigned o0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, dt_pk(s0[0], s0[1])), z)) & keepm;
+                const unsigned o1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, dt_pk(s1[0], s1[1])), z)) & keepm;
+                *(u32x2_t*)(xp + 32 * t) = u32x2_t{o0, o1};
 #ifdef VGH_DT_DEBUG_STEM  // diagnostic build: every in-map stem pixel also goes to the stem tensor (a.in)
-                if (keep != 0.0f) *(bf16x4_t*)((uint16_t*)a.in + (((size_t)b * a.H + gy) * a.W + gx) * a.in_pitch + a.in_coff + 16 * t + 4 * kg) = o;
+                if (keepm) *(u32x2_t*)((uint16_t*)a.in + (((size_t)dbg_b * a.H + gy) * a.W + gx) * a.in_pitch + a.in_coff + 16 * t + 4 * kg) = u32x2_t{o0, o1};
 #endif
             }
         }
     };
-    // the 19 units of a tile over the four waves (the loader wave has the image patch to convert)
     // (straight-line code per branch: the units' LDS reads, MFMA chains and epilogues interleave -- one unit at a time exposed every unit's read latency: 736 cycles each)
     auto stem_share = [&](int tile, int ibuf, int xbuf) __attribute__((always_inline)) {
         const int b = dt_div(tile, dv.m_per, dv.s_per);
         const int rem = tile - b * per;
         const int tyi = dt_div(rem, dv.m_nsx, dv.s_nsx), txi = rem - tyi * nsx;
+#ifdef VGH_DT_DEBUG_STEM
+        dbg_b = b;
+#endif
         if (w == 3) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) stem_unit(b, tyi, txi, ibuf, xbuf, 15 + i);
+            for (int i = 0; i < 4; ++i) stem_unit(tyi, txi, ibuf, xbuf, i);
         } else {
-            const int g0 = w * 5;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) stem_unit(b, tyi, txi, ibuf, xbuf, g0 + i);
+            for (int i = 0; i < 5; ++i) stem_unit(tyi, txi, ibuf, xbuf, i);
         }
     };
 
