@@ -44,8 +44,10 @@ if fs and ws:
     from head_detector_amd import arch
 
     P = arch.build_program(variant, arch.random_state_dict(variant, 1), 640)
-    alg = arch.program_algorithmic_bytes(P, batch)
     launches = fn["FETCH_SIZE"]["net"] / forwards
+    n_ops = sum(1 for op in P.ops if op["kind"] in (0, 1, 2))
+    stem_in = round(launches / split) == n_ops - len(arch.b2b_pairs(P)) - 1  # u8 images: the stem conv ran inside the stage-1 pair's launch (one dispatch fewer): its tensor does not exist
+    alg = arch.program_algorithmic_bytes(P, batch, fused_stem=stem_in)
     rd = fs["FETCH_SIZE"]["net"] * 1024 * 2 / forwards
     wr = ws["WRITE_SIZE"]["net"] * 1024 / forwards
     d = dict(workload=f"{variant} bf16 batch {batch} @ 640x640, {split} batch-split lane(s)", forwards_in_run=forwards, launches_per_forward=launches,
