@@ -77,6 +77,9 @@ struct StemArgs {
 #define DT_ABLATE(a, bit) 0
 #endif
 
+#ifndef DT_SPREAD
+#define DT_SPREAD 0  // 1 (u tile): the second pixel group's epilogue blocks / stores of the previous tile move from the K loop's slots 14.. into the stem phase, between the units (A/B knob)
+#endif
 #ifndef DT_FULL_WIDTH
 #define DT_FULL_WIDTH 0  // 1: every lane's launch takes all CUs (A/B knob) instead of its share
 #endif
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
     __amdgpu_buffer_rsrc_t prsrc = out_rsrc(tile0);
     unsigned povo[2] = {DT_OOB, DT_OOB};  // (no previous tile yet: the stores of the first pass are out of range)
     const char* pex = smem + EXOFF;
-    auto pend = [&](int s) {
+    auto pend = [&](int s, bool in_loop = true) {
         if (s == 0 || s == 6) {
             const int j = s / 6;
 #pragma unroll
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int tt = 0; tt < NT2; ++tt) acc2[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[tt][f >> 1][f & 1], XF[j][f], acc2[j][tt], 0, 0, 0);
         }
-        if ((s >= 8 && s < 8 + 2 * NT2) || (s >= 14 && s < 14 + 2 * NT2)) {
+        if ((s >= 8 && s < 8 + 2 * NT2) || (s >= 14 && s < 14 + 2 * NT2 && !(DT_SPREAD && STEM && in_loop))) {
             const int j = s >= 14 ? 1 : 0, e = s >= 14 ? s - 14 : s - 8, tt = e >> 1, m = e & 1;
             if (T2 == 6 || 2 * w + tt < T2) {
                 const u32x4_t v = dt_epi8(acc2[j][tt], m, BV2[tt][m][0], BV2[tt][m][1], bound2);
@@ -524,22 +527,39 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int m = 0; m < 2; ++m) *(u32x4_t*)(ex + ((j * 3 + w) * 2 + m) * 1024 + lane * 16) = dt_epi8(acc[j], m, BV1[m][0], BV1[m][1], bound1);
         DT_MARK(5);
+        if constexpr (STEM) {  // this wave's share of the next tile's stem pixels (DT_SPREAD: with the deferred epilogue blocks of tile k - 1 between the units)
+            if (k + 1 < n_my) {
+                if constexpr (DT_SPREAD) {
+                    const int nt = tile0 + (k + 1) * gpx;
+                    const int nb_ = dt_div(nt, dv.m_per, dv.s_per);
+                    const int nrem = nt - nb_ * per;
+                    const int ntyi = dt_div(nrem, dv.m_nsx, dv.s_nsx), ntxi = nrem - ntyi * nsx;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        stem_unit(ntyi, ntxi, (k + 1) & 1, (k + 1) & 1, i);
+                        if (i < 2 * NT2) pend(14 + i, false);
+                    }
+                } else {
+                    stem_share(tile0 + (k + 1) * gpx, (k + 1) & 1, (k + 1) & 1);
+                }
+            } else if (DT_SPREAD) {
+#pragma unroll
+                for (int e = 0; e < 2 * NT2; ++e) pend(14 + e, false);
+            }
+        }
         // tile k becomes the previous tile
         prsrc = out_rsrc(tile);
         povo[0] = ovo[0];
         povo[1] = ovo[1];
         pex = ex;
         pb = STEM ? (pb ^ 1) : (pb == 2 ? 0 : pb + 1);
-        if constexpr (STEM) {
-            if (k + 1 < n_my) stem_share(tile0 + (k + 1) * gpx, (k + 1) & 1, (k + 1) & 1);  // this wave's share of the next tile's stem pixels
-        }
         DT_MARK(7);
         ++tno;
     }
     dt_barrier();  // the last tile's exchange area
 #pragma unroll
     for (int s = 0; s < 14 + 2 * NT2; ++s) {
-        pend(s);
+        pend(s, false);
         __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef VGH_EXPERIMENTS
