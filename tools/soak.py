@@ -16,11 +16,12 @@ from head_detector_amd.synthetic import synthetic_flame_model  # noqa: E402
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     dev = torch.device("cuda", 0)
-    B, S = 16, 640
+    variant = sys.argv[2] if len(sys.argv) > 2 else "vgg_heads_m"
+    B, S = (int(sys.argv[3]) if len(sys.argv) > 3 else 16), 640
     g = torch.Generator().manual_seed(7)
     xs = [torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(dev) for _ in range(2)]
     fl = FLAMELayer(model=synthetic_flame_model(seed=3), device=dev, max_heads=B * 100)
-    eng = VGHeadsEngine("vgg_heads_m", image_size=S, max_batch=B, seed=1)
+    eng = VGHeadsEngine(variant, image_size=S, max_batch=B, seed=1)
     conf = float(eng.model(xs[0])[1][:, 40, 0].max())
 
     def snap(d):
