@@ -21,6 +21,7 @@
 // This file also holds the tile's relatives: "u" (STEM = 1: the stem conv inside the same launch, the default for u8 images), "r" (ds_conv_kernel: plain 3x3 / stride-2
 // convs with 96 input channels) and the "w" candidates (w_conv_kernel: stride-1, 96 / 128 input channels).
 #include <atomic>
+#include <type_traits>
 
 #include "vgh_internal.h"
 
@@ -79,9 +80,6 @@ struct StemArgs {
 #define DT_ABLATE(a, bit) 0
 #endif
 
-#ifndef DT_SPREAD
-#define DT_SPREAD 0  // 1 (u tile): the second pixel group's epilogue blocks / stores of the previous tile move from the K loop's slots 14.. into the stem phase, between the units (A/B knob)
-#endif
 #ifndef DT_FULL_WIDTH
 #define DT_FULL_WIDTH 0  // 1: every lane's launch takes all CUs (A/B knob) instead of its share
 #endif
@@ -212,43 +210,53 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) su_rd[i] = (unsigned)(kg < 3 ? kg * ST_RP + 4 * i : (i < 3 ? i : 0) * ST_RP + 16);
     }
-    auto stem_unit = [&](int tyi, int txi, int ibuf, int xbuf, int i) __attribute__((always_inline)) {
+    // a wave's units in three PHASES -- every unit's four dwords, then every unit's nine MFMAs, then every unit's epilogue and plane writes: unit by unit, hipcc keeps a unit's
+    // LDS reads behind the previous unit's LDS writes (it cannot prove image patch and planes apart) and every unit paid its own read + MFMA-chain latency (~650 cycles each)
+    auto stem_units = [&](int tyi, int txi, int ibuf, int xbuf, auto NU) __attribute__((always_inline)) {
+        constexpr int N = decltype(NU)::value;
         const int kg = lane >> 4;
-        const bool has = su_sy[i] >= 0;
-        const int gy = 16 * tyi - 1 + su_sy[i], gx = 16 * txi - 1 + su_sx[i];  // position in the stem map; outside it: the 3x3 conv's zero padding
-        const unsigned keepm = (has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? 0xffffffffu : 0u;
-        const char* const img = smem + ST_IMG + ibuf * ST_IMGB + su_img[i];
-        unsigned d[4];
+        const char* const img0 = smem + ST_IMG + ibuf * ST_IMGB;
+        unsigned d[N][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] = *(const unsigned*)(img + su_rd[r]);
-        const u32x4_t bv = kg < 3 ? u32x4_t{d[0], d[1], d[2], d[3]} : u32x4_t{(d[0] & 0xffffu) | (d[1] << 16), d[2] & 0xffffu, 0u, 0u};
-        const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, bv);
-        f32x4_t acc[3];
+        for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int r = 0; r < 4; ++r) d[i][r] = *(const unsigned*)(img0 + su_img[i] + su_rd[r]);
+        f32x4_t acc[N][3];
 #pragma unroll
-            for (int sp3 = 2; sp3 >= 0; --sp3) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SAw[t][sp3], bfr, acc[t], 0, 0, 0);
-        }
-        if (has) {
-            typedef __attribute__((ext_vector_type(2))) short s16x2;
-            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-            char* const xp = smem + xbuf * DT_BUF + su_xp[i];
+        for (int i = 0; i < N; ++i) {
+            const u32x4_t bv = kg < 3 ? u32x4_t{d[i][0], d[i][1], d[i][2], d[i][3]} : u32x4_t{(d[i][0] & 0xffffu) | (d[i][1] << 16), d[i][2] & 0xffffu, 0u, 0u};
+            const bf16x8_t bfr = __builtin_bit_cast(bf16x8_t, bv);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                // + bias (packed fp32), ONE rounding to bf16, ReLU on the packed values (a bf16 is negative as int16 exactly when the float is), zero outside the stem map (a mask)
-                const f32x2_t s0 = f32x2_t{acc[t][0], acc[t][1]} + f32x2_t{sbq[t][0], sbq[t][1]}, s1 = f32x2_t{acc[t][2], acc[t][3]} + f32x2_t{sbq[t][2], sbq[t][3]};
-                const s16x2 z = {0, 0};
-                const unsigned o0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, dt_pk(s0[0], s0[1])), z)) & keepm;
-                const unsigned o1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, dt_pk(s1[0], s1[1])), z)) & keepm;
-                *(u32x2_t*)(xp + 32 * t) = u32x2_t{o0, o1};
+                acc[i][t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int sp3 = 2; sp3 >= 0; --sp3) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SAw[t][sp3], bfr, acc[i][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const bool has = su_sy[i] >= 0;
+            const int gy = 16 * tyi - 1 + su_sy[i], gx = 16 * txi - 1 + su_sx[i];  // position in the stem map; outside it: the 3x3 conv's zero padding
+            const unsigned keepm = (has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? 0xffffffffu : 0u;
+            if (has) {
+                typedef __attribute__((ext_vector_type(2))) short s16x2;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                char* const xp = smem + xbuf * DT_BUF + su_xp[i];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    // + bias (packed fp32), ONE rounding to bf16, ReLU on the packed values (a bf16 is negative as int16 exactly when the float is), zero outside the stem map (a mask)
+                    const f32x2_t s0 = f32x2_t{acc[i][t][0], acc[i][t][1]} + f32x2_t{sbq[t][0], sbq[t][1]}, s1 = f32x2_t{acc[i][t][2], acc[i][t][3]} + f32x2_t{sbq[t][2], sbq[t][3]};
+                    const s16x2 z = {0, 0};
+                    const unsigned o0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, dt_pk(s0[0], s0[1])), z)) & keepm;
+                    const unsigned o1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, dt_pk(s1[0], s1[1])), z)) & keepm;
+                    *(u32x2_t*)(xp + 32 * t) = u32x2_t{o0, o1};
 #ifdef VGH_DT_DEBUG_STEM  // diagnostic build: every in-map stem pixel also goes to the stem tensor (a.in)
-                if (keepm) *(u32x2_t*)((uint16_t*)a.in + (((size_t)dbg_b * a.H + gy) * a.W + gx) * a.in_pitch + a.in_coff + 16 * t + 4 * kg) = u32x2_t{o0, o1};
+                    if (keepm) *(u32x2_t*)((uint16_t*)a.in + (((size_t)dbg_b * a.H + gy) * a.W + gx) * a.in_pitch + a.in_coff + 16 * t + 4 * kg) = u32x2_t{o0, o1};
 #endif
+                }
             }
         }
     };
-    // (straight-line code per branch: the units' LDS reads, MFMA chains and epilogues interleave -- one unit at a time exposed every unit's read latency: 736 cycles each)
     auto stem_share = [&](int tile, int ibuf, int xbuf) __attribute__((always_inline)) {
         const int b = dt_div(tile, dv.m_per, dv.s_per);
         const int rem = tile - b * per;
@@ -256,13 +264,10 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #ifdef VGH_DT_DEBUG_STEM
         dbg_b = b;
 #endif
-        if (w == 3) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) stem_unit(tyi, txi, ibuf, xbuf, i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) stem_unit(tyi, txi, ibuf, xbuf, i);
-        }
+        if (w == 3)
+            stem_units(tyi, txi, ibuf, xbuf, std::integral_constant<int, 4>{});
+        else
+            stem_units(tyi, txi, ibuf, xbuf, std::integral_constant<int, 5>{});
     };
 
     if (w == 3 && STEM) {
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
     __amdgpu_buffer_rsrc_t prsrc = out_rsrc(tile0);
     unsigned povo[2] = {DT_OOB, DT_OOB};  // (no previous tile yet: the stores of the first pass are out of range)
     const char* pex = smem + EXOFF;
-    auto pend = [&](int s, bool in_loop = true) {
+    auto pend = [&](int s) {
         if (s == 0 || s == 6) {
             const int j = s / 6;
 #pragma unroll
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int tt = 0; tt < NT2; ++tt) acc2[j][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2[tt][f >> 1][f & 1], XF[j][f], acc2[j][tt], 0, 0, 0);
         }
-        if ((s >= 8 && s < 8 + 2 * NT2) || (s >= 14 && s < 14 + 2 * NT2 && !(DT_SPREAD && STEM && in_loop))) {
+        if ((s >= 8 && s < 8 + 2 * NT2) || (s >= 14 && s < 14 + 2 * NT2)) {
             const int j = s >= 14 ? 1 : 0, e = s >= 14 ? s - 14 : s - 8, tt = e >> 1, m = e & 1;
             if (T2 == 6 || 2 * w + tt < T2) {
                 const u32x4_t v = dt_epi8(acc2[j][tt], m, BV2[tt][m][0], BV2[tt][m][1], bound2);
@@ -529,25 +534,8 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int m = 0; m < 2; ++m) *(u32x4_t*)(ex + ((j * 3 + w) * 2 + m) * 1024 + lane * 16) = dt_epi8(acc[j], m, BV1[m][0], BV1[m][1], bound1);
         DT_MARK(5);
-        if constexpr (STEM) {  // this wave's share of the next tile's stem pixels (DT_SPREAD: with the deferred epilogue blocks of tile k - 1 between the units)
-            if (k + 1 < n_my) {
-                if constexpr (DT_SPREAD) {
-                    const int nt = tile0 + (k + 1) * gpx;
-                    const int nb_ = dt_div(nt, dv.m_per, dv.s_per);
-                    const int nrem = nt - nb_ * per;
-                    const int ntyi = dt_div(nrem, dv.m_nsx, dv.s_nsx), ntxi = nrem - ntyi * nsx;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        stem_unit(ntyi, ntxi, (k + 1) & 1, (k + 1) & 1, i);
-                        if (i < 2 * NT2) pend(14 + i, false);
-                    }
-                } else {
-                    stem_share(tile0 + (k + 1) * gpx, (k + 1) & 1, (k + 1) & 1);
-                }
-            } else if (DT_SPREAD) {
-#pragma unroll
-                for (int e = 0; e < 2 * NT2; ++e) pend(14 + e, false);
-            }
+        if constexpr (STEM) {
+            if (k + 1 < n_my) stem_share(tile0 + (k + 1) * gpx, (k + 1) & 1, (k + 1) & 1);  // this wave's share of the next tile's stem pixels
         }
         // tile k becomes the previous tile
         prsrc = out_rsrc(tile);
@@ -561,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void ds_b2b_kernel(const ConvArgs a, const 
     dt_barrier();  // the last tile's exchange area
 #pragma unroll
     for (int s = 0; s < 14 + 2 * NT2; ++s) {
-        pend(s, false);
+        pend(s);
         __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef VGH_EXPERIMENTS
