@@ -546,7 +546,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))  # spawn'ed ranks inherit sys.path and import the module by name
         import dryrun_dist as mod
 
-        sys.exit(mod.main(["--gpus", str(max(args.gpus, 2)), "--steps", str(min(args.steps, 20))] + (["--compact"] if args.compact_gather else [])))
+        sys.exit(mod.main(["--gpus", str(max(args.gpus, 2)), "--steps", str(max(6, min(args.steps, 20)))] + (["--compact"] if args.compact_gather else [])))
     leaked = sorted(k for k in os.environ if k.startswith("VGH_"))
     if leaked:
         sys.exit(f"bench.py: refusing to measure with experiment switches in the environment: {leaked}")
